@@ -1,0 +1,104 @@
+"""ctypes mirror of include/halo_trace.h (the C-ABI boundary).  Plumbing only: no compute here.
+
+Struct layouts follow the header field-for-field; `tests/test_abi_layout.py` checks sizes against the
+compiled library (`halo_abi_sizeof`).
+"""
+import ctypes as C
+
+HALO_OK, HALO_UNAVAILABLE, HALO_FATAL = 0, 1, 2
+MAX_LAYERS, MAX_ENTRIES, MAX_HITS, MAX_FACES, MAX_FACE_VTX, MAX_TRIS = 4, 16, 64, 20, 12, 64
+LUT_NODES, WL_POOL_MAX, PATH_CAP = 257, 255, 16
+
+DIST_NONE, DIST_UNIFORM, DIST_GAUSS, DIST_ZIGZAG, DIST_LAPLACIAN, DIST_GAUSS_LEGACY = range(6)
+CRYSTAL_PRISM, CRYSTAL_PYRAMID = 0, 1
+(LENS_LINEAR, LENS_FISHEYE_EQUAL_AREA, LENS_FISHEYE_EQUIDISTANT, LENS_FISHEYE_STEREOGRAPHIC,
+ LENS_DUAL_FISHEYE_EQUAL_AREA, LENS_DUAL_FISHEYE_EQUIDISTANT, LENS_DUAL_FISHEYE_STEREOGRAPHIC,
+ LENS_RECTANGULAR, LENS_FISHEYE_ORTHOGRAPHIC, LENS_DUAL_FISHEYE_ORTHOGRAPHIC, LENS_GLOBE) = range(11)
+VISIBLE_UPPER, VISIBLE_LOWER, VISIBLE_FULL = 0, 1, 2
+ILLUM = {"D50": 0, "D55": 1, "D65": 2, "D75": 3, "A": 4, "E": 5}
+
+
+class HaloDist(C.Structure):
+    _fields_ = [("type", C.c_int32), ("center", C.c_float), ("spread", C.c_float)]
+
+
+class HaloAxis(C.Structure):
+    _fields_ = [("azimuth", HaloDist), ("latitude", HaloDist), ("roll", HaloDist)]
+
+
+class HaloCrystal(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("height", HaloDist * 3), ("face_dist", HaloDist * 6),
+                ("sync_group", C.c_int32 * 9), ("wedge_upper_deg", C.c_float), ("wedge_lower_deg", C.c_float)]
+
+
+class HaloEntry(C.Structure):
+    _fields_ = [("crystal", HaloCrystal), ("axis", HaloAxis), ("proportion", C.c_float),
+                ("crystal_config_id", C.c_int32)]
+
+
+class HaloLayer(C.Structure):
+    _fields_ = [("prob", C.c_float), ("entry_count", C.c_int32), ("entries", HaloEntry * MAX_ENTRIES)]
+
+
+class HaloScene(C.Structure):
+    _fields_ = [("sun_altitude", C.c_float), ("sun_azimuth", C.c_float), ("sun_diameter", C.c_float),
+                ("max_hits", C.c_int32), ("layer_count", C.c_int32), ("layers", HaloLayer * MAX_LAYERS)]
+
+
+class HaloRender(C.Structure):
+    _fields_ = [("lens_type", C.c_int32), ("fov", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("lens_shift", C.c_int32 * 2), ("view_az", C.c_float), ("view_el", C.c_float),
+                ("view_ro", C.c_float), ("visible", C.c_int32), ("overlap", C.c_float)]
+
+
+class HaloWl(C.Structure):
+    _fields_ = [("wavelength", C.c_float), ("weight", C.c_float), ("illuminant", C.c_int32),
+                ("pool_size", C.c_int32)]
+
+
+class HaloHostRays(C.Structure):
+    _fields_ = [("d", C.POINTER(C.c_float)), ("p", C.POINTER(C.c_float)), ("w", C.POINTER(C.c_float)),
+                ("tf", C.POINTER(C.c_uint32))]
+
+
+class HaloLayerStats(C.Structure):
+    _fields_ = [("root_count", C.c_uint64), ("exit_count", C.c_uint64), ("continuation_count", C.c_uint64),
+                ("exit_w_sum", C.c_double), ("kernel_ms", C.c_double)]
+
+
+class HaloExitRecord(C.Structure):
+    _fields_ = [("dir", C.c_float * 3), ("weight", C.c_float), ("root", C.c_uint32), ("seq", C.c_uint16),
+                ("layer", C.c_uint8), ("path_len", C.c_uint8), ("path", C.c_uint8 * PATH_CAP),
+                ("pixel", C.c_int32), ("crystal_id", C.c_uint16), ("wl_idx", C.c_uint16)]
+
+
+class HaloGeomTables(C.Structure):
+    _fields_ = [("face_cnt", C.c_int32), ("face_n", C.c_float * (MAX_FACES * 3)), ("face_d", C.c_float * MAX_FACES),
+                ("face_number", C.c_int32 * MAX_FACES), ("tri_cnt", C.c_int32), ("tri_v", C.c_float * (MAX_TRIS * 9)),
+                ("tri_n", C.c_float * (MAX_TRIS * 3)), ("tri_area", C.c_float * MAX_TRIS),
+                ("tri_face", C.c_int32 * MAX_TRIS)]
+
+
+class ProjParams(C.Structure):
+    """lm_proj::ProjParams — reference src/core/shared/projection_shared.h:106-118 (76 bytes)."""
+    _fields_ = [("proj_type", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32), ("visible_range", C.c_int32),
+                ("lens_shift_x", C.c_int32), ("lens_shift_y", C.c_int32), ("scale", C.c_float), ("az0", C.c_float),
+                ("r_scale", C.c_float), ("max_abs_dz", C.c_float), ("rot", C.c_float * 9)]
+
+
+def dist(spec=None, default=0.0):
+    """HaloDist from a JSON-style value: number | {"type","mean","std"} (reference doc/configuration.md)."""
+    d = HaloDist()
+    if spec is None:
+        d.type, d.center, d.spread = DIST_NONE, float(default), 0.0
+    elif isinstance(spec, (int, float)):
+        d.type, d.center, d.spread = DIST_NONE, float(spec), 0.0
+    elif isinstance(spec, HaloDist):
+        return spec
+    else:
+        names = {"none": DIST_NONE, "uniform": DIST_UNIFORM, "gauss": DIST_GAUSS, "zigzag": DIST_ZIGZAG,
+                 "laplacian": DIST_LAPLACIAN, "gauss_legacy": DIST_GAUSS_LEGACY}
+        d.type = names[spec["type"]]
+        d.center = float(spec.get("mean", 0.0))
+        d.spread = float(spec.get("std", 0.0))
+    return d

@@ -1,0 +1,258 @@
+/*
+ * halo_trace.h — C ABI of the MI355X-native ice-halo trace backend (libhalo_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of Lumice (LoveDaisy/ice_halo_sim): the per-ray trace
+ * hot path behind `lumice::TraceBackend` (reference: src/core/backend/trace_backend.hpp:367-641).
+ * The reference has no C-ABI plugin loader (backends are C++ classes compiled in and picked by
+ * `CreateBackend`, src/core/simulator.cpp:854-919); this header is the stable C boundary we put
+ * UNDER a thin C++ adapter (`ice_halo_sim_amd/csrc/hip_trace_backend.hpp`).
+ *
+ * Each entry point names the reference virtual it replaces.  Plain pointers and sizes only.
+ * All functions return HALO_OK (0), HALO_UNAVAILABLE (1 → adapter throws BackendUnavailableError,
+ * trace_backend.hpp:140-158) or HALO_FATAL (2).  One handle = one backend instance; a handle is
+ * single-threaded (trace_backend.hpp:114-116, simulator.cpp:970-979).
+ *
+ * Everything crossing this boundary is WORLD-space (trace_backend.hpp:71-89) except injected golden
+ * rays, which follow the reference's host-ingest convention: crystal-local, identity rotation
+ * (src/core/backend/cpu_trace_backend.cpp:121-144).
+ */
+#ifndef HALO_TRACE_H_
+#define HALO_TRACE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALO_ABI_VERSION 1
+
+enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
+
+/* Compile-time caps — reference src/core/def.hpp:23-31 (kMaxMsNum, kMaxHits, kMaxCrystalNum). */
+#define HALO_MAX_LAYERS 4
+#define HALO_MAX_ENTRIES 16
+#define HALO_MAX_HITS 64
+#define HALO_MAX_FACES 20        /* CrystalGeom face slots, src/core/crystal.hpp:78 */
+#define HALO_MAX_FACE_VTX 12     /* kCrystalGeomMaxVtxPerFace */
+#define HALO_MAX_TRIS 64         /* lm_pcg::kMaxTriPerKernel, src/core/shared/pcg_shared.h:71 */
+#define HALO_LUT_NODES 257       /* LatLut::kNodes, src/core/lat_lut.hpp:31 */
+#define HALO_WL_POOL_MAX 255     /* kWlPoolSizeMax, src/core/backend/wl_pool.hpp:41 */
+#define HALO_PATH_CAP 16         /* face numbers kept per exit record (reference ExitFaceSeq::kCap is 64) */
+
+/* DistributionType — src/core/math.hpp:123-130 (values are wire values, pcg_shared.h:64-69). */
+enum {
+  HALO_DIST_NONE = 0,
+  HALO_DIST_UNIFORM = 1,   /* spread = FULL range */
+  HALO_DIST_GAUSS = 2,
+  HALO_DIST_ZIGZAG = 3,
+  HALO_DIST_LAPLACIAN = 4,
+  HALO_DIST_GAUSS_LEGACY = 5
+};
+
+/* Distribution{type, center, spread} — src/core/math.hpp:165-190. */
+typedef struct HaloDist {
+  int32_t type;
+  float center;
+  float spread;
+} HaloDist;
+
+/* AxisDistribution — src/core/math.hpp:271-310.  Degrees.  `latitude` is the INTERNAL latitude
+ * (JSON `zenith` = 90 - latitude, src/core/math.cpp:679-714). */
+typedef struct HaloAxis {
+  HaloDist azimuth;
+  HaloDist latitude;
+  HaloDist roll;
+} HaloAxis;
+
+enum { HALO_CRYSTAL_PRISM = 0, HALO_CRYSTAL_PYRAMID = 1 };
+
+/* PrismCrystalParam / PyramidCrystalParam — src/config/crystal_config.hpp.
+ * Shape-scalar slot order = RNG draw order (src/core/simulator.cpp:405-425):
+ *   prism  : height[0]=h, face_dist[0..5]
+ *   pyramid: height[0]=upper_h, height[1]=prism_h, height[2]=lower_h, face_dist[0..5]
+ * sync_group[k] (0 = independent) indexes [h0,h1,h2,d0..d5]; members of one group share one draw
+ * (src/core/simulator.cpp:344-393). */
+typedef struct HaloCrystal {
+  int32_t kind;
+  HaloDist height[3];
+  HaloDist face_dist[6];
+  int32_t sync_group[9];
+  float wedge_upper_deg; /* pyramid only */
+  float wedge_lower_deg;
+} HaloCrystal;
+
+/* One scattering-layer entry: MsInfo::setting_[ci] — src/config/proj_config.hpp:27-38. */
+typedef struct HaloEntry {
+  HaloCrystal crystal;
+  HaloAxis axis;
+  float proportion;
+  int32_t crystal_config_id;
+} HaloEntry;
+
+typedef struct HaloLayer {
+  float prob; /* MsInfo::prob_ — continuation probability to the next layer */
+  int32_t entry_count;
+  HaloEntry entries[HALO_MAX_ENTRIES];
+} HaloLayer;
+
+/* SceneConfig fields read on the path (sun: src/config/light_config.hpp SunParam). Degrees. */
+typedef struct HaloScene {
+  float sun_altitude;
+  float sun_azimuth;
+  float sun_diameter;
+  int32_t max_hits; /* counts surface interactions INCLUDING the entry face (simulator.cpp:1308) */
+  int32_t layer_count;
+  HaloLayer layers[HALO_MAX_LAYERS];
+} HaloScene;
+
+/* LensParam::LensType integer values — src/core/shared/projection_shared.h:136-146. */
+enum {
+  HALO_LENS_LINEAR = 0,
+  HALO_LENS_FISHEYE_EQUAL_AREA = 1,
+  HALO_LENS_FISHEYE_EQUIDISTANT = 2,
+  HALO_LENS_FISHEYE_STEREOGRAPHIC = 3,
+  HALO_LENS_DUAL_FISHEYE_EQUAL_AREA = 4,
+  HALO_LENS_DUAL_FISHEYE_EQUIDISTANT = 5,
+  HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC = 6,
+  HALO_LENS_RECTANGULAR = 7,
+  HALO_LENS_FISHEYE_ORTHOGRAPHIC = 8,
+  HALO_LENS_DUAL_FISHEYE_ORTHOGRAPHIC = 9,
+  HALO_LENS_GLOBE = 10
+};
+enum { HALO_VISIBLE_UPPER = 0, HALO_VISIBLE_LOWER = 1, HALO_VISIBLE_FULL = 2 };
+
+/* RenderConfig fields read by BuildProjParams — src/core/lens_proj_build.hpp:79-137,
+ * src/config/render_config.hpp:71-103.  Degrees. */
+typedef struct HaloRender {
+  int32_t lens_type;
+  float fov;
+  int32_t width;
+  int32_t height;
+  int32_t lens_shift[2];
+  float view_az;
+  float view_el;
+  float view_ro;
+  int32_t visible;
+  float overlap; /* dual-fisheye overlap band (max |dz|), 0 = off */
+} HaloRender;
+
+/* Illuminants — src/util/illuminant_data.hpp:12-19. */
+enum { HALO_ILLUM_D50 = 0, HALO_ILLUM_D55 = 1, HALO_ILLUM_D65 = 2, HALO_ILLUM_D75 = 3, HALO_ILLUM_A = 4, HALO_ILLUM_E = 5 };
+
+/* WlParam (discrete: one session per wavelength) or illuminant pool
+ * (src/core/backend/wl_pool.hpp:67-91: M mid-point wavelengths on [380,780], per-ray pick). */
+typedef struct HaloWl {
+  float wavelength; /* nm; used when illuminant < 0 */
+  float weight;     /* spectral weight; used when illuminant < 0 */
+  int32_t illuminant; /* -1 = discrete wavelength, else HALO_ILLUM_* */
+  int32_t pool_size;  /* illuminant pool entries M (0 → 64 default, cap 255) */
+} HaloWl;
+
+/* HostRayBatch — src/core/backend/trace_backend.hpp:230-239.  Crystal-local golden-ray ingest. */
+typedef struct HaloHostRays {
+  const float* d;      /* 3*count */
+  const float* p;      /* 3*count */
+  const float* w;      /* count */
+  const uint32_t* tf;  /* count — compact polygon-face id of the entry face */
+} HaloHostRays;
+
+/* LayerStats — trace_backend.hpp:296-299 (+ continuation count from LayerHandle). */
+typedef struct HaloLayerStats {
+  uint64_t root_count;
+  uint64_t exit_count;       /* exits emitted to the image (or captured) in this layer */
+  uint64_t continuation_count;
+  double exit_w_sum;
+  double kernel_ms;          /* HIP-event time of this layer's kernels on the backend stream */
+} HaloLayerStats;
+
+/* ExitRayRecord — src/core/exit_seam.hpp:40-53, trimmed to what the parity tests read.
+ * Only produced when option "capture_exits" is on (test path; production accumulates on device). */
+typedef struct HaloExitRecord {
+  float dir[3];     /* world-space exit direction */
+  float weight;
+  uint32_t root;    /* root-ray index within the layer dispatch */
+  uint16_t seq;     /* 0 = entry-face external reflection, k = k-th interior interaction */
+  uint8_t layer;
+  uint8_t path_len;
+  uint8_t path[HALO_PATH_CAP]; /* crystal face NUMBERS (1..8 prism; pyramid 1,2,3-8,13-18,23-28) */
+  int32_t pixel;    /* flat pixel index of the primary hit, -1 = culled / out of frame */
+  uint16_t crystal_id;
+  uint16_t wl_idx;
+} HaloExitRecord;
+
+typedef struct HaloBackend* halo_handle_t;
+
+/* --- lifecycle ---------------------------------------------------------------------------- */
+/* Number of visible HIP devices (CudaDeviceAvailable analogue, cuda_trace_backend.cu:147-193). */
+int halo_device_count(void);
+/* CreateBackend(BackendKind) — simulator.cpp:854-919.  seed must be non-zero (effective_seed_,
+ * simulator.cpp:782-798); the backend seeds ONCE and keeps monotone ray counters across sessions
+ * (cpu_trace_backend.hpp:131-140, cuda_trace_backend.cu:3724-3741). */
+int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out);
+int halo_destroy(halo_handle_t h);
+const char* halo_last_error(halo_handle_t h);
+/* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
+ * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams),
+ * "chunk" (max rays per kernel launch), "aggregate" (LDS hot-pixel cache 0/1). */
+int halo_set_option(halo_handle_t h, const char* key, int64_t value);
+/* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
+int halo_set_stream(halo_handle_t h, void* hip_stream);
+/* Bind an externally-owned device accumulator of width*height*3+4 floats (e.g. a torch tensor, so
+ * torch.distributed can reduce it in place).  NULL = backend-owned.  Layout: xyz image then
+ * [landed_lo, landed_hi, 0, 0] (landed weight kept as a float pair). */
+int halo_bind_accumulator(halo_handle_t h, void* device_ptr, uint64_t n_floats);
+
+/* --- session ------------------------------------------------------------------------------ */
+/* TraceBackend::BeginSession(SessionSpec) — trace_backend.hpp:374-378. scene/render are COPIED. */
+int halo_begin(halo_handle_t h, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t ray_num_hint);
+/* TraceBackend::TraceLayer(RootRaySource) — trace_backend.hpp:380-389.  First call of a session:
+ * host mode, `count` roots self-generated on device (rays == NULL) or injected (rays != NULL).
+ * Later calls: device mode, consumes the continuation produced by halo_recombine (count ignored). */
+int halo_trace_layer(halo_handle_t h, uint64_t count, const HaloHostRays* rays, HaloLayerStats* stats);
+/* TraceBackend::Recombine(handle, RecombineSpec{shuffle}) — trace_backend.hpp:391-395. */
+int halo_recombine(halo_handle_t h, int shuffle, uint64_t* continuation_count);
+/* TraceBackend::DrainExits — trace_backend.hpp:430-448 (only with "capture_exits"). */
+int halo_drain_exits(halo_handle_t h, HaloExitRecord* out, uint64_t cap, uint64_t* count);
+/* TraceBackend::EndSession. The accumulator persists (SupportsThirdClockDrain, cu:4801-4808). */
+int halo_end(halo_handle_t h);
+/* TraceBackend::ReadbackXyzAccum — trace_backend.hpp:461-469, cuda_trace_backend.cu:4800-4846:
+ * sync, ADD landed weight into *landed_weight, copy W*H*3 floats, zero the device accumulator. */
+int halo_readback_xyz(halo_handle_t h, float* xyz, int width, int height, float* landed_weight);
+/* Same, but returns landed weight in double and does not add. */
+int halo_readback_xyz64(halo_handle_t h, float* xyz, int width, int height, double* landed_weight);
+int halo_sync(halo_handle_t h);
+
+/* --- host-side pieces of the path, exported for parity tests (no GPU needed) ---------------- */
+/* Geometry tables the kernels consume (reference: Crystal::PopulateFromCfGeom crystal.cpp:304-347,
+ * detail::BuildEntrySubTris simulator.cpp:90-129). */
+typedef struct HaloGeomTables {
+  int32_t face_cnt;                 /* compact present faces */
+  float face_n[HALO_MAX_FACES * 3];
+  float face_d[HALO_MAX_FACES];
+  int32_t face_number[HALO_MAX_FACES];
+  int32_t tri_cnt;
+  float tri_v[HALO_MAX_TRIS * 9];
+  float tri_n[HALO_MAX_TRIS * 3];
+  float tri_area[HALO_MAX_TRIS];
+  int32_t tri_face[HALO_MAX_TRIS];
+} HaloGeomTables;
+/* Crystal::CreatePrism(h, dist) — crystal.cpp:349-377. Returns HALO_OK; face_cnt==0 = empty crystal. */
+int halo_host_prism_geometry(float h, const float dist[6], HaloGeomTables* out);
+/* Crystal::CreatePyramid(wedge_u, wedge_l, h1, h2, h3, dist) — crystal.cpp:379-426. */
+int halo_host_pyramid_geometry(float wedge_upper_deg, float wedge_lower_deg, float h1, float h2, float h3,
+                               const float dist[6], HaloGeomTables* out);
+/* BuildLatLut — lat_lut.cpp:74-204. theta/cdf/flip are HALO_LUT_NODES floats each. */
+int halo_host_build_lat_lut(const HaloDist* latitude, float* theta, float* cdf, float* flip);
+/* BuildProjParams — lens_proj_build.hpp:79-137 → 19 x 4 bytes laid out as lm_proj::ProjParams. */
+int halo_host_build_proj_params(const HaloRender* render, void* proj_params_76_bytes);
+/* PartitionCrystalRayNum — simulator.cpp:519-582. carry has n entries and persists across calls. */
+int halo_host_partition(const float* proportions, int n, uint64_t ray_num, double* carry, uint64_t* out_counts);
+/* IceRefractiveIndex::Get — optics.cpp:180-197. */
+double halo_host_refractive_index(double wavelength_nm);
+int halo_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALO_TRACE_H_ */
