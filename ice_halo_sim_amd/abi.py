@@ -63,7 +63,7 @@ class HaloHostRays(C.Structure):
 
 class HaloLayerStats(C.Structure):
     _fields_ = [("root_count", C.c_uint64), ("exit_count", C.c_uint64), ("continuation_count", C.c_uint64),
-                ("exit_w_sum", C.c_double), ("kernel_ms", C.c_double)]
+                ("exit_w_sum", C.c_double), ("kernel_ms", C.c_double), ("pixel_hits", C.c_uint64), ("launches", C.c_uint64)]
 
 
 class HaloExitRecord(C.Structure):

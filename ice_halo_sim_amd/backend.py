@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's trace-backend seam over the C ABI (libhalo_hip.so).
+
+`HipTraceBackend` follows `lumice::TraceBackend` (reference src/core/backend/trace_backend.hpp:367-641)
+method for method: BeginSession / TraceLayer / Recombine / DrainExits / ReadbackXyzAccum / EndSession,
+same state machine, `BackendUnavailableError` as the one recoverable error.  It is a thin ctypes layer:
+all computing happens in the HIP library, and importing this module without the built library (or
+without a gfx950 device at create time) fails loudly — there is no CPU fallback here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhalo_hip.so")
+_lib = None
+
+
+class BackendUnavailableError(RuntimeError):
+    """Reference: BackendUnavailableError, trace_backend.hpp:140-158 (the only recoverable error)."""
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree HIP library and declare every symbol of include/halo_trace.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libhalo_hip.so is not built — run `python -m ice_halo_sim_amd.build` (needs hipcc)")
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    f32p = C.POINTER(C.c_float)
+    sig = {
+        "halo_abi_version": (C.c_int, []),
+        "halo_abi_sizeof": (C.c_uint64, [C.c_int]),
+        "halo_device_count": (C.c_int, []),
+        "halo_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(H)]),
+        "halo_destroy": (C.c_int, [H]),
+        "halo_last_error": (C.c_char_p, [H]),
+        "halo_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
+        "halo_set_stream": (C.c_int, [H, C.c_void_p]),
+        "halo_bind_accumulator": (C.c_int, [H, C.c_void_p, C.c_uint64]),
+        "halo_begin": (C.c_int, [H, C.POINTER(abi.HaloScene), C.POINTER(abi.HaloRender), C.POINTER(abi.HaloWl), C.c_uint64]),
+        "halo_trace_layer": (C.c_int, [H, C.c_uint64, C.POINTER(abi.HaloHostRays), C.POINTER(abi.HaloLayerStats)]),
+        "halo_recombine": (C.c_int, [H, C.c_int, C.POINTER(C.c_uint64)]),
+        "halo_drain_exits": (C.c_int, [H, C.POINTER(abi.HaloExitRecord), C.c_uint64, C.POINTER(C.c_uint64)]),
+        "halo_end": (C.c_int, [H]),
+        "halo_readback_xyz": (C.c_int, [H, f32p, C.c_int, C.c_int, f32p]),
+        "halo_readback_xyz64": (C.c_int, [H, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+        "halo_sync": (C.c_int, [H]),
+        "halo_take_landed": (C.c_int, [H, C.POINTER(C.c_double)]),
+        "halo_host_prism_geometry": (C.c_int, [C.c_float, f32p, C.POINTER(abi.HaloGeomTables)]),
+        "halo_host_pyramid_geometry": (C.c_int, [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]),
+        "halo_host_build_lat_lut": (C.c_int, [C.POINTER(abi.HaloDist), f32p, f32p, f32p]),
+        "halo_host_build_proj_params": (C.c_int, [C.POINTER(abi.HaloRender), C.c_void_p]),
+        "halo_host_partition": (C.c_int, [f32p, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "halo_host_refractive_index": (C.c_double, [C.c_double]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
+    "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_begin", "halo_trace_layer", "halo_recombine",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_take_landed", "halo_host_prism_geometry",
+    "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
+    "halo_host_refractive_index",
+]
+
+
+class HipTraceBackend:
+    """One backend instance = one `Simulator::Run()` thread's backend (single-threaded use)."""
+
+    def __init__(self, device=0, seed=42, **options):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.halo_create(int(device), int(seed) & 0xFFFFFFFF, C.byref(self._h))
+        if rc == abi.HALO_UNAVAILABLE:
+            raise BackendUnavailableError("no gfx950 device %d (halo_create)" % device)
+        if rc != abi.HALO_OK:
+            raise BackendError("halo_create failed")
+        self._render = None
+        self._scene = None
+        self._pending_roots = 0
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    # --- plumbing ---
+    def _check(self, rc):
+        if rc == abi.HALO_OK:
+            return
+        msg = self._L.halo_last_error(self._h)
+        msg = msg.decode() if msg else "?"
+        if rc == abi.HALO_UNAVAILABLE:
+            raise BackendUnavailableError(msg)
+        raise BackendError(msg)
+
+    def close(self):
+        if self._h:
+            self._L.halo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._check(self._L.halo_set_option(self._h, key.encode(), int(value)))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._L.halo_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def bind_accumulator(self, device_ptr, n_floats):
+        self._check(self._L.halo_bind_accumulator(self._h, C.c_void_p(device_ptr), int(n_floats)))
+
+    def sync(self):
+        self._check(self._L.halo_sync(self._h))
+
+    def take_landed(self):
+        v = C.c_double()
+        self._check(self._L.halo_take_landed(self._h, C.byref(v)))
+        return v.value
+
+    # --- the seam (trace_backend.hpp:374-632) ---
+    def SupportsDeviceXyzAccum(self):
+        return True
+
+    def SupportsThirdClockDrain(self):
+        return True
+
+    def BeginSession(self, scene, render, wl, ray_num=0):
+        self._render = render
+        self._scene = scene
+        self._check(self._L.halo_begin(self._h, C.byref(scene), C.byref(render), C.byref(wl), int(ray_num)))
+
+    def TraceLayer(self, count=0, host_rays=None):
+        """First layer: `count` self-generated roots, or injected crystal-local rays (d, p, w, tf arrays).
+        Later layers: consumes the continuation from Recombine.  Returns HaloLayerStats."""
+        stats = abi.HaloLayerStats()
+        if host_rays is None:
+            self._check(self._L.halo_trace_layer(self._h, int(count), None, C.byref(stats)))
+            self._pending_roots += int(stats.root_count)
+            return stats
+        d, p, w, tf = (np.ascontiguousarray(host_rays[0], np.float32), np.ascontiguousarray(host_rays[1], np.float32),
+                       np.ascontiguousarray(host_rays[2], np.float32), np.ascontiguousarray(host_rays[3], np.uint32))
+        n = w.shape[0]
+        hr = abi.HaloHostRays(d.ctypes.data_as(C.POINTER(C.c_float)), p.ctypes.data_as(C.POINTER(C.c_float)),
+                              w.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_uint32)))
+        self._check(self._L.halo_trace_layer(self._h, n, C.byref(hr), C.byref(stats)))
+        self._pending_roots += int(stats.root_count)
+        return stats
+
+    def Recombine(self, shuffle=True):
+        n = C.c_uint64()
+        self._check(self._L.halo_recombine(self._h, 1 if shuffle else 0, C.byref(n)))
+        return n.value
+
+    def DrainExits(self, max_records=None):
+        """Captured exit records since the last drain (only with option capture_exits=1); destructive."""
+        if max_records is None:
+            max_records = max(1, self._pending_roots * (self._scene.max_hits + 1))
+        buf = (abi.HaloExitRecord * int(max_records))()
+        n = C.c_uint64()
+        self._check(self._L.halo_drain_exits(self._h, buf, int(max_records), C.byref(n)))
+        self._pending_roots = 0
+        k = min(n.value, int(max_records))
+        return np.frombuffer(buf, dtype=EXIT_DTYPE, count=k).copy()
+
+    def ReadbackXyzAccum(self):
+        """Returns (xyz[H,W,3] float32, landed_weight float64) and zeroes the device accumulator."""
+        w, h = self._render.width, self._render.height
+        img = np.empty((h, w, 3), np.float32)
+        landed = C.c_double()
+        self._check(self._L.halo_readback_xyz64(self._h, img.ctypes.data_as(C.POINTER(C.c_float)), w, h, C.byref(landed)))
+        return img, landed.value
+
+    def EndSession(self):
+        self._check(self._L.halo_end(self._h))
+
+
+EXIT_DTYPE = np.dtype([("dir", np.float32, 3), ("weight", np.float32), ("root", np.uint32), ("seq", np.uint16),
+                       ("layer", np.uint8), ("path_len", np.uint8), ("path", np.uint8, abi.PATH_CAP),
+                       ("pixel", np.int32), ("crystal_id", np.uint16), ("wl_idx", np.uint16)])
+assert EXIT_DTYPE.itemsize == C.sizeof(abi.HaloExitRecord)

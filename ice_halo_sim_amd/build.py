@@ -1,0 +1,61 @@
+"""Build libhalo_hip.so (gfx950 only) in-tree with hipcc.  `python -m ice_halo_sim_amd.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libhalo_hip.so")
+SOURCES = ["halo_kernels.hip", "halo_backend.cpp", "halo_host.cpp"]
+HEADERS = ["halo_device.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cc = hipcc()
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    common = ["-std=c++17", "-fPIC", "-I", os.path.join(HERE, "..", "include")]
+    for src in SOURCES:
+        obj = os.path.join(bdir, src + ".o")
+        if src.endswith(".hip"):
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
+        else:  # host tables must round like the reference's host build: no FMA contraction
+            cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on " + src)
+        if src.endswith(".hip"):
+            with open(os.path.join(bdir, "resource_usage.txt"), "w") as f:
+                f.write(r.stderr)
+        objs.append(obj)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,586 @@
+// halo_backend.cpp — the C ABI of include/halo_trace.h: session state machine, per-(layer, entry) dispatch,
+// device memory, streams/events.  Host C++ only; kernels live in halo_kernels.hip.
+//
+// State machine (reference trace_backend.hpp:91-116):
+//   halo_begin → (halo_trace_layer → halo_recombine)* → halo_trace_layer → halo_end ; halo_readback_xyz any time.
+// There is no CPU fallback in this library: every entry point that computes needs a gfx950 device and fails
+// with HALO_UNAVAILABLE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "halo_device.h"
+#include "halo_host.hpp"
+
+namespace halo {
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool);
+}
+
+using namespace halo;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+  T* ptr = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct HaloBackend {
+  int device = 0;
+  uint32_t seed = 1;
+  std::string error;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int cu_count = 256;
+
+  // options
+  int capture = 0;
+  uint32_t geom_clock = 32;  // simulator.hpp:144 (rays per sampled shape)
+  uint64_t chunk = 1ull << 26;
+  int aggregate = 0;
+  int blocks_per_cu = 8;
+
+  // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
+  uint64_t gen_count = 0, gate_count = 0, transit_count = 0, shape_count = 0;
+
+  // session
+  bool in_session = false;
+  HaloScene scene{};
+  HaloRender render{};
+  HaloWl wl{};
+  ProjDev proj{};
+  int layer_idx = 0;
+  double carry[HALO_MAX_LAYERS][HALO_MAX_ENTRIES] = {};
+
+  // device state
+  DevBuf<float> acc_own;       // W*H*3 + 4
+  float* acc = nullptr;        // bound accumulator (own or external)
+  uint64_t acc_floats = 0;
+  int acc_w = 0, acc_h = 0;
+  DevBuf<double> sums;         // kSumNum
+  DevBuf<uint32_t> counters;   // kCntNum
+  DevBuf<float> lut;
+  DevBuf<WlEntryDev> wl_pool;
+  uint32_t wl_pool_size = 0;
+  DevBuf<ShapeDev> shapes;
+  DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
+  uint32_t cont_stride[2] = {0, 0};
+  int cont_out_slot = 0;
+  uint64_t cont_in_n = 0;
+  int cont_shuffle = 1;
+  DevBuf<HaloExitRecord> exits;
+  uint64_t exits_pending = 0;
+  DevBuf<float> host_f;        // injected rays: d | p | w
+  DevBuf<uint32_t> host_u;
+  double landed_host = 0.0;    // landed weight already folded from `sums` (kept in fp64 on the host)
+};
+
+namespace {
+
+int fail(HaloBackend* b, int code, const std::string& msg) {
+  if (b) b->error = msg;
+  return code;
+}
+int hip_fail(HaloBackend* b, hipError_t e, const char* what) {
+  return fail(b, (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorOutOfMemory) ? HALO_UNAVAILABLE : HALO_FATAL,
+              std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(b, call)                                   \
+  do {                                                    \
+    hipError_t e__ = (call);                              \
+    if (e__ != hipSuccess) return hip_fail(b, e__, #call); \
+  } while (0)
+
+int ensure_accumulator(HaloBackend* b, int w, int h) {
+  const uint64_t need = static_cast<uint64_t>(w) * h * 3 + 4;
+  if (b->acc && b->acc != b->acc_own.ptr) {  // external binding
+    if (b->acc_floats < need) return fail(b, HALO_FATAL, "bound accumulator smaller than width*height*3+4 floats");
+    b->acc_w = w;
+    b->acc_h = h;
+    return HALO_OK;
+  }
+  if (!b->acc_own.ptr || b->acc_w != w || b->acc_h != h) {
+    HIPCHK(b, b->acc_own.reserve(need));
+    HIPCHK(b, hipMemsetAsync(b->acc_own.ptr, 0, need * sizeof(float), b->stream));
+    b->acc_w = w;
+    b->acc_h = h;
+    b->landed_host = 0.0;
+  }
+  b->acc = b->acc_own.ptr;
+  b->acc_floats = need;
+  return HALO_OK;
+}
+
+// fold the device landed-weight tally into the host fp64 running sum (after a stream sync)
+int fold_sums(HaloBackend* b, double out[kSumNum]) {
+  HIPCHK(b, hipMemcpyAsync(out, b->sums.ptr, kSumNum * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  return HALO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int halo_abi_version(void) { return HALO_ABI_VERSION; }
+
+int halo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
+  if (!out) return HALO_FATAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return HALO_UNAVAILABLE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return HALO_UNAVAILABLE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return HALO_UNAVAILABLE;  // this library carries gfx950 code only
+  auto* b = new HaloBackend();
+  b->device = device_ordinal;
+  b->seed = seed ? seed : 1u;
+  b->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
+    delete b;
+    return HALO_UNAVAILABLE;
+  }
+  b->stream = b->own_stream;
+  if (b->sums.reserve(kSumNum) != hipSuccess || b->counters.reserve(kCntNum) != hipSuccess) {
+    delete b;
+    return HALO_UNAVAILABLE;
+  }
+  (void)hipMemsetAsync(b->sums.ptr, 0, kSumNum * sizeof(double), b->stream);
+  (void)hipMemsetAsync(b->counters.ptr, 0, kCntNum * sizeof(uint32_t), b->stream);
+  *out = b;
+  return HALO_OK;
+}
+
+int halo_destroy(halo_handle_t b) {
+  if (!b) return HALO_OK;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  b->acc_own.release();
+  b->sums.release();
+  b->counters.release();
+  b->lut.release();
+  b->wl_pool.release();
+  b->shapes.release();
+  b->cont[0].release();
+  b->cont[1].release();
+  b->exits.release();
+  b->host_f.release();
+  b->host_u.release();
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+  delete b;
+  return HALO_OK;
+}
+
+const char* halo_last_error(halo_handle_t b) { return b ? b->error.c_str() : "null handle"; }
+
+int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
+  if (!b || !key) return HALO_FATAL;
+  const std::string k(key);
+  if (k == "capture_exits") b->capture = v ? 1 : 0;
+  else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
+  else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
+  else if (k == "aggregate") b->aggregate = v ? 1 : 0;
+  else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 16));
+  else if (k == "rank") {
+    // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
+    const uint64_t base = static_cast<uint64_t>(v) << 40;
+    b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
+  } else return fail(b, HALO_FATAL, "unknown option: " + k);
+  return HALO_OK;
+}
+
+int halo_set_stream(halo_handle_t b, void* s) {
+  if (!b) return HALO_FATAL;
+  (void)hipStreamSynchronize(b->stream);
+  b->stream = s ? static_cast<hipStream_t>(s) : b->own_stream;
+  return HALO_OK;
+}
+
+int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) {
+  if (!b) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "bind_accumulator inside a session");
+  if (!device_ptr) {
+    b->acc = b->acc_own.ptr;
+    b->acc_floats = b->acc_own.cap;
+    return HALO_OK;
+  }
+  b->acc = static_cast<float*>(device_ptr);
+  b->acc_floats = n_floats;
+  b->landed_host = 0.0;
+  return HALO_OK;
+}
+
+int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t) {
+  if (!b || !scene || !render || !wl) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "BeginSession inside a session");
+  if (scene->layer_count < 1 || scene->layer_count > HALO_MAX_LAYERS) return fail(b, HALO_FATAL, "layer_count out of range");
+  if (scene->max_hits < 1 || scene->max_hits > HALO_MAX_HITS) return fail(b, HALO_FATAL, "max_hits out of range");
+  if (render->width <= 0 || render->height <= 0) return fail(b, HALO_FATAL, "bad resolution");
+  for (int l = 0; l < scene->layer_count; l++) {
+    if (scene->layers[l].entry_count < 1 || scene->layers[l].entry_count > HALO_MAX_ENTRIES)
+      return fail(b, HALO_FATAL, "entry_count out of range");
+    for (int e = 0; e < scene->layers[l].entry_count; e++)
+      if (scene->layers[l].entries[e].crystal.kind != HALO_CRYSTAL_PRISM)
+        return fail(b, HALO_UNAVAILABLE, "pyramid crystals are not supported by this backend yet");
+  }
+  HIPCHK(b, hipSetDevice(b->device));
+  b->scene = *scene;
+  b->render = *render;
+  b->wl = *wl;
+  b->proj = host::BuildProj(*render);
+  int rc = ensure_accumulator(b, render->width, render->height);
+  if (rc != HALO_OK) return rc;
+  std::vector<WlEntryDev> pool = host::BuildWlPool(*wl);
+  b->wl_pool_size = static_cast<uint32_t>(pool.size());
+  HIPCHK(b, b->wl_pool.reserve(HALO_WL_POOL_MAX));
+  HIPCHK(b, hipMemcpyAsync(b->wl_pool.ptr, pool.data(), pool.size() * sizeof(WlEntryDev), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` dies at scope exit
+  b->in_session = true;
+  b->layer_idx = 0;
+  b->cont_in_n = 0;
+  b->cont_out_slot = 0;
+  return HALO_OK;
+}
+
+int halo_end(halo_handle_t b) {
+  if (!b) return HALO_FATAL;
+  b->in_session = false;
+  return HALO_OK;
+}
+
+int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, HaloLayerStats* stats) {
+  if (!b) return HALO_FATAL;
+  if (!b->in_session) return fail(b, HALO_FATAL, "TraceLayer outside a session");
+  const int layer = b->layer_idx;
+  if (layer >= b->scene.layer_count) return fail(b, HALO_FATAL, "TraceLayer past the last layer");
+  HIPCHK(b, hipSetDevice(b->device));
+  const HaloLayer& L = b->scene.layers[layer];
+  const uint64_t n = (layer == 0) ? count : b->cont_in_n;
+  const bool final_layer = (layer == b->scene.layer_count - 1);
+  if (n > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "more than 2^32 rays in one layer dispatch; split the batch");
+  if (layer > 0 && rays) return fail(b, HALO_FATAL, "host rays are first-layer only");
+
+  // continuation output pool: every root emits at most max_hits candidates
+  const int out_slot = b->cont_out_slot;
+  uint32_t out_cap = 0;
+  if (!final_layer) {
+    const uint64_t need = n * static_cast<uint64_t>(b->scene.max_hits);
+    if (need > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "continuation pool would exceed 2^32 rays; split the batch");
+    const uint64_t stride = (need + 63) & ~63ull;
+    HIPCHK(b, b->cont[out_slot].reserve(stride * 5));
+    b->cont_stride[out_slot] = static_cast<uint32_t>(stride);
+    out_cap = static_cast<uint32_t>(need);
+  }
+  HIPCHK(b, hipMemsetAsync(b->counters.ptr, 0, sizeof(uint32_t), b->stream));  // continuation counter only
+  HIPCHK(b, hipMemsetAsync(b->sums.ptr + kSumExitW, 0, 3 * sizeof(double), b->stream));
+  if (b->capture) {
+    const uint64_t need = b->exits_pending + n * static_cast<uint64_t>(b->scene.max_hits + 1);
+    if (need > b->exits.cap) {
+      DevBuf<HaloExitRecord> bigger;
+      HIPCHK(b, bigger.reserve(need));
+      if (b->exits_pending)
+        HIPCHK(b, hipMemcpyAsync(bigger.ptr, b->exits.ptr, b->exits_pending * sizeof(HaloExitRecord), hipMemcpyDeviceToDevice, b->stream));
+      HIPCHK(b, hipStreamSynchronize(b->stream));
+      b->exits.release();
+      b->exits = bigger;
+    }
+  }
+
+  float props[HALO_MAX_ENTRIES];
+  for (int ci = 0; ci < L.entry_count; ci++) props[ci] = L.entries[ci].proportion;
+  std::vector<uint64_t> per_ci = host::Partition(props, L.entry_count, n, b->carry[layer]);
+  if (rays && layer == 0) {  // host ingest is a single population (cpu_trace_backend.cpp:121-127)
+    std::fill(per_ci.begin(), per_ci.end(), 0);
+    per_ci[0] = n;
+    HIPCHK(b, b->host_f.reserve(n * 7));
+    HIPCHK(b, b->host_u.reserve(n));
+    HIPCHK(b, hipMemcpyAsync(b->host_f.ptr, rays->d, n * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(b, hipMemcpyAsync(b->host_f.ptr + n * 3, rays->p, n * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(b, hipMemcpyAsync(b->host_f.ptr + n * 6, rays->w, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(b, hipMemcpyAsync(b->host_u.ptr, rays->tf, n * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(b, hipStreamSynchronize(b->stream));
+  }
+
+  double kernel_ms = 0.0;
+  uint64_t launches = 0;
+  uint64_t ci_start = 0;
+  for (int ci = 0; ci < L.entry_count; ci++) {
+    const uint64_t n_ci = per_ci[ci];
+    if (n_ci == 0) continue;
+    const HaloEntry& E = L.entries[ci];
+    DispatchParams P{};
+    P.source = rays ? kSrcHost : (layer == 0 ? kSrcGen : kSrcTransit);
+    P.layer = static_cast<uint32_t>(layer);
+    P.final_layer = final_layer ? 1u : 0u;
+    P.max_hits = static_cast<uint32_t>(b->scene.max_hits);
+    P.prob = L.prob;
+    P.crystal_id = static_cast<uint32_t>(E.crystal_config_id);
+    P.capture = static_cast<uint32_t>(b->capture);
+    P.gen_seed = b->seed ^ kNonceGen;
+    P.gate_seed = b->seed ^ kNonceGate;
+    P.transit_seed = b->seed ^ kNonceTransit;
+    P.shuffle = static_cast<uint32_t>(b->cont_shuffle);
+    P.shuffle_seed = (b->seed ^ kNonceShuffle) ^ static_cast<uint32_t>(layer);  // cuda_trace_backend.cu:4541
+    // orientation wire params (BuildTransitGpParams cuda_trace_backend.cu:342-383)
+    P.lat_path = host::SelectLatPath(E.axis);
+    P.lat_mean_rad = E.axis.latitude.center * host::kDegToRad;
+    P.lat_std_rad = E.axis.latitude.spread * host::kDegToRad;
+    P.az_type = static_cast<uint32_t>(E.axis.azimuth.type);
+    P.az_mean_rad = E.axis.azimuth.center * host::kDegToRad;
+    P.az_std_rad = E.axis.azimuth.spread * host::kDegToRad;
+    P.roll_type = static_cast<uint32_t>(E.axis.roll.type);
+    P.roll_mean_rad = E.axis.roll.center * host::kDegToRad;
+    P.roll_std_rad = E.axis.roll.spread * host::kDegToRad;
+    {  // BuildGenGpParams cuda_trace_backend.cu:391-399, trig evaluated once on the host
+      const float sun_lon = (b->scene.sun_azimuth + 180.0f) * host::kDegToRad;
+      const float sun_lat = -b->scene.sun_altitude * host::kDegToRad;
+      const float half = (b->scene.sun_diameter * 0.5f) * host::kDegToRad;
+      P.c_cap = std::cos(half);
+      P.c_lon = std::cos(sun_lon);
+      P.s_lon = std::sin(sun_lon);
+      P.c_lat = std::cos(sun_lat);
+      P.s_lat = std::sin(sun_lat);
+    }
+    P.wl_pool_size = b->wl_pool_size;
+    P.wl_pool = b->wl_pool.ptr;
+    P.proj = b->proj;
+    if (P.lat_path == kLatLut) {
+      host::LatLut lut = host::BuildLatLut(E.axis.latitude);
+      std::vector<float> flat(3 * kLutNodes);
+      std::copy(lut.theta.begin(), lut.theta.end(), flat.begin());
+      std::copy(lut.cdf.begin(), lut.cdf.end(), flat.begin() + kLutNodes);
+      std::copy(lut.flip.begin(), lut.flip.end(), flat.begin() + 2 * kLutNodes);
+      HIPCHK(b, b->lut.reserve(3 * kLutNodes));
+      HIPCHK(b, hipMemcpyAsync(b->lut.ptr, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(b, hipStreamSynchronize(b->stream));
+    }
+    P.lut = b->lut.ptr;
+    P.cont_in = b->cont[out_slot ^ 1].ptr;
+    P.cont_in_n = static_cast<uint32_t>(b->cont_in_n);
+    P.cont_in_stride = b->cont_stride[out_slot ^ 1];
+    P.cont_out = b->cont[out_slot].ptr;
+    P.cont_out_stride = b->cont_stride[out_slot];
+    P.cont_out_cap = out_cap;
+    P.counters = b->counters.ptr;
+    P.xyz = b->acc;
+    P.sums = b->sums.ptr;
+    P.exits = b->exits.ptr;
+    P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
+    P.aggregate = static_cast<uint32_t>(b->aggregate);
+    P.geom_clock = b->geom_clock;
+
+    const bool deterministic = host::IsDeterministic(E.crystal);
+    // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
+    for (uint64_t off = 0; off < n_ci;) {
+      uint64_t m = std::min<uint64_t>(n_ci - off, b->chunk);
+      if (!deterministic) m = std::min<uint64_t>(m, 1ull << 22);
+      const uint32_t shape_cnt = deterministic ? 1u : static_cast<uint32_t>((m + b->geom_clock - 1) / b->geom_clock);
+      std::vector<ShapeDev> pool(shape_cnt);
+      for (uint32_t k = 0; k < shape_cnt; k++) {
+        HaloGeomTables g;
+        host::MakeShape(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), g);
+        host::ToShapeDev(g, pool[k]);
+      }
+      if (!deterministic) b->shape_count += shape_cnt;
+      HIPCHK(b, b->shapes.reserve(shape_cnt));
+      HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+      P.shapes = b->shapes.ptr;
+      P.shape_cnt = shape_cnt;
+      P.n_rays = static_cast<uint32_t>(m);
+      P.ci_start = static_cast<uint32_t>(ci_start + off);
+      auto split = [](uint64_t v, uint32_t& lo, uint32_t& hi) {  // SplitPcgRayBase trace_backend.hpp:184-190
+        lo = static_cast<uint32_t>(v & 0xFFFFFFFFull);
+        hi = static_cast<uint32_t>(v >> 32);
+      };
+      split(b->gen_count, P.gen_lo, P.gen_hi);
+      split(b->gate_count, P.gate_lo, P.gate_hi);
+      split(b->transit_count, P.transit_lo, P.transit_hi);
+      if (rays) {
+        P.host_d = b->host_f.ptr + off * 3;
+        P.host_p = b->host_f.ptr + n * 3 + off * 3;
+        P.host_w = b->host_f.ptr + n * 6 + off;
+        P.host_tf = b->host_u.ptr + off;
+      }
+      const int max_blocks = b->cu_count * b->blocks_per_cu;
+      const int blocks = static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
+      HIPCHK(b, hipEventRecord(b->ev0, b->stream));  // HIP events on the launch stream bracket the kernel alone
+      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic);
+      if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
+      HIPCHK(b, hipEventRecord(b->ev1, b->stream));
+      HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` (pageable H2D source) must outlive the copy
+      {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
+        kernel_ms += ms;
+        launches++;
+      }
+      if (P.source == kSrcGen) b->gen_count += m;
+      if (P.source == kSrcTransit) b->transit_count += m;
+      b->gate_count += m;
+      off += m;
+    }
+    ci_start += n_ci;
+  }
+  double s[kSumNum] = {0, 0, 0, 0};
+  int rc = fold_sums(b, s);
+  if (rc != HALO_OK) return rc;
+  uint32_t cnt[kCntNum] = {0, 0, 0, 0};
+  HIPCHK(b, hipMemcpy(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (!final_layer && cnt[kCntCont] > out_cap) return fail(b, HALO_FATAL, "continuation pool overflow");
+  b->exits_pending = std::min<uint64_t>(cnt[kCntExit], b->exits.cap);
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->root_count = n;
+    stats->exit_count = static_cast<uint64_t>(s[kSumExitN] + 0.5);
+    stats->exit_w_sum = s[kSumExitW];
+    stats->continuation_count = final_layer ? 0 : cnt[kCntCont];
+    stats->kernel_ms = kernel_ms;
+    stats->pixel_hits = static_cast<uint64_t>(s[kSumPixN] + 0.5);
+    stats->launches = launches;
+  }
+  b->cont_in_n = final_layer ? 0 : cnt[kCntCont];  // becomes the next layer's input at Recombine
+  return HALO_OK;
+}
+
+int halo_recombine(halo_handle_t b, int shuffle, uint64_t* continuation_count) {
+  if (!b) return HALO_FATAL;
+  if (!b->in_session) return fail(b, HALO_FATAL, "Recombine outside a session");
+  // No data moves: the pools swap roles and the Feistel permutation (shuffle_cont_kernel, cu:1633-1657) is
+  // applied as a gather index by the next layer's kernel.
+  b->cont_out_slot ^= 1;
+  b->cont_shuffle = shuffle ? 1 : 0;
+  b->layer_idx++;
+  if (continuation_count) *continuation_count = b->cont_in_n;
+  return HALO_OK;
+}
+
+int halo_drain_exits(halo_handle_t b, HaloExitRecord* out, uint64_t cap, uint64_t* count) {
+  if (!b) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  const uint64_t n = b->exits_pending;
+  if (count) *count = n;
+  if (out && n) HIPCHK(b, hipMemcpy(out, b->exits.ptr, std::min(n, cap) * sizeof(HaloExitRecord), hipMemcpyDeviceToHost));
+  b->exits_pending = 0;
+  HIPCHK(b, hipMemsetAsync(b->counters.ptr + kCntExit, 0, sizeof(uint32_t), b->stream));
+  return HALO_OK;
+}
+
+int halo_sync(halo_handle_t b) {
+  if (!b) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  return HALO_OK;
+}
+
+int halo_take_landed(halo_handle_t b, double* landed) {
+  if (!b || !landed) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  HIPCHK(b, hipMemcpyAsync(landed, b->sums.ptr, sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  return HALO_OK;
+}
+
+int halo_readback_xyz64(halo_handle_t b, float* xyz, int width, int height, double* landed) {
+  if (!b || !xyz) return HALO_FATAL;
+  if (!b->acc || width != b->acc_w || height != b->acc_h) return fail(b, HALO_FATAL, "readback size does not match the session render");
+  HIPCHK(b, hipSetDevice(b->device));
+  const size_t n = static_cast<size_t>(width) * height * 3;
+  double s[kSumNum];
+  HIPCHK(b, hipMemcpyAsync(xyz, b->acc, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemcpyAsync(s, b->sums.ptr, sizeof(s), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemsetAsync(b->acc, 0, (n + 4) * sizeof(float), b->stream));  // readback ZEROES the accumulator (cu:4832-4846)
+  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  if (landed) *landed = s[kSumLanded];
+  return HALO_OK;
+}
+
+int halo_readback_xyz(halo_handle_t b, float* xyz, int width, int height, float* landed_weight) {
+  double l = 0.0;
+  int rc = halo_readback_xyz64(b, xyz, width, height, &l);
+  if (rc == HALO_OK && landed_weight) *landed_weight += static_cast<float>(l);  // ADDS (trace_backend.hpp:461-469)
+  return rc;
+}
+
+// ---- host-side pieces, exported for parity tests -------------------------------------------------------
+int halo_host_prism_geometry(float h, const float dist[6], HaloGeomTables* out) {
+  if (!out || !dist) return HALO_FATAL;
+  host::BuildPrism(h, dist, *out);
+  return HALO_OK;
+}
+int halo_host_pyramid_geometry(float wu, float wl, float h1, float h2, float h3, const float dist[6], HaloGeomTables* out) {
+  if (!out || !dist) return HALO_FATAL;
+  return host::BuildPyramid(wu, wl, h1, h2, h3, dist, *out) ? HALO_OK : HALO_UNAVAILABLE;
+}
+int halo_host_build_lat_lut(const HaloDist* lat, float* theta, float* cdf, float* flip) {
+  if (!lat || !theta || !cdf || !flip) return HALO_FATAL;
+  host::LatLut l = host::BuildLatLut(*lat);
+  std::copy(l.theta.begin(), l.theta.end(), theta);
+  std::copy(l.cdf.begin(), l.cdf.end(), cdf);
+  std::copy(l.flip.begin(), l.flip.end(), flip);
+  return HALO_OK;
+}
+int halo_host_build_proj_params(const HaloRender* render, void* out76) {
+  if (!render || !out76) return HALO_FATAL;
+  ProjDev p = host::BuildProj(*render);
+  static_assert(sizeof(ProjDev) == 76, "ProjDev mirrors lm_proj::ProjParams");
+  std::memcpy(out76, &p, sizeof(p));
+  return HALO_OK;
+}
+int halo_host_partition(const float* prop, int n, uint64_t ray_num, double* carry, uint64_t* out) {
+  if (!prop || !carry || !out || n < 0) return HALO_FATAL;
+  std::vector<uint64_t> v = host::Partition(prop, n, ray_num, carry);
+  std::copy(v.begin(), v.end(), out);
+  return HALO_OK;
+}
+double halo_host_refractive_index(double wl) { return host::IceRefractiveIndex(wl); }
+
+// sizes of the boundary structs, for the Python layout check
+uint64_t halo_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(HaloScene);
+    case 1: return sizeof(HaloRender);
+    case 2: return sizeof(HaloWl);
+    case 3: return sizeof(HaloExitRecord);
+    case 4: return sizeof(HaloGeomTables);
+    case 5: return sizeof(HaloLayerStats);
+    case 6: return sizeof(HaloEntry);
+    default: return 0;
+  }
+}
+
+}  // extern "C"

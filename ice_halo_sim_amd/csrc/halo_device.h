@@ -1,0 +1,116 @@
+// halo_device.h — POD parameter blocks shared by the host orchestration (halo_backend.cpp) and the
+// gfx950 kernels (halo_kernels.hip).  gfx950 only; no other backend is supported or dispatched.
+#ifndef HALO_DEVICE_H_
+#define HALO_DEVICE_H_
+
+#include <stdint.h>
+
+#include "../../include/halo_trace.h"
+
+namespace halo {
+
+constexpr int kBlock = 256;          // 4 wave64 per workgroup: one per SIMD of a CU
+constexpr int kMaxFaces = HALO_MAX_FACES;
+constexpr int kMaxTris = HALO_MAX_TRIS;
+constexpr int kLutNodes = HALO_LUT_NODES;
+
+// lm_pcg::kLatPath* wire values (reference src/core/shared/pcg_shared.h:56-59)
+enum : uint32_t { kLatFullSphere = 0u, kLatNoRandom = 1u, kLatGaussLegacy = 3u, kLatLut = 6u };
+
+// PCG stream-family nonces (reference cuda_trace_backend.cu:259-278, pcg_shared.h:119-120)
+constexpr uint32_t kNonceTransit = 0xA5A5A5A5u;
+constexpr uint32_t kNonceGate = 0x5A5A5A5Au;
+constexpr uint32_t kNonceGen = 0x3C9A7F11u;
+constexpr uint32_t kNonceShuffle = 0xB17CA3D9u;
+constexpr uint32_t kNonceWl = 0x9E3779B9u;
+constexpr uint32_t kNonceShapeHost = 0x6A09E667u;
+
+// One crystal shape as the kernels read it.  Face rows are {nx, ny, nz, d}; triangle rows carry the fan
+// triangle (v0, v1, v2), its raw winding normal, area and compact face id (reference
+// Crystal::PopulateFromCfGeom crystal.cpp:304-347, detail::BuildEntrySubTris simulator.cpp:90-129).
+struct ShapeDev {
+  int32_t face_cnt;
+  int32_t tri_cnt;
+  int32_t pad0, pad1;
+  float face[kMaxFaces][4];
+  float tri_v[kMaxTris][9];
+  float tri_na[kMaxTris][4];          // nx, ny, nz, area
+  uint8_t tri_face[kMaxTris];
+  uint8_t face_number[kMaxFaces];
+  uint8_t pad2[12];
+};
+static_assert(sizeof(ShapeDev) % 16 == 0, "ShapeDev rows are read as float4");
+
+struct WlEntryDev {  // reference WlEntry, src/core/backend/wl_pool.hpp:29-35 (+pad to 32 B)
+  float n_idx, spd_weight, cmf_x, cmf_y, cmf_z, pad0, pad1, pad2;
+};
+
+struct ProjDev {  // lm_proj::ProjParams (projection_shared.h:106-118), host-predigested
+  int32_t proj_type, img_w, img_h, visible_range, lens_shift_x, lens_shift_y;
+  float scale, az0, r_scale, max_abs_dz;
+  float rot[9];
+};
+
+enum : uint32_t { kSrcGen = 0u, kSrcTransit = 1u, kSrcHost = 2u };
+
+// Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
+struct DispatchParams {
+  // --- ray source -------------------------------------------------------------------------
+  uint32_t source;       // kSrcGen | kSrcTransit | kSrcHost
+  uint32_t n_rays;
+  uint32_t layer;
+  uint32_t final_layer;
+  uint32_t max_hits;     // surface interactions incl. entry (legacy semantics, simulator.cpp:1308)
+  float prob;
+  uint32_t crystal_id;
+  uint32_t capture;
+  // --- RNG streams (64-bit counters split lo/hi, trace_backend.hpp:184) ---------------------
+  uint32_t gen_seed, gen_lo, gen_hi;
+  uint32_t gate_seed, gate_lo, gate_hi;
+  uint32_t transit_seed, transit_lo, transit_hi;
+  uint32_t shuffle, shuffle_seed;
+  // --- orientation sampler (GenRootKernelParams, pcg_shared.h:150-189) ------------------------
+  uint32_t lat_path;
+  float lat_mean_rad, lat_std_rad;
+  uint32_t az_type;
+  float az_mean_rad, az_std_rad;
+  uint32_t roll_type;
+  float roll_mean_rad, roll_std_rad;
+  // --- sun cone: host-evaluated trig of (az+180, -alt, diameter/2) (cu:391-399) ------------------
+  float c_cap, c_lon, s_lon, c_lat, s_lat;
+  // --- tables ------------------------------------------------------------------------------
+  uint32_t wl_pool_size;
+  uint32_t shape_cnt;
+  uint32_t geom_clock;
+  ProjDev proj;
+  const float* lut;            // theta[257] | cdf[257] | flip[257]
+  const WlEntryDev* wl_pool;
+  const ShapeDev* shapes;
+  // --- continuation pools (SoA: dx | dy | dz | w | wl_idx, each cont_stride apart) ---------------
+  const float* cont_in;
+  uint32_t cont_in_n;
+  uint32_t cont_in_stride;
+  uint32_t ci_start;
+  float* cont_out;
+  uint32_t cont_out_stride;
+  uint32_t cont_out_cap;
+  uint32_t* counters;          // [0] continuation count, [1] captured exits, [2] exit count lo.. see kCnt*
+  // --- host-injected rays (crystal-local) -------------------------------------------------------
+  const float* host_d;
+  const float* host_p;
+  const float* host_w;
+  const uint32_t* host_tf;
+  // --- outputs -------------------------------------------------------------------------------
+  float* xyz;                  // W*H*3 image
+  double* sums;                // [0] landed weight, [1] exit weight sum, [2] exit count (as double)
+  HaloExitRecord* exits;
+  uint32_t exit_cap;
+  uint32_t aggregate;          // LDS hot-pixel cache on/off
+};
+
+enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };
+enum { kSumLanded = 0, kSumExitW = 1, kSumExitN = 2, kSumPixN = 3, kSumNum = 4 };
+
+}  // namespace halo
+
+#endif

@@ -1,0 +1,58 @@
+// halo_host.hpp — host-side producers of the tables the gfx950 kernels consume: crystal geometry, latitude
+// LUT, projection POD, wavelength pool, ray partition.  Plain C++17, no device code, no torch.
+#ifndef HALO_HOST_HPP_
+#define HALO_HOST_HPP_
+
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include "halo_device.h"
+
+namespace halo {
+namespace host {
+
+// math.hpp:21-31 constants (float, as the reference evaluates them)
+constexpr float kPi = 3.14159265359f;
+constexpr float kPiHalf = kPi / 2.0f;
+constexpr float kFloatEps = 1e-5f;
+constexpr float kDegToRad = kPi / 180.0f;
+constexpr float kSqrt3 = 1.73205080757f;
+
+// Closed-form hexagonal prism → kernel tables. Returns false for the empty crystal
+// (Crystal::MakePrismClosedForm crystal.cpp:349-368).
+bool BuildPrism(float h, const float dist[6], HaloGeomTables& out);
+bool BuildPyramid(float wedge_u_deg, float wedge_l_deg, float h1, float h2, float h3, const float dist[6],
+                  HaloGeomTables& out);
+void ToShapeDev(const HaloGeomTables& g, ShapeDev& out);
+
+struct LatLut {
+  std::array<float, kLutNodes> theta{}, cdf{}, flip{};
+};
+LatLut BuildLatLut(const HaloDist& latitude);               // lat_lut.cpp:74-204
+uint32_t SelectLatPath(const HaloAxis& axis);               // lat_path_selection.hpp:62-75
+
+ProjDev BuildProj(const HaloRender& render);                // lens_proj_build.hpp:79-137
+double IceRefractiveIndex(double wavelength_nm);            // optics.cpp:180-197
+float IlluminantSpd(int illuminant, float wavelength_nm);   // util/illuminant.cpp:113-134
+std::vector<WlEntryDev> BuildWlPool(const HaloWl& wl);      // wl_pool.hpp:67-91
+std::vector<uint64_t> Partition(const float* proportions, int n, uint64_t ray_num, double* carry);  // simulator.cpp:519-582
+
+bool IsDeterministic(const HaloCrystal& c);                 // simulator.cpp:453-471
+// One sampled crystal instance (MakeCrystal simulator.cpp:448 with SyncGroupSampler :361-393), shape scalars
+// drawn from the host PCG stream (seed, shape_index).
+bool MakeShape(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, HaloGeomTables& out);
+
+// tiny counter-based stream used for host-side shape scalars (same hash as the device streams)
+struct Pcg {
+  uint32_t seed, key, slot;
+  float Uniform();
+  float Gaussian();
+  float Get(const HaloDist& d);
+};
+uint32_t PcgHash(uint32_t x);
+
+}  // namespace host
+}  // namespace halo
+
+#endif

@@ -1,0 +1,669 @@
+// halo_kernels.hip — gfx950 (CDNA4 / MI355X) kernels of the ice-halo trace hot path.
+//
+// One fused kernel per (scattering layer, crystal entry) dispatch:
+//     root generation | layer hop  →  entry Fresnel  →  ≤ max_hits-1 interior interactions
+//     →  emit gate  →  lens projection  →  CIE-XYZ accumulation  |  continuation append
+// Ray state lives in VGPRs for its whole life; the crystal plane/fan tables, the latitude LUT and the
+// wavelength pool are staged once per workgroup into LDS and read back as wave-wide broadcasts
+// (ds_read_b128, conflict-free); HBM sees only the accumulator atomics and — for multi-scatter layers —
+// the 20-byte SoA continuation record, appended with wave64 ballot compaction (one atomic per wave per
+// emit site) and gathered by the next layer through the Feistel permutation, so neither the reference's
+// 80 B/ray root buffers nor its separate gen / transit / shuffle kernels exist here.
+//
+// What each block restates (reference /root/reference, file:line):
+//   PCG streams, orientation, sun cone, entry pick   src/core/shared/pcg_shared.h:193-624,
+//                                                     cuda_trace_backend.cu:1417-1616 (gen), :1220-1403 (transit)
+//   Fresnel split / refraction                        src/core/optics.cpp:18-53, shared/optics_shared.h:17-24
+//   convex slab traversal                             src/core/optics.cpp:64-158, shared/traversal_shared.h:61-71
+//   hit loop + emit gate (legacy semantics)           src/core/simulator.cpp:585-762, 1308-1336
+//   projection (11 lenses)                            src/core/shared/projection_shared.h:42-375
+//   XYZ accumulation + landed weight                  shared/accum_shared.h:40-47, cuda_trace_backend.cu:433-480
+//   continuation permutation                          pcg_shared.h:550-603, cuda_trace_backend.cu:1633-1657
+#include <hip/hip_runtime.h>
+
+#include "halo_device.h"
+
+namespace halo {
+
+#define HD __device__ __forceinline__
+
+constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
+constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
+constexpr float kSlabEps = 1e-5f;                 // traversal_shared.h:46
+
+// ------------------------------------------------------------------------------------------------
+// counter-based RNG (pcg_shared.h:193-274)
+// ------------------------------------------------------------------------------------------------
+HD uint32_t pcg_hash(uint32_t x) {
+  x = x * 747796405u + 2891336453u;
+  x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+  return (x >> 22u) ^ x;
+}
+
+struct Stream {
+  uint32_t seed;
+  uint32_t key;   // global_idx * 1000003u, hoisted
+  uint32_t slot;
+};
+
+HD Stream make_stream(uint32_t seed, uint32_t lo, uint32_t hi, uint32_t tid) {
+  // pcg_advance_hi + pcg_seed_with_high (pcg_shared.h:257-268): the 64-bit ray index = hi:lo + tid
+  uint32_t g = lo + tid;
+  uint32_t h = hi + ((g < lo) ? 1u : 0u);
+  Stream s;
+  s.seed = (h == 0u) ? seed : (seed ^ pcg_hash(h));
+  s.key = g * 1000003u;
+  s.slot = 0u;
+  return s;
+}
+
+HD float uniform(Stream& s) {
+  uint32_t h = pcg_hash(s.seed ^ pcg_hash(s.key + s.slot));
+  s.slot++;
+  return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
+}
+
+HD float gaussian(Stream& s) {  // Box-Muller, pcg_shared.h:277-281
+  float u1 = fmaxf(uniform(s), 1e-7f);
+  float u2 = uniform(s);
+  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * kPiF * u2);
+}
+
+HD float get_dist(Stream& s, uint32_t dtype, float mean, float spread) {  // pcg_shared.h:290-308
+  if (dtype == HALO_DIST_NONE) return mean;
+  if (dtype == HALO_DIST_UNIFORM) return (uniform(s) - 0.5f) * spread + mean;
+  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return gaussian(s) * spread + mean;
+  if (dtype == HALO_DIST_ZIGZAG) return fabsf(spread * sinf(uniform(s) * 2.0f * kPiF) + mean);
+  float u = uniform(s);
+  float sgn = (u < 0.5f) ? -1.0f : 1.0f;
+  float arg = fmaxf(1.0f - 2.0f * fabsf(u - 0.5f), 1e-30f);
+  return mean - spread * sgn * logf(arg);
+}
+
+// 4-round balanced Feistel + cycle walk on [0, n)  (pcg_shared.h:550-603)
+HD uint32_t feistel_bijection(uint32_t i, uint32_t n, uint32_t seed) {
+  if (n <= 1u) return i;
+  if (n == 2u) return i ^ 1u;
+  uint32_t bits = 32u - __clz(n - 1u);  // smallest b with 2^b >= n (n >= 3)
+  if (bits > 30u) bits = 30u;
+  if (bits & 1u) bits++;
+  const uint32_t half_bits = bits >> 1u;
+  const uint32_t hm = (1u << half_bits) - 1u;
+  uint32_t cur = i;
+  for (uint32_t guard = 0u; guard < 64u; guard++) {
+    uint32_t L = (cur >> half_bits) & hm;
+    uint32_t R = cur & hm;
+    const uint32_t rc[4] = {0x9E3779B9u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t f = pcg_hash(seed ^ R ^ rc[k]) & hm;
+      uint32_t nr = L ^ f;
+      L = R;
+      R = nr;
+    }
+    uint32_t out = (L << half_bits) | R;
+    if (out < n) return out;
+    cur = out;
+  }
+  return cur % n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation (pcg_shared.h:311-483)
+// ------------------------------------------------------------------------------------------------
+HD void normalize_latitude(float phi, float& phi_out, bool& flip) {
+  float theta = kPi2F - phi;
+  theta = fmodf(theta, 2.0f * kPiF);
+  if (theta < 0.0f) theta += 2.0f * kPiF;
+  flip = theta > kPiF;
+  if (flip) theta = 2.0f * kPiF - theta;
+  phi_out = kPi2F - theta;
+}
+
+// LUT in LDS: [0..256] theta, [257..513] cdf, [514..770] flip
+HD float invert_lat_lut(float xi, const float* lut) {
+  const float* th = lut;
+  const float* cdf = lut + kLutNodes;
+  xi = fminf(fmaxf(xi, cdf[0]), cdf[kLutNodes - 1]);
+  uint32_t lo = 0u, hi = kLutNodes - 1u;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {  // 256 intervals → exactly 8 halvings, wave-uniform trip count
+    uint32_t mid = (lo + hi) >> 1u;
+    bool le = cdf[mid] <= xi;
+    lo = le ? mid : lo;
+    hi = le ? hi : mid;
+  }
+  float c0 = cdf[lo], c1 = cdf[lo + 1u];
+  float denom = c1 - c0;
+  float w = denom > 0.0f ? (xi - c0) / denom : 0.0f;
+  return th[lo] + w * (th[lo + 1u] - th[lo]);
+}
+
+HD uint32_t lat_lut_bin(float theta, const float* lut) {
+  float span = lut[kLutNodes - 1] - lut[0];
+  float t = span > 0.0f ? (theta - lut[0]) / span : 0.0f;
+  int idx = static_cast<int>(t * static_cast<float>(kLutNodes - 1));
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > kLutNodes - 2 ? kLutNodes - 2 : idx;
+  return static_cast<uint32_t>(idx);
+}
+
+HD void sample_lat_lon_roll(Stream& s, const DispatchParams& P, const float* lut, float& lon, float& lat, float& roll) {
+  float phi = 0.0f;
+  bool flip = false;
+  lon = 0.0f;
+  if (P.lat_path == kLatFullSphere) {
+    float u = uniform(s) * 2.0f - 1.0f;
+    u = fminf(fmaxf(u, -1.0f), 1.0f);
+    phi = asinf(u);
+    lon = uniform(s) * 2.0f * kPiF;
+  } else if (P.lat_path == kLatNoRandom) {
+    phi = P.lat_mean_rad;
+  } else if (P.lat_path == kLatGaussLegacy) {
+    float raw = get_dist(s, HALO_DIST_GAUSS_LEGACY, P.lat_mean_rad, P.lat_std_rad);
+    normalize_latitude(raw, phi, flip);
+  } else {  // kLatLut
+    float xi = uniform(s);
+    float colat = invert_lat_lut(xi, lut);
+    phi = kPi2F - colat;
+    uint32_t bin = lat_lut_bin(colat, lut);
+    flip = uniform(s) < lut[2 * kLutNodes + bin];
+  }
+  if (P.lat_path != kLatFullSphere) lon = get_dist(s, P.az_type, P.az_mean_rad, P.az_std_rad);
+  roll = get_dist(s, P.roll_type, P.roll_mean_rad, P.roll_std_rad);
+  if (flip) {
+    lon += kPiF;
+    roll += kPiF;
+  }
+  lat = phi;
+}
+
+// R = Rz(lon - pi) * Ry(lat - pi/2) * Rz(roll), row-major (pcg_shared.h:441-483).  Evaluated in the sparse
+// form the dense axis-angle / 3x3 chain reduces to; `k = (1 - c) + c` keeps the reference's diagonal term.
+HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
+  float s1, c1, s2, c2, s3, c3;
+  sincosf(roll, &s1, &c1);
+  sincosf(lat - kPi2F, &s2, &c2);
+  sincosf(lon - kPiF, &s3, &c3);
+  float k1 = (1.0f - c1) + c1, k2 = (1.0f - c2) + c2, k3 = (1.0f - c3) + c3;
+  // t = Ry * Rz(roll)
+  float t00 = c2 * c1, t01 = c2 * (-s1), t02 = s2 * k1;
+  float t10 = k2 * s1, t11 = k2 * c1;  // t12 = 0
+  float t20 = (-s2) * c1, t21 = (-s2) * (-s1), t22 = c2 * k1;
+  R[0] = c3 * t00 + (-s3) * t10;
+  R[1] = c3 * t01 + (-s3) * t11;
+  R[2] = c3 * t02;
+  R[3] = s3 * t00 + c3 * t10;
+  R[4] = s3 * t01 + c3 * t11;
+  R[5] = s3 * t02;
+  R[6] = k3 * t20;
+  R[7] = k3 * t21;
+  R[8] = k3 * t22;
+}
+
+HD void apply_inverse(const float* R, float x, float y, float z, float* o) {  // o = R^T v
+  o[0] = R[0] * x + R[3] * y + R[6] * z;
+  o[1] = R[1] * x + R[4] * y + R[7] * z;
+  o[2] = R[2] * x + R[5] * y + R[8] * z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection (projection_shared.h:42-375); proj_type is dispatch-uniform → scalar branches
+// ------------------------------------------------------------------------------------------------
+struct XY {
+  float x, y;
+  bool valid;
+};
+
+HD XY fisheye_equal_area(float dx, float dy, float dz, float rs) {
+  float k = rs / sqrtf(1.0f + fminf(fmaxf(dz, -1.0f + 1e-6f), 1.0f));
+  return {k * dx, k * dy, true};
+}
+HD XY fisheye_equidistant(float dx, float dy, float dz, float rs) {
+  float rho = sqrtf(dx * dx + dy * dy);
+  if (rho < 1e-10f) return {0.0f, 0.0f, true};
+  float theta = acosf(fminf(fmaxf(dz, -1.0f), 1.0f));
+  float sc = rs * theta / (kPi2F * rho);
+  return {sc * dx, sc * dy, true};
+}
+HD XY fisheye_stereographic(float dx, float dy, float dz, float rs) {
+  float rho = sqrtf(dx * dx + dy * dy);
+  if (rho < 1e-10f) return {0.0f, 0.0f, true};
+  float theta = acosf(fminf(fmaxf(dz, -1.0f), 1.0f));
+  float sc = rs * tanf(theta / 2.0f) / rho;
+  return {sc * dx, sc * dy, true};
+}
+HD XY fisheye_orthographic(float dx, float dy, float dz, float rs) {
+  if (dz < 0.0f) return {0.0f, 0.0f, false};
+  return {rs * dx, rs * dy, true};
+}
+HD XY dual_forward(int t, float sx, float sy, float z, float rs) {
+  if (t == HALO_LENS_DUAL_FISHEYE_EQUAL_AREA) return fisheye_equal_area(sx, sy, z, rs);
+  if (t == HALO_LENS_DUAL_FISHEYE_EQUIDISTANT) return fisheye_equidistant(sx, sy, z, rs);
+  if (t == HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC) return fisheye_stereographic(sx, sy, z, rs);
+  return fisheye_orthographic(sx, sy, z, rs);
+}
+HD void dual_to_pixel(float xn, float yn, bool upper, int w, int h, float& fx, float& fy) {
+  int half_w = w / 2;
+  int short_res = half_w < h ? half_w : h;
+  float r = static_cast<float>(short_res) / 2.0f;
+  float cy = static_cast<float>(h) / 2.0f;
+  float cx = upper ? static_cast<float>(w) / 2.0f - r : static_cast<float>(w) / 2.0f + r;
+  fx = (upper ? -yn : yn) * r + cx;
+  fy = xn * r + cy;
+}
+
+struct Hits {
+  int px0, py0, px1, py1;
+  int count;
+};
+
+HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz) {
+  Hits r;
+  r.count = 0;
+  r.px0 = r.py0 = r.px1 = r.py1 = 0;
+  const int t = p.proj_type;
+  if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT ||
+      t == HALO_LENS_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
+    if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
+    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
+    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
+    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
+    XY xy;
+    if (t == HALO_LENS_LINEAR) {
+      if (cz <= 0.0f) return r;
+      xy = {cx / cz, cy / cz, true};
+    } else {
+      if (cz <= 0.0f) return r;
+      if (t == HALO_LENS_FISHEYE_EQUAL_AREA) xy = fisheye_equal_area(cx, cy, cz, 1.0f);
+      else if (t == HALO_LENS_FISHEYE_EQUIDISTANT) xy = fisheye_equidistant(cx, cy, cz, 1.0f);
+      else if (t == HALO_LENS_FISHEYE_STEREOGRAPHIC) xy = fisheye_stereographic(cx, cy, cz, 1.0f);
+      else xy = fisheye_orthographic(cx, cy, cz, 1.0f);
+    }
+    if (!xy.valid) return r;
+    xy.x = -xy.x;
+    r.px0 = static_cast<int>(floorf(xy.x * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
+    r.py0 = static_cast<int>(floorf(xy.y * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
+    r.count = 1;
+    return r;
+  }
+  if (t == HALO_LENS_RECTANGULAR) {
+    float lon = atan2f(-wy, -wx) - p.az0;
+    float lat = asinf(fminf(fmaxf(-wz, -1.0f), 1.0f));
+    while (lon < -kPiF) lon += 2.0f * kPiF;
+    while (lon > kPiF) lon -= 2.0f * kPiF;
+    int raw_x = static_cast<int>(floorf(lon * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f));
+    r.px0 = ((raw_x % p.img_w) + p.img_w) % p.img_w;
+    r.py0 = static_cast<int>(floorf(-lat * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f));
+    r.count = 1;
+    return r;
+  }
+  if (t == HALO_LENS_DUAL_FISHEYE_EQUAL_AREA || t == HALO_LENS_DUAL_FISHEYE_EQUIDISTANT ||
+      t == HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_DUAL_FISHEYE_ORTHOGRAPHIC) {
+    float sx = -wx, sy = -wy, sz = -wz;
+    bool upper = (sz >= 0.0f);
+    float z_hemi = upper ? sz : -sz;
+    XY xy = dual_forward(t, sx, sy, z_hemi, p.r_scale);
+    float fx, fy;
+    dual_to_pixel(xy.x, xy.y, upper, p.img_w, p.img_h, fx, fy);
+    r.px0 = static_cast<int>(floorf(fx + 0.5f));
+    r.py0 = static_cast<int>(floorf(fy + 0.5f));
+    r.count = 1;
+    if (p.max_abs_dz > 0.0f && fabsf(sz) < p.max_abs_dz) {
+      XY xy2 = dual_forward(t, sx, sy, -z_hemi, p.r_scale);
+      dual_to_pixel(xy2.x, xy2.y, !upper, p.img_w, p.img_h, fx, fy);
+      r.px1 = static_cast<int>(floorf(fx + 0.5f));
+      r.py1 = static_cast<int>(floorf(fy + 0.5f));
+      r.count = 2;
+    }
+    return r;
+  }
+  if (t == HALO_LENS_GLOBE) {
+    const float kGlobeCameraD = 4.0f;
+    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
+    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
+    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
+    if (cz >= -1.0f / kGlobeCameraD) return r;
+    float denom = kGlobeCameraD + cz;
+    r.px0 = static_cast<int>(floorf(-cx / denom * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
+    r.py0 = static_cast<int>(floorf(cy / denom * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
+    r.count = 1;
+    return r;
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulation
+// ------------------------------------------------------------------------------------------------
+HD void atomic_add_f32(float* addr, float v) {
+  // hardware global_atomic_add_f32 (no CAS loop); the accumulator is ordinary coarse-grained device memory
+  unsafeAtomicAdd(addr, v);
+}
+
+struct RaySums {
+  float landed;
+  float exit_w;
+  uint32_t exit_n;
+  uint32_t pix_n;
+};
+
+// ------------------------------------------------------------------------------------------------
+// the fused kernel
+// ------------------------------------------------------------------------------------------------
+struct LdsTables {
+  float lut[3 * kLutNodes];
+  WlEntryDev wl[HALO_WL_POOL_MAX];
+  ShapeDev shape;
+};
+
+template <bool CAPTURE>
+HD void emit_gate(const DispatchParams& P, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
+                  const uint8_t* path, uint32_t path_len, RaySums& sums) {
+  // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
+  float wx = R[0] * lx + R[1] * ly + R[2] * lz;
+  float wy = R[3] * lx + R[4] * ly + R[5] * lz;
+  float wz = R[6] * lx + R[7] * ly + R[8] * lz;
+  // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
+  // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
+  bool pass = false;
+  if (P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
+  if (pass) {
+    if (P.final_layer) return;  // "continue" with no next layer is dropped (simulator.cpp:719-722)
+    // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
+    const uint64_t mask = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(&P.counters[kCntCont], static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, static_cast<int>(leader));
+    const uint32_t slot = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+    if (slot < P.cont_out_cap) {
+      const uint32_t st = P.cont_out_stride;
+      P.cont_out[slot] = wx;
+      P.cont_out[st + slot] = wy;
+      P.cont_out[2u * st + slot] = wz;
+      P.cont_out[3u * st + slot] = w;
+      reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
+    }
+    return;
+  }
+  Hits h = project_exit(P.proj, wx, wy, wz);
+  int primary = -1;
+  if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
+    uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
+    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
+    atomic_add_f32(dst + 0, cmf_x * w);
+    atomic_add_f32(dst + 1, cmf_y * w);
+    atomic_add_f32(dst + 2, cmf_z * w);
+    sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
+    sums.pix_n++;
+    primary = static_cast<int>(pix);
+  }
+  if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
+    uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
+    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
+    atomic_add_f32(dst + 0, cmf_x * w);
+    atomic_add_f32(dst + 1, cmf_y * w);
+    atomic_add_f32(dst + 2, cmf_z * w);
+    sums.pix_n++;
+  }
+  sums.exit_w += w;
+  sums.exit_n++;
+  if (CAPTURE) {
+    uint32_t slot = atomicAdd(&P.counters[kCntExit], 1u);
+    if (slot < P.exit_cap) {
+      HaloExitRecord rec;
+      rec.dir[0] = wx;
+      rec.dir[1] = wy;
+      rec.dir[2] = wz;
+      rec.weight = w;
+      rec.root = root;
+      rec.seq = static_cast<uint16_t>(seq);
+      rec.layer = static_cast<uint8_t>(P.layer);
+      rec.path_len = static_cast<uint8_t>(path_len < HALO_PATH_CAP ? path_len : HALO_PATH_CAP);
+      for (int k = 0; k < HALO_PATH_CAP; k++) rec.path[k] = (static_cast<uint32_t>(k) < path_len) ? path[k] : 0;
+      rec.pixel = primary;
+      rec.crystal_id = static_cast<uint16_t>(P.crystal_id);
+      rec.wl_idx = static_cast<uint16_t>(wl_idx);
+      P.exits[slot] = rec;
+    }
+  }
+}
+
+// Projected-area categorical entry pick + uniform point (InitRay_p_fid simulator.cpp:133-192 in its device form
+// gen_root_kernel cu:1556-1597).  Two passes over the fan table instead of a 64-float private array.
+template <typename ShapePtr>
+HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* p) {
+  const float u_cat = uniform(s);
+  if (tri_cnt == 0) {
+    p[0] = p[1] = p[2] = 0.0f;
+    return -1;
+  }
+  float total = 0.0f;
+  for (int t = 0; t < tri_cnt; ++t) {
+    const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
+    float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
+    total += fmaxf(-dot * na.w, 0.0f);
+  }
+  int tri = 0;
+  if (total > 0.0f) {
+    const float target = u_cat * total;
+    float cum = 0.0f;
+    tri = tri_cnt - 1;
+    for (int t = 0; t < tri_cnt; ++t) {
+      const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
+      float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
+      cum += fmaxf(-dot * na.w, 0.0f);
+      if (cum > target) {
+        tri = t;
+        break;
+      }
+    }
+  }
+  float u = uniform(s);
+  float v = uniform(s);
+  if (u + v > 1.0f) {
+    u = 1.0f - u;
+    v = 1.0f - v;
+  }
+  const float* vt = sh->tri_v[tri];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float a = vt[k], b = vt[3 + k], c = vt[6 + k];
+    p[k] = u * (b - a) + v * (c - a) + a;
+  }
+  return static_cast<int>(sh->tri_face[tri]);
+}
+
+template <bool CAPTURE, typename ShapePtr>
+HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint32_t tid, RaySums& sums) {
+  float R[9], d[3], p[3], w;
+  int face;
+  uint32_t wl_idx = 0u;
+  const int face_cnt = sh->face_cnt;
+  Stream gate = make_stream(P.gate_seed, P.gate_lo, P.gate_hi, tid);
+
+  if (P.source == kSrcGen) {
+    Stream s = make_stream(P.gen_seed, P.gen_lo, P.gen_hi, tid);
+    // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
+    Stream wls = s;
+    wls.seed ^= kNonceWl;
+    wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(P.wl_pool_size));
+    if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
+    float lon, lat, roll;
+    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    build_crystal_rotation(lon, lat, roll, R);
+    // sun cone (sample_sph_cap pcg_shared.h:514-529; trig of the fixed sun angles is host-evaluated)
+    float u = uniform(s);
+    float x = u + (1.0f - u) * P.c_cap;
+    float r = sqrtf(fmaxf(1.0f - x * x, 0.0f));
+    float phi = uniform(s) * 2.0f * kPiF;
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    float y = cp * r, z = sp * r;
+    float dwx = P.c_lon * P.c_lat * x - P.s_lon * y - P.c_lon * P.s_lat * z;
+    float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
+    float dwz = P.s_lat * x + P.c_lat * z;
+    apply_inverse(R, dwx, dwy, dwz, d);
+    face = sample_entry(s, sh, sh->tri_cnt, d, p);
+    w = T.wl[wl_idx].spd_weight;
+  } else if (P.source == kSrcTransit) {
+    Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
+    const uint32_t pos = P.ci_start + tid;
+    const uint32_t src = P.shuffle ? feistel_bijection(pos, P.cont_in_n, P.shuffle_seed) : pos;
+    const uint32_t st = P.cont_in_stride;
+    float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
+    w = P.cont_in[3u * st + src];
+    wl_idx = reinterpret_cast<const uint32_t*>(P.cont_in)[4u * st + src];
+    float lon, lat, roll;
+    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    build_crystal_rotation(lon, lat, roll, R);
+    apply_inverse(R, dwx, dwy, dwz, d);
+    face = sample_entry(s, sh, sh->tri_cnt, d, p);
+  } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)
+    R[0] = R[4] = R[8] = 1.0f;
+    R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      d[k] = P.host_d[static_cast<size_t>(tid) * 3 + k];
+      p[k] = P.host_p[static_cast<size_t>(tid) * 3 + k];
+    }
+    w = P.host_w[tid];
+    face = static_cast<int>(P.host_tf[tid]);
+  }
+  if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
+
+  const float n_idx = T.wl[wl_idx].n_idx;
+  const float inv_n = 1.0f / n_idx;
+  const float cmf_x = T.wl[wl_idx].cmf_x, cmf_y = T.wl[wl_idx].cmf_y, cmf_z = T.wl[wl_idx].cmf_z;
+
+  uint8_t path[CAPTURE ? HALO_PATH_CAP : 1];
+  uint32_t path_len = 0u;
+  if (CAPTURE) path[path_len++] = sh->face_number[face];
+
+  for (uint32_t i = 0u; i < P.max_hits; ++i) {
+    // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
+    const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
+    const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
+    const float rr = cos_t > 0.0f ? n_idx : inv_n;
+    const float dd = (1.0f - rr * rr) / (cos_t * cos_t) + rr * rr;
+    const bool tir = dd <= 0.0f;
+    const float sq = sqrtf(fmaxf(dd, 0.0f));
+    float Rs = (rr - sq) / (rr + sq);
+    Rs *= Rs;
+    float Rp = (1.0f - rr * sq) / (1.0f + rr * sq);
+    Rp *= Rp;
+    const float w_refl = (Rs + Rp) * 0.5f * w;
+    const float w_refr = w - w_refl;
+    const float k_refl = 2.0f * cos_t;
+    const float k_refr = (rr - sq) * cos_t;
+    const float rlx = d[0] - k_refl * fn.x, rly = d[1] - k_refl * fn.y, rlz = d[2] - k_refl * fn.z;
+    const float rfx = rr * d[0] - k_refr * fn.x, rfy = rr * d[1] - k_refr * fn.y, rfz = rr * d[2] - k_refr * fn.z;
+    // On a convex body exactly one child stays inside: the refracted one when entering (cos<0), the reflected
+    // one otherwise; the other child leaves through `face` and is the outgoing candidate.
+    const bool entering = cos_t < 0.0f;
+    const bool has_exit = entering || !tir;
+    if (has_exit) {
+      emit_gate<CAPTURE>(P, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, tid, i, path, path_len, sums);
+    }
+    if (i + 1u == P.max_hits) break;
+    d[0] = entering ? rfx : rlx;
+    d[1] = entering ? rfy : rly;
+    d[2] = entering ? rfz : rlz;
+    w = entering ? w_refr : w_refl;
+    // --- next face on the convex body (PropagateSlab optics.cpp:64-158) ---
+    float t_best = 1e30f;
+    int hit = -1;
+    for (int fi = 0; fi < face_cnt; ++fi) {
+      const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
+      const float denom = d[0] * g.x + d[1] * g.y + d[2] * g.z;
+      const float num = -(p[0] * g.x + p[1] * g.y + p[2] * g.z + g.w);
+      const float t = (denom > kSlabEps) ? num / denom : 1e30f;
+      const bool better = (fi != face) && (t < t_best);
+      t_best = better ? t : t_best;
+      hit = better ? fi : hit;
+    }
+    if (hit < 0 || t_best <= -kSlabEps) {
+      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
+      emit_gate<CAPTURE>(P, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, tid, i + 1u, path, path_len, sums);
+      break;
+    }
+    p[0] += t_best * d[0];
+    p[1] += t_best * d[1];
+    p[2] += t_best * d[2];
+    face = hit;
+    if (CAPTURE) {
+      if (path_len < HALO_PATH_CAP) path[path_len] = sh->face_number[face];
+      path_len++;
+    }
+  }
+}
+
+HD float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
+}
+
+template <bool CAPTURE, bool POOL>
+__global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams P) {
+  __shared__ __attribute__((aligned(16))) LdsTables T;
+  // ---- stage the dispatch-constant tables into LDS ----
+  if (P.lat_path == kLatLut)
+    for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
+  {
+    const uint32_t n4 = P.wl_pool_size * (sizeof(WlEntryDev) / 16u);
+    const float4* src = reinterpret_cast<const float4*>(P.wl_pool);
+    float4* dst = reinterpret_cast<float4*>(T.wl);
+    for (uint32_t i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
+  }
+  if (!POOL) {
+    const float4* src = reinterpret_cast<const float4*>(P.shapes);
+    float4* dst = reinterpret_cast<float4*>(&T.shape);
+    for (uint32_t i = threadIdx.x; i < sizeof(ShapeDev) / 16u; i += kBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  RaySums sums = {0.0f, 0.0f, 0u, 0u};
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t tid = blockIdx.x * kBlock + threadIdx.x; tid < P.n_rays; tid += stride) {
+    if (POOL) {
+      // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275);
+      // a half-wave reads the same rows → broadcast loads served by L1/L2
+      const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
+      trace_one<CAPTURE>(P, T, sh, tid, sums);
+    } else {
+      const ShapeDev* sh = &T.shape;  // LDS: ds_read_b128 broadcasts
+      trace_one<CAPTURE>(P, T, sh, tid, sums);
+    }
+  }
+  // ---- per-wave reduction of the scalar tallies: one fp64 atomic per wave, not per exit ----
+  float landed = wave_sum(sums.landed);
+  float exit_w = wave_sum(sums.exit_w);
+  float exit_n = wave_sum(static_cast<float>(sums.exit_n));
+  float pix_n = wave_sum(static_cast<float>(sums.pix_n));
+  if ((threadIdx.x & 63) == 0) {
+    if (pix_n != 0.0f) atomicAdd(&P.sums[kSumPixN], static_cast<double>(pix_n));
+    if (landed != 0.0f) atomicAdd(&P.sums[kSumLanded], static_cast<double>(landed));
+    if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
+    if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
+  }
+}
+
+// host-callable launcher (halo_backend.cpp is plain C++ and never sees <<<>>>)
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool) {
+  dim3 grid(blocks), block(kBlock);
+  if (capture) {
+    if (pool) hipLaunchKernelGGL((halo_trace_kernel<true, true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((halo_trace_kernel<true, false>), grid, block, 0, stream, P);
+  } else {
+    if (pool) hipLaunchKernelGGL((halo_trace_kernel<false, true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((halo_trace_kernel<false, false>), grid, block, 0, stream, P);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace halo

@@ -1,0 +1,82 @@
+"""Multi-GPU sharding of the trace path: one process per GPU, rays split by root-index range, ONE sum-reduce of the
+XYZ accumulator (+ the landed-weight scalar) at the drain point.  torch is plumbing here: it owns the accumulator
+tensor (so torch.distributed — RCCL on ROCm, gloo in CPU tests — can reduce it in place) and the stream.
+
+Reference: there is no multi-GPU code in Lumice; the only reduction is N worker threads → one consumer
+(src/server/server.cpp:1189).  The drain point we reduce at is Simulator::DrainDeviceXyz (simulator.cpp:1409-1477).
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous split of `total` root rays: rank r gets [start, start+count); counts differ by at most one."""
+    base, rem = divmod(int(total), int(world))
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def reduce_accumulators(acc, landed, group=None, dst=0):
+    """Sum-reduce every rank's accumulator tensor and landed scalar onto `dst`; non-root ranks are drained (zeroed).
+    Works on any torch.distributed backend (nccl == RCCL on ROCm; gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return acc, landed
+    rank = dist.get_rank(group)
+    dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    lt = torch.tensor([landed], dtype=torch.float64, device=acc.device)
+    dist.reduce(lt, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if rank != dst:
+        acc.zero_()
+        return acc, 0.0
+    return acc, float(lt.item())
+
+
+class ShardedTracer:
+    """One rank's slice of a trace job on one MI355X."""
+
+    def __init__(self, scene, render, seed=42, device=0, rank=0, world=1, **options):
+        import torch
+        from .backend import HipTraceBackend
+        self.torch = torch
+        self.scene, self.render = scene, render
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", device)
+        self.backend = HipTraceBackend(device=device, seed=seed, **options)
+        self.backend.set_option("rank", rank)      # disjoint 64-bit RNG counter range per shard
+        self.n_floats = render.width * render.height * 3 + 4
+        self.acc = torch.zeros(self.n_floats, dtype=torch.float32, device=self.device)
+        self.backend.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
+        self.landed = 0.0
+
+    def trace_session(self, wl, n_rays, shuffle=True):
+        """BeginSession → layers → EndSession for this rank's `n_rays` roots. Returns the last layer's stats."""
+        b = self.backend
+        b.BeginSession(self.scene, self.render, wl, n_rays)
+        st = None
+        for li in range(self.scene.layer_count):
+            st = b.TraceLayer(n_rays if li == 0 else 0)
+            if li + 1 < self.scene.layer_count:
+                b.Recombine(shuffle)
+        b.EndSession()
+        return st
+
+    def reduce_to_root(self):
+        self.landed += self.backend.take_landed()
+        self.acc, self.landed = reduce_accumulators(self.acc, self.landed)
+
+    def zero(self):
+        self.backend.take_landed()
+        self.acc.zero_()
+        self.landed = 0.0
+        self.torch.cuda.synchronize(self.device)
+
+    def readback(self):
+        self.landed += self.backend.take_landed()
+        w, h = self.render.width, self.render.height
+        img = self.acc[: w * h * 3].cpu().numpy().reshape(h, w, 3).copy()
+        landed = self.landed
+        self.zero()
+        return img, landed

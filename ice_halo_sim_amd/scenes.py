@@ -1,0 +1,109 @@
+"""Programmatic scene builders (the reference builds its test scenes the same way:
+test/cpu_test_helpers.hpp:26-68 MakeCpuScene / MakeRectangularRender) and the BASELINE.json configs."""
+from . import abi
+
+
+def prism_crystal(height=1.0, face_distance=None, sync_group=None):
+    c = abi.HaloCrystal()
+    c.kind = abi.CRYSTAL_PRISM
+    c.height[0] = abi.dist(height)
+    fd = face_distance if face_distance is not None else [1.0] * 6
+    for i in range(6):
+        c.face_dist[i] = abi.dist(fd[i])
+    for i in range(9):
+        c.sync_group[i] = 0 if sync_group is None else int(sync_group[i])
+    return c
+
+
+def axis(zenith=None, azimuth=None, roll=None):
+    """JSON-convention axis → internal AxisDistribution (reference src/core/math.cpp:679-726):
+    latitude = 90 - zenith (center only; spread kept); when the `axis` object is present, azimuth and roll
+    default to uniform over 360; when absent everything is fixed with zenith 0."""
+    a = abi.HaloAxis()
+    present = not (zenith is None and azimuth is None and roll is None)
+    z = abi.dist(zenith, 0.0)
+    a.latitude.type, a.latitude.center, a.latitude.spread = z.type, 90.0 - z.center, z.spread
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    a.azimuth = abi.dist(azimuth if azimuth is not None else (full if present else None), 0.0)
+    a.roll = abi.dist(roll if roll is not None else (full if present else None), 0.0)
+    return a
+
+
+def entry(crystal, axis_dist, proportion=1.0, crystal_config_id=1):
+    e = abi.HaloEntry()
+    e.crystal = crystal
+    e.axis = axis_dist
+    e.proportion = float(proportion)
+    e.crystal_config_id = int(crystal_config_id)
+    return e
+
+
+def scene(layers, max_hits=7, sun_altitude=20.0, sun_azimuth=0.0, sun_diameter=0.5):
+    """layers: list of (prob, [entries])."""
+    s = abi.HaloScene()
+    s.sun_altitude, s.sun_azimuth, s.sun_diameter = float(sun_altitude), float(sun_azimuth), float(sun_diameter)
+    s.max_hits = int(max_hits)
+    s.layer_count = len(layers)
+    for li, (prob, entries) in enumerate(layers):
+        s.layers[li].prob = float(prob)
+        s.layers[li].entry_count = len(entries)
+        for ei, e in enumerate(entries):
+            s.layers[li].entries[ei] = e
+    return s
+
+
+def render(lens=abi.LENS_FISHEYE_EQUAL_AREA, width=1920, height=1080, fov=180.0, az=0.0, el=30.0, ro=0.0,
+           visible=abi.VISIBLE_UPPER, overlap=0.0, lens_shift=(0, 0)):
+    r = abi.HaloRender()
+    r.lens_type, r.fov, r.width, r.height = int(lens), float(fov), int(width), int(height)
+    r.lens_shift[0], r.lens_shift[1] = int(lens_shift[0]), int(lens_shift[1])
+    r.view_az, r.view_el, r.view_ro = float(az), float(el), float(ro)
+    r.visible, r.overlap = int(visible), float(overlap)
+    return r
+
+
+def wl_discrete(wavelength, weight=1.0):
+    w = abi.HaloWl()
+    w.wavelength, w.weight, w.illuminant, w.pool_size = float(wavelength), float(weight), -1, 0
+    return w
+
+
+def wl_illuminant(name="D65", pool_size=64):
+    w = abi.HaloWl()
+    w.wavelength, w.weight, w.illuminant, w.pool_size = 0.0, 0.0, abi.ILLUM[name], int(pool_size)
+    return w
+
+
+# --- BASELINE.json configs -----------------------------------------------------------------
+CONFIG_WAVELENGTHS_9 = [450.0 + 40.0 * i for i in range(9)]  # examples/config_example.json:217-227
+
+
+def column_crystal_entry():
+    """examples/config_example.json crystal id 3: prism h=1.3, zenith gauss(90, 0.3), azimuth/roll uniform 360."""
+    return entry(prism_crystal(1.3, [1.0] * 6),
+                 axis(zenith={"type": "gauss", "mean": 90, "std": 0.3}, azimuth={"type": "uniform", "mean": 0, "std": 360},
+                      roll={"type": "uniform", "mean": 0, "std": 360}), proportion=10.0, crystal_config_id=3)
+
+
+def config2_scene():
+    """configs[1]: single-scatter hex column, max_hits 7."""
+    return scene([(0.0, [column_crystal_entry()])], max_hits=7)
+
+
+def config2_render(width=1920, height=1080):
+    return render(abi.LENS_FISHEYE_EQUAL_AREA, width, height, fov=180.0, el=30.0, visible=abi.VISIBLE_UPPER)
+
+
+def config3_scene():
+    """configs[2]: plate (h=0.3, zenith gauss(0, 0.8)) prob 1.0 over a random column (full-sphere axis)."""
+    plate = entry(prism_crystal(0.3), axis(zenith={"type": "gauss", "mean": 0, "std": 0.8}), 1.0, 6)
+    col = entry(prism_crystal(1.3, [1.0] * 6),
+                axis(zenith={"type": "uniform", "mean": 90, "std": 360}, azimuth={"type": "uniform", "mean": 0, "std": 360}), 1.0, 3)
+    return scene([(1.0, [plate]), (0.0, [col])], max_hits=7)
+
+
+def stochastic_prism_entry():
+    """examples/bench_config_stoch.json: prism h=1, six face distances gauss(1, 0.15), full-sphere axis."""
+    g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    return entry(prism_crystal(1.0, [g] * 6), axis(zenith=full, azimuth=full, roll=full), 100.0, 1)

@@ -164,6 +164,8 @@ typedef struct HaloLayerStats {
   uint64_t continuation_count;
   double exit_w_sum;
   double kernel_ms;          /* HIP-event time of this layer's kernels on the backend stream */
+  uint64_t pixel_hits;       /* in-frame pixel writes (primary + overlap): 3 fp32 accumulator RMWs each */
+  uint64_t launches;         /* kernel launches this layer took */
 } HaloLayerStats;
 
 /* ExitRayRecord — src/core/exit_seam.hpp:40-53, trimmed to what the parity tests read.
@@ -222,6 +224,9 @@ int halo_readback_xyz(halo_handle_t h, float* xyz, int width, int height, float*
 /* Same, but returns landed weight in double and does not add. */
 int halo_readback_xyz64(halo_handle_t h, float* xyz, int width, int height, double* landed_weight);
 int halo_sync(halo_handle_t h);
+/* Read AND zero the device landed-weight tally (fp64) without touching the image: used when the image lives in a
+ * bound external accumulator that is reduced across ranks in place. */
+int halo_take_landed(halo_handle_t h, double* landed_weight);
 
 /* --- host-side pieces of the path, exported for parity tests (no GPU needed) ---------------- */
 /* Geometry tables the kernels consume (reference: Crystal::PopulateFromCfGeom crystal.cpp:304-347,
@@ -251,6 +256,8 @@ int halo_host_partition(const float* proportions, int n, uint64_t ray_num, doubl
 /* IceRefractiveIndex::Get — optics.cpp:180-197. */
 double halo_host_refractive_index(double wavelength_nm);
 int halo_abi_version(void);
+/* sizeof() of boundary structs as compiled (0 scene, 1 render, 2 wl, 3 exit record, 4 geom tables, 5 layer stats, 6 entry). */
+uint64_t halo_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

@@ -1131,6 +1131,7 @@ typedef struct { /* per-thread output sink */
   double landed;
   double exit_w_sum;
   uint64_t exit_count;
+  uint64_t pixel_hits;
 } HoSink;
 
 static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const float exit_world[3], float w, int32_t* primary_pix) {
@@ -1155,6 +1156,7 @@ static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const f
       dst[1] += a1;
       dst[2] += a2;
 #endif
+      sink->pixel_hits++;
       if (r.hits[hi].bump_landed) {
         sink->landed += (double)w;
         *primary_pix = (int32_t)pix;
@@ -1507,6 +1509,7 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
         total.landed += sink.landed;
         total.exit_count += sink.exit_count;
         total.exit_w_sum += sink.exit_w_sum;
+        total.pixel_hits += sink.pixel_hits;
       }
     }
     if (layer == 0 && !rays) b->gen_count += n_ci;
@@ -1524,6 +1527,7 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     stats->exit_count = total.exit_count;
     stats->exit_w_sum = total.exit_w_sum;
     stats->continuation_count = final_layer ? 0 : b->cont_n;
+    stats->pixel_hits = total.pixel_hits;
   }
   return HALO_OK;
 }
