@@ -37,6 +37,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
+            if os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast
+                cmd.append("-ffp-contract=" + os.environ["HALO_FP_CONTRACT"])
         else:  # host tables must round like the reference's host build: no FMA contraction
             cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -31,6 +31,20 @@ constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
 constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
 constexpr float kSlabEps = 1e-5f;                 // traversal_shared.h:46
 
+// Separately-rounded multiply / add that the compiler cannot re-fuse into an FMA (the backend fuses any
+// fmul+fadd pair under -ffp-contract=fast, whatever the source says).  Used only where the reference's formula
+// cancels catastrophically and a fused product would move the result by orders of magnitude more than an ulp.
+HD float mul_rn(float a, float b) {
+  float r;
+  asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+HD float add_rn(float a, float b) {
+  float r;
+  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // counter-based RNG (pcg_shared.h:193-274)
 // ------------------------------------------------------------------------------------------------
@@ -497,8 +511,10 @@ HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint
     build_crystal_rotation(lon, lat, roll, R);
     // sun cone (sample_sph_cap pcg_shared.h:514-529; trig of the fixed sun angles is host-evaluated)
     float u = uniform(s);
-    float x = u + (1.0f - u) * P.c_cap;
-    float r = sqrtf(fmaxf(1.0f - x * x, 0.0f));
+    float x = add_rn(u, mul_rn(1.0f - u, P.c_cap));  // separately rounded: see the note on r below
+    // x is within 1e-5 of 1: `1 - x*x` cancels catastrophically, so keep the product separately rounded like the
+    // reference's host evaluation (a contracted fma here moves r by up to ~2e-4 for rays near the cone axis)
+    float r = sqrtf(fmaxf(add_rn(1.0f, -mul_rn(x, x)), 0.0f));
     float phi = uniform(s) * 2.0f * kPiF;
     float sp, cp;
     sincosf(phi, &sp, &cp);
@@ -567,9 +583,10 @@ HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint
     const bool has_exit = entering || !tir;
     if (has_exit) {
       emit_gate<CAPTURE>(P, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
-                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, tid, i, path, path_len, sums);
+                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
+    const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
     d[0] = entering ? rfx : rlx;
     d[1] = entering ? rfy : rly;
     d[2] = entering ? rfz : rlz;
@@ -588,7 +605,7 @@ HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint
     }
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<CAPTURE>(P, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, tid, i + 1u, path, path_len, sums);
+      emit_gate<CAPTURE>(P, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];

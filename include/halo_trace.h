@@ -173,8 +173,8 @@ typedef struct HaloLayerStats {
 typedef struct HaloExitRecord {
   float dir[3];     /* world-space exit direction */
   float weight;
-  uint32_t root;    /* root-ray index within the layer dispatch */
-  uint16_t seq;     /* 0 = entry-face external reflection, k = k-th interior interaction */
+  uint32_t root;    /* root-ray index within the layer (entries are laid out back to back) */
+  uint16_t seq;     /* 2*interaction_index + child (0 = reflected, 1 = refracted); 0 = entry-face external reflection */
   uint8_t layer;
   uint8_t path_len;
   uint8_t path[HALO_PATH_CAP]; /* crystal face NUMBERS (1..8 prism; pyramid 1,2,3-8,13-18,23-28) */

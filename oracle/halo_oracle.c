@@ -1251,7 +1251,6 @@ static void trace_root(const HoCiCtx* c, HoSink* sink, const HaloGeomTables* g, 
   cur[0].face = face0;
   path_cur[0][0] = (uint8_t)g->face_number[face0]; /* InitRay_other_info RecorderAppend(GetFn(to_face_)) :270 */
   plen_cur[0] = 1;
-  int seq = 0;
   for (int i = 0; i < c->max_hits && n_cur > 0; i++) {
     int n_nxt = 0;
     for (int k = 0; k < n_cur && k < 2; k++) {
@@ -1275,7 +1274,7 @@ static void trace_root(const HoCiCtx* c, HoSink* sink, const HaloGeomTables* g, 
         float p_new[3];
         int f_new = propagate_slab(g, dirs[ch], s->p, s->face, p_new);
         if (f_new < 0) { /* outgoing candidate */
-          emit_gate(c, sink, gate, rot, wle, wl_idx, dirs[ch], ws[ch], root, seq++, path_cur[k], plen_cur[k]);
+          emit_gate(c, sink, gate, rot, wle, wl_idx, dirs[ch], ws[ch], root, 2 * i + ch, path_cur[k], plen_cur[k]);
         } else if (n_nxt < 4) {
           HoSeg* o = &nxt[n_nxt];
           memcpy(o->d, dirs[ch], 12);
@@ -1367,7 +1366,7 @@ static void run_ray(const HoCiCtx* c, HoSink* sink, uint32_t tid) {
     if (face < 0) w = 0.0f;
   }
   const HoWlEntry* wle = &b->pool[wl_idx];
-  trace_root(c, sink, g, rot, wle->n_idx, wle, wl_idx, d_crystal, p, w, face, tid, &gate);
+  trace_root(c, sink, g, rot, wle->n_idx, wle, wl_idx, d_crystal, p, w, face, (uint32_t)(c->ci_start + tid), &gate);
 }
 
 /* shape scalars: SamplePrismShapeScalars simulator.cpp:405-412 + SyncGroupSampler :361-393, host PCG stream */

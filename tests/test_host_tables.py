@@ -1,0 +1,124 @@
+"""Host-side table producers of the PRODUCT (exported through the C ABI, no GPU needed) against the CPU oracle.
+Both restate the same reference routines; they are compiled by different compilers (hipcc/clang vs gcc) from
+independently written code, so bit-equality here is a real cross-check of geometry, LUT, projection POD,
+partition and refractive index.  Also checks that the library loads and exports every declared symbol."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, backend, scenes
+from tests import _libs
+from tests._libs import fptr
+
+RNG = np.random.default_rng(77)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = backend.load_library()
+    header = open(os.path.join(ROOT, "include", "halo_trace.h")).read()
+    declared = set(re.findall(r"\b(halo_[a-z0-9_]+)\s*\(", header)) - {"halo_handle_t"}
+    assert declared, "no declarations parsed"
+    for sym in sorted(declared):
+        assert hasattr(L, sym), "libhalo_hip.so does not export " + sym
+    assert declared == set(backend.EXPORTED_SYMBOLS), declared ^ set(backend.EXPORTED_SYMBOLS)
+    assert L.halo_abi_version() == 1
+    for i, t in enumerate([abi.HaloScene, abi.HaloRender, abi.HaloWl, abi.HaloExitRecord, abi.HaloGeomTables,
+                           abi.HaloLayerStats, abi.HaloEntry]):
+        assert L.halo_abi_sizeof(i) == C.sizeof(t), t.__name__
+
+
+def test_product_fails_loudly_without_gpu():
+    L = backend.load_library()
+    if L.halo_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(backend.BackendUnavailableError):
+        backend.HipTraceBackend(device=0, seed=1)
+
+
+def geom_equal(a, b):
+    assert a.face_cnt == b.face_cnt and a.tri_cnt == b.tri_cnt
+    for name in ("face_n", "face_d", "tri_v", "tri_n", "tri_area"):
+        x, y = np.frombuffer(getattr(a, name), np.uint32), np.frombuffer(getattr(b, name), np.uint32)
+        assert (x == y).all(), name
+    assert list(a.face_number) == list(b.face_number) and list(a.tri_face) == list(b.tri_face)
+
+
+def test_prism_geometry_bit_exact():
+    L, O = backend.load_library(), _libs.oracle()
+    cases = [(1.0, np.ones(6)), (1.3, np.ones(6)), (0.3, np.ones(6)), (0.0, np.ones(6)), (1e-6, np.ones(6)),
+             (1.0, np.array([1, 1, 1, 1, 1, -1.5])), (1.0, np.array([1, 0.2, 1, 1, 0.2, 1])), (2.0, np.array([1, 3, 1, 3, 1, 3]))]
+    for _ in range(400):
+        cases.append((float(abs(RNG.normal(1.0, 0.5))), 1.0 + RNG.normal(0, RNG.choice([0.05, 0.2, 0.5, 0.8]), 6)))
+    empty = 0
+    for h, dist in cases:
+        d = np.asarray(dist, np.float32)
+        a, b = abi.HaloGeomTables(), abi.HaloGeomTables()
+        assert L.halo_host_prism_geometry(float(h), fptr(d), C.byref(a)) == 0
+        O.ho_prism_geometry(float(h), fptr(d), C.byref(b))
+        geom_equal(a, b)
+        empty += a.face_cnt == 0
+    assert empty >= 3
+    # regular hexagon invariants (reference test_closed_form_prism.cpp:164-187)
+    g = abi.HaloGeomTables()
+    L.halo_host_prism_geometry(1.0, fptr(np.ones(6, np.float32)), C.byref(g))
+    assert g.face_cnt == 8 and g.tri_cnt == 20 and list(g.face_number)[:8] == [1, 2, 3, 4, 5, 6, 7, 8]
+    d = np.frombuffer(g.face_d, np.float32)[:8]
+    assert np.allclose(d[:2], -0.5) and np.allclose(d[2:], -np.sqrt(3) / 4, atol=1e-7)
+    area = np.frombuffer(g.tri_area, np.float32)[:20]
+    hexa = 3 * np.sqrt(3) / 2 * 0.25
+    assert area[:4].sum() == pytest.approx(hexa, rel=1e-6) and area[8:].sum() == pytest.approx(6 * 0.5 * 1.0, rel=1e-6)
+
+
+@pytest.mark.parametrize("dist", [(abi.DIST_GAUSS, 0.0, 0.3), (abi.DIST_GAUSS, 90.0, 0.8), (abi.DIST_GAUSS, 85.0, 10.0),
+                                  (abi.DIST_UNIFORM, 45.0, 30.0), (abi.DIST_UNIFORM, 90.0, 360.0), (abi.DIST_ZIGZAG, 85.0, 30.0),
+                                  (abi.DIST_LAPLACIAN, 0.0, 2.0), (abi.DIST_LAPLACIAN, 90.0, 2.0), (abi.DIST_GAUSS, 10.0, 0.0)])
+def test_lat_lut_bit_exact_and_monotone(dist):
+    L, O = backend.load_library(), _libs.oracle()
+    d = abi.HaloDist(*dist)
+    a = [np.zeros(257, np.float32) for _ in range(3)]
+    b = [np.zeros(257, np.float32) for _ in range(3)]
+    assert L.halo_host_build_lat_lut(C.byref(d), *[fptr(x) for x in a]) == 0
+    O.ho_build_lat_lut(C.byref(d), *[fptr(x) for x in b])
+    for x, y in zip(a, b):
+        assert (x.view(np.uint32) == y.view(np.uint32)).all()
+    theta, cdf, flip = a
+    # BuildLatLut contract (reference lat_lut.hpp:14-30): cdf strictly increasing (or the degenerate ramp), theta
+    # non-decreasing inside [0, pi], flip probabilities in [0, 1]
+    assert (np.diff(cdf) > 0).all() and (np.diff(theta) >= 0).all()
+    assert 0 <= theta[0] and theta[-1] <= np.float32(np.pi) + 1e-6 and ((flip >= 0) & (flip <= 1)).all()
+
+
+def test_proj_params_bit_exact():
+    L, O = backend.load_library(), _libs.oracle()
+    for lens in range(11):
+        for _ in range(20):
+            cfg = scenes.render(lens, int(RNG.choice([512, 1920, 2048])), int(RNG.choice([256, 1080, 1024])), fov=float(RNG.uniform(20, 180)),
+                                az=float(RNG.uniform(-180, 180)), el=float(RNG.uniform(-90, 90)), ro=float(RNG.uniform(-45, 45)),
+                                visible=int(RNG.integers(0, 3)), overlap=float(RNG.choice([0.0, 0.0872])),
+                                lens_shift=(int(RNG.integers(-99, 99)), int(RNG.integers(-99, 99))))
+            a, b = abi.ProjParams(), abi.ProjParams()
+            assert L.halo_host_build_proj_params(C.byref(cfg), C.byref(a)) == 0
+            O.ho_build_proj_params(C.byref(cfg), C.byref(b))
+            assert bytes(a) == bytes(b)
+
+
+def test_partition_sequences_and_refractive_index():
+    L, O = backend.load_library(), _libs.oracle()
+    for _ in range(200):
+        n = int(RNG.integers(1, 9))
+        prop = RNG.uniform(-0.2, 5, n).astype(np.float32)
+        ca, cb = np.zeros(n), np.zeros(n)
+        for _batch in range(6):
+            rays = int(RNG.integers(0, 1000))
+            oa, ob = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+            L.halo_host_partition(fptr(prop), n, rays, ca.ctypes.data_as(C.POINTER(C.c_double)), oa.ctypes.data_as(C.POINTER(C.c_uint64)))
+            O.ho_partition(fptr(prop), n, rays, cb.ctypes.data_as(C.POINTER(C.c_double)), ob.ctypes.data_as(C.POINTER(C.c_uint64)))
+            assert (oa == ob).all() and np.array_equal(ca, cb)
+            if prop.clip(0).sum() > 0:
+                assert oa.sum() == rays  # exact total (reference test_simulator.cpp:38-233)
+    for wl in np.linspace(300, 950, 261):
+        assert L.halo_host_refractive_index(float(wl)) == O.ho_ice_refractive_index(float(wl))
