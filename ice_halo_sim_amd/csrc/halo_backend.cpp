@@ -18,7 +18,8 @@
 #include "halo_host.hpp"
 
 namespace halo {
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool);
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream);
 }
 
 using namespace halo;
@@ -60,7 +61,8 @@ struct HaloBackend {
   int capture = 0;
   uint32_t geom_clock = 32;  // simulator.hpp:144 (rays per sampled shape)
   uint64_t chunk = 1ull << 26;
-  int aggregate = 0;
+  int aggregate = 1;
+  int mono_enabled = 1;
   int blocks_per_cu = 8;
 
   // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
@@ -80,6 +82,10 @@ struct HaloBackend {
   float* acc = nullptr;        // bound accumulator (own or external)
   uint64_t acc_floats = 0;
   int acc_w = 0, acc_h = 0;
+  DevBuf<float> mono;          // W*H scalar plane for discrete-wavelength sessions
+  bool mono_session = false;
+  bool mono_dirty = false;
+  float mono_cmf[3] = {0, 0, 0};
   DevBuf<double> sums;         // kSumNum
   DevBuf<uint32_t> counters;   // kCntNum
   DevBuf<float> lut;
@@ -187,6 +193,7 @@ int halo_destroy(halo_handle_t b) {
   (void)hipStreamSynchronize(b->stream);
   b->acc_own.release();
   b->sums.release();
+  b->mono.release();
   b->counters.release();
   b->lut.release();
   b->wl_pool.release();
@@ -211,7 +218,8 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (k == "capture_exits") b->capture = v ? 1 : 0;
   else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
   else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
-  else if (k == "aggregate") b->aggregate = v ? 1 : 0;
+  else if (k == "aggregate") b->aggregate = static_cast<int>(v);
+  else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 16));
   else if (k == "rank") {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
@@ -267,6 +275,18 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   HIPCHK(b, b->wl_pool.reserve(HALO_WL_POOL_MAX));
   HIPCHK(b, hipMemcpyAsync(b->wl_pool.ptr, pool.data(), pool.size() * sizeof(WlEntryDev), hipMemcpyHostToDevice, b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` dies at scope exit
+  // discrete wavelength → one-channel accumulation, CMF applied once at EndSession
+  b->mono_session = b->mono_enabled && wl->illuminant < 0;
+  if (b->mono_session) {
+    const size_t npix = static_cast<size_t>(render->width) * render->height;
+    if (b->mono.cap < npix) {
+      HIPCHK(b, b->mono.reserve(npix));
+      HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, npix * sizeof(float), b->stream));
+    }
+    b->mono_cmf[0] = pool[0].cmf_x;
+    b->mono_cmf[1] = pool[0].cmf_y;
+    b->mono_cmf[2] = pool[0].cmf_z;
+  }
   b->in_session = true;
   b->layer_idx = 0;
   b->cont_in_n = 0;
@@ -274,10 +294,21 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   return HALO_OK;
 }
 
+static int fold_if_dirty(HaloBackend* b) {
+  if (!b->mono_dirty) return HALO_OK;
+  HIPCHK(b, hipSetDevice(b->device));
+  const uint32_t npix = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
+  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->cu_count * 4, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
+  b->mono_dirty = false;
+  return HALO_OK;
+}
+
 int halo_end(halo_handle_t b) {
   if (!b) return HALO_FATAL;
+  int rc = fold_if_dirty(b);  // a discrete-wavelength session closes by applying its CMF to the scalar plane
   b->in_session = false;
-  return HALO_OK;
+  return rc;
 }
 
 int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, HaloLayerStats* stats) {
@@ -395,6 +426,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.cont_out_cap = out_cap;
     P.counters = b->counters.ptr;
     P.xyz = b->acc;
+    P.mono = b->mono.ptr;
     P.sums = b->sums.ptr;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
@@ -436,7 +468,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const int max_blocks = b->cu_count * b->blocks_per_cu;
       const int blocks = static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
       HIPCHK(b, hipEventRecord(b->ev0, b->stream));  // HIP events on the launch stream bracket the kernel alone
-      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic);
+      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
+      b->mono_dirty = b->mono_dirty || b->mono_session;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       HIPCHK(b, hipEventRecord(b->ev1, b->stream));
       HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` (pageable H2D source) must outlive the copy
@@ -508,6 +541,10 @@ int halo_sync(halo_handle_t b) {
 int halo_take_landed(halo_handle_t b, double* landed) {
   if (!b || !landed) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
+  {
+    int rc = fold_if_dirty(b);
+    if (rc != HALO_OK) return rc;
+  }
   HIPCHK(b, hipMemcpyAsync(landed, b->sums.ptr, sizeof(double), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));
@@ -518,6 +555,10 @@ int halo_readback_xyz64(halo_handle_t b, float* xyz, int width, int height, doub
   if (!b || !xyz) return HALO_FATAL;
   if (!b->acc || width != b->acc_w || height != b->acc_h) return fail(b, HALO_FATAL, "readback size does not match the session render");
   HIPCHK(b, hipSetDevice(b->device));
+  {
+    int rc = fold_if_dirty(b);
+    if (rc != HALO_OK) return rc;
+  }
   const size_t n = static_cast<size_t>(width) * height * 3;
   double s[kSumNum];
   HIPCHK(b, hipMemcpyAsync(xyz, b->acc, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));

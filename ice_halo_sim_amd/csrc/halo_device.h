@@ -102,10 +102,11 @@ struct DispatchParams {
   const uint32_t* host_tf;
   // --- outputs -------------------------------------------------------------------------------
   float* xyz;                  // W*H*3 image
+  float* mono;                 // W*H scalar plane (discrete-wavelength sessions), folded into xyz at EndSession
   double* sums;                // [0] landed weight, [1] exit weight sum, [2] exit count (as double)
   HaloExitRecord* exits;
   uint32_t exit_cap;
-  uint32_t aggregate;          // LDS hot-pixel cache on/off
+  uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
 };
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };

@@ -355,6 +355,52 @@ HD void atomic_add_f32(float* addr, float v) {
   unsafeAtomicAdd(addr, v);
 }
 
+// Measured on MI355X (tools/atomic_bench.hip): scattered fp32 atomics retire at ~20.7 G/s whatever the scope or
+// buffer size, but same-cache-line atomics serialize — and a third of all exits land on the ~20 pixels of the
+// sun disc (rays crossing two parallel faces keep their direction).  Two measures keep that off the fabric:
+//  * MONO: in a discrete-wavelength session every exit's XYZ is cmf(lambda)*w, so the kernel accumulates the
+//    scalar w into a one-channel plane (1 atomic per hit, not 3) and halo_fold_kernel applies the CMF once per
+//    session (AccumXyzToPixel accum_shared.h:40-47 distributes over the sum);
+//  * a per-workgroup direct-mapped pixel cache in LDS: the first pixel to claim a slot accumulates there with
+//    ds_add_f32 for the rest of the kernel and is flushed once; pixels that lose the claim go straight to HBM.
+//    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
+constexpr int kCacheLog2 = 10;
+constexpr int kCacheN = 1 << kCacheLog2;
+
+template <bool MONO>
+struct PixCache {
+  uint32_t tag[kCacheN];                 // pixel + 1, 0 = free
+  float val[kCacheN * (MONO ? 1 : 3)];
+};
+
+template <bool MONO>
+HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, float w, float cx, float cy, float cz) {
+  if (P.aggregate == 2u) return;  // diagnostic: trace + project only
+  if (P.aggregate == 1u) {
+    const uint32_t slot = (pix * 2654435761u) >> (32 - kCacheLog2);
+    const uint32_t key = pix + 1u;
+    const uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
+    if (old == 0u || old == key) {
+      if (MONO) {
+        unsafeAtomicAdd(&C.val[slot], w);
+      } else {
+        unsafeAtomicAdd(&C.val[slot * 3 + 0], cx * w);
+        unsafeAtomicAdd(&C.val[slot * 3 + 1], cy * w);
+        unsafeAtomicAdd(&C.val[slot * 3 + 2], cz * w);
+      }
+      return;
+    }
+  }
+  if (MONO) {
+    atomic_add_f32(P.mono + pix, w);
+  } else {
+    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
+    atomic_add_f32(dst + 0, cx * w);
+    atomic_add_f32(dst + 1, cy * w);
+    atomic_add_f32(dst + 2, cz * w);
+  }
+}
+
 struct RaySums {
   float landed;
   float exit_w;
@@ -365,14 +411,16 @@ struct RaySums {
 // ------------------------------------------------------------------------------------------------
 // the fused kernel
 // ------------------------------------------------------------------------------------------------
+template <bool MONO>
 struct LdsTables {
   float lut[3 * kLutNodes];
   WlEntryDev wl[HALO_WL_POOL_MAX];
   ShapeDev shape;
+  PixCache<MONO> cache;
 };
 
-template <bool CAPTURE>
-HD void emit_gate(const DispatchParams& P, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+template <bool CAPTURE, bool MONO>
+HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
                   const uint8_t* path, uint32_t path_len, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
@@ -407,20 +455,14 @@ HD void emit_gate(const DispatchParams& P, Stream& gate, const float* R, float l
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
-    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
-    atomic_add_f32(dst + 0, cmf_x * w);
-    atomic_add_f32(dst + 1, cmf_y * w);
-    atomic_add_f32(dst + 2, cmf_z * w);
+    accumulate<MONO>(P, cache, pix, w, cmf_x, cmf_y, cmf_z);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
     primary = static_cast<int>(pix);
   }
   if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
-    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
-    atomic_add_f32(dst + 0, cmf_x * w);
-    atomic_add_f32(dst + 1, cmf_y * w);
-    atomic_add_f32(dst + 2, cmf_z * w);
+    accumulate<MONO>(P, cache, pix, w, cmf_x, cmf_y, cmf_z);
     sums.pix_n++;
   }
   sums.exit_w += w;
@@ -491,8 +533,8 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
   return static_cast<int>(sh->tri_face[tri]);
 }
 
-template <bool CAPTURE, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint32_t tid, RaySums& sums) {
+template <bool CAPTURE, bool MONO, typename ShapePtr>
+HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint32_t tid, RaySums& sums) {
   float R[9], d[3], p[3], w;
   int face;
   uint32_t wl_idx = 0u;
@@ -582,7 +624,7 @@ HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     if (has_exit) {
-      emit_gate<CAPTURE>(P, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+      emit_gate<CAPTURE, MONO>(P, T.cache, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
                          entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
@@ -605,7 +647,7 @@ HD void trace_one(const DispatchParams& P, const LdsTables& T, ShapePtr sh, uint
     }
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<CAPTURE>(P, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<CAPTURE, MONO>(P, T.cache, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];
@@ -625,9 +667,13 @@ HD float wave_sum(float v) {
   return v;
 }
 
-template <bool CAPTURE, bool POOL>
+template <bool CAPTURE, bool POOL, bool MONO>
 __global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams P) {
-  __shared__ __attribute__((aligned(16))) LdsTables T;
+  __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
+  if (P.aggregate == 1u) {
+    for (int i = threadIdx.x; i < kCacheN; i += kBlock) T.cache.tag[i] = 0u;
+    for (int i = threadIdx.x; i < kCacheN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
+  }
   // ---- stage the dispatch-constant tables into LDS ----
   if (P.lat_path == kLatLut)
     for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
@@ -651,10 +697,28 @@ __global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams
       // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275);
       // a half-wave reads the same rows → broadcast loads served by L1/L2
       const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-      trace_one<CAPTURE>(P, T, sh, tid, sums);
+      trace_one<CAPTURE, MONO>(P, T, sh, tid, sums);
     } else {
       const ShapeDev* sh = &T.shape;  // LDS: ds_read_b128 broadcasts
-      trace_one<CAPTURE>(P, T, sh, tid, sums);
+      trace_one<CAPTURE, MONO>(P, T, sh, tid, sums);
+    }
+  }
+  // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
+  if (P.aggregate == 1u) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kCacheN; i += kBlock) {
+      const uint32_t key = T.cache.tag[i];
+      if (key == 0u) continue;
+      const uint32_t pix = key - 1u;
+      if (MONO) {
+        const float v = T.cache.val[i];
+        if (v != 0.0f) atomic_add_f32(P.mono + pix, v);
+      } else {
+        float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
+        atomic_add_f32(dst + 0, T.cache.val[i * 3 + 0]);
+        atomic_add_f32(dst + 1, T.cache.val[i * 3 + 1]);
+        atomic_add_f32(dst + 2, T.cache.val[i * 3 + 2]);
+      }
     }
   }
   // ---- per-wave reduction of the scalar tallies: one fp64 atomic per wave, not per exit ----
@@ -670,15 +734,41 @@ __global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams
   }
 }
 
+// xyz[pix] += cmf * mono[pix]; mono[pix] = 0 — closes a discrete-wavelength session (see MONO above).
+__global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ mono, uint32_t n_pix,
+                                                            float cx, float cy, float cz) {
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += stride) {
+    const float v = mono[i];
+    if (v != 0.0f) {
+      mono[i] = 0.0f;
+      xyz[3u * i + 0u] += cx * v;
+      xyz[3u * i + 1u] += cy * v;
+      xyz[3u * i + 2u] += cz * v;
+    }
+  }
+}
+
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, cx, cy, cz);
+  return hipGetLastError();
+}
+
 // host-callable launcher (halo_backend.cpp is plain C++ and never sees <<<>>>)
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool) {
+template <bool CAPTURE, bool POOL>
+static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
+  if (mono) hipLaunchKernelGGL((halo_trace_kernel<CAPTURE, POOL, true>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((halo_trace_kernel<CAPTURE, POOL, false>), grid, block, 0, stream, P);
+}
+
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono) {
   dim3 grid(blocks), block(kBlock);
   if (capture) {
-    if (pool) hipLaunchKernelGGL((halo_trace_kernel<true, true>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((halo_trace_kernel<true, false>), grid, block, 0, stream, P);
+    if (pool) launch_mono<true, true>(P, grid, block, stream, mono);
+    else launch_mono<true, false>(P, grid, block, stream, mono);
   } else {
-    if (pool) hipLaunchKernelGGL((halo_trace_kernel<false, true>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((halo_trace_kernel<false, false>), grid, block, 0, stream, P);
+    if (pool) launch_mono<false, true>(P, grid, block, stream, mono);
+    else launch_mono<false, false>(P, grid, block, stream, mono);
   }
   return hipGetLastError();
 }

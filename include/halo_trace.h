@@ -196,7 +196,8 @@ int halo_destroy(halo_handle_t h);
 const char* halo_last_error(halo_handle_t h);
 /* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
  * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams),
- * "chunk" (max rays per kernel launch), "aggregate" (LDS hot-pixel cache 0/1). */
+ * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
+ * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "blocks_per_cu". */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
 int halo_set_stream(halo_handle_t h, void* hip_stream);

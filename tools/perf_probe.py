@@ -1,0 +1,39 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ice_halo_sim_amd import abi, scenes
+from ice_halo_sim_amd.backend import HipTraceBackend
+from tests._oracle_backend import run_session
+
+def run(label, sc, rd, n=10_000_000, reps=3, wl=550.0, **opts):
+    hb = HipTraceBackend(device=0, seed=42, **opts)
+    ms = []
+    for r in range(reps):
+        st = run_session(hb, sc, rd, scenes.wl_discrete(wl), n)
+        ms.append(sum(s.kernel_ms for s in st))
+    hb.close()
+    best = min(ms)
+    print("%-46s kernel %8.3f ms  %8.1f M rays/s" % (label, best, n / best / 1e3), flush=True)
+    return best
+
+sc = scenes.config2_scene()
+rd = scenes.config2_render()
+which = sys.argv[1:] or ["base"]
+if "base" in which:
+    run("config2 1920x1080 upper (default)", sc, rd)
+    run("  no accumulation (aggregate=2)", sc, rd, aggregate=2)
+    run("  aggregate=0 mono=1", sc, rd, aggregate=0)
+    run("  aggregate=1 mono=0", sc, rd, mono=0)
+    run("  aggregate=0 mono=0 (old)", sc, rd, aggregate=0, mono=0)
+    run("  visible full", sc, scenes.render(1, 1920, 1080, fov=180, el=30, visible=abi.VISIBLE_FULL))
+    run("  512x256", sc, scenes.config2_render(512, 256))
+    run("  blocks_per_cu=4", sc, rd, blocks_per_cu=4)
+    run("  blocks_per_cu=16", sc, rd, blocks_per_cu=16)
+    run("  n=50M", sc, rd, n=50_000_000, reps=2)
+    sc_fs = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith={"type": "uniform", "mean": 90, "std": 360}, azimuth={"type": "uniform", "mean": 0, "std": 360}))])], max_hits=7)
+    run("  full-sphere orientation", sc_fs, rd)
+    run("  full-sphere, no accumulation", sc_fs, rd, aggregate=2)
+if "ms" in which:
+    run("config3 multi-scatter 10M", scenes.config3_scene(), rd)
+if "stoch" in which:
+    run("stochastic prism 4M", scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8), scenes.render(7, 2048, 1024, el=0, visible=2), n=4_000_000)
