@@ -1,0 +1,238 @@
+"""Pin the oracle (and the product's host exports) against the golden vectors the reference's own tests hold
+(tests/golden/ref_test_vectors.json) and against the committed fixture generated from the reference's shared
+headers (tests/golden/ref_shared_fixture.npz).  Runs anywhere — no /root/reference, no GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, backend, scenes
+from tests import _libs
+from tests._libs import HoStream, bits, fptr, i32ptr
+from tests._oracle_backend import OracleBackend, run_session
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+V = json.load(open(os.path.join(HERE, "golden", "ref_test_vectors.json")))
+FX = np.load(os.path.join(HERE, "golden", "ref_shared_fixture.npz"))
+
+
+# ---------------------------------------------------------------- reference-test golden vectors
+def test_refractive_index_known_values():
+    O, L = _libs.oracle(), backend.load_library()
+    g = V["ice_refractive_index"]
+    for wl, n in g["cases"]:
+        assert abs(O.ho_ice_refractive_index(wl) - n) < g["tolerance"]
+        assert abs(L.halo_host_refractive_index(wl) - n) < g["tolerance"]
+    for wl in g["out_of_range_returns_1"]:
+        assert O.ho_ice_refractive_index(wl) == 1.0 and L.halo_host_refractive_index(wl) == 1.0
+
+
+def test_reflect_ratio_known_values():
+    O = _libs.oracle()
+    g = V["reflect_ratio"]["normal_incidence"]
+    r = O.ho_reflect_ratio(g["delta"], g["rr"])
+    n = np.float32(g["rr"])
+    assert abs(r - ((n - 1) / (n + 1)) ** 2) < 1e-5 and abs(r - g["expected"]) < g["tolerance"]
+    k = V["reflect_ratio"]["known_values"]
+    sq = np.sqrt(np.float32(k["delta"]))
+    rs = ((np.float32(k["rr"]) - sq) / (np.float32(k["rr"]) + sq)) ** 2
+    rp = ((1 - np.float32(k["rr"]) * sq) / (1 + np.float32(k["rr"]) * sq)) ** 2
+    assert abs(O.ho_reflect_ratio(k["delta"], k["rr"]) - (rs + rp) / 2) < 1e-5
+
+
+def test_build_crystal_rotation_poses():
+    O = _libs.oracle()
+    g = V["build_crystal_rotation"]
+    for c in g["cases"]:
+        m = np.zeros(9, np.float32)
+        O.ho_build_crystal_rotation_9(np.deg2rad(c["az"]), np.deg2rad(90.0 - c["zenith"]), np.deg2rad(c["roll"]), fptr(m))
+        R = m.reshape(3, 3)
+        assert np.abs(R @ [0, 0, 1] - c["n1"]).max() < g["tolerance"]
+        assert np.abs(R @ [1, 0, 0] - c["n3"]).max() < g["tolerance"]
+
+
+def _partition(fn, prop, n, carry):
+    p = np.asarray(prop, np.float32)
+    out = np.zeros(len(prop), np.uint64)
+    fn(fptr(p), len(prop), n, carry.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_partition_reference_cases(which):
+    fn = _libs.oracle().ho_partition if which == "oracle" else backend.load_library().halo_host_partition
+    g = V["partition_crystal_ray_num"]
+    for c in g["exact"]:
+        carry = np.zeros(len(c["proportions"]))
+        assert list(_partition(fn, c["proportions"], c["ray_num"], carry)) == c["expected"]
+        if "carry" in c:
+            assert list(carry) == c["carry"]
+    for c in g["sum_and_min"]:
+        out = _partition(fn, c["proportions"], c["ray_num"], np.zeros(len(c["proportions"])))
+        assert out.sum() == c["sum"]
+        if "min_first_n" in c:
+            assert (out[: c["min_first_n"][0]] >= c["min_first_n"][1]).all()
+        if "last_at_least" in c:
+            assert out[-1] >= c["last_at_least"]
+    c = g["carry_range"]
+    carry = np.zeros(3)
+    assert _partition(fn, c["proportions"], c["ray_num"], carry).sum() == c["sum"]
+    assert (carry >= c["carry_min"]).all() and (carry < c["carry_max_exclusive"]).all()
+    c = g["cross_batch"]
+    carry = np.zeros(10)
+    tot = np.zeros(10, np.uint64)
+    for b in range(c["position_batches"]):
+        out = _partition(fn, c["proportions"], c["ray_num"], carry)
+        assert out.sum() == c["ray_num"]
+        tot += out
+        if b + 1 == c["fairness_batches"]:
+            assert (tot[:9] > 0).all()
+    assert tot[:9].max() - tot[:9].min() <= c["max_spread_equal_entries"]
+
+
+def test_fov_scale_anchors():
+    O = _libs.oracle()
+    for c in V["fov_scale"]["cases"]:
+        cfg = scenes.render(c["lens"], c["width"], c["height"], fov=c["fov"], az=0.0, el=90.0, ro=0.0, visible=abi.VISIBLE_FULL)
+        pp = abi.ProjParams()
+        O.ho_build_proj_params(C.byref(cfg), C.byref(pp))
+        # optical axis in world space: the exit direction that lands on the image centre is -R*(0,0,1)
+        R = np.frombuffer(pp.rot, np.float32).reshape(3, 3)
+        axis = R @ np.array([0, 0, 1.0])
+        side = R @ np.array([1.0, 0, 0])
+        t = np.deg2rad(c["off_axis_deg"])
+        sky = np.cos(t) * axis + np.sin(t) * side
+        hit = O.ho_project_exit_to_pixel(C.byref(pp), float(-sky[0]), float(-sky[1]), float(-sky[2]))
+        assert hit.count == 1
+        r = np.hypot(hit.hits[0].px - c["width"] / 2, hit.hits[0].py - c["height"] / 2)
+        assert abs(r - c["radius_px"]) <= c["tolerance"] + 0.5
+        ctr = O.ho_project_exit_to_pixel(C.byref(pp), float(-axis[0]), float(-axis[1]), float(-axis[2]))
+        assert (ctr.hits[0].px, ctr.hits[0].py) == (c["width"] // 2, c["height"] // 2)
+
+
+def test_golden_rays_on_the_oracle():
+    g = V["golden_rays"]
+    n_idx = np.float32(_libs.oracle().ho_ice_refractive_index(550.0))
+
+    def T(cos_i, rr):
+        dd = (1 - rr * rr) / (cos_i * cos_i) + rr * rr
+        sq = np.sqrt(dd)
+        return 1 - 0.5 * (((rr - sq) / (rr + sq)) ** 2 + ((1 - rr * sq) / (1 + rr * sq)) ** 2)
+
+    for c in g["cases"] + [g["energy"]]:
+        sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.0), scenes.axis())])], max_hits=c["max_hits"])
+        rd = scenes.render(abi.LENS_RECTANGULAR, 64, 32, visible=abi.VISIBLE_FULL)
+        ob = OracleBackend(seed=42, capture_exits=1)
+        ob.BeginSession(sc, rd, scenes.wl_discrete(550.0), 1)
+        th = np.deg2rad(c["theta_deg"])
+        s, co = np.float32(np.sin(th)), np.float32(np.cos(th))
+        ob.TraceLayer(host_rays=([[s, 0, -co]], [[0, 0, 0.5]], [1.0], [0]))
+        ex = ob.DrainExits()
+        ob.EndSession()
+        assert len(ex) >= 2 and (ex["weight"] >= 0).all()
+        if "sum_w_max" in c:
+            assert ex["weight"].sum(dtype=np.float64) <= c["sum_w_max"]
+            continue
+        sin_in = s / n_idx
+        t_in, t_out = T(co, 1 / n_idx), T(np.sqrt(1 - sin_in * sin_in), n_idx)
+        up = ex[np.argmax(ex["dir"] @ np.array([s, 0, co], np.float32))]
+        down = ex[np.argmax(ex["dir"] @ np.array([s, 0, -co], np.float32))]
+        assert np.abs(up["dir"] - [s, 0, co]).max() < g["direction_tolerance"]
+        assert np.abs(down["dir"] - [s, 0, -co]).max() < g["direction_tolerance"]
+        assert abs(up["weight"] - (1 - t_in)) < g["weight_tolerance"]
+        assert abs(down["weight"] - t_in * t_out) < g["weight_tolerance"]
+
+
+def test_regular_prism_and_reference_measurements():
+    O = _libs.oracle()
+    g = V["regular_prism"]
+    cx, cy, present = np.zeros(12, np.float32), np.zeros(12, np.float32), np.zeros(8, np.int32)
+    n = O.ho_prism_corner_ring(g["h"], fptr(np.asarray(g["dist"], np.float32)), fptr(cx), fptr(cy), i32ptr(present))
+    assert n == g["corner_count"] and present.sum() == g["faces_present"]
+    assert np.allclose(np.hypot(cx[:6], cy[:6]), 0.5, atol=1e-6)  # circumradius 0.5 (diameter 1)
+    n0 = O.ho_prism_corner_ring(0.0, fptr(np.ones(6, np.float32)), fptr(cx), fptr(cy), i32ptr(present))
+    assert n0 == 0 and present.sum() == g["zero_height_present"]
+    m = V["reference_measurements"]
+    ob = OracleBackend(seed=42, threads=4)
+    st = run_session(ob, scenes.config2_scene(), scenes.config2_render(96, 54), scenes.wl_discrete(550.0), 60_000)[0]
+    assert abs(st.exit_count / 60_000 - m["exits_per_root_column_max_hits_7"]) < m["tolerance"]
+    ob2 = OracleBackend(seed=42, threads=4)
+    st2 = run_session(ob2, scenes.config3_scene(), scenes.config2_render(96, 54), scenes.wl_discrete(550.0), 30_000)
+    assert abs(st2[0].continuation_count / 30_000 - m["continuation_amplification_config3"]) < 0.15
+
+
+# ---------------------------------------------------------------- fixture generated from the reference's headers
+def test_fixture_pcg_and_streams():
+    O = _libs.oracle()
+    assert [O.ho_pcg_hash(int(v)) for v in FX["hash_in"]] == list(FX["hash_out"])
+    for (s, g), uni, ga in zip(FX["stream_seeds"], FX["stream_uniform8"], FX["stream_gauss_after8"]):
+        st = HoStream(int(s), int(g), 0)
+        got = [O.ho_pcg_uniform(C.byref(st)) for _ in range(8)]
+        assert (bits(got) == uni.view(np.uint32)).all()
+        assert bits(O.ho_pcg_gaussian(C.byref(st))) == bits(ga)
+    for (a, b, c, d), adv, sd in zip(FX["hi_in"], FX["hi_adv"], FX["hi_seed"]):
+        assert O.ho_pcg_advance_hi(int(a), int(b), int(c)) == adv and O.ho_pcg_seed_with_high(int(d), int(b)) == sd
+    for (s, g), row, out in zip(FX["getdist_seed"], FX["getdist_in"], FX["getdist_out"]):
+        st = HoStream(int(s), int(g), 0)
+        assert bits(O.ho_pcg_get_dist(C.byref(st), int(row[0]), float(row[1]), float(row[2]))) == bits(out)
+        assert st.slot == int(row[3])
+
+
+def test_fixture_rotation_samplers_optics():
+    O = _libs.oracle()
+    for ang, m, v, inv in zip(FX["rot_angles"], FX["rot_mat9"], FX["rot_vec"], FX["rot_inv"]):
+        got = np.zeros(9, np.float32)
+        O.ho_build_crystal_rotation_9(float(ang[0]), float(ang[1]), float(ang[2]), fptr(got))
+        assert (got.view(np.uint32) == m.view(np.uint32)).all()
+        o = np.zeros(3, np.float32)
+        O.ho_apply_inverse_mat9(fptr(got), fptr(np.ascontiguousarray(v)), fptr(o))
+        assert (o.view(np.uint32) == inv.view(np.uint32)).all()
+    for (s, g), tv, tp, ci, cd in zip(FX["tc_seed"], FX["tri_v"], FX["tri_p"], FX["cap_in"], FX["cap_d"]):
+        st = HoStream(int(s), int(g), 0)
+        p = np.zeros(3, np.float32)
+        O.ho_sample_triangle(C.byref(st), fptr(np.ascontiguousarray(tv)), fptr(p))
+        assert (p.view(np.uint32) == tp.view(np.uint32)).all()
+        O.ho_sample_sph_cap(C.byref(st), float(ci[0]), float(ci[1]), float(ci[2]), fptr(p))
+        assert (p.view(np.uint32) == cd.view(np.uint32)).all()
+    for w, u, out in zip(FX["cat_w"], FX["cat_u"], FX["cat_out"]):
+        assert O.ho_categorical_sample(fptr(np.ascontiguousarray(w)), 20, float(u)) == out
+    for i, n, seed, out in FX["feistel"]:
+        assert O.ho_feistel_bijection(int(i), int(n), int(seed)) == out
+    for (a, b), out in zip(FX["fresnel_in"], FX["fresnel_out"]):
+        assert bits(O.ho_reflect_ratio(float(a), float(b))) == bits(out)
+    for r, out in zip(FX["slab_in"], FX["slab_out"]):
+        got = O.ho_slab_face_t(fptr(np.ascontiguousarray(r[0:3])), fptr(np.ascontiguousarray(r[3:6])), fptr(np.ascontiguousarray(r[6:9])), float(r[9]))
+        assert bits(got) == bits(out)
+
+
+def test_fixture_lut_lookup_projection_cmf_prism_pool():
+    O = _libs.oracle()
+    th, cdf = np.ascontiguousarray(FX["lut_theta"]), np.ascontiguousarray(FX["lut_cdf"])
+    for xi, inv, b in zip(FX["lut_xi"], FX["lut_inv"], FX["lut_bin"]):
+        got = O.ho_invert_lat_lut(float(xi), fptr(th), fptr(cdf), 257)
+        assert bits(got) == bits(inv) and O.ho_lat_lut_bin(got, fptr(th), 257) == b
+    for v, (po, fl) in zip(FX["normlat_in"], FX["normlat_out"]):
+        a, f = C.c_float(), C.c_int()
+        O.ho_normalize_latitude(float(v), C.byref(a), C.byref(f))
+        assert bits(a.value) == bits(po) and f.value == int(fl)
+    dirs = FX["proj_dirs"]
+    for raw, outs in zip(FX["proj_params"], FX["proj_out"]):
+        pp = abi.ProjParams.from_buffer_copy(raw.tobytes())
+        for d, exp in zip(dirs, outs):
+            h = O.ho_project_exit_to_pixel(C.byref(pp), float(d[0]), float(d[1]), float(d[2]))
+            assert h.count == exp[0]
+            for k in range(h.count):
+                assert (h.hits[k].px, h.hits[k].py, h.hits[k].bump_landed) == tuple(exp[1 + 3 * k: 4 + 3 * k])
+    for wl, xyz in zip(FX["cmf_wl"], FX["cmf_xyz"]):
+        x, y, z = C.c_float(), C.c_float(), C.c_float()
+        O.ho_cmf(float(wl), C.byref(x), C.byref(y), C.byref(z))
+        assert (bits([x.value, y.value, z.value]) == xyz.view(np.uint32)).all()
+    # the reference's well-conditioned prism pool: closed form agrees with the exact-integer oracle on every sample
+    # (test_closed_form_prism.cpp:246-299 WellConditionedThreeWayAgreement)
+    for dist, verdict in zip(FX["prism_pool_dist"], FX["prism_pool_exact"]):
+        cx, cy, present = np.zeros(12, np.float32), np.zeros(12, np.float32), np.zeros(8, np.int32)
+        n = O.ho_prism_corner_ring(1.0, fptr(np.ascontiguousarray(dist)), fptr(cx), fptr(cy), i32ptr(present))
+        assert verdict[1] == 0 and n == verdict[0]
+        assert [bool(p) for p in present[2:8]] == [bin(int(m)).count("1") >= 2 for m in verdict[2:8]]
