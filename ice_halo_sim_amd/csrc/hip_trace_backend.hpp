@@ -1,0 +1,102 @@
+// hip_trace_backend.hpp — C++ adapter: the C ABI of include/halo_trace.h presented with the method set, state
+// machine and error behaviour of `lumice::TraceBackend` (reference src/core/backend/trace_backend.hpp:367-641).
+//
+// Header-only, depends on nothing but <stdexcept>/<vector> and halo_trace.h, so it compiles in this repo (see
+// tests/test_cpp_adapter.py) AND inside a Lumice checkout.  There, INTEGRATION.md shows the 30-line glue that
+// derives from the real `lumice::TraceBackend`, converts SceneConfig/RenderConfig → HaloScene/HaloRender and
+// forwards to this class; nothing here includes reference headers.
+#ifndef HALO_HIP_TRACE_BACKEND_HPP_
+#define HALO_HIP_TRACE_BACKEND_HPP_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/halo_trace.h"
+
+namespace halo {
+
+// Mirrors lumice::BackendUnavailableError (trace_backend.hpp:140-158): the ONE recoverable error; the caller drops
+// the backend for the rest of Run() and re-runs the wavelength on the legacy CPU path (simulator.cpp:1049-1062).
+class BackendUnavailableError : public std::runtime_error {
+ public:
+  using std::runtime_error::runtime_error;
+};
+
+struct XyzImageData {  // trace_backend.hpp:356-360
+  float* data = nullptr;
+  int width = 0;
+  int height = 0;
+};
+
+struct LayerHandle {  // trace_backend.hpp:309-333 (value type here: the device state lives in the backend)
+  HaloLayerStats stats{};
+  size_t ContinuationCount() const { return static_cast<size_t>(stats.continuation_count); }
+};
+
+class HipTraceBackend {
+ public:
+  // CreateBackend(BackendKind::kHip): simulator.cpp:854-919.  seed = effective_seed_ (non-zero).
+  explicit HipTraceBackend(int device_ordinal = 0, uint32_t seed = 1) {
+    int rc = halo_create(device_ordinal, seed, &h_);
+    if (rc == HALO_UNAVAILABLE) throw BackendUnavailableError("halo: no usable gfx950 device");
+    if (rc != HALO_OK) throw std::runtime_error("halo_create failed");
+  }
+  ~HipTraceBackend() { halo_destroy(h_); }
+  HipTraceBackend(const HipTraceBackend&) = delete;
+  HipTraceBackend& operator=(const HipTraceBackend&) = delete;
+
+  void SetOption(const char* key, int64_t value) { Check(halo_set_option(h_, key, value)); }
+
+  // --- the seam ---------------------------------------------------------------------------------------------
+  void BeginSession(const HaloScene& scene, const HaloRender& render, const HaloWl& wl, size_t ray_num = 0) {
+    Check(halo_begin(h_, &scene, &render, &wl, ray_num));
+    width_ = render.width;
+    height_ = render.height;
+  }
+  // First call: host mode (count roots generated on device, or injected golden rays); later calls consume the
+  // continuation returned by Recombine (trace_backend.hpp:380-389).
+  LayerHandle TraceLayer(size_t count, const HaloHostRays* host = nullptr) {
+    LayerHandle lh;
+    Check(halo_trace_layer(h_, count, host, &lh.stats));
+    return lh;
+  }
+  size_t Recombine(const LayerHandle&, bool shuffle = true) {
+    uint64_t n = 0;
+    Check(halo_recombine(h_, shuffle ? 1 : 0, &n));
+    return static_cast<size_t>(n);
+  }
+  // Device-accumulating backend: DrainExits returns 0 records in production (trace_backend.hpp:430-448); with the
+  // "capture_exits" option (tests) it returns the captured records.
+  size_t DrainExits(std::vector<HaloExitRecord>& out, size_t max_records = 0) {
+    uint64_t n = 0;
+    out.resize(max_records);
+    Check(halo_drain_exits(h_, max_records ? out.data() : nullptr, max_records, &n));
+    out.resize(static_cast<size_t>(n < max_records ? n : max_records));
+    return out.size();
+  }
+  bool SupportsDeviceXyzAccum() const { return true; }
+  bool SupportsThirdClockDrain() const { return true; }  // accumulator persists across sessions (cu:4801-4808)
+  uint32_t WlPoolSize() const { return 64; }             // illuminant mode: per-ray pool (wl_pool.hpp:41)
+  // Adds into landed_weight, copies W*H*3 floats, zeroes the device accumulator (trace_backend.hpp:461-469).
+  void ReadbackXyzAccum(XyzImageData& xyz, float& landed_weight) {
+    Check(halo_readback_xyz(h_, xyz.data, xyz.width, xyz.height, &landed_weight));
+  }
+  void EndSession() { Check(halo_end(h_)); }
+  bool IsCompatible(const HaloRender& render) const { return render.width > 0 && render.height > 0; }
+
+ private:
+  void Check(int rc) {
+    if (rc == HALO_OK) return;
+    std::string msg = halo_last_error(h_);
+    if (rc == HALO_UNAVAILABLE) throw BackendUnavailableError(msg);
+    throw std::runtime_error(msg);
+  }
+  halo_handle_t h_ = nullptr;
+  int width_ = 0, height_ = 0;
+};
+
+}  // namespace halo
+
+#endif

@@ -1,0 +1,62 @@
+// Exercises ice_halo_sim_amd/csrc/hip_trace_backend.hpp the way Simulator::SimulateOneWavelengthWithBackend drives a
+// backend (reference simulator.cpp:1498-1632).  Exit codes: 0 ok, 3 BackendUnavailableError (no gfx950), 1 failure.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../ice_halo_sim_amd/csrc/hip_trace_backend.hpp"
+
+int main() {
+  try {
+    halo::HipTraceBackend be(0, 42);
+    HaloScene sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.sun_altitude = 20.0f;
+    sc.sun_diameter = 0.5f;
+    sc.max_hits = 7;
+    sc.layer_count = 1;
+    sc.layers[0].prob = 0.0f;
+    sc.layers[0].entry_count = 1;
+    HaloEntry& e = sc.layers[0].entries[0];
+    e.crystal.kind = HALO_CRYSTAL_PRISM;
+    e.crystal.height[0] = {HALO_DIST_NONE, 1.3f, 0.0f};
+    for (int i = 0; i < 6; i++) e.crystal.face_dist[i] = {HALO_DIST_NONE, 1.0f, 0.0f};
+    e.axis.azimuth = {HALO_DIST_UNIFORM, 0.0f, 360.0f};
+    e.axis.latitude = {HALO_DIST_GAUSS, 0.0f, 0.3f};
+    e.axis.roll = {HALO_DIST_UNIFORM, 0.0f, 360.0f};
+    e.proportion = 1.0f;
+    e.crystal_config_id = 3;
+    HaloRender rd;
+    std::memset(&rd, 0, sizeof(rd));
+    rd.lens_type = HALO_LENS_FISHEYE_EQUAL_AREA;
+    rd.fov = 180.0f;
+    rd.width = 320;
+    rd.height = 180;
+    rd.view_el = 30.0f;
+    rd.visible = HALO_VISIBLE_UPPER;
+    HaloWl wl = {550.0f, 1.0f, -1, 0};
+    const size_t n = 100000;
+    be.BeginSession(sc, rd, wl, n);
+    halo::LayerHandle lh = be.TraceLayer(n);
+    std::vector<HaloExitRecord> none;
+    size_t drained = be.DrainExits(none);
+    be.EndSession();
+    std::vector<float> img(static_cast<size_t>(rd.width) * rd.height * 3);
+    halo::XyzImageData xyz{img.data(), rd.width, rd.height};
+    float landed = 0.0f;
+    be.ReadbackXyzAccum(xyz, landed);  // after EndSession: third-clock drain
+    double y = 0.0;
+    for (size_t i = 1; i < img.size(); i += 3) y += img[i];
+    std::printf("roots %llu exits %llu landed %.3f sumY %.3f drained %zu\n", (unsigned long long)lh.stats.root_count,
+                (unsigned long long)lh.stats.exit_count, landed, y, drained);
+    bool ok = lh.stats.root_count == n && drained == 0 && landed > 0.4f * n && landed < n && std::fabs(y / (0.995 * landed) - 1.0) < 0.02;
+    return ok ? 0 : 1;
+  } catch (const halo::BackendUnavailableError& e) {
+    std::printf("BackendUnavailableError: %s\n", e.what());
+    return 3;
+  } catch (const std::exception& e) {
+    std::printf("error: %s\n", e.what());
+    return 1;
+  }
+}
