@@ -37,6 +37,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
+            if os.environ.get("HALO_MIN_WAVES"):
+                cmd.append("-DHALO_MIN_WAVES=" + os.environ["HALO_MIN_WAVES"])
             if os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast
                 cmd.append("-ffp-contract=" + os.environ["HALO_FP_CONTRACT"])
         else:  # host tables must round like the reference's host build: no FMA contraction

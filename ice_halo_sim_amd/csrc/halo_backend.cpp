@@ -259,9 +259,10 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   for (int l = 0; l < scene->layer_count; l++) {
     if (scene->layers[l].entry_count < 1 || scene->layers[l].entry_count > HALO_MAX_ENTRIES)
       return fail(b, HALO_FATAL, "entry_count out of range");
-    for (int e = 0; e < scene->layers[l].entry_count; e++)
-      if (scene->layers[l].entries[e].crystal.kind != HALO_CRYSTAL_PRISM)
-        return fail(b, HALO_UNAVAILABLE, "pyramid crystals are not supported by this backend yet");
+    for (int e = 0; e < scene->layers[l].entry_count; e++) {
+      const int kind = scene->layers[l].entries[e].crystal.kind;
+      if (kind != HALO_CRYSTAL_PRISM && kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
+    }
   }
   HIPCHK(b, hipSetDevice(b->device));
   b->scene = *scene;

@@ -81,6 +81,7 @@ float Pcg::Get(const HaloDist& d) {  // RandomNumberGenerator::Get math.cpp:418-
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr double kPiD = 3.14159265358979323846;
 // exact 60-degree direction tables (geo3d_closedform.hpp:48-52)
 constexpr double kCos6[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
 constexpr double kS = 0.86602540378443864676;
@@ -244,9 +245,159 @@ bool BuildPrism(float h, const float dist[6], HaloGeomTables& out) {
   return out.face_cnt > 0;
 }
 
-bool BuildPyramid(float, float, float, float, float, const float*, HaloGeomTables& out) {
+// ---------------------------------------------------------------------------------------------------
+// pyramid family (Crystal::CreatePyramid crystal.cpp:379-426).  Plane set, cone slope, wedge legality and the
+// basal cut follow the reference (FillHexCrystalCoef geo3d.cpp:346-512; ComputeClosedFormPyramid
+// geo3d_closedform.cpp:1404-1420); the solid is assembled as a half-space intersection: every feasible
+// concurrence of three planes is a vertex, a face is the CCW-sorted set of vertices on its plane.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Plane {
+  double a = 0, b = 0, c = 0, d = 0;
+  double Eval(const double x[3]) const { return a * x[0] + b * x[1] + c * x[2] + d; }
+};
+
+bool Concurrence(const Plane& p, const Plane& q, const Plane& r, double out[3]) {
+  const double det = p.a * (q.b * r.c - q.c * r.b) - p.b * (q.a * r.c - q.c * r.a) + p.c * (q.a * r.b - q.b * r.a);
+  if (std::fabs(det) < 1e-9) return false;
+  const double dx = -p.d, dy = -q.d, dz = -r.d;
+  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) / det;
+  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) / det;
+  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) / det;
+  return true;
+}
+
+// extreme z over the feasible vertices of one cone's six planes = its natural apex
+bool ConeApexZ(const Plane* cone, double tol, int sign, double& z) {
+  bool found = false;
+  double x[3];
+  for (int i = 0; i < 6; i++)
+    for (int j = i + 1; j < 6; j++)
+      for (int k = j + 1; k < 6; k++) {
+        if (!Concurrence(cone[i], cone[j], cone[k], x)) continue;
+        bool ok = true;
+        for (int m = 0; m < 6 && ok; m++) ok = cone[m].Eval(x) <= tol;
+        if (!ok) continue;
+        if (!found || sign * x[2] > sign * z) z = x[2];
+        found = true;
+      }
+  return found;
+}
+
+}  // namespace
+
+bool BuildPyramid(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HaloGeomTables& out) {
   std::memset(&out, 0, sizeof(out));
-  return false;  // pyramid family: not built this round (scope table)
+  static const int kNumber[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
+  const bool upper = h1 > kFloatEps && wedge_u >= 0.1f && wedge_u <= 89.9f;
+  const bool lower = h3 > kFloatEps && wedge_l >= 0.1f && wedge_l <= 89.9f;
+  if (!upper && !lower && h2 < kFloatEps) return false;
+  const double k8 = static_cast<double>(kSqrt3) / 8.0, half = 0.5 * static_cast<double>(h2);
+  const double a1 = upper ? static_cast<double>(kSqrt3 / 4.0f) / std::tan(static_cast<double>(wedge_u) * static_cast<double>(kDegToRad)) : -1.0;
+  const double a2 = lower ? static_cast<double>(kSqrt3 / 4.0f) / std::tan(static_cast<double>(wedge_l) * static_cast<double>(kDegToRad)) : -1.0;
+  Plane raw[20], unit[20];
+  bool active[20] = {};
+  for (int i = 0; i < 6; i++) {
+    raw[2 + i] = {0.5 * kCos6[i], 0.5 * kSin6[i], 0.0, -k8 * static_cast<double>(dist[i])};
+    active[2 + i] = true;
+    if (upper) {
+      raw[8 + i] = {0.5 * a1 * kCos6[i], 0.5 * a1 * kSin6[i], k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
+      active[8 + i] = true;
+    }
+    if (lower) {
+      raw[14 + i] = {0.5 * a2 * kCos6[i], 0.5 * a2 * kSin6[i], -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
+      active[14 + i] = true;
+    }
+  }
+  double scale = std::fabs(half);
+  for (int s = 2; s < 20; s++) {
+    if (!active[s]) continue;
+    const double len = std::sqrt(raw[s].a * raw[s].a + raw[s].b * raw[s].b + raw[s].c * raw[s].c);
+    unit[s] = {raw[s].a / len, raw[s].b / len, raw[s].c / len, raw[s].d / len};
+    scale = std::fmax(scale, std::fabs(unit[s].d));
+  }
+  const double tol = 5.0 * static_cast<double>(kFloatEps) * std::fmax(scale, 1e-3);
+  double z_top = half, z_bot = -half, apex = 0.0;
+  if (upper) {
+    if (!ConeApexZ(unit + 8, tol, +1, apex)) return false;
+    z_top = half + static_cast<double>(h1) * (apex - half);
+  }
+  if (lower) {
+    if (!ConeApexZ(unit + 14, tol, -1, apex)) return false;
+    z_bot = -half + static_cast<double>(h3) * (apex + half);
+  }
+  raw[0] = unit[0] = {0.0, 0.0, 1.0, -z_top};
+  raw[1] = unit[1] = {0.0, 0.0, -1.0, z_bot};
+  active[0] = active[1] = true;
+
+  std::vector<std::array<double, 3>> verts;
+  for (int i = 0; i < 20; i++) {
+    if (!active[i]) continue;
+    for (int j = i + 1; j < 20; j++) {
+      if (!active[j]) continue;
+      for (int k = j + 1; k < 20; k++) {
+        if (!active[k]) continue;
+        double x[3];
+        if (!Concurrence(unit[i], unit[j], unit[k], x)) continue;
+        bool ok = true;
+        for (int m = 0; m < 20 && ok; m++)
+          if (active[m]) ok = unit[m].Eval(x) <= tol;
+        if (!ok) continue;
+        bool dup = false;
+        for (const auto& v : verts) {
+          const double dx = v[0] - x[0], dy = v[1] - x[1], dz = v[2] - x[2];
+          if (std::sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+            dup = true;
+            break;
+          }
+        }
+        if (!dup && verts.size() < 96) verts.push_back({x[0], x[1], x[2]});
+      }
+    }
+  }
+  std::vector<FaceLoop> faces(20);
+  int present = 0;
+  for (int s = 0; s < 20; s++) {
+    FaceLoop& f = faces[s];
+    f.number = kNumber[s];
+    if (!active[s]) continue;
+    f.plane[0] = static_cast<float>(raw[s].a);
+    f.plane[1] = static_cast<float>(raw[s].b);
+    f.plane[2] = static_cast<float>(raw[s].c);
+    f.plane[3] = static_cast<float>(raw[s].d);
+    f.normal[0] = static_cast<float>(unit[s].a);
+    f.normal[1] = static_cast<float>(unit[s].b);
+    f.normal[2] = static_cast<float>(unit[s].c);
+    std::vector<int> on;
+    for (size_t v = 0; v < verts.size(); v++)
+      if (std::fabs(unit[s].Eval(verts[v].data())) <= 2.0 * tol && on.size() < HALO_MAX_FACE_VTX) on.push_back(static_cast<int>(v));
+    if (on.size() < 3) continue;
+    double c[3] = {0, 0, 0};
+    for (int v : on)
+      for (int a = 0; a < 3; a++) c[a] += verts[v][a] / static_cast<double>(on.size());
+    const double n[3] = {unit[s].a, unit[s].b, unit[s].c};
+    double e1[3] = {verts[on[0]][0] - c[0], verts[on[0]][1] - c[1], verts[on[0]][2] - c[2]};
+    const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    if (l1 <= tol) continue;
+    for (double& e : e1) e /= l1;
+    const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+    std::vector<std::pair<double, int>> order;
+    for (size_t k = 0; k < on.size(); k++) {
+      const double r[3] = {verts[on[k]][0] - c[0], verts[on[k]][1] - c[1], verts[on[k]][2] - c[2]};
+      double ang = (k == 0) ? 0.0 : std::atan2(r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2]);
+      if (ang < 0.0) ang += 2.0 * kPiD;
+      order.emplace_back(ang, on[k]);
+    }
+    std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    f.present = true;
+    for (const auto& o : order)
+      f.loop.push_back({static_cast<float>(verts[o.second][0]), static_cast<float>(verts[o.second][1]), static_cast<float>(verts[o.second][2])});
+    present++;
+  }
+  if (present < 4) return false;  // IsValidClosedFormPyramid crystal.cpp:93-101
+  Tabulate(faces, out);
+  return out.face_cnt > 0;
 }
 
 void ToShapeDev(const HaloGeomTables& g, ShapeDev& s) {
@@ -314,7 +465,6 @@ bool MakeShape(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, HaloGe
 // latitude LUT (lat_lut.cpp:24-204)
 // ---------------------------------------------------------------------------------------------------
 namespace {
-constexpr double kPiD = 3.14159265358979323846;
 constexpr int kFine = 4096;
 constexpr int kQuad = 1 << 16;
 

@@ -45,6 +45,32 @@ HD float add_rn(float a, float b) {
   return r;
 }
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the inner-loop quotients whose last bit does
+// not steer a discrete decision; IEEE division costs ~10 VALU ops here and the loop had nine of them per hit.
+HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// sin and cos together for |x| below a few turns (every angle on this path is): two-term Cody-Waite reduction by
+// pi/2 with FMAs, then the classic degree-7 / degree-8 minimax kernels on [-pi/4, pi/4].  ~1 ulp; replaces the
+// library sincosf whose general-argument reduction dominated root generation.
+HD void sincos_small(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.6366197466850281f);
+  float r = fmaf(k, -1.5707963705062866f, x);
+  r = fmaf(k, 4.371138828673793e-08f, r);
+  const int q = static_cast<int>(k);
+  const float z = r * r;
+  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const bool swap = (q & 1) != 0;
+  float so = swap ? cp : sp;
+  float co = swap ? sp : cp;
+  so = (q & 2) ? -so : so;
+  co = ((q + 1) & 2) ? -co : co;
+  *sn = so;
+  *cs = co;
+}
+
 // ------------------------------------------------------------------------------------------------
 // counter-based RNG (pcg_shared.h:193-274)
 // ------------------------------------------------------------------------------------------------
@@ -149,7 +175,7 @@ HD float invert_lat_lut(float xi, const float* lut) {
   }
   float c0 = cdf[lo], c1 = cdf[lo + 1u];
   float denom = c1 - c0;
-  float w = denom > 0.0f ? (xi - c0) / denom : 0.0f;
+  float w = denom > 0.0f ? (xi - c0) * fast_rcp(denom) : 0.0f;
   return th[lo] + w * (th[lo + 1u] - th[lo]);
 }
 
@@ -196,9 +222,9 @@ HD void sample_lat_lon_roll(Stream& s, const DispatchParams& P, const float* lut
 // form the dense axis-angle / 3x3 chain reduces to; `k = (1 - c) + c` keeps the reference's diagonal term.
 HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
   float s1, c1, s2, c2, s3, c3;
-  sincosf(roll, &s1, &c1);
-  sincosf(lat - kPi2F, &s2, &c2);
-  sincosf(lon - kPiF, &s3, &c3);
+  sincos_small(roll, &s1, &c1);
+  sincos_small(lat - kPi2F, &s2, &c2);
+  sincos_small(lon - kPiF, &s3, &c3);
   float k1 = (1.0f - c1) + c1, k2 = (1.0f - c2) + c2, k3 = (1.0f - c3) + c3;
   // t = Ry * Rz(roll)
   float t00 = c2 * c1, t01 = c2 * (-s1), t02 = s2 * k1;
@@ -376,7 +402,7 @@ struct PixCache {
 template <bool MONO>
 HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, float w, float cx, float cy, float cz) {
   if (P.aggregate == 2u) return;  // diagnostic: trace + project only
-  if (P.aggregate == 1u) {
+  if (P.aggregate == 1u || P.aggregate == 3u) {
     const uint32_t slot = (pix * 2654435761u) >> (32 - kCacheLog2);
     const uint32_t key = pix + 1u;
     const uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
@@ -390,6 +416,7 @@ HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, flo
       }
       return;
     }
+    if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
     atomic_add_f32(P.mono + pix, w);
@@ -559,7 +586,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
     float r = sqrtf(fmaxf(add_rn(1.0f, -mul_rn(x, x)), 0.0f));
     float phi = uniform(s) * 2.0f * kPiF;
     float sp, cp;
-    sincosf(phi, &sp, &cp);
+    sincos_small(phi, &sp, &cp);
     float y = cp * r, z = sp * r;
     float dwx = P.c_lon * P.c_lat * x - P.s_lon * y - P.c_lon * P.s_lat * z;
     float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
@@ -594,7 +621,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
   if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
 
   const float n_idx = T.wl[wl_idx].n_idx;
-  const float inv_n = 1.0f / n_idx;
+  const float inv_n = 1.0f / n_idx;  // once per ray, IEEE like the reference
   const float cmf_x = T.wl[wl_idx].cmf_x, cmf_y = T.wl[wl_idx].cmf_y, cmf_z = T.wl[wl_idx].cmf_z;
 
   uint8_t path[CAPTURE ? HALO_PATH_CAP : 1];
@@ -606,12 +633,12 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
     const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
     const float rr = cos_t > 0.0f ? n_idx : inv_n;
-    const float dd = (1.0f - rr * rr) / (cos_t * cos_t) + rr * rr;
+    const float dd = (1.0f - rr * rr) * fast_rcp(cos_t * cos_t) + rr * rr;
     const bool tir = dd <= 0.0f;
-    const float sq = sqrtf(fmaxf(dd, 0.0f));
-    float Rs = (rr - sq) / (rr + sq);
+    const float sq = fast_sqrt(fmaxf(dd, 0.0f));
+    float Rs = (rr - sq) * fast_rcp(rr + sq);
     Rs *= Rs;
-    float Rp = (1.0f - rr * sq) / (1.0f + rr * sq);
+    float Rp = (1.0f - rr * sq) * fast_rcp(1.0f + rr * sq);
     Rp *= Rp;
     const float w_refl = (Rs + Rp) * 0.5f * w;
     const float w_refr = w - w_refl;
@@ -634,17 +661,20 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
     d[2] = entering ? rfz : rlz;
     w = entering ? w_refr : w_refl;
     // --- next face on the convex body (PropagateSlab optics.cpp:64-158) ---
-    float t_best = 1e30f;
+    // min over candidate faces of t = num/den (den > eps > 0) without dividing: num_i/den_i < num_b/den_b
+    // <=> num_i*den_b < num_b*den_i.  One reciprocal at the end.
+    float num_b = 1e30f, den_b = 1.0f;
     int hit = -1;
     for (int fi = 0; fi < face_cnt; ++fi) {
       const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
-      const float denom = d[0] * g.x + d[1] * g.y + d[2] * g.z;
+      const float den = d[0] * g.x + d[1] * g.y + d[2] * g.z;
       const float num = -(p[0] * g.x + p[1] * g.y + p[2] * g.z + g.w);
-      const float t = (denom > kSlabEps) ? num / denom : 1e30f;
-      const bool better = (fi != face) && (t < t_best);
-      t_best = better ? t : t_best;
+      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
+      num_b = better ? num : num_b;
+      den_b = better ? den : den_b;
       hit = better ? fi : hit;
     }
+    const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
       emit_gate<CAPTURE, MONO>(P, T.cache, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
@@ -668,9 +698,12 @@ HD float wave_sum(float v) {
 }
 
 template <bool CAPTURE, bool POOL, bool MONO>
-__global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams P) {
+#ifndef HALO_MIN_WAVES
+#define HALO_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
-  if (P.aggregate == 1u) {
+  if (P.aggregate == 1u || P.aggregate == 3u) {
     for (int i = threadIdx.x; i < kCacheN; i += kBlock) T.cache.tag[i] = 0u;
     for (int i = threadIdx.x; i < kCacheN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
   }
@@ -704,7 +737,7 @@ __global__ void __launch_bounds__(kBlock) halo_trace_kernel(const DispatchParams
     }
   }
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
-  if (P.aggregate == 1u) {
+  if (P.aggregate == 1u || P.aggregate == 3u) {
     __syncthreads();
     for (int i = threadIdx.x; i < kCacheN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];

@@ -66,6 +66,10 @@ class ShardedTracer:
     def reduce_to_root(self):
         self.landed += self.backend.take_landed()
         self.acc, self.landed = reduce_accumulators(self.acc, self.landed)
+        if self.world > 1:
+            # the collective (and the drain of non-root ranks) is stream-ordered inside torch only; the backend
+            # launches on its own stream, so fence on the host before the next trace touches the accumulator
+            self.torch.cuda.synchronize(self.device)
 
     def zero(self):
         self.backend.take_landed()

@@ -15,6 +15,34 @@ def prism_crystal(height=1.0, face_distance=None, sync_group=None):
     return c
 
 
+ICE_CRYSTAL_C = 1.629  # kIceCrystalC (reference src/core/crystal.hpp)
+
+
+def miller_wedge_deg(i1, i4):
+    """Crystal::CreatePyramid(Miller) → wedge angle (reference crystal.cpp:413-426): atan((sqrt3/2) * i4 / i1 / c)."""
+    import numpy as np
+    if i1 == 0:
+        return 0.0
+    return float(np.float32(np.arctan(np.float32(np.float32(1.73205080757) / 2) * i4 / i1 / np.float32(ICE_CRYSTAL_C))) * np.float32(180.0 / 3.14159265359))
+
+
+def pyramid_crystal(upper_h=0.2, prism_h=1.0, lower_h=0.2, upper_wedge=None, lower_wedge=None, face_distance=None,
+                    upper_miller=(1, 1), lower_miller=(1, 1), sync_group=None):
+    """PyramidCrystalParam: heights are fractions of the way from the shoulder to the natural apex; wedge angles in
+    degrees, or Miller indices (i1, i4) (doc/configuration.md; examples/config_example.json crystal id 5)."""
+    c = abi.HaloCrystal()
+    c.kind = abi.CRYSTAL_PYRAMID
+    c.height[0], c.height[1], c.height[2] = abi.dist(upper_h), abi.dist(prism_h), abi.dist(lower_h)
+    fd = face_distance if face_distance is not None else [1.0] * 6
+    for i in range(6):
+        c.face_dist[i] = abi.dist(fd[i])
+    for i in range(9):
+        c.sync_group[i] = 0 if sync_group is None else int(sync_group[i])
+    c.wedge_upper_deg = float(upper_wedge) if upper_wedge is not None else miller_wedge_deg(*upper_miller)
+    c.wedge_lower_deg = float(lower_wedge) if lower_wedge is not None else miller_wedge_deg(*lower_miller)
+    return c
+
+
 def axis(zenith=None, azimuth=None, roll=None):
     """JSON-convention axis → internal AxisDistribution (reference src/core/math.cpp:679-726):
     latitude = 90 - zenith (center only; spread kept); when the `axis` object is present, azimuth and roll

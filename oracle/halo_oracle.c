@@ -24,6 +24,7 @@
 #define LM_PI_F 3.14159265358979323846f
 #define LM_PI_2F 1.5707963267948966f
 
+static const double kPiD = 3.14159265358979323846;
 static float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); } /* std::clamp on finite input */
 
 /* ======================================================================================== */
@@ -534,7 +535,6 @@ void ho_build_proj_params(const HaloRender* cfg, HoProjParams* p) {
 /* ======================================================================================== */
 #define HO_LUT_FINE 4096
 #define HO_LUT_QUAD (1 << 16)
-static const double kPiD = 3.14159265358979323846;
 
 static double proposal_lat_from_u(int type, double mean_rad, double scale_rad, double u) { /* lat_lut.cpp:30-45 */
   switch (type) {
@@ -880,6 +880,190 @@ int ho_prism_corner_ring(float h, const float dist[6], float* cx, float* cy, int
   int n = prism_cf_geom(h, dist, &g, cx, cy);
   for (int i = 0; i < 8; i++) face_present8[i] = g.face_present[i];
   return n;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* pyramid family: Crystal::CreatePyramid crystal.cpp:379-426 → ComputeClosedFormPyramid      */
+/* geo3d_closedform.cpp:743-1460.  Same plane set and validity gates as the reference         */
+/* (FillHexCrystalCoef geo3d.cpp:346-512: basal, 6 prism, 6 upper-cone, 6 lower-cone planes,   */
+/* cone slope a = (sqrt3/4)/tan(wedge), legal wedge 0.1..89.9 deg, basal cut at fraction h1/h3  */
+/* of the way from the shoulder to the natural apex).  The solid itself is built as the generic */
+/* half-space intersection the reference's mesh builder used (plane triples in double, feasible */
+/* vertices, per-plane grouping, CCW ordering: math.cpp:938-1004,1173-1216) rather than by the   */
+/* closed-form event walk; on well-conditioned inputs both yield the same polytope, which the    */
+/* tests pin against the reference's topology goldens (vertex count + present-face mask).        */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct { double a, b, c, d; } HoPlane;
+
+static int solve3_planes(const HoPlane* p, const HoPlane* q, const HoPlane* r, double out[3]) {
+  /* Cramer on unit-normal planes; singular when the normals are (nearly) coplanar */
+  double det = p->a * (q->b * r->c - q->c * r->b) - p->b * (q->a * r->c - q->c * r->a) + p->c * (q->a * r->b - q->b * r->a);
+  if (fabs(det) < 1e-9) return 0;
+  double dx = -p->d, dy = -q->d, dz = -r->d;
+  out[0] = (dx * (q->b * r->c - q->c * r->b) - p->b * (dy * r->c - q->c * dz) + p->c * (dy * r->b - q->b * dz)) / det;
+  out[1] = (p->a * (dy * r->c - q->c * dz) - dx * (q->a * r->c - q->c * r->a) + p->c * (q->a * dz - dy * r->a)) / det;
+  out[2] = (p->a * (q->b * dz - dy * r->b) - p->b * (q->a * dz - dy * r->a) + dx * (q->a * r->b - q->b * r->a)) / det;
+  return 1;
+}
+
+/* max (sign=+1) or min (sign=-1) z over the feasible 3-plane concurrences of one cone's six planes: the natural apex */
+static int cone_apex_z(const HoPlane cone[6], double tol, int sign, double* z_out) {
+  int found = 0;
+  double best = 0.0, x[3];
+  for (int i = 0; i < 6; i++)
+    for (int j = i + 1; j < 6; j++)
+      for (int k = j + 1; k < 6; k++) {
+        if (!solve3_planes(&cone[i], &cone[j], &cone[k], x)) continue;
+        int ok = 1;
+        for (int m = 0; m < 6 && ok; m++)
+          if (cone[m].a * x[0] + cone[m].b * x[1] + cone[m].c * x[2] + cone[m].d > tol) ok = 0;
+        if (!ok) continue;
+        if (!found || sign * x[2] > sign * best) best = x[2];
+        found = 1;
+      }
+  *z_out = best;
+  return found;
+}
+
+typedef struct { double ang; int idx; } HoAngIdx;
+static int cmp_ang(const void* a, const void* b) {
+  double x = ((const HoAngIdx*)a)->ang, y = ((const HoAngIdx*)b)->ang;
+  return (x > y) - (x < y);
+}
+
+int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HoCfGeom* g,
+                        int* vtx_cnt_out) {
+  memset(g, 0, sizeof(*g));
+  if (vtx_cnt_out) *vtx_cnt_out = 0;
+  g->face_cnt = 20;
+  static const int kFaceNumber[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
+  for (int i = 0; i < 20; i++) g->face_number[i] = kFaceNumber[i];
+  const int has_upper = h1 > HO_FLOAT_EPS && wedge_u >= 0.1f && wedge_u <= 89.9f;
+  const int has_lower = h3 > HO_FLOAT_EPS && wedge_l >= 0.1f && wedge_l <= 89.9f;
+  if (!has_upper && !has_lower && h2 < HO_FLOAT_EPS) return 0; /* zero-volume guard geo3d.cpp:395-399 */
+  const double k8 = (double)HO_SQRT3_F / 8.0, h2_2 = 0.5 * (double)h2;
+  const double a1 = has_upper ? ((double)(HO_SQRT3_F / 4.0f)) / tan((double)wedge_u * (double)HO_DEG2RAD) : -1.0;
+  const double a2 = has_lower ? ((double)(HO_SQRT3_F / 4.0f)) / tan((double)wedge_l * (double)HO_DEG2RAD) : -1.0;
+  HoPlane raw[20];
+  int active[20] = {0};
+  for (int i = 0; i < 6; i++) {
+    raw[2 + i] = (HoPlane){0.5 * kHexFaceCos[i], 0.5 * kHexFaceSin[i], 0.0, -k8 * (double)dist[i]};
+    active[2 + i] = 1;
+    if (has_upper) {
+      raw[8 + i] = (HoPlane){0.5 * a1 * kHexFaceCos[i], 0.5 * a1 * kHexFaceSin[i], k8, -k8 * (h2_2 + a1 * (double)dist[i])};
+      active[8 + i] = 1;
+    }
+    if (has_lower) {
+      raw[14 + i] = (HoPlane){0.5 * a2 * kHexFaceCos[i], 0.5 * a2 * kHexFaceSin[i], -k8, -k8 * (h2_2 + a2 * (double)dist[i])};
+      active[14 + i] = 1;
+    }
+  }
+  /* unit-normal copies for distance-valued tolerances */
+  HoPlane unit[20];
+  double scale = fabs(h2_2);
+  for (int s = 2; s < 20; s++) {
+    if (!active[s]) continue;
+    double len = sqrt(raw[s].a * raw[s].a + raw[s].b * raw[s].b + raw[s].c * raw[s].c);
+    unit[s] = (HoPlane){raw[s].a / len, raw[s].b / len, raw[s].c / len, raw[s].d / len};
+    scale = fmax(scale, fabs(unit[s].d));
+  }
+  const double tol = 5.0 * (double)HO_FLOAT_EPS * fmax(scale, 1e-3);
+  double z_top = h2_2, z_bot = -h2_2;
+  if (has_upper) {
+    double z_apex;
+    if (!cone_apex_z(unit + 8, tol, +1, &z_apex)) return 0; /* empty feasible region geo3d.cpp:486-494 */
+    z_top = h2_2 + (double)h1 * (z_apex - h2_2);
+  }
+  if (has_lower) {
+    double z_apex;
+    if (!cone_apex_z(unit + 14, tol, -1, &z_apex)) return 0;
+    z_bot = -h2_2 + (double)h3 * (z_apex + h2_2);
+  }
+  raw[0] = unit[0] = (HoPlane){0.0, 0.0, 1.0, -z_top};
+  raw[1] = unit[1] = (HoPlane){0.0, 0.0, -1.0, z_bot};
+  active[0] = active[1] = 1;
+  /* vertices: feasible, de-duplicated concurrences of plane triples */
+  double vx[96][3];
+  int nv = 0;
+  for (int i = 0; i < 20; i++) {
+    if (!active[i]) continue;
+    for (int j = i + 1; j < 20; j++) {
+      if (!active[j]) continue;
+      for (int k = j + 1; k < 20; k++) {
+        if (!active[k]) continue;
+        double x[3];
+        if (!solve3_planes(&unit[i], &unit[j], &unit[k], x)) continue;
+        int ok = 1;
+        for (int m = 0; m < 20 && ok; m++)
+          if (active[m] && unit[m].a * x[0] + unit[m].b * x[1] + unit[m].c * x[2] + unit[m].d > tol) ok = 0;
+        if (!ok) continue;
+        int dup = 0;
+        for (int v = 0; v < nv && !dup; v++) {
+          double dx = vx[v][0] - x[0], dy = vx[v][1] - x[1], dz = vx[v][2] - x[2];
+          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = 1;
+        }
+        if (dup || nv >= 96) continue;
+        memcpy(vx[nv++], x, sizeof(x));
+      }
+    }
+  }
+  if (vtx_cnt_out) *vtx_cnt_out = nv;
+  /* faces: vertices lying on each plane, ordered CCW seen from outside */
+  int present_cnt = 0;
+  for (int s = 0; s < 20; s++) {
+    if (!active[s]) continue;
+    int on[HALO_MAX_FACE_VTX], n_on = 0;
+    for (int v = 0; v < nv; v++)
+      if (fabs(unit[s].a * vx[v][0] + unit[s].b * vx[v][1] + unit[s].c * vx[v][2] + unit[s].d) <= 2.0 * tol && n_on < HALO_MAX_FACE_VTX) on[n_on++] = v;
+    g->plane_coef[s * 4 + 0] = (float)raw[s].a;
+    g->plane_coef[s * 4 + 1] = (float)raw[s].b;
+    g->plane_coef[s * 4 + 2] = (float)raw[s].c;
+    g->plane_coef[s * 4 + 3] = (float)raw[s].d;
+    g->face_normal[s * 3 + 0] = (float)unit[s].a;
+    g->face_normal[s * 3 + 1] = (float)unit[s].b;
+    g->face_normal[s * 3 + 2] = (float)unit[s].c;
+    if (n_on < 3) continue;
+    double c[3] = {0, 0, 0};
+    for (int k = 0; k < n_on; k++) for (int a = 0; a < 3; a++) c[a] += vx[on[k]][a] / n_on;
+    double n[3] = {unit[s].a, unit[s].b, unit[s].c};
+    double e1[3] = {vx[on[0]][0] - c[0], vx[on[0]][1] - c[1], vx[on[0]][2] - c[2]};
+    double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    if (l1 <= tol) continue;
+    for (int a = 0; a < 3; a++) e1[a] /= l1;
+    double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+    HoAngIdx ord[HALO_MAX_FACE_VTX];
+    for (int k = 0; k < n_on; k++) {
+      double r[3] = {vx[on[k]][0] - c[0], vx[on[k]][1] - c[1], vx[on[k]][2] - c[2]};
+      ord[k].ang = (k == 0) ? 0.0 : atan2(r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2]);
+      if (ord[k].ang < 0.0) ord[k].ang += 2.0 * kPiD;
+      ord[k].idx = on[k];
+    }
+    qsort(ord, (size_t)n_on, sizeof(HoAngIdx), cmp_ang);
+    g->face_present[s] = 1;
+    g->face_vtx_cnt[s] = n_on;
+    float* base = g->face_vtx + (size_t)s * HALO_MAX_FACE_VTX * 3;
+    for (int k = 0; k < n_on; k++) for (int a = 0; a < 3; a++) base[k * 3 + a] = (float)vx[ord[k].idx][a];
+    present_cnt++;
+  }
+  return present_cnt;
+}
+
+int ho_pyramid_face_mask(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], int* vtx_cnt) {
+  HoCfGeom g;
+  ho_pyramid_topology(wedge_u, wedge_l, h1, h2, h3, dist, &g, vtx_cnt);
+  int mask = 0;
+  for (int s = 0; s < 20; s++) if (g.face_present[s]) mask |= 1 << s;
+  return mask;
+}
+
+void ho_pyramid_geometry(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HaloGeomTables* out) {
+  HoCfGeom g;
+  int present = ho_pyramid_topology(wedge_u, wedge_l, h1, h2, h3, dist, &g, NULL);
+  if (present < 4) { /* IsValidClosedFormPyramid crystal.cpp:93-101 */
+    memset(out, 0, sizeof(*out));
+    return;
+  }
+  cf_geom_to_tables(&g, out);
 }
 
 /* ======================================================================================== */
@@ -1402,8 +1586,13 @@ static void make_shape(const HoBackend* b, const HaloCrystal* cr, uint64_t shape
     float h = fabsf(sync_draw(&y, cr->sync_group[0], &cr->height[0]));
     for (int i = 0; i < 6; i++) dist[i] = sync_draw(&y, cr->sync_group[3 + i], &cr->face_dist[i]);
     ho_prism_geometry(h, dist, out);
-  } else {
-    memset(out, 0, sizeof(*out)); /* pyramid: not restated yet */
+  } else { /* SamplePyramidShapeScalars simulator.cpp:416-425 */
+    float dist[6];
+    float p1 = fabsf(sync_draw(&y, cr->sync_group[0], &cr->height[0]));
+    float p2 = fabsf(sync_draw(&y, cr->sync_group[1], &cr->height[1]));
+    float p3 = fabsf(sync_draw(&y, cr->sync_group[2], &cr->height[2]));
+    for (int i = 0; i < 6; i++) dist[i] = sync_draw(&y, cr->sync_group[3 + i], &cr->face_dist[i]);
+    ho_pyramid_geometry(cr->wedge_upper_deg, cr->wedge_lower_deg, p1, p2, p3, dist, out);
   }
 }
 

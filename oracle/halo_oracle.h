@@ -88,6 +88,8 @@ HoProjResult ho_project_exit_to_pixel(const HoProjParams* p, float wx, float wy,
 void ho_build_lat_lut(const HaloDist* lat, float* theta, float* cdf, float* flip);  /* lat_lut.cpp:74 */
 uint32_t ho_select_lat_path(const HaloAxis* axis);                                   /* lat_path_selection.hpp:62 */
 void ho_prism_geometry(float h, const float dist[6], HaloGeomTables* out);           /* geo3d_closedform.cpp:1318, crystal.cpp:109-347 */
+void ho_pyramid_geometry(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HaloGeomTables* out); /* crystal.cpp:379-426 */
+int ho_pyramid_face_mask(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], int* vtx_cnt); /* test hook: present-face bitmask */
 int ho_prism_corner_ring(float h, const float dist[6], float* cx, float* cy, int* face_present8); /* test hook */
 void ho_partition(const float* proportions, int n, uint64_t ray_num, double* carry, uint64_t* out); /* simulator.cpp:519 */
 float ho_illuminant_spd(int illuminant, float wavelength_nm);                        /* util/illuminant.cpp:113 */

@@ -207,6 +207,24 @@ def test_stochastic_geometry_and_wl_pool_parity():
     assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
 
 
+def test_pyramid_crystal_parity():
+    """examples/config_example.json crystal id 5 (pyramid, upper Miller (2,0,3)) + a stochastic pyramid entry."""
+    p5 = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3)), scenes.axis(zenith=0), 1.0, 5)
+    g = {"type": "gauss", "mean": 1.0, "std": 0.1}
+    ps = scenes.entry(scenes.pyramid_crystal({"type": "uniform", "mean": 0.3, "std": 0.2}, 1.0, 0.4, upper_wedge=35.0, lower_wedge=50.0,
+                                             face_distance=[g] * 6),
+                      scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 5}, roll={"type": "uniform", "mean": 0, "std": 360}), 1.0, 9)
+    sc = scenes.scene([(0.0, [p5, ps])], max_hits=8)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL, overlap=0.0872)
+    r = run_both(sc, rd, scenes.wl_discrete(490.0), 80_000, seed=5)
+    frac, pix, path = match_exits(r["eh"], r["eo"])
+    assert frac >= 0.998 and pix >= 0.995 and path >= 0.999
+    assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
+    assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
+    paths = set(int(v) for v in np.unique(r["eh"]["path"][:, 0]))
+    assert paths & {13, 14, 15, 16, 17, 18} and paths & {23, 24, 25, 26, 27, 28}  # pyramidal face numbers appear
+
+
 def test_multi_entry_layer_partition_parity():
     e1 = scenes.column_crystal_entry()
     e2 = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 0.8}), 5.0, 6)

@@ -122,3 +122,38 @@ def test_partition_sequences_and_refractive_index():
                 assert oa.sum() == rays  # exact total (reference test_simulator.cpp:38-233)
     for wl in np.linspace(300, 950, 261):
         assert L.halo_host_refractive_index(float(wl)) == O.ho_ice_refractive_index(float(wl))
+
+
+def test_pyramid_topology_matches_reference_goldens_and_oracle():
+    """The reference's fixed pyramid pools (closed_form_samples_generated.hpp) with its own topology goldens
+    (pyramid_topology_golden_generated.hpp: vertex count + present-face mask): the oracle must reproduce them, and the
+    product's tables must equal the oracle's bit for bit."""
+    L, O = backend.load_library(), _libs.oracle()
+    O.ho_pyramid_face_mask.restype = C.c_int
+    O.ho_pyramid_face_mask.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    O.ho_pyramid_geometry.restype = None
+    O.ho_pyramid_geometry.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_float), C.POINTER(abi.HaloGeomTables)]
+    G = np.load(os.path.join(ROOT, "tests", "golden", "ref_pyramid_goldens.npz"))
+
+    def check(wu, wl, h1, h2, h3, dist, golden):
+        n = C.c_int()
+        mask = O.ho_pyramid_face_mask(wu, wl, h1, h2, h3, fptr(dist), C.byref(n))
+        assert (n.value, mask) == (int(golden[0]), int(golden[1]))
+        a, b = abi.HaloGeomTables(), abi.HaloGeomTables()
+        assert L.halo_host_pyramid_geometry(wu, wl, h1, h2, h3, fptr(dist), C.byref(a)) == 0
+        O.ho_pyramid_geometry(wu, wl, h1, h2, h3, fptr(dist), C.byref(b))
+        assert bytes(a) == bytes(b)
+        assert a.face_cnt == bin(mask).count("1") and 0 < a.tri_cnt <= 64
+        # closed solid: fan areas weighted by outward normals sum to zero (divergence theorem)
+        nrm = np.frombuffer(a.tri_n, np.float32)[: a.tri_cnt * 3].reshape(-1, 3)
+        area = np.frombuffer(a.tri_area, np.float32)[: a.tri_cnt]
+        assert np.abs((nrm * area[:, None]).sum(0)).max() < 1e-4
+
+    for s, t in zip(G["wc_samples"], G["wc_topology"]):
+        check(float(s[0]), float(s[1]), float(s[2]), float(s[3]), float(s[4]), np.ascontiguousarray(s[5:11]), t)
+    for s, t in zip(G["miller_samples"], G["miller_topology"]):
+        wu, wl = scenes.miller_wedge_deg(int(s[0]), int(s[1])), scenes.miller_wedge_deg(int(s[2]), int(s[3]))
+        check(wu, wl, float(s[4]), float(s[5]), float(s[6]), np.ascontiguousarray(s[7:13]), t)
+    # empty / degenerate inputs give the empty crystal on both sides
+    e = abi.HaloGeomTables()
+    assert L.halo_host_pyramid_geometry(28.0, 28.0, 0.0, 0.0, 0.0, fptr(np.ones(6, np.float32)), C.byref(e)) != 0 and e.face_cnt == 0

@@ -23,6 +23,7 @@ if "base" in which:
     run("config2 1920x1080 upper (default)", sc, rd)
     run("  no accumulation (aggregate=2)", sc, rd, aggregate=2)
     run("  aggregate=0 mono=1", sc, rd, aggregate=0)
+    run("  aggregate=3 (cache only, misses dropped)", sc, rd, aggregate=3)
     run("  aggregate=1 mono=0", sc, rd, mono=0)
     run("  aggregate=0 mono=0 (old)", sc, rd, aggregate=0, mono=0)
     run("  visible full", sc, scenes.render(1, 1920, 1080, fov=180, el=30, visible=abi.VISIBLE_FULL))
