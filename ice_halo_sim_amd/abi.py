@@ -79,6 +79,10 @@ class HaloGeomTables(C.Structure):
                 ("tri_face", C.c_int32 * MAX_TRIS)]
 
 
+class HaloDisplay(C.Structure):
+    _fields_ = [("intensity_factor", C.c_float), ("ray_color", C.c_float * 3), ("background", C.c_float * 3)]
+
+
 class ProjParams(C.Structure):
     """lm_proj::ProjParams — reference src/core/shared/projection_shared.h:106-118 (76 bytes)."""
     _fields_ = [("proj_type", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32), ("visible_range", C.c_int32),

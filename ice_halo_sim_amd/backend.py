@@ -55,6 +55,9 @@ def load_library():
         "halo_readback_xyz64": (C.c_int, [H, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "halo_sync": (C.c_int, [H]),
         "halo_take_landed": (C.c_int, [H, C.POINTER(C.c_double)]),
+        "halo_consumer_fold": (C.c_int, [H]),
+        "halo_consumer_snapshot": (C.c_int, [H, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]),
+        "halo_consumer_reset": (C.c_int, [H]),
         "halo_host_prism_geometry": (C.c_int, [C.c_float, f32p, C.POINTER(abi.HaloGeomTables)]),
         "halo_host_pyramid_geometry": (C.c_int, [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]),
         "halo_host_build_lat_lut": (C.c_int, [C.POINTER(abi.HaloDist), f32p, f32p, f32p]),
@@ -73,7 +76,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_take_landed", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index",
 ]
@@ -189,6 +192,25 @@ class HipTraceBackend:
 
     def EndSession(self):
         self._check(self._L.halo_end(self._h))
+
+    # --- consumer on device (RenderConsumer, reference src/server/render.cpp) ---
+    def ConsumeDeviceFused(self):
+        """Fold the device accumulator into the Neumaier running image and zero it (render.cpp:138-201)."""
+        self._check(self._L.halo_consumer_fold(self._h))
+
+    def Snapshot(self, intensity_factor=1.0, ray_color=(-1.0, -1.0, -1.0), background=(0.0, 0.0, 0.0), want_xyz=True):
+        """PrepareSnapshot + PostSnapshot: returns (rgb uint8[H,W,3], xyz float32[H,W,3] | None, total_intensity)."""
+        w, h = self._render.width, self._render.height
+        d = abi.HaloDisplay(float(intensity_factor), (C.c_float * 3)(*ray_color), (C.c_float * 3)(*background))
+        rgb = np.empty((h, w, 3), np.uint8)
+        xyz = np.empty((h, w, 3), np.float32) if want_xyz else None
+        tot = C.c_double()
+        self._check(self._L.halo_consumer_snapshot(self._h, C.byref(d), rgb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                   xyz.ctypes.data_as(C.POINTER(C.c_float)) if want_xyz else None, C.byref(tot)))
+        return rgb, xyz, tot.value
+
+    def ResetConsumer(self):
+        self._check(self._L.halo_consumer_reset(self._h))
 
 
 EXIT_DTYPE = np.dtype([("dir", np.float32, 3), ("weight", np.float32), ("root", np.uint32), ("seq", np.uint16),

@@ -1,0 +1,267 @@
+"""Reader for Lumice's JSON configuration surface, restricted to what the trace path consumes.
+
+Restates the reference parsers (paths under /root/reference/src):
+  config/config_manager.cpp:96-231  ParseSceneConfig / from_json(ConfigManager)   scene, scattering, render lookup
+  config/crystal_config.cpp:282-433 prism / pyramid shape (+ sync_group, Miller indices → wedge angle)
+  core/math.cpp:593-726             Distribution and axis (zenith → latitude, azimuth/roll default uniform 360)
+  config/light_config.cpp:44-79     sun + spectrum (wavelength list | illuminant name)
+  config/render_config.cpp:55-118   lens (fov | focal length f), config_manager.cpp:36-80 render entry
+  server/ray_num_semantics.hpp      per-wavelength ray count = ceil(ray_num / N_wavelengths)
+Host-side plumbing only: it fills the C-ABI structs; nothing is computed here.
+"""
+import json
+import math
+
+from . import abi, scenes
+
+LENS_NAMES = {
+    "linear": abi.LENS_LINEAR, "fisheye_equal_area": abi.LENS_FISHEYE_EQUAL_AREA,
+    "fisheye_equidistant": abi.LENS_FISHEYE_EQUIDISTANT, "fisheye_stereographic": abi.LENS_FISHEYE_STEREOGRAPHIC,
+    "dual_fisheye_equal_area": abi.LENS_DUAL_FISHEYE_EQUAL_AREA, "dual_fisheye_equidistant": abi.LENS_DUAL_FISHEYE_EQUIDISTANT,
+    "dual_fisheye_stereographic": abi.LENS_DUAL_FISHEYE_STEREOGRAPHIC, "rectangular": abi.LENS_RECTANGULAR,
+    "fisheye_orthographic": abi.LENS_FISHEYE_ORTHOGRAPHIC, "dual_fisheye_orthographic": abi.LENS_DUAL_FISHEYE_ORTHOGRAPHIC,
+    "globe": abi.LENS_GLOBE,
+}
+VISIBLE_NAMES = {"upper": abi.VISIBLE_UPPER, "lower": abi.VISIBLE_LOWER, "full": abi.VISIBLE_FULL}
+MAX_HITS = 64  # kMaxHits, core/def.hpp:27 (enforced at parse time, config_manager.cpp:144-146)
+
+
+class ConfigError(ValueError):
+    pass
+
+
+class UnsupportedConfig(ConfigError):
+    """The configuration is valid Lumice JSON but asks for something this backend does not implement; the reference
+    would answer `IsCompatible() == false` / BackendUnavailableError and fall back to its legacy CPU path."""
+
+
+def _dist(obj):
+    if isinstance(obj, bool):
+        raise ConfigError("distribution value is neither a number nor an object: %r" % (obj,))
+    if isinstance(obj, (int, float)):
+        return abi.dist(float(obj))
+    if isinstance(obj, dict):
+        if "type" not in obj:
+            raise ConfigError('distribution object is missing required key "type"')
+        try:
+            return abi.dist(obj)
+        except KeyError:
+            raise ConfigError("unknown distribution type: %r" % (obj["type"],))
+    raise ConfigError("distribution value is neither a number nor an object: %r" % (obj,))
+
+
+def _canonical_sync_groups(groups, applicable):
+    """CanonicalizeSyncGroups (crystal_config.cpp:48-98): drop groups on absent slots and one-member groups, renumber
+    1..N by first appearance."""
+    g = [groups[i] if applicable[i] else 0 for i in range(len(groups))]
+    g = [v if (v and g.count(v) >= 2) else 0 for v in g]
+    remap, out = {}, []
+    for v in g:
+        if v and v not in remap:
+            remap[v] = len(remap) + 1
+        out.append(remap.get(v, 0))
+    return out
+
+
+def _miller_to_alpha(i1, i4):
+    # MillerToAlpha, crystal_config.cpp:328-336 (i1 == 0 → default 28 degrees)
+    if i1 == 0:
+        return 28.0
+    return math.degrees(math.atan(0.866025403784 * i4 / i1 / 1.629))
+
+
+def parse_crystal(j):
+    """CrystalConfig from_json (crystal_config.cpp:414-431). Returns (HaloCrystal, HaloAxis)."""
+    shape = j.get("shape", {})
+    kind = j["type"]
+    fd = [abi.dist(1.0)] * 6
+    if "face_distance" in shape:
+        vals = list(shape["face_distance"])[:6]
+        fd = [_dist(v) for v in vals] + [abi.dist(1.0)] * (6 - len(vals))
+    sg = shape.get("sync_group", {})
+    face_groups = list(sg.get("face_distance", [0] * 6))[:6]
+    face_groups += [0] * (6 - len(face_groups))
+    c = abi.HaloCrystal()
+    if kind == "prism":
+        c.kind = abi.CRYSTAL_PRISM
+        heights = [_dist(shape["height"]) if "height" in shape else abi.dist(1.0), abi.dist(0.0), abi.dist(0.0)]
+        groups = _canonical_sync_groups([int(sg.get("height", 0)), 0, 0] + [int(v) for v in face_groups],
+                                        [True, False, False] + [True] * 6)
+        c.wedge_upper_deg = c.wedge_lower_deg = 28.0
+    elif kind == "pyramid":
+        c.kind = abi.CRYSTAL_PYRAMID
+        if "prism_h" not in shape:
+            raise ConfigError('pyramid shape is missing required key "prism_h"')
+        heights = [_dist(shape.get("upper_h", 0.0)), _dist(shape["prism_h"]), _dist(shape.get("lower_h", 0.0))]
+        groups = _canonical_sync_groups([int(sg.get("upper_h", 0)), int(sg.get("prism_h", 0)), int(sg.get("lower_h", 0))] +
+                                        [int(v) for v in face_groups], [True] * 9)
+        wedge = {}
+        for side in ("upper", "lower"):
+            wedge[side] = 28.0  # PyramidCrystalParam defaults, crystal_config.hpp:74-75
+            if side + "_wedge_angle" in shape:
+                wedge[side] = float(shape[side + "_wedge_angle"])
+            elif isinstance(shape.get(side + "_indices"), list) and len(shape[side + "_indices"]) == 3:
+                idx = shape[side + "_indices"]
+                wedge[side] = _miller_to_alpha(int(idx[0]), int(idx[2]))
+        c.wedge_upper_deg, c.wedge_lower_deg = wedge["upper"], wedge["lower"]
+    else:
+        raise ConfigError('unknown crystal type: %r. Write either "prism" or "pyramid".' % (kind,))
+    # NormalizeSyncGroups (crystal_config.cpp:102-133): members take their group leader's distribution
+    slots = heights + fd
+    for i in range(9):
+        if groups[i]:
+            leader = next(k for k in range(9) if groups[k] == groups[i])
+            slots[i] = slots[leader]
+    for i in range(3):
+        c.height[i] = slots[i]
+    for i in range(6):
+        c.face_dist[i] = slots[3 + i]
+    for i in range(9):
+        c.sync_group[i] = groups[i]
+    ax = j.get("axis")
+    if ax is None:
+        axis = scenes.axis()
+    else:
+        if "zenith" not in ax:
+            raise ConfigError('axis is present but has no "zenith"')
+        for key in ("zenith", "azimuth", "roll"):
+            if isinstance(ax.get(key), dict) and "type" not in ax[key]:
+                raise ConfigError('axis.%s is a distribution object with no "type"' % key)
+        axis = scenes.axis(zenith=ax["zenith"], azimuth=ax.get("azimuth"), roll=ax.get("roll"))
+    return c, axis
+
+
+def parse_lens(j):
+    """LensParam from_json (render_config.cpp:55-118): `fov` in degrees or focal length `f` on 35 mm film."""
+    if j["type"] not in LENS_NAMES:
+        raise ConfigError("unknown lens type: %r" % (j["type"],))
+    t = LENS_NAMES[j["type"]]
+    if "fov" in j:
+        fov = float(j["fov"])
+    elif "f" in j:
+        f, d = float(j["f"]), 12.0
+        if t in (abi.LENS_LINEAR, abi.LENS_GLOBE):
+            fov = math.degrees(math.atan2(d, f) * 2)
+        elif t in (abi.LENS_FISHEYE_EQUAL_AREA, abi.LENS_DUAL_FISHEYE_EQUAL_AREA):
+            if d / (2 * f) > 1.0:
+                raise ConfigError("focal length too short for equal area fisheye (f >= 6mm required)")
+            fov = math.degrees(math.asin(d / (2 * f)) * 4)
+        elif t in (abi.LENS_FISHEYE_EQUIDISTANT, abi.LENS_DUAL_FISHEYE_EQUIDISTANT):
+            fov = math.degrees(d / f)
+        elif t in (abi.LENS_FISHEYE_STEREOGRAPHIC, abi.LENS_DUAL_FISHEYE_STEREOGRAPHIC):
+            fov = math.degrees(math.atan(d / (2 * f)) * 4)
+        elif t == abi.LENS_RECTANGULAR:
+            fov = 0.0
+        else:
+            if d / f > 1.0:
+                raise ConfigError("focal length too short for orthographic fisheye")
+            fov = math.degrees(math.asin(d / f) * 2)
+    else:
+        raise ConfigError("missing key [fov] or [f]")
+    max_fov = {abi.LENS_LINEAR: 179.0, abi.LENS_FISHEYE_STEREOGRAPHIC: 359.0, abi.LENS_FISHEYE_ORTHOGRAPHIC: 180.0,
+               abi.LENS_DUAL_FISHEYE_ORTHOGRAPHIC: 180.0, abi.LENS_GLOBE: 90.0}.get(t, 360.0)
+    if t != abi.LENS_RECTANGULAR and not (0 < fov <= max_fov):
+        raise ConfigError("fov must be in (0, %d] degrees for this lens type" % int(max_fov))
+    return t, fov
+
+
+def parse_render(j):
+    """ParseRenderConfig (config_manager.cpp:36-80); defaults RenderConfig render_config.hpp:71-103."""
+    t, fov = (abi.LENS_LINEAR, 90.0)
+    if "lens" in j:
+        t, fov = parse_lens(j["lens"])
+    res = j["resolution"]
+    view = j.get("view", {})
+    vis = j.get("visible", "upper")
+    if vis not in VISIBLE_NAMES:
+        raise ConfigError("unknown visible range: %r" % (vis,))
+    return scenes.render(t, int(res[0]), int(res[1]), fov=fov, az=float(view.get("azimuth", 0.0)),
+                         el=float(view.get("elevation", 0.0)), ro=float(view.get("roll", 0.0)), visible=VISIBLE_NAMES[vis],
+                         overlap=max(0.0, float(j.get("overlap", 0.0))), lens_shift=tuple(j.get("lens_shift", (0, 0))))
+
+
+class TraceJob:
+    """Everything the trace path needs from one Lumice config document."""
+
+    def __init__(self):
+        self.scene = None
+        self.renders = {}          # id -> HaloRender
+        self.render_meta = {}      # id -> {"intensity_factor": ...}
+        self.wavelengths = []      # list of HaloWl (one per discrete wavelength, or a single illuminant entry)
+        self.ray_num = 0           # total root rays requested (None = "infinite")
+        self.geom_clock = None
+
+    def per_wavelength_ray_num(self):
+        """ceil(ray_num / N_wl) — server/ray_num_semantics.hpp:13-17."""
+        n = max(1, len(self.wavelengths))
+        return None if self.ray_num is None else -(-int(self.ray_num) // n)
+
+
+def load_config(source):
+    """source: path, JSON text or dict → TraceJob.  Mirrors from_json(ConfigManager) (config_manager.cpp:170-231)."""
+    if isinstance(source, dict):
+        doc = source
+    else:
+        text = source
+        if not text.lstrip().startswith("{"):
+            with open(source) as f:
+                text = f.read()
+        doc = json.loads(text)
+    crystals = {}
+    for jc in doc["crystal"]:
+        try:
+            crystals[int(jc["id"])] = parse_crystal(jc)
+        except ConfigError as e:
+            raise ConfigError("crystal[id=%s]: %s" % (jc.get("id"), e))
+    filters = {int(jf["id"]): jf for jf in doc.get("filter", [])}
+    job = TraceJob()
+    for jr in doc.get("render", []):
+        r = parse_render(jr)
+        job.renders[int(jr["id"])] = r
+        job.render_meta[int(jr["id"])] = {"intensity_factor": float(jr.get("intensity_factor", 1.0))}
+    js = doc["scene"]
+    rn = js["ray_num"]
+    job.ray_num = None if rn == "infinite" else int(rn)
+    max_hits = int(js["max_hits"])
+    if max_hits == 0 or max_hits > MAX_HITS:
+        raise ConfigError("max_hits must be in [1, %d]" % MAX_HITS)
+    if "geom_clock" in js:
+        job.geom_clock = int(js["geom_clock"])
+    ls = js["light_source"]
+    if ls.get("type") != "sun":
+        raise ConfigError("unknown light source type: %r" % (ls.get("type"),))
+    spec = ls["spectrum"]
+    if isinstance(spec, str):
+        if spec not in abi.ILLUM:
+            raise ConfigError("unknown illuminant: %r" % (spec,))
+        job.wavelengths = [scenes.wl_illuminant(spec, 64)]
+    elif isinstance(spec, list):
+        job.wavelengths = [scenes.wl_discrete(float(w["wavelength"]), float(w["weight"])) for w in spec]
+    else:
+        raise ConfigError("light_source.spectrum is neither a string nor an array")
+    layers = []
+    for li, jl in enumerate(js["scattering"]):
+        if "prob" not in jl:
+            raise ConfigError('scene.scattering[%d] is missing required field "prob"' % li)
+        entries = []
+        for je in jl["entries"]:
+            cid = int(je["crystal"])
+            if cid not in crystals:
+                raise ConfigError("scattering entry refers to unknown crystal id %d" % cid)
+            if "filter" in je:
+                fid = int(je["filter"])
+                if fid not in filters:
+                    raise ConfigError("scattering entry refers to unknown filter id %d" % fid)
+                if filters[fid].get("type") != "none":
+                    raise UnsupportedConfig("emit-gate filters are not implemented by this backend yet (filter id %d, type %r)"
+                                            % (fid, filters[fid].get("type")))
+            crystal, axis = crystals[cid]
+            entries.append(scenes.entry(crystal, axis, float(je.get("proportion", 100.0)), cid))
+        layers.append((float(jl["prob"]), entries))
+    if len(layers) > abi.MAX_LAYERS or any(len(e) > abi.MAX_ENTRIES for _, e in layers):
+        raise UnsupportedConfig("more scattering layers / entries than the backend's caps")
+    job.scene = scenes.scene(layers, max_hits=max_hits, sun_altitude=float(ls["altitude"]),
+                             sun_azimuth=float(ls.get("azimuth", 0.0)), sun_diameter=float(ls.get("diameter", 0.0)))
+    if "raypath_color" in doc and doc["raypath_color"]:
+        raise UnsupportedConfig("raypath_color classes are not implemented by this backend")
+    return job

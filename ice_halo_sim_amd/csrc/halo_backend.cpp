@@ -20,6 +20,9 @@
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
 hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream);
+hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
+hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
+                                const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
 }
 
 using namespace halo;
@@ -86,6 +89,11 @@ struct HaloBackend {
   bool mono_session = false;
   bool mono_dirty = false;
   float mono_cmf[3] = {0, 0, 0};
+  // consumer (RenderConsumer state, server/render.hpp): Neumaier running image + total landed intensity
+  DevBuf<float> cons_sum, cons_comp, cons_xyz_out;
+  DevBuf<uint8_t> cons_rgb;
+  int cons_w = 0, cons_h = 0;
+  double total_intensity = 0.0;
   DevBuf<double> sums;         // kSumNum
   DevBuf<uint32_t> counters;   // kCntNum
   DevBuf<float> lut;
@@ -194,6 +202,10 @@ int halo_destroy(halo_handle_t b) {
   b->acc_own.release();
   b->sums.release();
   b->mono.release();
+  b->cons_sum.release();
+  b->cons_comp.release();
+  b->cons_xyz_out.release();
+  b->cons_rgb.release();
   b->counters.release();
   b->lut.release();
   b->wl_pool.release();
@@ -576,6 +588,68 @@ int halo_readback_xyz(halo_handle_t b, float* xyz, int width, int height, float*
   int rc = halo_readback_xyz64(b, xyz, width, height, &l);
   if (rc == HALO_OK && landed_weight) *landed_weight += static_cast<float>(l);  // ADDS (trace_backend.hpp:461-469)
   return rc;
+}
+
+// ---- consumer on device ------------------------------------------------------------------------------------
+int halo_consumer_reset(halo_handle_t b) {
+  if (!b) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  if (b->cons_sum.ptr) {
+    const size_t n = static_cast<size_t>(b->cons_w) * b->cons_h * 3;
+    HIPCHK(b, hipMemsetAsync(b->cons_sum.ptr, 0, n * sizeof(float), b->stream));
+    HIPCHK(b, hipMemsetAsync(b->cons_comp.ptr, 0, n * sizeof(float), b->stream));
+  }
+  b->total_intensity = 0.0;
+  return HALO_OK;
+}
+
+int halo_consumer_fold(halo_handle_t b) {
+  if (!b) return HALO_FATAL;
+  if (!b->acc || b->acc_w <= 0) return fail(b, HALO_FATAL, "consumer_fold before any session");
+  HIPCHK(b, hipSetDevice(b->device));
+  int rc = fold_if_dirty(b);
+  if (rc != HALO_OK) return rc;
+  const size_t n = static_cast<size_t>(b->acc_w) * b->acc_h * 3;
+  if (b->cons_w != b->acc_w || b->cons_h != b->acc_h || !b->cons_sum.ptr) {
+    HIPCHK(b, b->cons_sum.reserve(n));
+    HIPCHK(b, b->cons_comp.reserve(n));
+    b->cons_w = b->acc_w;
+    b->cons_h = b->acc_h;
+    HIPCHK(b, hipMemsetAsync(b->cons_sum.ptr, 0, n * sizeof(float), b->stream));
+    HIPCHK(b, hipMemsetAsync(b->cons_comp.ptr, 0, n * sizeof(float), b->stream));
+    b->total_intensity = 0.0;
+  }
+  hipError_t e = launch_consumer_fold(b->acc, b->cons_sum.ptr, b->cons_comp.ptr, static_cast<uint32_t>(n), b->cu_count * 8, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_consumer_fold_kernel launch");
+  double landed = 0.0;
+  HIPCHK(b, hipMemcpyAsync(&landed, b->sums.ptr, sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  b->total_intensity += landed;  // total_intensity_ += xyz_landed_weight_ (render.cpp:149)
+  return HALO_OK;
+}
+
+int halo_consumer_snapshot(halo_handle_t b, const HaloDisplay* dsp, uint8_t* rgb_out, float* xyz_out, double* total_intensity) {
+  if (!b || !dsp) return HALO_FATAL;
+  if (!b->cons_sum.ptr) return fail(b, HALO_FATAL, "consumer_snapshot before consumer_fold");
+  HIPCHK(b, hipSetDevice(b->device));
+  const uint32_t npix = static_cast<uint32_t>(b->cons_w) * static_cast<uint32_t>(b->cons_h);
+  const size_t n = static_cast<size_t>(npix) * 3;
+  // ExposureScale (render.cpp:96-102), evaluated in float like the reference
+  const float snapshot_intensity = static_cast<float>(b->total_intensity);
+  const float scale = (npix == 0 || snapshot_intensity <= 0.0f) ? 0.0f : dsp->intensity_factor * 0.08f * static_cast<float>(npix) / snapshot_intensity;
+  if (rgb_out) HIPCHK(b, b->cons_rgb.reserve(n));
+  if (xyz_out) HIPCHK(b, b->cons_xyz_out.reserve(n));
+  hipError_t e = launch_post_snapshot(b->cons_sum.ptr, b->cons_comp.ptr, rgb_out ? b->cons_rgb.ptr : nullptr,
+                                      xyz_out ? b->cons_xyz_out.ptr : nullptr, npix, scale, dsp->ray_color, dsp->background,
+                                      b->cu_count * 8, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_post_snapshot_kernel launch");
+  if (rgb_out) HIPCHK(b, hipMemcpyAsync(rgb_out, b->cons_rgb.ptr, n, hipMemcpyDeviceToHost, b->stream));
+  if (xyz_out) HIPCHK(b, hipMemcpyAsync(xyz_out, b->cons_xyz_out.ptr, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  if (rgb_out && scale == 0.0f) std::memset(rgb_out, 0, n);  // PostSnapshot early-out (render.cpp:515-518)
+  if (total_intensity) *total_intensity = b->total_intensity;
+  return HALO_OK;
 }
 
 // ---- host-side pieces, exported for parity tests -------------------------------------------------------

@@ -782,6 +782,106 @@ __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ x
   }
 }
 
+// Consumer fold: running image += drained accumulator, Neumaier-compensated (accum_shared.h:70-74), accumulator zeroed.
+__global__ void __launch_bounds__(kBlock) halo_consumer_fold_kernel(float* __restrict__ acc, float* __restrict__ sum,
+                                                                     float* __restrict__ comp, uint32_t n) {
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const float delta = acc[i];
+    if (delta == 0.0f) continue;
+    acc[i] = 0.0f;
+    const float s = sum[i];
+    const float ns = s + delta;
+    comp[i] += (fabsf(delta) < fabsf(s)) ? ((s - ns) + delta) : ((delta - ns) + s);
+    sum[i] = ns;
+  }
+}
+
+struct DisplayDev {
+  float scale;
+  float ray_color[3];
+  float background[3];
+};
+
+// PostSnapshot (render.cpp:508-578): per pixel scale → gamut clip (color_space.cpp GamutClipXyz) → XYZ→linear RGB →
+// background + clamp → sRGB gamma → u8.  Also writes the raw snapshot (sum + comp) when xyz_out is set.
+__global__ void __launch_bounds__(kBlock) halo_post_snapshot_kernel(const float* __restrict__ sum, const float* __restrict__ comp,
+                                                                     uint8_t* __restrict__ rgb_out, float* __restrict__ xyz_out,
+                                                                     uint32_t n_pix, DisplayDev dsp) {
+  const float kWhite[3] = {0.95047f, 1.00000f, 1.08883f};                       // kWhitePointD65, util/color_data.hpp:6
+  const float kM[9] = {3.2404542f, -1.5371385f, -0.4985314f, -0.9692660f, 1.8760108f, 0.0415560f,
+                       0.0556434f, -0.2040259f, 1.0572252f};                    // kXyzToRgb, util/color_data.hpp:8-12
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += stride) {
+    float xyz[3], rgb[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float raw = sum[3u * i + j] + comp[3u * i + j];
+      if (xyz_out) xyz_out[3u * i + j] = raw;
+      xyz[j] = raw * dsp.scale;
+    }
+    if (rgb_out == nullptr) continue;
+    if (dsp.ray_color[0] < 0.0f) {
+      float gray[3], diff[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        gray[j] = kWhite[j] * xyz[1];
+        diff[j] = xyz[j] - gray[j];
+      }
+      float s = 1.0f;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          a += -gray[k] * kM[j * 3 + k];
+          b += diff[k] * kM[j * 3 + k];
+        }
+        if (a * b > 0.0f && a / b < s) s = a / b;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v += (diff[k] * s + gray[k]) * kM[j * 3 + k];
+        rgb[j] = fminf(fmaxf(v, 0.0f), 1.0f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v += (kWhite[k] * xyz[1]) * kM[j * 3 + k];
+        rgb[j] = v * dsp.ray_color[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float v = rgb[j] + dsp.background[j];
+      v = fminf(fmaxf(v, 0.0f), 1.0f);
+      v = (v < 0.0031308f) ? v * 12.92f : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+      rgb_out[3u * i + j] = static_cast<uint8_t>(v * 255.0f);
+    }
+  }
+}
+
+hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_consumer_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, acc, sum, comp, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
+                                const float ray_color[3], const float background[3], int blocks, hipStream_t stream) {
+  DisplayDev d;
+  d.scale = scale;
+  for (int j = 0; j < 3; j++) {
+    d.ray_color[j] = ray_color[j];
+    d.background[j] = background[j];
+  }
+  hipLaunchKernelGGL(halo_post_snapshot_kernel, dim3(blocks), dim3(kBlock), 0, stream, sum, comp, rgb_out, xyz_out, n_pix, d);
+  return hipGetLastError();
+}
+
 hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream) {
   hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, cx, cy, cz);
   return hipGetLastError();

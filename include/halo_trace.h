@@ -229,6 +229,22 @@ int halo_sync(halo_handle_t h);
  * bound external accumulator that is reduced across ranks in place. */
 int halo_take_landed(halo_handle_t h, double* landed_weight);
 
+/* --- consumer on device (RenderConsumer::ConsumeDeviceFused / PrepareSnapshot / PostSnapshot, server/render.cpp) -- */
+/* HaloDisplay: the RenderConfig fields PostSnapshot reads (render_config.hpp:84-92). ray_color[0] < 0 = real colour. */
+typedef struct HaloDisplay {
+  float intensity_factor;
+  float ray_color[3];
+  float background[3];
+} HaloDisplay;
+/* ConsumeDeviceFused (render.cpp:138-201): fold the device accumulator into the running image with Neumaier-compensated
+ * adds (accum_shared.h:70-74), add its landed weight to total_intensity, zero the accumulator.  All on device. */
+int halo_consumer_fold(halo_handle_t h);
+/* PrepareSnapshot + PostSnapshot (render.cpp:465-578): snapshot = sum + compensation; scale = intensity_factor * 0.08 *
+ * N_pix / total_intensity (ExposureScale :96-102); XYZ → gamut clip → linear RGB → sRGB u8 (util/color_space.cpp).
+ * rgb_out: W*H*3 bytes (nullable); xyz_out: W*H*3 floats raw snapshot (nullable); total_intensity out (nullable). */
+int halo_consumer_snapshot(halo_handle_t h, const HaloDisplay* display, uint8_t* rgb_out, float* xyz_out, double* total_intensity);
+int halo_consumer_reset(halo_handle_t h);
+
 /* --- host-side pieces of the path, exported for parity tests (no GPU needed) ---------------- */
 /* Geometry tables the kernels consume (reference: Crystal::PopulateFromCfGeom crystal.cpp:304-347,
  * detail::BuildEntrySubTris simulator.cpp:90-129). */

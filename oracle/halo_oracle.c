@@ -1204,6 +1204,11 @@ struct HoBackend {
   float* cont_in;
   uint64_t cont_in_n;
   int cont_shuffle;
+  /* consumer: RenderConsumer::internal_xyz_ / comp_xyz_ / total_intensity_ (server/render.hpp) */
+  float* cons_sum;
+  float* cons_comp;
+  int cons_w, cons_h;
+  float total_intensity; /* float in the reference (render.hpp) */
   /* capture */
   HaloExitRecord* exits;
   uint64_t exit_n, exit_cap;
@@ -1222,6 +1227,8 @@ void ho_destroy(HoBackend* b) {
   free(b->cont);
   free(b->cont_in);
   free(b->exits);
+  free(b->cons_sum);
+  free(b->cons_comp);
   free(b);
 }
 int ho_set_option(HoBackend* b, const char* key, int64_t v) {
@@ -1759,5 +1766,105 @@ int ho_readback_xyz64(HoBackend* b, float* xyz, int width, int height, double* l
   memset(b->xyz, 0, n * sizeof(float));
   if (landed) *landed = b->landed;
   b->landed = 0.0;
+  return HALO_OK;
+}
+
+/* ======================================================================================== */
+/* consumer: server/render.cpp:96-201,465-578; util/color_space.cpp; shared/accum_shared.h:70 */
+/* ======================================================================================== */
+static const float kWhitePointD65[3] = {0.95047f, 1.00000f, 1.08883f}; /* util/color_data.hpp:6 */
+static const float kXyzToRgb[9] = {3.2404542f, -1.5371385f, -0.4985314f, -0.9692660f, 1.8760108f,
+                                   0.0415560f, 0.0556434f,  -0.2040259f, 1.0572252f}; /* util/color_data.hpp:8-12 */
+
+void ho_neumaier_add(float* sum, float* comp, float delta) { /* accum_shared.h:70-74 */
+  float new_sum = *sum + delta;
+  *comp += (fabsf(delta) < fabsf(*sum)) ? ((*sum - new_sum) + delta) : ((delta - new_sum) + *sum);
+  *sum = new_sum;
+}
+
+void ho_gamut_clip_xyz(const float xyz[3], float clipped[3]) { /* color_space.cpp:13-39 */
+  float gray[3], diff[3];
+  for (int j = 0; j < 3; j++) gray[j] = kWhitePointD65[j] * xyz[1];
+  float s = 1.0f;
+  for (int j = 0; j < 3; j++) diff[j] = xyz[j] - gray[j];
+  for (int j = 0; j < 3; j++) {
+    float a = 0, b = 0;
+    for (int k = 0; k < 3; k++) {
+      a += -gray[k] * kXyzToRgb[j * 3 + k];
+      b += diff[k] * kXyzToRgb[j * 3 + k];
+    }
+    if (a * b > 0 && a / b < s) s = a / b;
+  }
+  for (int j = 0; j < 3; j++) clipped[j] = diff[j] * s + gray[j];
+}
+
+void ho_xyz_to_linear_rgb(const float xyz[3], float rgb[3]) { /* color_space.cpp:41-49 */
+  for (int j = 0; j < 3; j++) {
+    float v = 0;
+    for (int k = 0; k < 3; k++) v += xyz[k] * kXyzToRgb[j * 3 + k];
+    rgb[j] = clampf(v, 0.0f, 1.0f);
+  }
+}
+
+float ho_linear_to_srgb(float linear) { /* color_space.cpp:51-56 */
+  if (linear < 0.0031308f) return linear * 12.92f;
+  return 1.055f * powf(linear, 1.0f / 2.4f) - 0.055f;
+}
+
+int ho_consumer_fold(HoBackend* b) { /* ConsumeDeviceFused render.cpp:138-149 */
+  if (!b->xyz) return HALO_FATAL;
+  size_t n = (size_t)b->acc_w * b->acc_h * 3;
+  if (!b->cons_sum || b->cons_w != b->acc_w || b->cons_h != b->acc_h) {
+    free(b->cons_sum);
+    free(b->cons_comp);
+    b->cons_sum = (float*)calloc(n, sizeof(float));
+    b->cons_comp = (float*)calloc(n, sizeof(float));
+    b->cons_w = b->acc_w;
+    b->cons_h = b->acc_h;
+    b->total_intensity = 0.0f;
+  }
+  for (size_t i = 0; i < n; i++) ho_neumaier_add(&b->cons_sum[i], &b->cons_comp[i], b->xyz[i]);
+  memset(b->xyz, 0, n * sizeof(float));
+  b->total_intensity += (float)b->landed;
+  b->landed = 0.0;
+  return HALO_OK;
+}
+
+int ho_consumer_snapshot(HoBackend* b, const HaloDisplay* dsp, uint8_t* rgb_out, float* xyz_out, double* total_intensity) {
+  if (!b->cons_sum) return HALO_FATAL;
+  int total_pix = b->cons_w * b->cons_h;
+  float snapshot_intensity = b->total_intensity;
+  if (total_intensity) *total_intensity = (double)snapshot_intensity;
+  float scale = (total_pix <= 0 || snapshot_intensity <= 0.0f) ? 0.0f : dsp->intensity_factor * 0.08f * total_pix / snapshot_intensity; /* :96-102 */
+  int use_real_color = dsp->ray_color[0] < 0;
+  for (int i = 0; i < total_pix; i++) {
+    float xyz[3], rgb[3];
+    for (int j = 0; j < 3; j++) {
+      float raw = b->cons_sum[i * 3 + j] + b->cons_comp[i * 3 + j]; /* PrepareSnapshot :480-482 */
+      if (xyz_out) xyz_out[i * 3 + j] = raw;
+      xyz[j] = raw * scale;
+    }
+    if (!rgb_out) continue;
+    if (scale == 0.0f) { rgb_out[i * 3] = rgb_out[i * 3 + 1] = rgb_out[i * 3 + 2] = 0; continue; }
+    if (use_real_color) {
+      float clipped[3];
+      ho_gamut_clip_xyz(xyz, clipped);
+      ho_xyz_to_linear_rgb(clipped, rgb);
+    } else {
+      float gray[3];
+      for (int j = 0; j < 3; j++) gray[j] = kWhitePointD65[j] * xyz[1];
+      for (int j = 0; j < 3; j++) {
+        float v = 0;
+        for (int k = 0; k < 3; k++) v += gray[k] * kXyzToRgb[j * 3 + k];
+        rgb[j] = v * dsp->ray_color[j];
+      }
+    }
+    for (int j = 0; j < 3; j++) {
+      rgb[j] += dsp->background[j];
+      rgb[j] = clampf(rgb[j], 0.0f, 1.0f);
+      rgb[j] = ho_linear_to_srgb(rgb[j]);
+      rgb_out[i * 3 + j] = (uint8_t)(rgb[j] * 255);
+    }
+  }
   return HALO_OK;
 }

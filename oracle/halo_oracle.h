@@ -106,6 +106,13 @@ int ho_recombine(HoBackend* b, int shuffle, uint64_t* continuation_count);
 int ho_drain_exits(HoBackend* b, HaloExitRecord* out, uint64_t cap, uint64_t* count);
 int ho_end(HoBackend* b);
 int ho_readback_xyz64(HoBackend* b, float* xyz, int width, int height, double* landed_weight);
+/* consumer (server/render.cpp:96-201,465-578; util/color_space.cpp) */
+void ho_neumaier_add(float* sum, float* comp, float delta);
+void ho_gamut_clip_xyz(const float xyz[3], float clipped[3]);
+void ho_xyz_to_linear_rgb(const float xyz[3], float rgb[3]);
+float ho_linear_to_srgb(float linear);
+int ho_consumer_fold(HoBackend* b);
+int ho_consumer_snapshot(HoBackend* b, const HaloDisplay* display, uint8_t* rgb_out, float* xyz_out, double* total_intensity);
 /* continuation pool access for set-parity tests: n x {dx,dy,dz,w,wl_idx(as float)} */
 uint64_t ho_continuation_dump(HoBackend* b, float* out5, uint64_t cap);
 

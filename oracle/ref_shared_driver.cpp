@@ -5,6 +5,7 @@
 //   src/core/shared/{lm_shims,pcg_shared,optics_shared,traversal_shared,projection_shared,accum_shared}.h
 //   src/core/color_util.hpp + src/util/color_data.hpp      (std headers only)
 //   test/support/exact_prism_oracle.hpp                     (std headers only)
+//   src/util/color_space.cpp (+ color_space.hpp, color_data.hpp)   (std headers only; compiled as a second TU)
 // Output: oracle/_ref/libref_shared.so (git-ignored).  Used to validate oracle/halo_oracle.c
 // function-by-function and to generate tests/golden/ref_shared_fixture.npz.
 //
@@ -21,6 +22,7 @@
 #include "core/shared/projection_shared.h"
 #include "core/shared/traversal_shared.h"
 #include "core/color_util.hpp"
+#include "util/color_space.hpp"
 #include "support/exact_prism_oracle.hpp"
 
 using lm_pcg::PcgStream;
@@ -118,6 +120,13 @@ void ref_project_exit_to_pixel(const void* pp, float wx, float wy, float wz, int
 void ref_accum_xyz_to_pixel(float* buf, uint32_t pix, float cx, float cy, float cz, float w) { AccumXyzToPixel(buf, pix, cx, cy, cz, w); }
 // color_util.hpp:29 SpectrumToXyz for one sample into xyz[3]
 void ref_spectrum_to_xyz(float wl, float v, float* xyz3) { lumice::SpectrumToXyz(wl, &v, nullptr, xyz3, 1); }
+
+// util/color_space.cpp + accum_shared.h NeumaierAdd
+void ref_gamut_clip_xyz(const float* xyz, float* out) { lumice::GamutClipXyz(xyz, out); }
+void ref_xyz_to_linear_rgb(const float* xyz, float* out) { lumice::XyzToLinearRgb(xyz, out); }
+float ref_linear_to_srgb(float v) { return lumice::LinearToSrgb(v); }
+void ref_xyz_to_srgb_u8(const float* xyz, unsigned char* out, int n, float scale) { lumice::XyzToSrgbUint8(xyz, out, n, scale); }
+void ref_neumaier_add(float* sum, float* comp, float delta) { NeumaierAdd(*sum, *comp, delta); }
 
 // test/support/exact_prism_oracle.hpp — out8 = {corner_count, refused, mask0..mask5}
 void ref_exact_prism(const float* dist6, int* out8) {

@@ -98,6 +98,15 @@ def oracle():
     L.ho_readback_xyz64.restype = C.c_int
     L.ho_readback_xyz64.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.ho_continuation_dump.restype = C.c_uint64; L.ho_continuation_dump.argtypes = [C.c_void_p, f32p, C.c_uint64]
+    L.ho_pyramid_geometry.restype = None; L.ho_pyramid_geometry.argtypes = [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]
+    L.ho_pyramid_face_mask.restype = C.c_int; L.ho_pyramid_face_mask.argtypes = [C.c_float] * 5 + [f32p, i32p]
+    L.ho_neumaier_add.restype = None; L.ho_neumaier_add.argtypes = [f32p, f32p, C.c_float]
+    L.ho_gamut_clip_xyz.restype = None; L.ho_gamut_clip_xyz.argtypes = [f32p, f32p]
+    L.ho_xyz_to_linear_rgb.restype = None; L.ho_xyz_to_linear_rgb.argtypes = [f32p, f32p]
+    L.ho_linear_to_srgb.restype = C.c_float; L.ho_linear_to_srgb.argtypes = [C.c_float]
+    L.ho_consumer_fold.restype = C.c_int; L.ho_consumer_fold.argtypes = [C.c_void_p]
+    L.ho_consumer_snapshot.restype = C.c_int
+    L.ho_consumer_snapshot.argtypes = [C.c_void_p, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]
     _oracle = L
     return L
 
@@ -141,6 +150,11 @@ def ref():
     L.ref_project_exit_to_pixel.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, i32p]
     L.ref_spectrum_to_xyz.restype = None; L.ref_spectrum_to_xyz.argtypes = [C.c_float, C.c_float, f32p]
     L.ref_exact_prism.restype = None; L.ref_exact_prism.argtypes = [f32p, i32p]
+    L.ref_gamut_clip_xyz.restype = None; L.ref_gamut_clip_xyz.argtypes = [f32p, f32p]
+    L.ref_xyz_to_linear_rgb.restype = None; L.ref_xyz_to_linear_rgb.argtypes = [f32p, f32p]
+    L.ref_linear_to_srgb.restype = C.c_float; L.ref_linear_to_srgb.argtypes = [C.c_float]
+    L.ref_xyz_to_srgb_u8.restype = None; L.ref_xyz_to_srgb_u8.argtypes = [f32p, C.POINTER(C.c_uint8), C.c_int, C.c_float]
+    L.ref_neumaier_add.restype = None; L.ref_neumaier_add.argtypes = [f32p, f32p, C.c_float]
     _ref = L
     return L
 

@@ -79,6 +79,19 @@ class OracleBackend:
     def EndSession(self):
         assert self._L.ho_end(self._h) == 0
 
+    def ConsumeDeviceFused(self):
+        assert self._L.ho_consumer_fold(self._h) == 0
+
+    def Snapshot(self, intensity_factor=1.0, ray_color=(-1.0, -1.0, -1.0), background=(0.0, 0.0, 0.0), want_xyz=True):
+        w, h = self._render.width, self._render.height
+        d = abi.HaloDisplay(float(intensity_factor), (C.c_float * 3)(*ray_color), (C.c_float * 3)(*background))
+        rgb = np.empty((h, w, 3), np.uint8)
+        xyz = np.empty((h, w, 3), np.float32) if want_xyz else None
+        tot = C.c_double()
+        assert self._L.ho_consumer_snapshot(self._h, C.byref(d), rgb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            xyz.ctypes.data_as(C.POINTER(C.c_float)) if want_xyz else None, C.byref(tot)) == 0
+        return rgb, xyz, tot.value
+
 
 def run_session(backend, scene, render, wl, n_rays, shuffle=True):
     """BeginSession → layers (TraceLayer → Recombine) → EndSession, like

@@ -237,6 +237,34 @@ def test_multi_entry_layer_partition_parity():
     assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
 
 
+def test_consumer_fold_and_snapshot_parity():
+    """ConsumeDeviceFused + PrepareSnapshot + PostSnapshot on device vs the oracle (reference server/render.cpp:96-201,
+    465-578): two drains folded with Neumaier compensation, exposure scale, gamut clip, sRGB bytes."""
+    sc, rd = scenes.config2_scene(), scenes.config2_render(480, 270)
+    hb, ob = hip_backend(seed=9), OracleBackend(seed=9, threads=8)
+    for drain in range(2):
+        for wl in (450.0, 570.0, 650.0):
+            run_session(hb, sc, rd, scenes.wl_discrete(wl), 120_000)
+            run_session(ob, sc, rd, scenes.wl_discrete(wl), 120_000)
+        hb.ConsumeDeviceFused()
+        ob.ConsumeDeviceFused()
+    z, lz = hb.ReadbackXyzAccum()
+    assert z.sum() == 0 and lz == 0                      # the fold drained the accumulator
+    for kw in (dict(intensity_factor=1.0), dict(intensity_factor=4.0, background=(0.02, 0.0, 0.05)),
+               dict(intensity_factor=2.0, ray_color=(1.0, 0.8, 0.6))):
+        rh, xh, th = hb.Snapshot(**kw)
+        ro, xo, to = ob.Snapshot(**kw)
+        assert th == pytest.approx(to, rel=1e-5)
+        assert rel_l2(block_mean(xh), block_mean(xo)) <= 2e-3
+        diff = np.abs(rh.astype(np.int16) - ro.astype(np.int16))
+        lit = (ro.max(axis=2) > 0)
+        assert lit.mean() > 0.05 and ro.max() > 100
+        # per-pixel Monte-Carlo sums differ by float-atomic ordering only → bytes agree to a few levels almost everywhere
+        assert (diff <= 2).mean() >= 0.995 and np.abs(block_mean(rh.astype(np.float32)) - block_mean(ro.astype(np.float32))).max() < 3.0
+    hb.ResetConsumer()
+    hb.close()
+
+
 def test_full_size_properties():
     """BASELINE size on the GPU alone: size-independent properties (no oracle at 50 M rays)."""
     sc, rd = scenes.config2_scene(), scenes.config2_render()

@@ -207,3 +207,23 @@ def test_cmf_and_prism_exact_oracle():
         if n == out8[0] and list(present[2:8] != 0) == exact_present:
             agree += 1
     assert agree >= 396  # near-degenerate draws may legitimately differ inside the merge tolerance
+
+
+def test_consumer_color_pipeline_and_neumaier():
+    """util/color_space.cpp (compiled from the reference as a second TU of _ref) and NeumaierAdd (accum_shared.h:70)."""
+    O, R = _libs.oracle(), _libs.ref()
+    for _ in range(4000):
+        x = (RNG.random(3) * RNG.choice([0.01, 1.0, 3.0])).astype(np.float32)
+        a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        O.ho_gamut_clip_xyz(fptr(x), fptr(a)); R.ref_gamut_clip_xyz(fptr(x), fptr(b))
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+        ra, rb = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        O.ho_xyz_to_linear_rgb(fptr(a), fptr(ra)); R.ref_xyz_to_linear_rgb(fptr(b), fptr(rb))
+        assert (ra.view(np.uint32) == rb.view(np.uint32)).all()
+        v = float(np.float32(RNG.random()))
+        assert bits(O.ho_linear_to_srgb(v)) == bits(R.ref_linear_to_srgb(v))
+        s1, c1 = C.c_float(float(np.float32(RNG.normal() * 100))), C.c_float(float(np.float32(RNG.normal() * 1e-4)))
+        s2, c2 = C.c_float(s1.value), C.c_float(c1.value)
+        d = float(np.float32(RNG.normal()))
+        O.ho_neumaier_add(C.byref(s1), C.byref(c1), d); R.ref_neumaier_add(C.byref(s2), C.byref(c2), d)
+        assert bits(s1.value) == bits(s2.value) and bits(c1.value) == bits(c2.value)
