@@ -33,7 +33,23 @@ class HaloCrystal(C.Structure):
 
 class HaloEntry(C.Structure):
     _fields_ = [("crystal", HaloCrystal), ("axis", HaloAxis), ("proportion", C.c_float),
-                ("crystal_config_id", C.c_int32)]
+                ("crystal_config_id", C.c_int32), ("filter_id", C.c_int32), ("reserved", C.c_int32)]
+
+
+FILTER_MAX_OR, FILTER_MAX_TERMS = 8, 16
+FILTER_NONE, FILTER_RAYPATH, FILTER_ENTRY_EXIT, FILTER_DIRECTION, FILTER_CRYSTAL = range(5)
+SYM_P, SYM_B, SYM_D = 1, 2, 4
+
+
+class HaloFilterTerm(C.Structure):
+    _fields_ = [("type", C.c_int32), ("raypath_len", C.c_int32), ("raypath", C.c_uint8 * MAX_HITS), ("has_entry", C.c_int32),
+                ("entry", C.c_int32), ("has_exit", C.c_int32), ("exit_face", C.c_int32), ("min_len", C.c_uint32),
+                ("max_len", C.c_uint32), ("az", C.c_float), ("el", C.c_float), ("radii", C.c_float), ("crystal_id", C.c_int32)]
+
+
+class HaloFilter(C.Structure):
+    _fields_ = [("action", C.c_int32), ("symmetry", C.c_int32), ("is_complex", C.c_int32), ("or_count", C.c_int32),
+                ("and_counts", C.c_int32 * FILTER_MAX_OR), ("terms", HaloFilterTerm * FILTER_MAX_TERMS)]
 
 
 class HaloLayer(C.Structure):

@@ -46,6 +46,7 @@ def load_library():
         "halo_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
         "halo_set_stream": (C.c_int, [H, C.c_void_p]),
         "halo_bind_accumulator": (C.c_int, [H, C.c_void_p, C.c_uint64]),
+        "halo_set_filters": (C.c_int, [H, C.POINTER(abi.HaloFilter), C.c_int32]),
         "halo_begin": (C.c_int, [H, C.POINTER(abi.HaloScene), C.POINTER(abi.HaloRender), C.POINTER(abi.HaloWl), C.c_uint64]),
         "halo_trace_layer": (C.c_int, [H, C.c_uint64, C.POINTER(abi.HaloHostRays), C.POINTER(abi.HaloLayerStats)]),
         "halo_recombine": (C.c_int, [H, C.c_int, C.POINTER(C.c_uint64)]),
@@ -64,6 +65,7 @@ def load_library():
         "halo_host_build_proj_params": (C.c_int, [C.POINTER(abi.HaloRender), C.c_void_p]),
         "halo_host_partition": (C.c_int, [f32p, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "halo_host_refractive_index": (C.c_double, [C.c_double]),
+        "halo_host_reduce_raypath": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol
@@ -75,10 +77,10 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
-    "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_begin", "halo_trace_layer", "halo_recombine",
+    "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
     "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
-    "halo_host_refractive_index",
+    "halo_host_refractive_index", "halo_host_reduce_raypath",
 ]
 
 
@@ -125,6 +127,11 @@ class HipTraceBackend:
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._L.halo_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_filters(self, filters):
+        """Filter table referenced by HaloEntry.filter_id (1-based; 0 = none)."""
+        arr = (abi.HaloFilter * max(1, len(filters)))(*filters)
+        self._check(self._L.halo_set_filters(self._h, arr, len(filters)))
 
     def bind_accumulator(self, device_ptr, n_floats):
         self._check(self._L.halo_bind_accumulator(self._h, C.c_void_p(device_ptr), int(n_floats)))

@@ -180,6 +180,54 @@ def parse_render(j):
                          overlap=max(0.0, float(j.get("overlap", 0.0))), lens_shift=tuple(j.get("lens_shift", (0, 0))))
 
 
+def _parse_simple_filter(j):
+    """SimpleFilterParam from_json (filter_config.cpp:62-118)."""
+    t = j.get("type", "none")
+    if t == "none":
+        return scenes.filter_term("none")
+    if t == "raypath":
+        return scenes.filter_term("raypath", raypath=[int(v) for v in j["raypath"]])
+    if t == "entry_exit":
+        mn = int(j["min_len"]) if j.get("min_len") is not None else 1
+        mx = int(j["max_len"]) if j.get("max_len") is not None else None
+        if mn < 1:
+            raise ConfigError("entry_exit filter: min_len must be >= 1, got %d" % mn)
+        if mx is not None and (mx < mn or mx > MAX_HITS):
+            raise ConfigError("entry_exit filter: max_len (%d) must be in [min_len, %d]" % (mx, MAX_HITS))
+        return scenes.filter_term("entry_exit", entry=j.get("entry"), exit=j.get("exit"), min_len=mn, max_len=mx)
+    if t == "direction":
+        return scenes.filter_term("direction", az=float(j["az"]), el=float(j["el"]), radii=float(j["radii"]))
+    if t == "crystal":
+        return scenes.filter_term("crystal", crystal_id=int(j["crystal_id"]))
+    raise ConfigError("SimpleFilterParam: unknown type %r" % (t,))
+
+
+def parse_filters(jfilters):
+    """from_json(ConfigManager) filter passes (config_manager.cpp:184-215): simple filters first, then complex ones, whose
+    `composition` is an OR-list of filter ids or AND-lists of ids.  Returns {id: HaloFilter}."""
+    simple, out = {}, {}
+    for jf in jfilters:
+        if jf.get("type") == "complex":
+            continue
+        term = _parse_simple_filter(jf)
+        simple[int(jf["id"])] = term
+        out[int(jf["id"])] = scenes.simple_filter(term, jf.get("symmetry", ""), jf.get("action", "filter_in"))
+    for jf in jfilters:
+        if jf.get("type") != "complex":
+            continue
+        clauses = []
+        for c in jf["composition"]:
+            ids = c if isinstance(c, list) else [c]
+            for fid in ids:
+                if int(fid) not in simple:
+                    raise ConfigError("complex filter %s refers to unknown simple filter id %s" % (jf.get("id"), fid))
+            clauses.append([simple[int(fid)] for fid in ids])
+        if len(clauses) > abi.FILTER_MAX_OR or sum(len(c) for c in clauses) > abi.FILTER_MAX_TERMS:
+            raise UnsupportedConfig("complex filter %s exceeds the backend's clause caps" % jf.get("id"))
+        out[int(jf["id"])] = scenes.complex_filter(clauses, jf.get("symmetry", ""), jf.get("action", "filter_in"))
+    return out
+
+
 class TraceJob:
     """Everything the trace path needs from one Lumice config document."""
 
@@ -190,6 +238,7 @@ class TraceJob:
         self.wavelengths = []      # list of HaloWl (one per discrete wavelength, or a single illuminant entry)
         self.ray_num = 0           # total root rays requested (None = "infinite")
         self.geom_clock = None
+        self.filters = []          # HaloFilter table; HaloEntry.filter_id is a 1-based index into it
 
     def per_wavelength_ray_num(self):
         """ceil(ray_num / N_wl) — server/ray_num_semantics.hpp:13-17."""
@@ -213,8 +262,9 @@ def load_config(source):
             crystals[int(jc["id"])] = parse_crystal(jc)
         except ConfigError as e:
             raise ConfigError("crystal[id=%s]: %s" % (jc.get("id"), e))
-    filters = {int(jf["id"]): jf for jf in doc.get("filter", [])}
+    filters = parse_filters(doc.get("filter", []))
     job = TraceJob()
+    filter_slot = {}
     for jr in doc.get("render", []):
         r = parse_render(jr)
         job.renders[int(jr["id"])] = r
@@ -248,15 +298,17 @@ def load_config(source):
             cid = int(je["crystal"])
             if cid not in crystals:
                 raise ConfigError("scattering entry refers to unknown crystal id %d" % cid)
+            slot = 0
             if "filter" in je:
                 fid = int(je["filter"])
                 if fid not in filters:
                     raise ConfigError("scattering entry refers to unknown filter id %d" % fid)
-                if filters[fid].get("type") != "none":
-                    raise UnsupportedConfig("emit-gate filters are not implemented by this backend yet (filter id %d, type %r)"
-                                            % (fid, filters[fid].get("type")))
+                if fid not in filter_slot:
+                    job.filters.append(filters[fid])
+                    filter_slot[fid] = len(job.filters)
+                slot = filter_slot[fid]
             crystal, axis = crystals[cid]
-            entries.append(scenes.entry(crystal, axis, float(je.get("proportion", 100.0)), cid))
+            entries.append(scenes.entry(crystal, axis, float(je.get("proportion", 100.0)), cid, slot))
         layers.append((float(jl["prob"]), entries))
     if len(layers) > abi.MAX_LAYERS or any(len(e) > abi.MAX_ENTRIES for _, e in layers):
         raise UnsupportedConfig("more scattering layers / entries than the backend's caps")

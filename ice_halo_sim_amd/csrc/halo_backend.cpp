@@ -85,6 +85,8 @@ struct HaloBackend {
   float* acc = nullptr;        // bound accumulator (own or external)
   uint64_t acc_floats = 0;
   int acc_w = 0, acc_h = 0;
+  std::vector<HaloFilter> filters;  // table referenced by HaloEntry::filter_id
+  DevBuf<FilterDev> filter_dev;
   DevBuf<float> mono;          // W*H scalar plane for discrete-wavelength sessions
   bool mono_session = false;
   bool mono_dirty = false;
@@ -202,6 +204,7 @@ int halo_destroy(halo_handle_t b) {
   b->acc_own.release();
   b->sums.release();
   b->mono.release();
+  b->filter_dev.release();
   b->cons_sum.release();
   b->cons_comp.release();
   b->cons_xyz_out.release();
@@ -262,6 +265,22 @@ int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) 
   return HALO_OK;
 }
 
+int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) {
+  if (!b || count < 0 || (count > 0 && !filters)) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "set_filters inside a session");
+  for (int32_t i = 0; i < count; i++) {
+    const HaloFilter& f = filters[i];
+    int terms = f.is_complex ? 0 : 1;
+    if (f.is_complex) {
+      if (f.or_count < 0 || f.or_count > HALO_FILTER_MAX_OR) return fail(b, HALO_FATAL, "complex filter: too many OR-clauses");
+      for (int o = 0; o < f.or_count; o++) terms += f.and_counts[o];
+      if (terms > HALO_FILTER_MAX_TERMS) return fail(b, HALO_FATAL, "complex filter: too many terms");
+    }
+  }
+  b->filters.assign(filters, filters + count);
+  return HALO_OK;
+}
+
 int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t) {
   if (!b || !scene || !render || !wl) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "BeginSession inside a session");
@@ -272,6 +291,8 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     if (scene->layers[l].entry_count < 1 || scene->layers[l].entry_count > HALO_MAX_ENTRIES)
       return fail(b, HALO_FATAL, "entry_count out of range");
     for (int e = 0; e < scene->layers[l].entry_count; e++) {
+      const int fid = scene->layers[l].entries[e].filter_id;
+      if (fid < 0 || fid > static_cast<int>(b->filters.size())) return fail(b, HALO_FATAL, "entry refers to a filter_id outside the table");
       const int kind = scene->layers[l].entries[e].crystal.kind;
       if (kind != HALO_CRYSTAL_PRISM && kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
     }
@@ -445,6 +466,17 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
     P.aggregate = static_cast<uint32_t>(b->aggregate);
     P.geom_clock = b->geom_clock;
+    P.filter = nullptr;
+    if (E.filter_id > 0) {
+      const FilterDev fd = host::BuildFilter(b->filters[static_cast<size_t>(E.filter_id - 1)], E.axis);
+      const bool pass_all = !fd.is_complex && fd.terms[0].type == HALO_FILTER_NONE && fd.action == 0;
+      if (!pass_all) {
+        HIPCHK(b, b->filter_dev.reserve(1));
+        HIPCHK(b, hipMemcpyAsync(b->filter_dev.ptr, &fd, sizeof(fd), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(b, hipStreamSynchronize(b->stream));
+        P.filter = b->filter_dev.ptr;
+      }
+    }
 
     const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
@@ -680,6 +712,12 @@ int halo_host_build_proj_params(const HaloRender* render, void* out76) {
 int halo_host_partition(const float* prop, int n, uint64_t ray_num, double* carry, uint64_t* out) {
   if (!prop || !carry || !out || n < 0) return HALO_FATAL;
   std::vector<uint64_t> v = host::Partition(prop, n, ray_num, carry);
+  std::copy(v.begin(), v.end(), out);
+  return HALO_OK;
+}
+int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int32_t sigma_a, int32_t d_applicable, uint8_t* out) {
+  if (!rp || !out || n < 0 || n > HALO_MAX_HITS) return HALO_FATAL;
+  std::vector<uint8_t> v = host::ReduceRaypath(std::vector<uint8_t>(rp, rp + n), static_cast<uint8_t>(symmetry), sigma_a, d_applicable != 0);
   std::copy(v.begin(), v.end(), out);
   return HALO_OK;
 }

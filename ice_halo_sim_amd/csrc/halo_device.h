@@ -53,6 +53,25 @@ struct ProjDev {  // lm_proj::ProjParams (projection_shared.h:106-118), host-pre
 
 enum : uint32_t { kSrcGen = 0u, kSrcTransit = 1u, kSrcHost = 2u };
 
+// Emit-gate filter as the kernel evaluates it: DeviceFilterDesc (reference src/core/device_filter_desc.hpp:60-100)
+// with canonical face-number sequences already symmetry-reduced on the host.
+constexpr int kFilterPathCap = HALO_MAX_HITS;  // ExitFaceSeq::kCap
+struct FilterTermDev {
+  uint8_t type, has_entry, has_exit, canonical_len;
+  uint32_t min_len, max_len;
+  float dir[3];
+  float radii_c;
+  uint32_t crystal_id;
+  uint8_t canonical[kFilterPathCap];
+};
+struct FilterDev {
+  uint8_t is_complex, action, symmetry, d_applicable;
+  int32_t sigma_a;
+  uint32_t or_count;
+  uint8_t and_counts[HALO_FILTER_MAX_OR];
+  FilterTermDev terms[HALO_FILTER_MAX_TERMS];
+};
+
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
 struct DispatchParams {
   // --- ray source -------------------------------------------------------------------------
@@ -107,6 +126,7 @@ struct DispatchParams {
   HaloExitRecord* exits;
   uint32_t exit_cap;
   uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
+  const FilterDev* filter;     // nullptr = pass-all
 };
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };

@@ -421,6 +421,123 @@ void ToShapeDev(const HaloGeomTables& g, ShapeDev& s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// emit-gate filters
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kFnPeriod = 6;  // Crystal::fn_period_ for the hexagonal families (crystal.cpp:366,397)
+
+std::vector<uint8_t> PShift(std::vector<uint8_t> rp) {  // Crystal::PCanonicalShift crystal.cpp:514-532
+  int first = -1;
+  for (uint8_t& x : rp) {
+    if (x < 3) continue;
+    const int pyr = x / 10;
+    int pri = x % 10;
+    if (first < 0) first = pri;
+    pri = (pri + kFnPeriod - first) % kFnPeriod + 3;
+    x = static_cast<uint8_t>(pyr * 10 + pri);
+  }
+  return rp;
+}
+}  // namespace
+
+std::vector<uint8_t> ReduceRaypath(const std::vector<uint8_t>& rp, uint8_t symmetry, int sigma_a, bool d_applicable) {
+  if (symmetry == 0) return rp;
+  std::vector<uint8_t> cur = rp;
+  if (symmetry & HALO_SYM_P) cur = PShift(cur);
+  if ((symmetry & HALO_SYM_D) && d_applicable) {
+    std::vector<uint8_t> refl = cur;
+    for (uint8_t& x : refl) {
+      if (x < 3) continue;
+      const int pyr = x / 10;
+      int pri = x % 10 - 3;
+      pri = (sigma_a - pri + kFnPeriod) % kFnPeriod;
+      x = static_cast<uint8_t>(pyr * 10 + pri + 3);
+    }
+    if (symmetry & HALO_SYM_P) refl = PShift(refl);
+    if (refl < cur) cur = refl;
+  }
+  if (symmetry & HALO_SYM_B) {
+    std::vector<uint8_t> refl = cur;
+    bool changed = false;
+    for (uint8_t& x : refl) {
+      if (x <= 2) {
+        x = static_cast<uint8_t>(3 - x);
+        changed = true;
+      } else if (x >= 13 && x <= 18) {
+        x = static_cast<uint8_t>(x + 10);
+        changed = true;
+      } else if (x >= 23 && x <= 28) {
+        x = static_cast<uint8_t>(x - 10);
+        changed = true;
+      }
+    }
+    if (changed && refl < cur) cur = refl;
+  }
+  return cur;
+}
+
+int ComputeSigmaA(float roll) {
+  if (std::fabs(roll) > 1e6f) return 0;
+  const int n = (static_cast<int>(std::round(roll / 30.0f)) % 6 + 6) % 6;
+  return (6 - n) % 6;
+}
+
+bool IsDApplicable(const HaloAxis& a) {
+  auto near = [](float x, float y) { return std::fabs(x - y) < kFloatEps; };
+  const bool az_sym = a.azimuth.type == HALO_DIST_UNIFORM && near(a.azimuth.spread, 360.0f);  // IsAzRotationallySymmetric
+  const float rem = std::fmod(std::fmod(a.roll.center, 30.0f) + 30.0f, 30.0f);
+  return az_sym && (near(rem, 0.0f) || near(rem, 30.0f));
+}
+
+FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis) {
+  FilterDev d{};
+  d.is_complex = f.is_complex ? 1 : 0;
+  d.action = f.action ? 1 : 0;
+  d.symmetry = static_cast<uint8_t>(f.symmetry & 7);
+  const bool dap = IsDApplicable(axis);
+  d.d_applicable = dap ? 1 : 0;
+  d.sigma_a = dap ? ComputeSigmaA(axis.roll.center) : 0;
+  auto fill = [&](const HaloFilterTerm& t, FilterTermDev& o) {
+    o.type = static_cast<uint8_t>(t.type);
+    std::vector<uint8_t> rp;
+    if (t.type == HALO_FILTER_RAYPATH) {
+      for (int i = 0; i < t.raypath_len && i < kFilterPathCap; i++) rp.push_back(t.raypath[i]);
+    } else if (t.type == HALO_FILTER_ENTRY_EXIT) {
+      o.has_entry = t.has_entry ? 1 : 0;
+      o.has_exit = t.has_exit ? 1 : 0;
+      o.min_len = t.min_len;
+      o.max_len = t.max_len;
+      if (t.has_entry) rp.push_back(static_cast<uint8_t>(t.entry));
+      if (t.has_exit) rp.push_back(static_cast<uint8_t>(t.exit_face));
+    } else if (t.type == HALO_FILTER_DIRECTION) {  // FillDirection device_filter_desc.cpp:57-65
+      const float lon = t.az * kDegToRad, lat = t.el * kDegToRad;
+      o.dir[0] = std::cos(lat) * std::cos(lon);
+      o.dir[1] = std::cos(lat) * std::sin(lon);
+      o.dir[2] = std::sin(lat);
+      o.radii_c = std::cos(t.radii * kDegToRad);
+    } else if (t.type == HALO_FILTER_CRYSTAL) {
+      o.crystal_id = static_cast<uint32_t>(t.crystal_id);
+    }
+    if (!rp.empty()) {
+      const std::vector<uint8_t> canon = ReduceRaypath(rp, d.symmetry, d.sigma_a, dap);
+      o.canonical_len = static_cast<uint8_t>(canon.size());
+      std::copy(canon.begin(), canon.end(), o.canonical);
+    }
+  };
+  if (!f.is_complex) {
+    fill(f.terms[0], d.terms[0]);
+  } else {
+    d.or_count = static_cast<uint32_t>(std::min(f.or_count, HALO_FILTER_MAX_OR));
+    int k = 0;
+    for (uint32_t o = 0; o < d.or_count; o++) {
+      d.and_counts[o] = static_cast<uint8_t>(f.and_counts[o]);
+      for (int a = 0; a < f.and_counts[o] && k < HALO_FILTER_MAX_TERMS; a++, k++) fill(f.terms[k], d.terms[k]);
+    }
+  }
+  return d;
+}
+
 bool IsDeterministic(const HaloCrystal& c) {
   const int nh = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
   for (int i = 0; i < nh; i++)

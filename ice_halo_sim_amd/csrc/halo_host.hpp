@@ -38,6 +38,13 @@ float IlluminantSpd(int illuminant, float wavelength_nm);   // util/illuminant.c
 std::vector<WlEntryDev> BuildWlPool(const HaloWl& wl);      // wl_pool.hpp:67-91
 std::vector<uint64_t> Partition(const float* proportions, int n, uint64_t ray_num, double* carry);  // simulator.cpp:519-582
 
+// Emit-gate filter descriptor: BuildDeviceFilterDesc / BuildComplexSubDescs (device_filter_desc.cpp:121-170) with the
+// canonical sequences reduced by Crystal::ReduceRaypath (crystal.cpp:536-600).
+FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis);
+std::vector<uint8_t> ReduceRaypath(const std::vector<uint8_t>& rp, uint8_t symmetry, int sigma_a, bool d_applicable);
+int ComputeSigmaA(float roll_center_deg);       // crystal.cpp:720-726
+bool IsDApplicable(const HaloAxis& axis);       // crystal.cpp:728-730
+
 bool IsDeterministic(const HaloCrystal& c);                 // simulator.cpp:453-471
 // One sampled crystal instance (MakeCrystal simulator.cpp:448 with SyncGroupSampler :361-393), shape scalars
 // drawn from the host PCG stream (seed, shape_index).

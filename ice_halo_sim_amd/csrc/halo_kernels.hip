@@ -436,7 +436,121 @@ struct RaySums {
 };
 
 // ------------------------------------------------------------------------------------------------
-// the fused kernel
+// emit-gate filters (shared/filter_shared.h:53-315).  Paths are crystal face NUMBERS already, so the reference's
+// ApplyGetFn remap (poly index → face number) is the identity here.
+// ------------------------------------------------------------------------------------------------
+HD void p_canonical_shift(uint8_t* data, uint32_t size) {  // filter_shared.h:53-68
+  int first_pri = -1;
+  for (uint32_t i = 0; i < size; ++i) {
+    const uint8_t x = data[i];
+    if (x < 3u) continue;
+    const uint32_t pyr = x / 10u;
+    int pri = static_cast<int>(x % 10u);
+    if (first_pri < 0) first_pri = pri;
+    pri = (pri + 6 - first_pri) % 6 + 3;
+    data[i] = static_cast<uint8_t>(pyr * 10u + static_cast<uint32_t>(pri));
+  }
+}
+
+HD bool lex_less(const uint8_t* a, const uint8_t* b, uint32_t size) {
+  for (uint32_t i = 0; i < size; ++i)
+    if (a[i] != b[i]) return a[i] < b[i];
+  return false;
+}
+
+HD void reduce_buffer(uint8_t* data, uint32_t size, uint8_t symmetry, int32_t sigma_a, bool d_applicable) {  // :79-132
+  if (symmetry == 0u) return;
+  if (symmetry & HALO_SYM_P) p_canonical_shift(data, size);
+  uint8_t scratch[kFilterPathCap];
+  if ((symmetry & HALO_SYM_D) && d_applicable) {
+    for (uint32_t i = 0; i < size; ++i) {
+      const uint8_t x = data[i];
+      if (x < 3u) {
+        scratch[i] = x;
+        continue;
+      }
+      const uint32_t pyr = x / 10u;
+      const int pri0 = static_cast<int>(x % 10u) - 3;
+      const int np = ((sigma_a - pri0) % 6 + 6) % 6;
+      scratch[i] = static_cast<uint8_t>(pyr * 10u + static_cast<uint32_t>(np + 3));
+    }
+    if (symmetry & HALO_SYM_P) p_canonical_shift(scratch, size);
+    if (lex_less(scratch, data, size))
+      for (uint32_t i = 0; i < size; ++i) data[i] = scratch[i];
+  }
+  if (symmetry & HALO_SYM_B) {
+    bool changed = false;
+    for (uint32_t i = 0; i < size; ++i) {
+      const uint8_t x = data[i];
+      if (x <= 2u) {
+        scratch[i] = static_cast<uint8_t>(3u - x);
+        changed = true;
+      } else if (x >= 13u && x <= 18u) {
+        scratch[i] = static_cast<uint8_t>(x + 10u);
+        changed = true;
+      } else if (x >= 23u && x <= 28u) {
+        scratch[i] = static_cast<uint8_t>(x - 10u);
+        changed = true;
+      } else {
+        scratch[i] = x;
+      }
+    }
+    if (changed && lex_less(scratch, data, size))
+      for (uint32_t i = 0; i < size; ++i) data[i] = scratch[i];
+  }
+}
+
+HD bool filter_match_term(const FilterDev& f, const FilterTermDev& t, const uint8_t* path, uint32_t len, float wx, float wy, float wz,
+                          uint32_t crystal_id) {  // DeviceFilterMatchSimple :238-257
+  if (t.type == HALO_FILTER_NONE) return true;
+  if (t.type == HALO_FILTER_RAYPATH) {  // :156-178
+    if (len != t.canonical_len) return false;
+    uint8_t buf[kFilterPathCap];
+    for (uint32_t i = 0; i < len; ++i) buf[i] = path[i];
+    reduce_buffer(buf, len, f.symmetry, f.sigma_a, f.d_applicable != 0u);
+    for (uint32_t i = 0; i < len; ++i)
+      if (buf[i] != t.canonical[i]) return false;
+    return true;
+  }
+  if (t.type == HALO_FILTER_ENTRY_EXIT) {  // :180-224
+    if (len == 0u || len < t.min_len) return false;
+    if (t.max_len != 0u && len > t.max_len) return false;
+    if (!t.has_entry && !t.has_exit) return true;
+    uint8_t ee[2];
+    uint32_t n = 0u;
+    if (t.has_entry) ee[n++] = path[0];
+    if (t.has_exit) ee[n++] = path[len - 1u];
+    reduce_buffer(ee, n, f.symmetry, f.sigma_a, f.d_applicable != 0u);
+    if (f.symmetry != 0u && n != t.canonical_len) return false;
+    for (uint32_t i = 0; i < n; ++i)
+      if (ee[i] != t.canonical[i]) return false;
+    return true;
+  }
+  if (t.type == HALO_FILTER_DIRECTION) return t.dir[0] * wx + t.dir[1] * wy + t.dir[2] * wz > t.radii_c;  // :226-229
+  if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;                                    // :231-233
+  return false;
+}
+
+HD bool filter_check(const FilterDev& f, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
+  bool m;
+  if (!f.is_complex) {
+    m = filter_match_term(f, f.terms[0], path, len, wx, wy, wz, crystal_id);
+  } else {  // OR over AND-clauses; an empty complex filter matches nothing (:263-291)
+    m = false;
+    uint32_t idx = 0u;
+    for (uint32_t o = 0u; o < f.or_count && !m; ++o) {
+      const uint32_t n = f.and_counts[o];
+      bool all = true;
+      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f, f.terms[idx + a], path, len, wx, wy, wz, crystal_id);
+      idx += n;
+      m = all;
+    }
+  }
+  return (f.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused kernel.  MODE: 0 = production, 1 = + raypath recording and emit-gate filter, 2 = + exit capture (tests)
 // ------------------------------------------------------------------------------------------------
 template <bool MONO>
 struct LdsTables {
@@ -445,15 +559,28 @@ struct LdsTables {
   ShapeDev shape;
   PixCache<MONO> cache;
 };
+constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
+template <bool ON>
+struct FilterSlot {
+  FilterDev f;
+};
+template <>
+struct FilterSlot<false> {
+  uint32_t unused;
+};
 
-template <bool CAPTURE, bool MONO>
-HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+template <int MODE, bool MONO>
+HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, const FilterDev* filter, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
                   const uint8_t* path, uint32_t path_len, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
   float wx = R[0] * lx + R[1] * ly + R[2] * lz;
   float wy = R[3] * lx + R[4] * ly + R[5] * lz;
   float wz = R[6] * lx + R[7] * ly + R[8] * lz;
+  // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
+  if (MODE != kModePlain && filter != nullptr) {
+    if (!filter_check(*filter, path, path_len, wx, wy, wz, P.crystal_id)) return;
+  }
   // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
   // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
   bool pass = false;
@@ -494,7 +621,7 @@ HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, Stream& gate, 
   }
   sums.exit_w += w;
   sums.exit_n++;
-  if (CAPTURE) {
+  if (MODE == kModeCapture) {
     uint32_t slot = atomicAdd(&P.counters[kCntExit], 1u);
     if (slot < P.exit_cap) {
       HaloExitRecord rec;
@@ -560,8 +687,8 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
   return static_cast<int>(sh->tri_face[tri]);
 }
 
-template <bool CAPTURE, bool MONO, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint32_t tid, RaySums& sums) {
+template <int MODE, bool MONO, typename ShapePtr>
+HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* filter, ShapePtr sh, uint32_t tid, RaySums& sums) {
   float R[9], d[3], p[3], w;
   int face;
   uint32_t wl_idx = 0u;
@@ -624,9 +751,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
   const float inv_n = 1.0f / n_idx;  // once per ray, IEEE like the reference
   const float cmf_x = T.wl[wl_idx].cmf_x, cmf_y = T.wl[wl_idx].cmf_y, cmf_z = T.wl[wl_idx].cmf_z;
 
-  uint8_t path[CAPTURE ? HALO_PATH_CAP : 1];
+  uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
   uint32_t path_len = 0u;
-  if (CAPTURE) path[path_len++] = sh->face_number[face];
+  if (MODE != kModePlain) path[path_len++] = sh->face_number[face];
 
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
@@ -651,7 +778,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     if (has_exit) {
-      emit_gate<CAPTURE, MONO>(P, T.cache, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+      emit_gate<MODE, MONO>(P, T.cache, filter, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
                          entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
@@ -677,15 +804,15 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, ShapePtr sh, uint
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<CAPTURE, MONO>(P, T.cache, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<MODE, MONO>(P, T.cache, filter, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];
     p[1] += t_best * d[1];
     p[2] += t_best * d[2];
     face = hit;
-    if (CAPTURE) {
-      if (path_len < HALO_PATH_CAP) path[path_len] = sh->face_number[face];
+    if (MODE != kModePlain) {
+      if (path_len < kFilterPathCap) path[path_len] = sh->face_number[face];
       path_len++;
     }
   }
@@ -697,12 +824,20 @@ HD float wave_sum(float v) {
   return v;
 }
 
-template <bool CAPTURE, bool POOL, bool MONO>
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 4
 #endif
+template <int MODE, bool POOL, bool MONO>
 __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
+  __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
+  const FilterDev* filter = nullptr;
+  if (MODE != kModePlain && P.filter != nullptr) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.filter);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_filter);
+    for (uint32_t i = threadIdx.x; i < sizeof(FilterDev) / 4u; i += kBlock) dst[i] = src[i];
+    filter = reinterpret_cast<const FilterDev*>(&s_filter);
+  }
   if (P.aggregate == 1u || P.aggregate == 3u) {
     for (int i = threadIdx.x; i < kCacheN; i += kBlock) T.cache.tag[i] = 0u;
     for (int i = threadIdx.x; i < kCacheN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
@@ -730,10 +865,10 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275);
       // a half-wave reads the same rows → broadcast loads served by L1/L2
       const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-      trace_one<CAPTURE, MONO>(P, T, sh, tid, sums);
+      trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
     } else {
       const ShapeDev* sh = &T.shape;  // LDS: ds_read_b128 broadcasts
-      trace_one<CAPTURE, MONO>(P, T, sh, tid, sums);
+      trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
     }
   }
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
@@ -888,21 +1023,23 @@ hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float 
 }
 
 // host-callable launcher (halo_backend.cpp is plain C++ and never sees <<<>>>)
-template <bool CAPTURE, bool POOL>
+template <int MODE, bool POOL>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if (mono) hipLaunchKernelGGL((halo_trace_kernel<CAPTURE, POOL, true>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((halo_trace_kernel<CAPTURE, POOL, false>), grid, block, 0, stream, P);
+  if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, false>), grid, block, 0, stream, P);
+}
+
+template <int MODE>
+static void launch_pool(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool pool, bool mono) {
+  if (pool) launch_mono<MODE, true>(P, grid, block, stream, mono);
+  else launch_mono<MODE, false>(P, grid, block, stream, mono);
 }
 
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono) {
   dim3 grid(blocks), block(kBlock);
-  if (capture) {
-    if (pool) launch_mono<true, true>(P, grid, block, stream, mono);
-    else launch_mono<true, false>(P, grid, block, stream, mono);
-  } else {
-    if (pool) launch_mono<false, true>(P, grid, block, stream, mono);
-    else launch_mono<false, false>(P, grid, block, stream, mono);
-  }
+  if (capture) launch_pool<kModeCapture>(P, grid, block, stream, pool, mono);
+  else if (P.filter != nullptr) launch_pool<kModeFilter>(P, grid, block, stream, pool, mono);
+  else launch_pool<kModePlain>(P, grid, block, stream, pool, mono);
   return hipGetLastError();
 }
 

@@ -57,13 +57,55 @@ def axis(zenith=None, azimuth=None, roll=None):
     return a
 
 
-def entry(crystal, axis_dist, proportion=1.0, crystal_config_id=1):
+def entry(crystal, axis_dist, proportion=1.0, crystal_config_id=1, filter_id=0):
     e = abi.HaloEntry()
     e.crystal = crystal
     e.axis = axis_dist
     e.proportion = float(proportion)
     e.crystal_config_id = int(crystal_config_id)
+    e.filter_id = int(filter_id)
     return e
+
+
+def filter_term(kind="none", raypath=None, entry=None, exit=None, min_len=1, max_len=None, az=0.0, el=0.0, radii=0.0, crystal_id=0):
+    """SimpleFilterParam (reference src/config/filter_config.cpp:62-118)."""
+    t = abi.HaloFilterTerm()
+    t.type = {"none": abi.FILTER_NONE, "raypath": abi.FILTER_RAYPATH, "entry_exit": abi.FILTER_ENTRY_EXIT,
+              "direction": abi.FILTER_DIRECTION, "crystal": abi.FILTER_CRYSTAL}[kind]
+    if raypath is not None:
+        t.raypath_len = len(raypath)
+        for i, f in enumerate(raypath):
+            t.raypath[i] = int(f)
+    t.has_entry, t.entry = (0, 0) if entry is None else (1, int(entry))
+    t.has_exit, t.exit_face = (0, 0) if exit is None else (1, int(exit))
+    t.min_len, t.max_len = int(min_len), 0 if max_len is None else int(max_len)
+    t.az, t.el, t.radii, t.crystal_id = float(az), float(el), float(radii), int(crystal_id)
+    return t
+
+
+def simple_filter(term, symmetry="", action="filter_in"):
+    f = abi.HaloFilter()
+    f.action = 0 if action == "filter_in" else 1
+    f.symmetry = sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+    f.is_complex = 0
+    f.terms[0] = term
+    return f
+
+
+def complex_filter(or_clauses, symmetry="", action="filter_in"):
+    """or_clauses: list of AND-clauses, each a list of HaloFilterTerm (ComplexFilterParam, filter_config.hpp:44-46)."""
+    f = abi.HaloFilter()
+    f.action = 0 if action == "filter_in" else 1
+    f.symmetry = sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+    f.is_complex = 1
+    f.or_count = len(or_clauses)
+    k = 0
+    for i, clause in enumerate(or_clauses):
+        f.and_counts[i] = len(clause)
+        for t in clause:
+            f.terms[k] = t
+            k += 1
+    return f
 
 
 def scene(layers, max_hits=7, sun_altitude=20.0, sun_azimuth=0.0, sun_diameter=0.5):

@@ -88,7 +88,34 @@ typedef struct HaloEntry {
   HaloAxis axis;
   float proportion;
   int32_t crystal_config_id;
+  int32_t filter_id;  /* 0 = no filter (pass-all); k > 0 = filters[k-1] of the table given to halo_set_filters */
+  int32_t reserved;
 } HaloEntry;
+
+/* Emit-gate filters — FilterConfig (src/config/filter_config.hpp:20-86) as the device matcher consumes it
+ * (DeviceFilterDesc, src/core/device_filter_desc.hpp:60-100).  Face ids are crystal face NUMBERS. */
+#define HALO_FILTER_MAX_OR 8      /* kDeviceFilterMaxOrClauses */
+#define HALO_FILTER_MAX_TERMS 16  /* total simple terms over all AND-clauses of one complex filter */
+enum { HALO_FILTER_NONE = 0, HALO_FILTER_RAYPATH = 1, HALO_FILTER_ENTRY_EXIT = 2, HALO_FILTER_DIRECTION = 3,
+       HALO_FILTER_CRYSTAL = 4 };
+enum { HALO_SYM_P = 1, HALO_SYM_B = 2, HALO_SYM_D = 4 }; /* FilterConfig::kSymP/B/D */
+typedef struct HaloFilterTerm { /* SimpleFilterParam */
+  int32_t type;
+  int32_t raypath_len;
+  uint8_t raypath[HALO_MAX_HITS]; /* raypath: face-number sequence */
+  int32_t has_entry, entry, has_exit, exit_face; /* entry_exit: wildcards when has_* == 0 */
+  uint32_t min_len, max_len;      /* entry_exit: path length bounds; max_len 0 = unbounded */
+  float az, el, radii;            /* direction: degrees */
+  int32_t crystal_id;             /* crystal: CrystalConfig::id_ */
+} HaloFilterTerm;
+typedef struct HaloFilter {
+  int32_t action;    /* 0 = filter_in (match passes), 1 = filter_out */
+  int32_t symmetry;  /* HALO_SYM_* bitmask */
+  int32_t is_complex;
+  int32_t or_count;  /* complex: number of OR-clauses; terms[] holds their AND-terms back to back */
+  int32_t and_counts[HALO_FILTER_MAX_OR];
+  HaloFilterTerm terms[HALO_FILTER_MAX_TERMS]; /* simple filter: terms[0] */
+} HaloFilter;
 
 typedef struct HaloLayer {
   float prob; /* MsInfo::prob_ — continuation probability to the next layer */
@@ -205,6 +232,9 @@ int halo_set_stream(halo_handle_t h, void* hip_stream);
  * torch.distributed can reduce it in place).  NULL = backend-owned.  Layout: xyz image then
  * [landed_lo, landed_hi, 0, 0] (landed weight kept as a float pair). */
 int halo_bind_accumulator(halo_handle_t h, void* device_ptr, uint64_t n_floats);
+/* The filter table HaloEntry::filter_id indexes (ConfigManager::filters_, config_manager.cpp:184-215). Copied; stays in
+ * force until replaced.  A filter-failing exit is dropped: neither emitted nor continued (CollectData simulator.cpp:725). */
+int halo_set_filters(halo_handle_t h, const HaloFilter* filters, int32_t count);
 
 /* --- session ------------------------------------------------------------------------------ */
 /* TraceBackend::BeginSession(SessionSpec) — trace_backend.hpp:374-378. scene/render are COPIED. */
@@ -270,6 +300,8 @@ int halo_host_build_lat_lut(const HaloDist* latitude, float* theta, float* cdf, 
 int halo_host_build_proj_params(const HaloRender* render, void* proj_params_76_bytes);
 /* PartitionCrystalRayNum — simulator.cpp:519-582. carry has n entries and persists across calls. */
 int halo_host_partition(const float* proportions, int n, uint64_t ray_num, double* carry, uint64_t* out_counts);
+/* Crystal::ReduceRaypath(rp, symmetry, sigma_a, d_applicable) — crystal.cpp:536-600 (hexagonal families, fn_period 6). */
+int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int32_t sigma_a, int32_t d_applicable, uint8_t* out);
 /* IceRefractiveIndex::Get — optics.cpp:180-197. */
 double halo_host_refractive_index(double wavelength_nm);
 int halo_abi_version(void);

@@ -1170,6 +1170,124 @@ void ho_cmf(float wl, float* x, float* y, float* z) { /* wl_pool.hpp:49-59 */
 }
 
 /* ======================================================================================== */
+/* emit-gate filters: FilterSpec::Check semantics (core/filter_spec.hpp:42-45, filter_spec.cpp)  */
+/* in the byte-sequence form of shared/filter_shared.h:53-315; canonicalisation                  */
+/* Crystal::ReduceRaypath crystal.cpp:514-600; sigma_a / D-applicability crystal.cpp:708-730     */
+/* ======================================================================================== */
+static void p_canonical_shift(uint8_t* data, int size) { /* crystal.cpp:514-532 */
+  int first_pri = -1;
+  for (int i = 0; i < size; i++) {
+    int x = data[i];
+    if (x < 3) continue;
+    int pyr = x / 10, pri = x % 10;
+    if (first_pri < 0) first_pri = pri;
+    pri += 6 - first_pri;
+    pri %= 6;
+    pri += 3;
+    data[i] = (uint8_t)(pyr * 10 + pri);
+  }
+}
+
+static int seq_less(const uint8_t* a, const uint8_t* b, int n) {
+  for (int i = 0; i < n; i++) if (a[i] != b[i]) return a[i] < b[i];
+  return 0;
+}
+
+void ho_reduce_raypath(const uint8_t* rp, int n, int symmetry, int sigma_a, int d_applicable, uint8_t* out) {
+  memcpy(out, rp, (size_t)n);
+  if (symmetry == 0) return;
+  uint8_t alt[HALO_MAX_HITS + 1];
+  if (symmetry & HALO_SYM_P) p_canonical_shift(out, n);
+  if ((symmetry & HALO_SYM_D) && d_applicable) {
+    for (int i = 0; i < n; i++) {
+      int x = out[i];
+      if (x < 3) { alt[i] = (uint8_t)x; continue; }
+      int pyr = x / 10, pri = x % 10 - 3;
+      pri = (sigma_a - pri + 6) % 6;
+      alt[i] = (uint8_t)(pyr * 10 + pri + 3);
+    }
+    if (symmetry & HALO_SYM_P) p_canonical_shift(alt, n);
+    if (seq_less(alt, out, n)) memcpy(out, alt, (size_t)n);
+  }
+  if (symmetry & HALO_SYM_B) {
+    int changed = 0;
+    for (int i = 0; i < n; i++) {
+      int x = out[i];
+      if (x <= 2) { alt[i] = (uint8_t)(3 - x); changed = 1; }
+      else if (x >= 13 && x <= 18) { alt[i] = (uint8_t)(x + 10); changed = 1; }
+      else if (x >= 23 && x <= 28) { alt[i] = (uint8_t)(x - 10); changed = 1; }
+      else alt[i] = (uint8_t)x;
+    }
+    if (changed && seq_less(alt, out, n)) memcpy(out, alt, (size_t)n);
+  }
+}
+
+int ho_compute_sigma_a(float roll_mean_deg) { /* crystal.cpp:720-726 */
+  if (fabsf(roll_mean_deg) > 1e6f) return 0;
+  int n = ((int)roundf(roll_mean_deg / 30.0f) % 6 + 6) % 6;
+  return (6 - n) % 6;
+}
+
+int ho_is_d_applicable(const HaloAxis* d) { /* crystal.cpp:708-730, math.cpp IsAzRotationallySymmetric */
+  int az_sym = d->azimuth.type == HALO_DIST_UNIFORM && float_equal(d->azimuth.spread, 360.0f);
+  float remainder = fmodf(fmodf(d->roll.center, 30.0f) + 30.0f, 30.0f);
+  return az_sym && (float_equal(remainder, 0.0f) || float_equal(remainder, 30.0f));
+}
+
+static int filter_match_term(const HaloFilterTerm* t, int symmetry, int sigma_a, int dap, const uint8_t* path, int len,
+                             const float dir[3], int crystal_id) {
+  uint8_t a[HALO_MAX_HITS + 1], b[HALO_MAX_HITS + 1];
+  switch (t->type) {
+    case HALO_FILTER_NONE: return 1;
+    case HALO_FILTER_RAYPATH: {
+      if (len != t->raypath_len) return 0;
+      ho_reduce_raypath(path, len, symmetry, sigma_a, dap, a);
+      ho_reduce_raypath(t->raypath, t->raypath_len, symmetry, sigma_a, dap, b);
+      return memcmp(a, b, (size_t)len) == 0;
+    }
+    case HALO_FILTER_ENTRY_EXIT: {
+      if (len == 0 || (uint32_t)len < t->min_len) return 0;
+      if (t->max_len != 0 && (uint32_t)len > t->max_len) return 0;
+      if (!t->has_entry && !t->has_exit) return 1;
+      uint8_t ee[2], want[2];
+      int n = 0;
+      if (t->has_entry) { ee[n] = path[0]; want[n] = (uint8_t)t->entry; n++; }
+      if (t->has_exit) { ee[n] = path[len - 1]; want[n] = (uint8_t)t->exit_face; n++; }
+      ho_reduce_raypath(ee, n, symmetry, sigma_a, dap, a);
+      ho_reduce_raypath(want, n, symmetry, sigma_a, dap, b);
+      return memcmp(a, b, (size_t)n) == 0;
+    }
+    case HALO_FILTER_DIRECTION: { /* device_filter_desc.cpp:57-65 + filter_shared.h:226-229 */
+      float lon = t->az * HO_DEG2RAD, lat = t->el * HO_DEG2RAD;
+      float fx = cosf(lat) * cosf(lon), fy = cosf(lat) * sinf(lon), fz = sinf(lat);
+      float rc = cosf(t->radii * HO_DEG2RAD);
+      return fx * dir[0] + fy * dir[1] + fz * dir[2] > rc;
+    }
+    case HALO_FILTER_CRYSTAL: return crystal_id == t->crystal_id;
+  }
+  return 0;
+}
+
+int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id) {
+  int dap = ho_is_d_applicable(axis);
+  int sigma_a = dap ? ho_compute_sigma_a(axis->roll.center) : 0;
+  int m = 0;
+  if (!f->is_complex) {
+    m = filter_match_term(&f->terms[0], f->symmetry, sigma_a, dap, path, len, dir_world, crystal_id);
+  } else { /* ComplexSpec::Match: OR of AND-clauses; empty → false (filter_spec.cpp:274-288) */
+    int idx = 0;
+    for (int o = 0; o < f->or_count && !m; o++) {
+      int all = 1;
+      for (int k = 0; k < f->and_counts[o]; k++)
+        if (all && !filter_match_term(&f->terms[idx + k], f->symmetry, sigma_a, dap, path, len, dir_world, crystal_id)) all = 0;
+      idx += f->and_counts[o];
+      m = all;
+    }
+  }
+  return f->action == 0 ? m : !m;
+}
+
+/* ======================================================================================== */
 /* whole path: the backend state machine of include/halo_trace.h on the CPU                  */
 /* ======================================================================================== */
 typedef struct { float n_idx, spd_weight, cmf[3]; } HoWlEntry; /* wl_pool.hpp:29-35 */
@@ -1204,6 +1322,8 @@ struct HoBackend {
   float* cont_in;
   uint64_t cont_in_n;
   int cont_shuffle;
+  HaloFilter* filters;
+  int filter_count;
   /* consumer: RenderConsumer::internal_xyz_ / comp_xyz_ / total_intensity_ (server/render.hpp) */
   float* cons_sum;
   float* cons_comp;
@@ -1229,6 +1349,7 @@ void ho_destroy(HoBackend* b) {
   free(b->exits);
   free(b->cons_sum);
   free(b->cons_comp);
+  free(b->filters);
   free(b);
 }
 int ho_set_option(HoBackend* b, const char* key, int64_t v) {
@@ -1261,6 +1382,17 @@ static void build_wl_pool(HoBackend* b) { /* wl_pool.hpp:67-91 */
     e->spd_weight = b->wl.weight;
     ho_cmf(b->wl.wavelength, &e->cmf[0], &e->cmf[1], &e->cmf[2]);
   }
+}
+
+int ho_set_filters(HoBackend* b, const HaloFilter* filters, int32_t count) {
+  free(b->filters);
+  b->filters = NULL;
+  b->filter_count = count;
+  if (count > 0) {
+    b->filters = (HaloFilter*)malloc((size_t)count * sizeof(HaloFilter));
+    memcpy(b->filters, filters, (size_t)count * sizeof(HaloFilter));
+  }
+  return HALO_OK;
 }
 
 int ho_begin(HoBackend* b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t hint) {
@@ -1315,6 +1447,8 @@ typedef struct {
   uint32_t shuffle_seed;
   const HaloHostRays* host;
   int crystal_id;
+  const HaloFilter* filter; /* NULL = pass-all */
+  const HaloAxis* axis;
 } HoCiCtx;
 
 typedef struct { /* per-thread output sink */
@@ -1365,6 +1499,8 @@ static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const floa
   HoBackend* b = sink->b;
   float exit_world[3];
   ho_apply_mat9(rot, d_local, exit_world);
+  /* physical filter: fail = the ray terminates (CollectData simulator.cpp:689,725-728) */
+  if (c->filter && !ho_filter_check(c->filter, c->axis, path, path_len, exit_world, c->crystal_id)) return;
   int pass_prob = 0;
   if (c->prob > 0.0f) pass_prob = (c->prob >= 1.0f) ? 1 : (ho_pcg_uniform(gate) < c->prob); /* rng.GetUniform() < prob_ :719 */
   if (pass_prob) {
@@ -1650,6 +1786,8 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     c->prob = L->prob;
     c->max_hits = b->scene.max_hits;
     c->crystal_id = E->crystal_config_id;
+    c->filter = (E->filter_id > 0 && E->filter_id <= b->filter_count) ? &b->filters[E->filter_id - 1] : NULL;
+    c->axis = &E->axis;
     /* BuildTransitGpParams / BuildGenGpParams cuda_trace_backend.cu:342-399 */
     c->gp.lat_path = ho_select_lat_path(&E->axis);
     c->gp.lat_mean_rad = E->axis.latitude.center * HO_DEG2RAD;

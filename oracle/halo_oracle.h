@@ -106,6 +106,12 @@ int ho_recombine(HoBackend* b, int shuffle, uint64_t* continuation_count);
 int ho_drain_exits(HoBackend* b, HaloExitRecord* out, uint64_t cap, uint64_t* count);
 int ho_end(HoBackend* b);
 int ho_readback_xyz64(HoBackend* b, float* xyz, int width, int height, double* landed_weight);
+/* emit-gate filters (core/filter_spec.cpp, shared/filter_shared.h, crystal.cpp:514-600,708-730) */
+void ho_reduce_raypath(const uint8_t* rp, int n, int symmetry, int sigma_a, int d_applicable, uint8_t* out);
+int ho_compute_sigma_a(float roll_mean_deg);
+int ho_is_d_applicable(const HaloAxis* axis);
+int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id);
+int ho_set_filters(HoBackend* b, const HaloFilter* filters, int32_t count);
 /* consumer (server/render.cpp:96-201,465-578; util/color_space.cpp) */
 void ho_neumaier_add(float* sum, float* comp, float delta);
 void ho_gamut_clip_xyz(const float xyz[3], float clipped[3]);

@@ -100,6 +100,13 @@ def oracle():
     L.ho_continuation_dump.restype = C.c_uint64; L.ho_continuation_dump.argtypes = [C.c_void_p, f32p, C.c_uint64]
     L.ho_pyramid_geometry.restype = None; L.ho_pyramid_geometry.argtypes = [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]
     L.ho_pyramid_face_mask.restype = C.c_int; L.ho_pyramid_face_mask.argtypes = [C.c_float] * 5 + [f32p, i32p]
+    u8p = C.POINTER(C.c_uint8)
+    L.ho_reduce_raypath.restype = None; L.ho_reduce_raypath.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+    L.ho_compute_sigma_a.restype = C.c_int; L.ho_compute_sigma_a.argtypes = [C.c_float]
+    L.ho_is_d_applicable.restype = C.c_int; L.ho_is_d_applicable.argtypes = [C.POINTER(abi.HaloAxis)]
+    L.ho_filter_check.restype = C.c_int
+    L.ho_filter_check.argtypes = [C.POINTER(abi.HaloFilter), C.POINTER(abi.HaloAxis), u8p, C.c_int, f32p, C.c_int]
+    L.ho_set_filters.restype = C.c_int; L.ho_set_filters.argtypes = [C.c_void_p, C.POINTER(abi.HaloFilter), C.c_int32]
     L.ho_neumaier_add.restype = None; L.ho_neumaier_add.argtypes = [f32p, f32p, C.c_float]
     L.ho_gamut_clip_xyz.restype = None; L.ho_gamut_clip_xyz.argtypes = [f32p, f32p]
     L.ho_xyz_to_linear_rgb.restype = None; L.ho_xyz_to_linear_rgb.argtypes = [f32p, f32p]

@@ -31,6 +31,10 @@ class OracleBackend:
         rc = self._L.ho_set_option(self._h, key.encode(), int(value))
         assert rc == 0, key
 
+    def set_filters(self, filters):
+        arr = (abi.HaloFilter * max(1, len(filters)))(*filters)
+        assert self._L.ho_set_filters(self._h, arr, len(filters)) == 0
+
     def BeginSession(self, scene, render, wl, ray_num=0):
         self._render, self._scene = render, scene
         assert self._L.ho_begin(self._h, C.byref(scene), C.byref(render), C.byref(wl), int(ray_num)) == 0

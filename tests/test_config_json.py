@@ -1,0 +1,150 @@
+"""JSON config surface (reference src/config/*.cpp parsers; doc/configuration.md): the documents below follow the
+reference's published schema (keys `mean`/`std`, `zenith`, `upper_indices`, `scattering[].entries[]`, lens `f`)."""
+import copy
+import math
+import os
+
+import pytest
+
+from ice_halo_sim_amd import abi, config
+
+DOC = {
+    "crystal": [
+        {"id": 1, "type": "prism", "shape": {"height": 1.2}},
+        {"id": 3, "type": "prism", "shape": {"height": 1.3, "face_distance": [1, 1, 1, 1, 1, 1]},
+         "axis": {"zenith": {"type": "gauss", "mean": 90, "std": 0.3}, "roll": {"type": "uniform", "mean": 0, "std": 360},
+                  "azimuth": {"type": "uniform", "mean": 0, "std": 360}}},
+        {"id": 4, "type": "prism", "shape": {"height": {"type": "uniform", "mean": 0.5, "std": 0.4},
+                                             "face_distance": [{"type": "gauss", "mean": 1, "std": 0.2}] * 6,
+                                             "sync_group": {"height": 7, "face_distance": [7, 2, 2, 0, 9, 0]}},
+         "axis": {"zenith": {"type": "gauss", "mean": 0, "std": 1.2}}},
+        {"id": 5, "type": "pyramid", "shape": {"upper_h": 0.1, "lower_h": 0.5, "prism_h": 1.2, "upper_indices": [2, 0, 3]},
+         "axis": {"zenith": 0}},
+    ],
+    "filter": [{"id": 1, "type": "none"}, {"id": 2, "type": "raypath", "raypath": [3, 5], "symmetry": "P"}],
+    "scene": {
+        "light_source": {"type": "sun", "altitude": 20.0, "azimuth": 0, "diameter": 0.5,
+                         "spectrum": [{"wavelength": 450 + 40 * i, "weight": 1.0} for i in range(9)]},
+        "ray_num": 1000, "max_hits": 7,
+        "scattering": [{"prob": 0.0, "entries": [{"crystal": 3, "proportion": 10, "filter": 1}, {"crystal": 5}]}],
+    },
+    "render": [
+        {"id": 1, "lens": {"type": "linear", "f": 14}, "resolution": [1920, 1080], "lens_shift": [0, 200],
+         "view": {"azimuth": -10, "elevation": 20, "roll": 0}},
+        {"id": 4, "lens": {"type": "fisheye_equal_area", "fov": 120}, "resolution": [1920, 1080], "view": {"elevation": 30}},
+    ],
+}
+
+
+def test_document_maps_onto_the_abi_structs():
+    job = config.load_config(copy.deepcopy(DOC))
+    sc = job.scene
+    assert (sc.max_hits, sc.layer_count, sc.layers[0].entry_count) == (7, 1, 2)
+    assert (sc.sun_altitude, sc.sun_azimuth, sc.sun_diameter) == (20.0, 0.0, 0.5)
+    e = sc.layers[0].entries[0]
+    assert e.crystal_config_id == 3 and e.proportion == 10.0 and e.crystal.kind == abi.CRYSTAL_PRISM
+    assert e.crystal.height[0].center == pytest.approx(1.3)
+    # zenith gauss(90, 0.3) → internal latitude gauss(0, 0.3) (math.cpp:679-714)
+    assert (e.axis.latitude.type, e.axis.latitude.center, e.axis.latitude.spread) == (abi.DIST_GAUSS, 0.0, pytest.approx(0.3))
+    assert (e.axis.azimuth.type, e.axis.azimuth.spread) == (abi.DIST_UNIFORM, 360.0)
+    p = sc.layers[0].entries[1]
+    assert p.crystal.kind == abi.CRYSTAL_PYRAMID and p.proportion == 100.0  # default proportion (config_manager.cpp:110)
+    assert [p.crystal.height[i].center for i in range(3)] == [pytest.approx(0.1), pytest.approx(1.2), pytest.approx(0.5)]
+    assert p.crystal.wedge_upper_deg == pytest.approx(math.degrees(math.atan(0.866025403784 * 3 / 2 / 1.629)), rel=1e-6)
+    assert p.crystal.wedge_lower_deg == 28.0
+    assert (p.axis.latitude.type, p.axis.latitude.center) == (abi.DIST_NONE, 90.0)
+    assert p.axis.azimuth.type == abi.DIST_UNIFORM  # `axis` present → azimuth/roll default to uniform 360
+    assert len(job.wavelengths) == 9 and job.wavelengths[2].wavelength == 530.0 and job.wavelengths[0].illuminant == -1
+    assert job.per_wavelength_ray_num() == 112  # ceil(1000 / 9)
+    r1, r4 = job.renders[1], job.renders[4]
+    assert r1.lens_type == abi.LENS_LINEAR and r1.fov == pytest.approx(math.degrees(math.atan2(12.0, 14.0) * 2))
+    assert (r1.lens_shift[0], r1.lens_shift[1], r1.view_az, r1.view_el) == (0, 200, -10.0, 20.0)
+    assert (r4.lens_type, r4.fov, r4.visible, r4.view_el) == (abi.LENS_FISHEYE_EQUAL_AREA, 120.0, abi.VISIBLE_UPPER, 30.0)
+
+
+def test_absent_axis_and_sync_groups():
+    doc = copy.deepcopy(DOC)
+    doc["scene"]["scattering"][0]["entries"] = [{"crystal": 1}, {"crystal": 4}]
+    job = config.load_config(doc)
+    a = job.scene.layers[0].entries[0].axis  # no `axis`: everything fixed, zenith 0 (math.cpp AxisDistribution())
+    assert (a.latitude.type, a.latitude.center, a.azimuth.type, a.roll.type) == (abi.DIST_NONE, 90.0, abi.DIST_NONE, abi.DIST_NONE)
+    c = job.scene.layers[0].entries[1].crystal
+    # groups {7: height+d0, 2: d1+d2, 9: d4 alone} → canonical {1: height+d0, 2: d1+d2}, singleton dropped
+    assert list(c.sync_group) == [1, 0, 0, 1, 2, 2, 0, 0, 0]
+    # members take the leader's distribution (crystal_config.cpp:102-133): d0 follows height's uniform
+    assert (c.face_dist[0].type, c.face_dist[0].center) == (abi.DIST_UNIFORM, pytest.approx(0.5))
+    assert c.face_dist[1].type == abi.DIST_GAUSS
+
+
+def test_illuminant_and_rejections():
+    doc = copy.deepcopy(DOC)
+    doc["scene"]["light_source"]["spectrum"] = "D65"
+    job = config.load_config(doc)
+    assert len(job.wavelengths) == 1 and job.wavelengths[0].illuminant == abi.ILLUM["D65"]
+    bad = copy.deepcopy(DOC)
+    bad["crystal"][1]["axis"]["zenith"] = {"mean": 90, "std": 1}
+    with pytest.raises(config.ConfigError, match="type"):
+        config.load_config(bad)
+    bad = copy.deepcopy(DOC)
+    del bad["scene"]["scattering"][0]["prob"]
+    with pytest.raises(config.ConfigError, match="prob"):
+        config.load_config(bad)
+    bad = copy.deepcopy(DOC)
+    bad["scene"]["max_hits"] = 65
+    with pytest.raises(config.ConfigError, match="max_hits"):
+        config.load_config(bad)
+    rc = copy.deepcopy(DOC)
+    rc["raypath_color"] = [{"name": "x"}]
+    with pytest.raises(config.UnsupportedConfig):
+        config.load_config(rc)
+
+
+def test_filters_map_onto_the_filter_table():
+    doc = copy.deepcopy(DOC)
+    doc["filter"] = [
+        {"id": 1, "type": "none"},
+        {"id": 2, "type": "raypath", "raypath": [3, 1, 5, 7, 4], "symmetry": "PBD"},
+        {"id": 4, "type": "entry_exit", "entry": 3, "exit": 5, "action": "filter_in"},
+        {"id": 5, "type": "direction", "az": 180, "el": 25, "radii": 0.5, "action": "filter_out"},
+        {"id": 6, "type": "crystal", "crystal_id": 3},
+        {"id": 7, "type": "complex", "composition": [1, [2, 6], 5]},
+    ]
+    doc["scene"]["scattering"][0]["entries"] = [{"crystal": 3, "filter": 7}, {"crystal": 5, "filter": 2}, {"crystal": 1}]
+    job = config.load_config(doc)
+    ents = job.scene.layers[0].entries
+    assert [ents[i].filter_id for i in range(3)] == [1, 2, 0] and len(job.filters) == 2
+    f7, f2 = job.filters
+    assert f7.is_complex == 1 and f7.or_count == 3 and list(f7.and_counts)[:3] == [1, 2, 1]
+    assert [f7.terms[k].type for k in range(4)] == [abi.FILTER_NONE, abi.FILTER_RAYPATH, abi.FILTER_CRYSTAL, abi.FILTER_DIRECTION]
+    assert f7.terms[3].radii == 0.5 and f7.terms[2].crystal_id == 3
+    assert f2.is_complex == 0 and f2.symmetry == 7 and list(f2.terms[0].raypath)[:5] == [3, 1, 5, 7, 4] and f2.terms[0].raypath_len == 5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/examples"), reason="reference examples only exist in the build container")
+def test_reference_example_files_parse():
+    for name in ("bench_config.json", "bench_config_stoch.json", "lens_orthographic.json"):
+        path = os.path.join("/root/reference/examples", name)
+        if os.path.exists(path):
+            job = config.load_config(path)
+            assert job.scene.layer_count >= 1 and job.renders
+    job = config.load_config("/root/reference/examples/config_example.json")
+    assert job.ray_num == 450_000_000 and len(job.wavelengths) == 9 and sorted(job.renders) == [1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+def test_cli_benchmark_line(tmp_path):
+    import json
+    import subprocess
+    import sys
+    doc = copy.deepcopy(DOC)
+    doc["scene"]["ray_num"] = 9_000_000
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps(doc))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli", "-f", str(cfg), "--render", "4", "--benchmark",
+                        "--out-rgb", str(tmp_path / "o.ppm")], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("[BENCHMARK] ")][0]
+    rec = json.loads(line[len("[BENCHMARK] "):])
+    assert rec["rays"] == 9_000_000 and rec["rays_per_sec"] > 1e7 and rec["rate_basis"] in ("steady", "active_short")
+    assert (tmp_path / "o.ppm").stat().st_size > 1920 * 1080 * 3

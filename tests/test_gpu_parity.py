@@ -237,6 +237,74 @@ def test_multi_entry_layer_partition_parity():
     assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
 
 
+def _filter_table():
+    return [
+        scenes.simple_filter(scenes.filter_term("raypath", raypath=[3, 5]), "P"),                              # 1: 22-degree halo path
+        scenes.simple_filter(scenes.filter_term("entry_exit", entry=3, exit=5, min_len=2, max_len=4), "PBD"),  # 2
+        scenes.simple_filter(scenes.filter_term("direction", az=180, el=20, radii=2.0), "", "filter_out"),     # 3: mask the sun
+        scenes.complex_filter([[scenes.filter_term("raypath", raypath=[1, 3, 2])],
+                               [scenes.filter_term("entry_exit", entry=1), scenes.filter_term("crystal", crystal_id=6)],
+                               [scenes.filter_term("raypath", raypath=[3, 1, 5, 7, 4])]], "PBD"),             # 4: complex OR of ANDs
+        scenes.simple_filter(scenes.filter_term("none")),                                                      # 5
+        scenes.simple_filter(scenes.filter_term("raypath", raypath=[13, 25]), "PB"),                           # 6: pyramidal faces
+    ]
+
+
+@pytest.mark.parametrize("case", ["raypath_P", "entry_exit_PBD_d_applicable", "direction_out", "complex", "multi_scatter_gate", "pyramid_PB"])
+def test_emit_gate_filter_parity(case):
+    """Emit-gate filters (reference filter_shared.h / filter_spec.cpp): same per-ray survivors, paths and image as the oracle."""
+    col = scenes.column_crystal_entry()
+    plate = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 0.8}), 5.0, 6)
+    parry = scenes.entry(scenes.prism_crystal(1.5), scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 0.5}, roll=30.0), 4.0, 2)  # roll fixed → D applies
+    pyr = scenes.entry(scenes.pyramid_crystal(0.3, 1.0, 0.3, upper_wedge=28.0, lower_wedge=28.0),
+                       scenes.axis(zenith={"type": "uniform", "mean": 90, "std": 360}, azimuth={"type": "uniform", "mean": 0, "std": 360}), 3.0, 5)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    layers = {
+        "raypath_P": [(0.0, [_with(col, 1), _with(plate, 0)])],
+        "entry_exit_PBD_d_applicable": [(0.0, [_with(parry, 2)])],
+        "direction_out": [(0.0, [_with(col, 3)])],
+        "complex": [(0.0, [_with(col, 4), _with(plate, 4)])],
+        "multi_scatter_gate": [(0.6, [_with(plate, 2)]), (0.0, [_with(col, 1)])],
+        "pyramid_PB": [(0.0, [_with(pyr, 6), _with(col, 5)])],
+    }[case]
+    sc = scenes.scene(layers, max_hits=7)
+    n = 80_000
+    hb = hip_backend(seed=21, capture_exits=1)
+    ob = OracleBackend(seed=21, capture_exits=1, threads=8)
+    for b in (hb, ob):
+        b.set_filters(_filter_table())
+    sh = run_session(hb, sc, rd, scenes.wl_discrete(550.0), n)
+    so = run_session(ob, sc, rd, scenes.wl_discrete(550.0), n)
+    eh, eo = hb.DrainExits(), ob.DrainExits()
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    assert 0 < len(eo) < (8 if case == "direction_out" else 4.5) * n * len(layers)   # the filter really removed exits
+    if case == "multi_scatter_gate":                     # continuation order differs → statistical (see test_multi_scatter_parity)
+        assert sh[0].continuation_count == pytest.approx(so[0].continuation_count, rel=5e-3)
+        assert lh == pytest.approx(lo, rel=2e-2) and len(eh) == pytest.approx(len(eo), rel=2e-2)
+        l1 = eh[eh["layer"] == 1]
+        assert len(l1) and all(tuple(p[:2]) in {(3, 5), (4, 6), (5, 7), (6, 8), (7, 3), (8, 4)} for p in l1["path"][:500]) and (l1["path_len"] == 2).all()
+        return
+    frac, pix, path = match_exits(eh, eo)
+    assert frac >= 0.998 and pix >= 0.995 and path >= 0.999
+    assert abs(lh - lo) <= 2e-4 * max(lo, 1.0)
+    assert sh[0].exit_count == pytest.approx(so[0].exit_count, rel=3e-4)
+    if io.sum() > 0:
+        assert rel_l2(block_mean(ih), block_mean(io)) <= 3e-3
+    if case == "raypath_P":
+        c3 = eh[eh["crystal_id"] == 3]
+        assert (c3["path_len"] == 2).all() and set(map(tuple, np.unique(c3["path"][:, :2], axis=0))) <= {(3, 5), (4, 6), (5, 7), (6, 8), (7, 3), (8, 4)}
+    if case == "direction_out":
+        sun = np.array([np.cos(np.deg2rad(20)) * np.cos(np.pi), np.cos(np.deg2rad(20)) * np.sin(np.pi), np.sin(np.deg2rad(20))], np.float32)
+        assert (eh["dir"] @ sun <= np.cos(np.deg2rad(2.0)) + 1e-6).all()
+
+
+def _with(e, filter_id):
+    c = type(e).from_buffer_copy(bytes(e))
+    c.filter_id = filter_id
+    return c
+
+
 def test_consumer_fold_and_snapshot_parity():
     """ConsumeDeviceFused + PrepareSnapshot + PostSnapshot on device vs the oracle (reference server/render.cpp:96-201,
     465-578): two drains folded with Neumaier compensation, exposure scale, gamut clip, sRGB bytes."""

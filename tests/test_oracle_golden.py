@@ -236,3 +236,55 @@ def test_fixture_lut_lookup_projection_cmf_prism_pool():
         n = O.ho_prism_corner_ring(1.0, fptr(np.ascontiguousarray(dist)), fptr(cx), fptr(cy), i32ptr(present))
         assert verdict[1] == 0 and n == verdict[0]
         assert [bool(p) for p in present[2:8]] == [bin(int(m)).count("1") >= 2 for m in verdict[2:8]]
+
+
+# ---------------------------------------------------------------- emit-gate filters
+def _reduce(fn, rp, sym, sa, dap):
+    a = (C.c_uint8 * len(rp))(*rp)
+    out = (C.c_uint8 * len(rp))()
+    fn(a, len(rp), sym, sa, dap, out)
+    return list(out)
+
+
+def test_reduce_raypath_sigma_a_d_applicable_reference_vectors():
+    O, L = _libs.oracle(), backend.load_library()
+    g = V["reduce_raypath"]
+    for c in g["cases"]:
+        assert _reduce(O.ho_reduce_raypath, c["rp"], c["symmetry"], c["sigma_a"], c["d_applicable"]) == c["expected"]
+        assert _reduce(L.halo_host_reduce_raypath, c["rp"], c["symmetry"], c["sigma_a"], c["d_applicable"]) == c["expected"]
+    for c in g["same_orbit"]:
+        assert _reduce(O.ho_reduce_raypath, c["a"], c["symmetry"], c["sigma_a"], c["d_applicable"]) == \
+            _reduce(O.ho_reduce_raypath, c["b"], c["symmetry"], c["sigma_a"], c["d_applicable"])
+    for roll, sa in V["compute_sigma_a"]["cases"]:
+        assert O.ho_compute_sigma_a(float(roll)) == sa
+    for c in V["is_d_applicable"]["cases"]:
+        ax = abi.HaloAxis()
+        ax.azimuth = abi.HaloDist(c["az_type"], 0.0, c["az_spread"])
+        ax.roll = abi.HaloDist(abi.DIST_NONE, c["roll"], 0.0)
+        assert O.ho_is_d_applicable(C.byref(ax)) == c["expected"]
+
+
+def test_reduce_raypath_orbit_invariant_and_product_agreement():
+    """ReduceRaypath(rp) == ReduceRaypath(g.rp) for every symmetry operation g (reference test_reduce_raypath_audit.cpp:14-60),
+    and the product's host canonicaliser equals the oracle's on random paths."""
+    O, L = _libs.oracle(), backend.load_library()
+    rng = np.random.default_rng(12)
+    faces = [1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28]
+    for _ in range(3000):
+        n = int(rng.integers(1, 9))
+        rp = [int(v) for v in rng.choice(faces, n)]
+        sym, sa, dap = int(rng.integers(0, 8)), int(rng.integers(0, 6)), int(rng.integers(0, 2))
+        base = _reduce(O.ho_reduce_raypath, rp, sym, sa, dap)
+        assert base == _reduce(L.halo_host_reduce_raypath, rp, sym, sa, dap)
+        # idempotent
+        assert _reduce(O.ho_reduce_raypath, base, sym, sa, dap) == base
+        if sym & 1:  # P: rotate every lateral face by k
+            k = int(rng.integers(1, 6))
+            rot = [x if x < 3 else (x // 10) * 10 + ((x % 10 - 3 + k) % 6) + 3 for x in rp]
+            assert _reduce(O.ho_reduce_raypath, rot, sym, sa, dap) == base
+        if sym & 2:  # B: swap basal faces and upper/lower pyramidal faces
+            mir = [3 - x if x <= 2 else (x + 10 if 13 <= x <= 18 else (x - 10 if 23 <= x <= 28 else x)) for x in rp]
+            assert _reduce(O.ho_reduce_raypath, mir, sym, sa, dap) == base
+        if (sym & 4) and dap:  # D: sigma reflection
+            ref = [x if x < 3 else (x // 10) * 10 + ((sa - (x % 10 - 3)) % 6) + 3 for x in rp]
+            assert _reduce(O.ho_reduce_raypath, ref, sym, sa, dap) == base
