@@ -81,7 +81,7 @@ def main():
     from ice_halo_sim_amd.dist import ShardedTracer
 
     sc, rd = scenes.config2_scene(), scenes.config2_render()
-    tracer = ShardedTracer(sc, rd, seed=42, device=local_rank, rank=rank, world=world)
+    tracer = ShardedTracer(sc, rd, seed=42, device=local_rank, rank=rank, world=world, **{"async": 1})
     if args.blocks_per_cu > 0:
         tracer.backend.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.aggregate >= 0:
@@ -104,13 +104,14 @@ def main():
     for _ in range(args.warmup):
         step()
     tracer.zero()
+    tracer.backend.collect_stats()                            # drop the warm-up tallies
     barrier()
     t0 = time.perf_counter()
-    all_stats = []
     for _ in range(args.steps):
-        all_stats += step()
+        step()                                               # dispatches are queued; nothing waits on the host per launch
     barrier()
     dt = time.perf_counter() - t0
+    st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of the timed region
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,10 +119,8 @@ def main():
 
     rays_per_rank = args.steps * len(wls) * n
     total_rays = rays_per_rank * world
-    launches = sum(int(s.launches) for s in all_stats)
-    kernel_ms = sum(float(s.kernel_ms) for s in all_stats)
-    pixel_hits = sum(int(s.pixel_hits) for s in all_stats)
-    exits = sum(int(s.exit_count) for s in all_stats)
+    launches, kernel_ms, pixel_hits, exits = int(st.launches), float(st.kernel_ms), int(st.pixel_hits), int(st.exit_count)
+    assert int(st.root_count) == rays_per_rank
 
     if rank == 0:
         img, landed = tracer.readback()
@@ -147,7 +146,7 @@ def main():
                        "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "halo_trace_kernel<false,false>", "launches": launches,
+                         "kernel": "halo_trace_kernel<0,false,true>", "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "kernel_rays_per_s": (rays_per_rank / max(kernel_ms * 1e-3, 1e-12)),
                          "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is ALU/latency/atomic-bound, not HBM-bound (DESIGN.md §4)"},

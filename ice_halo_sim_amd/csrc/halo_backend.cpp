@@ -19,7 +19,8 @@
 
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream);
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz, int blocks,
+                       hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
@@ -57,7 +58,6 @@ struct HaloBackend {
   std::string error;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int cu_count = 256;
 
   // options
@@ -66,7 +66,10 @@ struct HaloBackend {
   uint64_t chunk = 1ull << 26;
   int aggregate = 1;
   int mono_enabled = 1;
+  int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
+  uint32_t mono_mask = 0;      // slots per copy - 1 (power of two >= W*H)
   int blocks_per_cu = 8;
+  int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
 
   // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
   uint64_t gen_count = 0, gate_count = 0, transit_count = 0, shape_count = 0;
@@ -96,11 +99,22 @@ struct HaloBackend {
   DevBuf<uint8_t> cons_rgb;
   int cons_w = 0, cons_h = 0;
   double total_intensity = 0.0;
-  DevBuf<double> sums;         // kSumNum
+  DevBuf<double> sums;         // [kSumLanded] persistent landed-weight tally
   DevBuf<uint32_t> counters;   // kCntNum
-  DevBuf<float> lut;
-  DevBuf<WlEntryDev> wl_pool;
+  // dispatch ring: device slots, pinned host mirrors, pinned tally read-back, per-slot events
+  static constexpr int kRing = 32;
+  DevBuf<DispatchSlot> ring_dev;
+  DispatchSlot* ring_host = nullptr;   // hipHostMalloc
+  double* ring_result = nullptr;       // hipHostMalloc, kRing x 4
+  hipEvent_t ring_ev0[kRing] = {}, ring_ev1[kRing] = {}, ring_done[kRing] = {};
+  bool ring_busy[kRing] = {};
+  int ring_next = 0;
+  HaloLayerStats pending{};    // harvested tallies not yet handed to the caller (async mode)
+  HaloLayerStats layer_acc{};  // tallies of the layer being traced
+  std::vector<WlEntryDev> wl_pool_host;
   uint32_t wl_pool_size = 0;
+  struct LutKey { int32_t type; float center, spread; host::LatLut lut; };
+  std::vector<LutKey> lut_cache;
   DevBuf<ShapeDev> shapes;
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
   uint32_t cont_stride[2] = {0, 0};
@@ -150,11 +164,38 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
   return HALO_OK;
 }
 
-// fold the device landed-weight tally into the host fp64 running sum (after a stream sync)
-int fold_sums(HaloBackend* b, double out[kSumNum]) {
-  HIPCHK(b, hipMemcpyAsync(out, b->sums.ptr, kSumNum * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
-  return HALO_OK;
+// take the tallies of one finished ring slot
+void harvest_slot(HaloBackend* b, int k) {
+  if (!b->ring_busy[k]) return;
+  (void)hipEventSynchronize(b->ring_done[k]);
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
+  const double* r = b->ring_result + 4 * k;
+  b->layer_acc.exit_w_sum += r[kSumExitW];
+  b->layer_acc.exit_count += static_cast<uint64_t>(r[kSumExitN] + 0.5);
+  b->layer_acc.pixel_hits += static_cast<uint64_t>(r[kSumPixN] + 0.5);
+  b->layer_acc.kernel_ms += ms;
+  b->layer_acc.launches += 1;
+  b->ring_busy[k] = false;
+}
+void harvest_all(HaloBackend* b) {
+  for (int k = 0; k < HaloBackend::kRing; k++) harvest_slot(b, k);
+}
+void add_stats(HaloLayerStats& dst, const HaloLayerStats& src) {
+  dst.root_count += src.root_count;
+  dst.exit_count += src.exit_count;
+  dst.continuation_count += src.continuation_count;
+  dst.exit_w_sum += src.exit_w_sum;
+  dst.kernel_ms += src.kernel_ms;
+  dst.pixel_hits += src.pixel_hits;
+  dst.launches += src.launches;
+}
+const host::LatLut& cached_lut(HaloBackend* b, const HaloDist& d) {
+  for (const auto& e : b->lut_cache)
+    if (e.type == d.type && e.center == d.center && e.spread == d.spread) return e.lut;
+  if (b->lut_cache.size() >= 64) b->lut_cache.clear();
+  b->lut_cache.push_back({d.type, d.center, d.spread, host::BuildLatLut(d)});
+  return b->lut_cache.back().lut;
 }
 
 }  // namespace
@@ -181,9 +222,18 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
   b->device = device_ordinal;
   b->seed = seed ? seed : 1u;
   b->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess) {
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete b;
+    return HALO_UNAVAILABLE;
+  }
+  bool ring_ok = b->ring_dev.reserve(HaloBackend::kRing) == hipSuccess &&
+                 hipHostMalloc(reinterpret_cast<void**>(&b->ring_host), HaloBackend::kRing * sizeof(DispatchSlot), hipHostMallocDefault) == hipSuccess &&
+                 hipHostMalloc(reinterpret_cast<void**>(&b->ring_result), HaloBackend::kRing * 4 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  for (int k = 0; ring_ok && k < HaloBackend::kRing; k++)
+    ring_ok = hipEventCreate(&b->ring_ev0[k]) == hipSuccess && hipEventCreate(&b->ring_ev1[k]) == hipSuccess &&
+              hipEventCreateWithFlags(&b->ring_done[k], hipEventDisableTiming) == hipSuccess;
+  if (!ring_ok) {
+    halo_destroy(b);
     return HALO_UNAVAILABLE;
   }
   b->stream = b->own_stream;
@@ -210,16 +260,20 @@ int halo_destroy(halo_handle_t b) {
   b->cons_xyz_out.release();
   b->cons_rgb.release();
   b->counters.release();
-  b->lut.release();
-  b->wl_pool.release();
+  b->ring_dev.release();
+  if (b->ring_host) (void)hipHostFree(b->ring_host);
+  if (b->ring_result) (void)hipHostFree(b->ring_result);
+  for (int k = 0; k < HaloBackend::kRing; k++) {
+    if (b->ring_ev0[k]) (void)hipEventDestroy(b->ring_ev0[k]);
+    if (b->ring_ev1[k]) (void)hipEventDestroy(b->ring_ev1[k]);
+    if (b->ring_done[k]) (void)hipEventDestroy(b->ring_done[k]);
+  }
   b->shapes.release();
   b->cont[0].release();
   b->cont[1].release();
   b->exits.release();
   b->host_f.release();
   b->host_u.release();
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
   return HALO_OK;
@@ -235,6 +289,14 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
+  else if (k == "async") b->async = v ? 1 : 0;
+  else if (k == "mono_copies") {
+    if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
+    int c = 1;
+    while (c < v && c < 64) c <<= 1;
+    if (c != b->mono_copies) b->mono.release();
+    b->mono_copies = c;
+  }
   else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 16));
   else if (k == "rank") {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
@@ -281,6 +343,8 @@ int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) 
   return HALO_OK;
 }
 
+static int fold_if_dirty(HaloBackend* b);
+
 int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t) {
   if (!b || !scene || !render || !wl) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "BeginSession inside a session");
@@ -302,20 +366,25 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->render = *render;
   b->wl = *wl;
   b->proj = host::BuildProj(*render);
-  int rc = ensure_accumulator(b, render->width, render->height);
+  int rc = fold_if_dirty(b);  // a session that was never ended still owes its plane to the accumulator (old layout)
+  if (rc != HALO_OK) return rc;
+  rc = ensure_accumulator(b, render->width, render->height);
   if (rc != HALO_OK) return rc;
   std::vector<WlEntryDev> pool = host::BuildWlPool(*wl);
   b->wl_pool_size = static_cast<uint32_t>(pool.size());
-  HIPCHK(b, b->wl_pool.reserve(HALO_WL_POOL_MAX));
-  HIPCHK(b, hipMemcpyAsync(b->wl_pool.ptr, pool.data(), pool.size() * sizeof(WlEntryDev), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` dies at scope exit
+  if (pool.empty() || pool.size() > HALO_WL_POOL_MAX) return fail(b, HALO_FATAL, "wavelength pool size out of range");
+  b->wl_pool_host = pool;  // travels to the device inside each dispatch slot
   // discrete wavelength → one-channel accumulation, CMF applied once at EndSession
   b->mono_session = b->mono_enabled && wl->illuminant < 0;
   if (b->mono_session) {
     const size_t npix = static_cast<size_t>(render->width) * render->height;
-    if (b->mono.cap < npix) {
-      HIPCHK(b, b->mono.reserve(npix));
-      HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, npix * sizeof(float), b->stream));
+    size_t slots = 1;
+    while (slots < npix) slots <<= 1;
+    const size_t need = slots * static_cast<size_t>(b->mono_copies);
+    if (b->mono.cap < need || b->mono_mask != slots - 1) {
+      HIPCHK(b, b->mono.reserve(need));
+      HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
+      b->mono_mask = static_cast<uint32_t>(slots - 1);
     }
     b->mono_cmf[0] = pool[0].cmf_x;
     b->mono_cmf[1] = pool[0].cmf_y;
@@ -332,7 +401,7 @@ static int fold_if_dirty(HaloBackend* b) {
   if (!b->mono_dirty) return HALO_OK;
   HIPCHK(b, hipSetDevice(b->device));
   const uint32_t npix = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
-  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->cu_count * 4, b->stream);
+  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_mask, static_cast<uint32_t>(b->mono_copies), b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->cu_count * 4, b->stream);
   if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   b->mono_dirty = false;
   return HALO_OK;
@@ -369,7 +438,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     out_cap = static_cast<uint32_t>(need);
   }
   HIPCHK(b, hipMemsetAsync(b->counters.ptr, 0, sizeof(uint32_t), b->stream));  // continuation counter only
-  HIPCHK(b, hipMemsetAsync(b->sums.ptr + kSumExitW, 0, 3 * sizeof(double), b->stream));
+  const bool defer = b->async && final_layer && !b->capture;  // nothing the caller needs before the next call
+  if (!defer) {  // earlier queued dispatches go to `pending`, so layer_acc ends up holding this layer alone
+    harvest_all(b);
+    add_stats(b->pending, b->layer_acc);
+    b->layer_acc = HaloLayerStats{};
+  }
   if (b->capture) {
     const uint64_t need = b->exits_pending + n * static_cast<uint64_t>(b->scene.max_hits + 1);
     if (need > b->exits.cap) {
@@ -398,8 +472,6 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     HIPCHK(b, hipStreamSynchronize(b->stream));
   }
 
-  double kernel_ms = 0.0;
-  uint64_t launches = 0;
   uint64_t ci_start = 0;
   for (int ci = 0; ci < L.entry_count; ci++) {
     const uint64_t n_ci = per_ci[ci];
@@ -439,19 +511,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       P.s_lat = std::sin(sun_lat);
     }
     P.wl_pool_size = b->wl_pool_size;
-    P.wl_pool = b->wl_pool.ptr;
     P.proj = b->proj;
-    if (P.lat_path == kLatLut) {
-      host::LatLut lut = host::BuildLatLut(E.axis.latitude);
-      std::vector<float> flat(3 * kLutNodes);
-      std::copy(lut.theta.begin(), lut.theta.end(), flat.begin());
-      std::copy(lut.cdf.begin(), lut.cdf.end(), flat.begin() + kLutNodes);
-      std::copy(lut.flip.begin(), lut.flip.end(), flat.begin() + 2 * kLutNodes);
-      HIPCHK(b, b->lut.reserve(3 * kLutNodes));
-      HIPCHK(b, hipMemcpyAsync(b->lut.ptr, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, b->stream));
-      HIPCHK(b, hipStreamSynchronize(b->stream));
-    }
-    P.lut = b->lut.ptr;
     P.cont_in = b->cont[out_slot ^ 1].ptr;
     P.cont_in_n = static_cast<uint32_t>(b->cont_in_n);
     P.cont_in_stride = b->cont_stride[out_slot ^ 1];
@@ -461,21 +521,18 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.counters = b->counters.ptr;
     P.xyz = b->acc;
     P.mono = b->mono.ptr;
-    P.sums = b->sums.ptr;
+    P.mono_mask = b->mono_mask;
+    P.mono_copy_mask = static_cast<uint32_t>(b->mono_copies - 1);
+    P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
     P.aggregate = static_cast<uint32_t>(b->aggregate);
     P.geom_clock = b->geom_clock;
-    P.filter = nullptr;
+    FilterDev fd{};
+    bool use_filter = false;
     if (E.filter_id > 0) {
-      const FilterDev fd = host::BuildFilter(b->filters[static_cast<size_t>(E.filter_id - 1)], E.axis);
-      const bool pass_all = !fd.is_complex && fd.terms[0].type == HALO_FILTER_NONE && fd.action == 0;
-      if (!pass_all) {
-        HIPCHK(b, b->filter_dev.reserve(1));
-        HIPCHK(b, hipMemcpyAsync(b->filter_dev.ptr, &fd, sizeof(fd), hipMemcpyHostToDevice, b->stream));
-        HIPCHK(b, hipStreamSynchronize(b->stream));
-        P.filter = b->filter_dev.ptr;
-      }
+      fd = host::BuildFilter(b->filters[static_cast<size_t>(E.filter_id - 1)], E.axis);
+      use_filter = fd.is_complex || fd.terms[0].type != HALO_FILTER_NONE || fd.action != 0;
     }
 
     const bool deterministic = host::IsDeterministic(E.crystal);
@@ -491,9 +548,34 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         host::ToShapeDev(g, pool[k]);
       }
       if (!deterministic) b->shape_count += shape_cnt;
-      HIPCHK(b, b->shapes.reserve(shape_cnt));
-      HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
-      P.shapes = b->shapes.ptr;
+      // ---- dispatch slot: tables + zeroed tallies go up in one copy from the pinned mirror ----
+      const int k = b->ring_next;
+      b->ring_next = (k + 1) % HaloBackend::kRing;
+      harvest_slot(b, k);  // blocks only if the ring has wrapped onto a dispatch still in flight
+      DispatchSlot& hs = b->ring_host[k];
+      DispatchSlot* ds = b->ring_dev.ptr + k;
+      if (P.lat_path == kLatLut) {
+        const host::LatLut& lut = cached_lut(b, E.axis.latitude);
+        std::copy(lut.theta.begin(), lut.theta.end(), hs.lut);
+        std::copy(lut.cdf.begin(), lut.cdf.end(), hs.lut + kLutNodes);
+        std::copy(lut.flip.begin(), lut.flip.end(), hs.lut + 2 * kLutNodes);
+      }
+      std::copy(b->wl_pool_host.begin(), b->wl_pool_host.end(), hs.wl);
+      if (deterministic) hs.shape = pool[0];
+      if (use_filter) hs.filter = fd;
+      for (double& v : hs.sums) v = 0.0;
+      HIPCHK(b, hipMemcpyAsync(ds, &hs, sizeof(DispatchSlot), hipMemcpyHostToDevice, b->stream));
+      P.lut = ds->lut;
+      P.wl_pool = ds->wl;
+      P.filter = use_filter ? &ds->filter : nullptr;
+      P.sums = ds->sums;
+      if (deterministic) {
+        P.shapes = &ds->shape;
+      } else {
+        HIPCHK(b, b->shapes.reserve(shape_cnt));
+        HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        P.shapes = b->shapes.ptr;
+      }
       P.shape_cnt = shape_cnt;
       P.n_rays = static_cast<uint32_t>(m);
       P.ci_start = static_cast<uint32_t>(ci_start + off);
@@ -512,18 +594,15 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       const int max_blocks = b->cu_count * b->blocks_per_cu;
       const int blocks = static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
-      HIPCHK(b, hipEventRecord(b->ev0, b->stream));  // HIP events on the launch stream bracket the kernel alone
+      HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
       b->mono_dirty = b->mono_dirty || b->mono_session;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
-      HIPCHK(b, hipEventRecord(b->ev1, b->stream));
-      HIPCHK(b, hipStreamSynchronize(b->stream));  // `pool` (pageable H2D source) must outlive the copy
-      {
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, b->ev0, b->ev1);
-        kernel_ms += ms;
-        launches++;
-      }
+      HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));
+      HIPCHK(b, hipMemcpyAsync(b->ring_result + 4 * k, ds->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+      HIPCHK(b, hipEventRecord(b->ring_done[k], b->stream));
+      b->ring_busy[k] = true;
+      if (!deterministic) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy
       if (P.source == kSrcGen) b->gen_count += m;
       if (P.source == kSrcTransit) b->transit_count += m;
       b->gate_count += m;
@@ -531,24 +610,39 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
     ci_start += n_ci;
   }
-  double s[kSumNum] = {0, 0, 0, 0};
-  int rc = fold_sums(b, s);
-  if (rc != HALO_OK) return rc;
+  if (defer) {  // queued, not waited for: the tallies arrive through halo_collect_stats
+    b->layer_acc.root_count += n;
+    if (stats) {
+      std::memset(stats, 0, sizeof(*stats));
+      stats->root_count = n;
+    }
+    b->cont_in_n = 0;
+    return HALO_OK;
+  }
   uint32_t cnt[kCntNum] = {0, 0, 0, 0};
-  HIPCHK(b, hipMemcpy(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost));
+  HIPCHK(b, hipMemcpyAsync(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  harvest_all(b);
   if (!final_layer && cnt[kCntCont] > out_cap) return fail(b, HALO_FATAL, "continuation pool overflow");
   b->exits_pending = std::min<uint64_t>(cnt[kCntExit], b->exits.cap);
-  if (stats) {
-    std::memset(stats, 0, sizeof(*stats));
-    stats->root_count = n;
-    stats->exit_count = static_cast<uint64_t>(s[kSumExitN] + 0.5);
-    stats->exit_w_sum = s[kSumExitW];
-    stats->continuation_count = final_layer ? 0 : cnt[kCntCont];
-    stats->kernel_ms = kernel_ms;
-    stats->pixel_hits = static_cast<uint64_t>(s[kSumPixN] + 0.5);
-    stats->launches = launches;
-  }
+  b->layer_acc.root_count = n;
+  b->layer_acc.continuation_count = final_layer ? 0 : cnt[kCntCont];
+  if (stats) *stats = b->layer_acc;
+  add_stats(b->pending, b->layer_acc);
+  b->layer_acc = HaloLayerStats{};
   b->cont_in_n = final_layer ? 0 : cnt[kCntCont];  // becomes the next layer's input at Recombine
+  return HALO_OK;
+}
+
+int halo_collect_stats(halo_handle_t b, HaloLayerStats* out) {
+  if (!b || !out) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  harvest_all(b);
+  add_stats(b->pending, b->layer_acc);
+  b->layer_acc = HaloLayerStats{};
+  *out = b->pending;
+  b->pending = HaloLayerStats{};
   return HALO_OK;
 }
 

@@ -72,6 +72,16 @@ struct FilterDev {
   FilterTermDev terms[HALO_FILTER_MAX_TERMS];
 };
 
+// Per-dispatch constants and tallies as they sit in HBM: one H2D copy of the whole block per dispatch from a pinned
+// mirror, taken from a ring so a dispatch can be queued while earlier ones still run (no host sync per launch).
+struct DispatchSlot {
+  alignas(16) float lut[3 * kLutNodes + 1];
+  alignas(16) WlEntryDev wl[HALO_WL_POOL_MAX + 1];
+  alignas(16) ShapeDev shape;
+  alignas(16) FilterDev filter;
+  alignas(16) double sums[4];
+};
+
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
 struct DispatchParams {
   // --- ray source -------------------------------------------------------------------------
@@ -121,13 +131,21 @@ struct DispatchParams {
   const uint32_t* host_tf;
   // --- outputs -------------------------------------------------------------------------------
   float* xyz;                  // W*H*3 image
-  float* mono;                 // W*H scalar plane (discrete-wavelength sessions), folded into xyz at EndSession
-  double* sums;                // [0] landed weight, [1] exit weight sum, [2] exit count (as double)
+  float* mono;                 // scalar plane(s) for discrete-wavelength sessions, folded into xyz at EndSession:
+                               // mono_copy_mask+1 copies of (mono_mask+1) floats, pixel p at slot (p*kMonoMul)&mono_mask
+  uint32_t mono_mask;
+  uint32_t mono_copy_mask;
+  double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
+  double* landed;              // persistent landed-weight tally (until readback / take_landed)
   HaloExitRecord* exits;
   uint32_t exit_cap;
   uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
   const FilterDev* filter;     // nullptr = pass-all
 };
+
+// odd multiplier of the pixel→slot bijection on 2^k slots: neighbouring pixels of a bright feature land on different
+// cache lines, so no line of the plane is hotter than its hottest single pixel
+constexpr uint32_t kMonoMul = 0x9E3779B1u;
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };
 enum { kSumLanded = 0, kSumExitW = 1, kSumExitN = 2, kSumPixN = 3, kSumNum = 4 };

@@ -399,6 +399,11 @@ struct PixCache {
   float val[kCacheN * (MONO ? 1 : 3)];
 };
 
+HD float* mono_slot(const DispatchParams& P, uint32_t pix) {
+  const uint32_t copy = blockIdx.x & P.mono_copy_mask;
+  return P.mono + static_cast<size_t>(copy) * (static_cast<size_t>(P.mono_mask) + 1u) + ((pix * kMonoMul) & P.mono_mask);
+}
+
 template <bool MONO>
 HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, float w, float cx, float cy, float cz) {
   if (P.aggregate == 2u) return;  // diagnostic: trace + project only
@@ -419,7 +424,7 @@ HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, flo
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
-    atomic_add_f32(P.mono + pix, w);
+    atomic_add_f32(mono_slot(P, pix), w);
   } else {
     float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
     atomic_add_f32(dst + 0, cx * w);
@@ -880,7 +885,7 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       const uint32_t pix = key - 1u;
       if (MONO) {
         const float v = T.cache.val[i];
-        if (v != 0.0f) atomic_add_f32(P.mono + pix, v);
+        if (v != 0.0f) atomic_add_f32(mono_slot(P, pix), v);
       } else {
         float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
         atomic_add_f32(dst + 0, T.cache.val[i * 3 + 0]);
@@ -896,20 +901,30 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   float pix_n = wave_sum(static_cast<float>(sums.pix_n));
   if ((threadIdx.x & 63) == 0) {
     if (pix_n != 0.0f) atomicAdd(&P.sums[kSumPixN], static_cast<double>(pix_n));
-    if (landed != 0.0f) atomicAdd(&P.sums[kSumLanded], static_cast<double>(landed));
+    if (landed != 0.0f) atomicAdd(P.landed, static_cast<double>(landed));
     if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
     if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
   }
 }
 
-// xyz[pix] += cmf * mono[pix]; mono[pix] = 0 — closes a discrete-wavelength session (see MONO above).
+// xyz[pix] += cmf * sum over copies of mono[slot(pix)]; the slots are zeroed — closes a discrete-wavelength session
+// (see MONO above).
 __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ mono, uint32_t n_pix,
-                                                            float cx, float cy, float cz) {
+                                                            uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz) {
   const uint32_t stride = gridDim.x * kBlock;
+  const size_t plane = static_cast<size_t>(mono_mask) + 1u;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += stride) {
-    const float v = mono[i];
+    const uint32_t slot = (i * kMonoMul) & mono_mask;
+    float v = 0.0f;
+    for (uint32_t c = 0; c < copies; ++c) {
+      float* q = mono + c * plane + slot;
+      const float x = *q;
+      if (x != 0.0f) {
+        *q = 0.0f;
+        v += x;
+      }
+    }
     if (v != 0.0f) {
-      mono[i] = 0.0f;
       xyz[3u * i + 0u] += cx * v;
       xyz[3u * i + 1u] += cy * v;
       xyz[3u * i + 2u] += cz * v;
@@ -1017,8 +1032,9 @@ hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rg
   return hipGetLastError();
 }
 
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, float cx, float cy, float cz, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, cx, cy, cz);
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz, int blocks,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, mono_mask, copies, cx, cy, cz);
   return hipGetLastError();
 }
 

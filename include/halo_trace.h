@@ -224,7 +224,9 @@ const char* halo_last_error(halo_handle_t h);
 /* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
  * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams),
  * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
- * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "blocks_per_cu". */
+ * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
+ * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
+ * "blocks_per_cu". */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
 int halo_set_stream(halo_handle_t h, void* hip_stream);
@@ -255,6 +257,11 @@ int halo_readback_xyz(halo_handle_t h, float* xyz, int width, int height, float*
 /* Same, but returns landed weight in double and does not add. */
 int halo_readback_xyz64(halo_handle_t h, float* xyz, int width, int height, double* landed_weight);
 int halo_sync(halo_handle_t h);
+/* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
+ * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the
+ * exit / pixel-hit / kernel-time tallies are delivered here — the reference's LayerStats are diagnostics
+ * (trace_backend.hpp:296-299), nothing on the path waits for them. */
+int halo_collect_stats(halo_handle_t h, HaloLayerStats* out);
 /* Read AND zero the device landed-weight tally (fp64) without touching the image: used when the image lives in a
  * bound external accumulator that is reduced across ranks in place. */
 int halo_take_landed(halo_handle_t h, double* landed_weight);

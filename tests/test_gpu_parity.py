@@ -354,3 +354,38 @@ def test_full_size_properties():
     assert landed2 == pytest.approx(landed, rel=2e-3)
     assert np.corrcoef(block_mean(img, 8).ravel(), block_mean(img2, 8).ravel())[0, 1] > 0.999
     hb.close()
+
+
+def test_async_dispatch_equals_synchronous():
+    """Option async=1 queues final-layer dispatches without a host sync; image, landed weight and the collected tallies must
+    equal the synchronous run's bit for bit (same launches, same streams)."""
+    sc = scenes.scene([(0.0, [scenes.column_crystal_entry(), scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 1.0}), 2.0, 4)])], max_hits=7)
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, 640, 360, el=30.0)
+    n = 300_000
+    out = {}
+    for mode in (0, 1):
+        hb = hip_backend(seed=77, **{"async": mode})
+        tot = abi.HaloLayerStats()
+        for wl in (450.0, 550.0, 650.0):
+            st = run_session(hb, sc, rd, scenes.wl_discrete(wl), n)
+            if mode == 0:
+                for f in ("exit_count", "pixel_hits", "launches", "root_count"):
+                    setattr(tot, f, getattr(tot, f) + getattr(st[-1], f))
+                tot.exit_w_sum += st[-1].exit_w_sum
+            else:
+                assert st[-1].root_count == n and st[-1].exit_count == 0      # deferred
+        c = hb.collect_stats()
+        if mode == 1:
+            tot = c
+        else:
+            assert (c.exit_count, c.pixel_hits, c.launches, c.root_count) == (tot.exit_count, tot.pixel_hits, tot.launches, tot.root_count)
+        assert hb.collect_stats().launches == 0                                # collect resets
+        img, landed = hb.ReadbackXyzAccum()
+        out[mode] = (img, landed, tot.exit_count, tot.pixel_hits, tot.launches, tot.root_count, tot.exit_w_sum, c.kernel_ms)
+        hb.close()
+    a, b = out[0], out[1]
+    assert a[2:6] == b[2:6] and a[5] == 3 * n and a[4] == 6
+    assert a[6] == pytest.approx(b[6], rel=1e-12)
+    assert a[1] == pytest.approx(b[1], rel=1e-6)
+    assert rel_l2(a[0], b[0]) <= 1e-6            # float atomics: order differs, values agree to rounding
+    assert b[7] > 0.0

@@ -34,6 +34,12 @@ if "base" in which:
     sc_fs = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith={"type": "uniform", "mean": 90, "std": 360}, azimuth={"type": "uniform", "mean": 0, "std": 360}))])], max_hits=7)
     run("  full-sphere orientation", sc_fs, rd)
     run("  full-sphere, no accumulation", sc_fs, rd, aggregate=2)
+if "copies" in which:
+    for c in (1, 2, 4, 8, 16, 32, 64):
+        run("config2 mono_copies=%d" % c, sc, rd, mono_copies=c)
+        run("  512x256 mono_copies=%d" % c, sc, scenes.config2_render(512, 256), mono_copies=c)
+    run("config2 mono_copies=8, plain atomics", sc, rd, mono_copies=8, aggregate=0)
+    run("config2 mono_copies=32, plain atomics", sc, rd, mono_copies=32, aggregate=0)
 if "ms" in which:
     run("config3 multi-scatter 10M", scenes.config3_scene(), rd)
 if "stoch" in which:
