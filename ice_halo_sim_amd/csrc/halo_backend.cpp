@@ -118,6 +118,9 @@ struct HaloBackend {
   DevBuf<ShapeDev> shapes;
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
   uint32_t cont_stride[2] = {0, 0};
+  uint32_t cont_region[2] = {0, 0};          // slots per shard region
+  DevBuf<uint32_t> cont_cnt;                 // kContShards * kContCntStride
+  uint32_t cont_seg[kContShards + 4] = {};   // prefix of the input pool's shard fill counts
   int cont_out_slot = 0;
   uint64_t cont_in_n = 0;
   int cont_shuffle = 1;
@@ -269,6 +272,7 @@ int halo_destroy(halo_handle_t b) {
     if (b->ring_done[k]) (void)hipEventDestroy(b->ring_done[k]);
   }
   b->shapes.release();
+  b->cont_cnt.release();
   b->cont[0].release();
   b->cont[1].release();
   b->exits.release();
@@ -426,18 +430,50 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   if (n > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "more than 2^32 rays in one layer dispatch; split the batch");
   if (layer > 0 && rays) return fail(b, HALO_FATAL, "host rays are first-layer only");
 
-  // continuation output pool: every root emits at most max_hits candidates
+  float props[HALO_MAX_ENTRIES];
+  for (int ci = 0; ci < L.entry_count; ci++) props[ci] = L.entries[ci].proportion;
+  std::vector<uint64_t> per_ci = host::Partition(props, L.entry_count, n, b->carry[layer]);
+  if (rays && layer == 0) {  // host ingest is a single population (cpu_trace_backend.cpp:121-127)
+    std::fill(per_ci.begin(), per_ci.end(), 0);
+    per_ci[0] = n;
+  }
+  // launch plan: chunking bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
+  const int max_blocks = b->cu_count * b->blocks_per_cu;
+  auto chunk_of = [&](uint64_t left, bool deterministic) {
+    uint64_t m = std::min<uint64_t>(left, b->chunk);
+    if (!deterministic) m = std::min<uint64_t>(m, 1ull << 22);
+    return m;
+  };
+  auto blocks_of = [&](uint64_t m) {
+    return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
+  };
+
+  // continuation output pool: kContShards regions; a region must hold everything its blocks can emit over the layer's
+  // dispatches (every root emits at most max_hits candidates)
   const int out_slot = b->cont_out_slot;
   uint32_t out_cap = 0;
   if (!final_layer) {
-    const uint64_t need = n * static_cast<uint64_t>(b->scene.max_hits);
-    if (need > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "continuation pool would exceed 2^32 rays; split the batch");
-    const uint64_t stride = (need + 63) & ~63ull;
+    uint64_t region = 0;
+    for (int ci = 0; ci < L.entry_count; ci++) {
+      const bool det = host::IsDeterministic(L.entries[ci].crystal);
+      for (uint64_t off = 0; off < per_ci[ci];) {
+        const uint64_t m = chunk_of(per_ci[ci] - off, det);
+        const uint64_t nb = static_cast<uint64_t>(blocks_of(m));
+        const uint64_t per_block = (m + nb * kBlock - 1) / (nb * kBlock) * kBlock;   // grid-stride share, rounded up
+        region += (nb + kContShards - 1) / kContShards * per_block * static_cast<uint64_t>(b->scene.max_hits);
+        off += m;
+      }
+    }
+    region = (region + 63) & ~63ull;
+    const uint64_t stride = region * kContShards;
+    if (stride > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "continuation pool would exceed 2^32 rays; split the batch");
     HIPCHK(b, b->cont[out_slot].reserve(stride * 5));
     b->cont_stride[out_slot] = static_cast<uint32_t>(stride);
-    out_cap = static_cast<uint32_t>(need);
+    b->cont_region[out_slot] = static_cast<uint32_t>(region);
+    out_cap = static_cast<uint32_t>(region);
+    HIPCHK(b, b->cont_cnt.reserve(kContShards * kContCntStride));
+    HIPCHK(b, hipMemsetAsync(b->cont_cnt.ptr, 0, kContShards * kContCntStride * sizeof(uint32_t), b->stream));
   }
-  HIPCHK(b, hipMemsetAsync(b->counters.ptr, 0, sizeof(uint32_t), b->stream));  // continuation counter only
   const bool defer = b->async && final_layer && !b->capture;  // nothing the caller needs before the next call
   if (!defer) {  // earlier queued dispatches go to `pending`, so layer_acc ends up holding this layer alone
     harvest_all(b);
@@ -457,12 +493,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
   }
 
-  float props[HALO_MAX_ENTRIES];
-  for (int ci = 0; ci < L.entry_count; ci++) props[ci] = L.entries[ci].proportion;
-  std::vector<uint64_t> per_ci = host::Partition(props, L.entry_count, n, b->carry[layer]);
-  if (rays && layer == 0) {  // host ingest is a single population (cpu_trace_backend.cpp:121-127)
-    std::fill(per_ci.begin(), per_ci.end(), 0);
-    per_ci[0] = n;
+  if (rays && layer == 0) {
     HIPCHK(b, b->host_f.reserve(n * 7));
     HIPCHK(b, b->host_u.reserve(n));
     HIPCHK(b, hipMemcpyAsync(b->host_f.ptr, rays->d, n * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream));
@@ -518,6 +549,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.cont_out = b->cont[out_slot].ptr;
     P.cont_out_stride = b->cont_stride[out_slot];
     P.cont_out_cap = out_cap;
+    P.cont_in_region = b->cont_region[out_slot ^ 1];
+    P.cont_cnt = b->cont_cnt.ptr;
     P.counters = b->counters.ptr;
     P.xyz = b->acc;
     P.mono = b->mono.ptr;
@@ -538,8 +571,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
     for (uint64_t off = 0; off < n_ci;) {
-      uint64_t m = std::min<uint64_t>(n_ci - off, b->chunk);
-      if (!deterministic) m = std::min<uint64_t>(m, 1ull << 22);
+      const uint64_t m = chunk_of(n_ci - off, deterministic);
       const uint32_t shape_cnt = deterministic ? 1u : static_cast<uint32_t>((m + b->geom_clock - 1) / b->geom_clock);
       std::vector<ShapeDev> pool(shape_cnt);
       for (uint32_t k = 0; k < shape_cnt; k++) {
@@ -564,11 +596,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       if (deterministic) hs.shape = pool[0];
       if (use_filter) hs.filter = fd;
       for (double& v : hs.sums) v = 0.0;
+      if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
       HIPCHK(b, hipMemcpyAsync(ds, &hs, sizeof(DispatchSlot), hipMemcpyHostToDevice, b->stream));
       P.lut = ds->lut;
       P.wl_pool = ds->wl;
       P.filter = use_filter ? &ds->filter : nullptr;
       P.sums = ds->sums;
+      P.cont_in_seg = ds->seg;
       if (deterministic) {
         P.shapes = &ds->shape;
       } else {
@@ -592,8 +626,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.host_w = b->host_f.ptr + n * 6 + off;
         P.host_tf = b->host_u.ptr + off;
       }
-      const int max_blocks = b->cu_count * b->blocks_per_cu;
-      const int blocks = static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
+      const int blocks = blocks_of(m);
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
       b->mono_dirty = b->mono_dirty || b->mono_session;
@@ -620,17 +653,28 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     return HALO_OK;
   }
   uint32_t cnt[kCntNum] = {0, 0, 0, 0};
+  std::vector<uint32_t> fill(final_layer ? 0 : kContShards * kContCntStride);
   HIPCHK(b, hipMemcpyAsync(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost, b->stream));
+  if (!final_layer) HIPCHK(b, hipMemcpyAsync(fill.data(), b->cont_cnt.ptr, fill.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));
   harvest_all(b);
-  if (!final_layer && cnt[kCntCont] > out_cap) return fail(b, HALO_FATAL, "continuation pool overflow");
+  uint64_t n_cont = 0;
+  if (!final_layer) {  // the next layer addresses the pool through the prefix of the shard fill counts
+    for (int sI = 0; sI < kContShards; sI++) {
+      const uint32_t c = fill[static_cast<size_t>(sI) * kContCntStride];
+      if (c > out_cap) return fail(b, HALO_FATAL, "continuation pool overflow");
+      b->cont_seg[sI] = static_cast<uint32_t>(n_cont);
+      n_cont += c;
+    }
+    b->cont_seg[kContShards] = static_cast<uint32_t>(n_cont);
+  }
   b->exits_pending = std::min<uint64_t>(cnt[kCntExit], b->exits.cap);
   b->layer_acc.root_count = n;
-  b->layer_acc.continuation_count = final_layer ? 0 : cnt[kCntCont];
+  b->layer_acc.continuation_count = n_cont;
   if (stats) *stats = b->layer_acc;
   add_stats(b->pending, b->layer_acc);
   b->layer_acc = HaloLayerStats{};
-  b->cont_in_n = final_layer ? 0 : cnt[kCntCont];  // becomes the next layer's input at Recombine
+  b->cont_in_n = n_cont;  // becomes the next layer's input at Recombine
   return HALO_OK;
 }
 

@@ -72,6 +72,13 @@ struct FilterDev {
   FilterTermDev terms[HALO_FILTER_MAX_TERMS];
 };
 
+// Continuation pool sharding.  One device counter saturates at ~88 M returning atomics/s (measured, MI355X), and every
+// wave appends once per emit site — so the pool is cut into kContShards regions, block b appends to region b % kContShards
+// through that region's own counter (64 B apart: same-line atomics serialise), and the next layer reads logical index j
+// through the prefix table of the fill counts.  Dense logical order, no holes, no compaction pass.
+constexpr int kContShards = 256;
+constexpr int kContCntStride = 16;
+
 // Per-dispatch constants and tallies as they sit in HBM: one H2D copy of the whole block per dispatch from a pinned
 // mirror, taken from a ring so a dispatch can be queued while earlier ones still run (no host sync per launch).
 struct DispatchSlot {
@@ -80,6 +87,7 @@ struct DispatchSlot {
   alignas(16) ShapeDev shape;
   alignas(16) FilterDev filter;
   alignas(16) double sums[4];
+  alignas(16) uint32_t seg[kContShards + 4];
 };
 
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
@@ -119,10 +127,13 @@ struct DispatchParams {
   const float* cont_in;
   uint32_t cont_in_n;
   uint32_t cont_in_stride;
+  uint32_t cont_in_region;     // slots per shard region of the input pool
+  const uint32_t* cont_in_seg; // [kContShards+1] prefix of the shard fill counts: logical index → (shard, offset)
   uint32_t ci_start;
   float* cont_out;
   uint32_t cont_out_stride;
-  uint32_t cont_out_cap;
+  uint32_t cont_out_cap;       // slots per shard region of the output pool
+  uint32_t* cont_cnt;          // [kContShards * kContCntStride] fill count of each shard region
   uint32_t* counters;          // [0] continuation count, [1] captured exits, [2] exit count lo.. see kCnt*
   // --- host-injected rays (crystal-local) -------------------------------------------------------
   const float* host_d;

@@ -563,6 +563,7 @@ struct LdsTables {
   WlEntryDev wl[HALO_WL_POOL_MAX];
   ShapeDev shape;
   PixCache<MONO> cache;
+  uint32_t seg[kContShards + 4];
 };
 constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
 template <bool ON>
@@ -597,10 +598,12 @@ HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, const FilterDe
     const uint32_t lane = __lane_id();
     const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
     uint32_t base = 0u;
-    if (lane == leader) base = atomicAdd(&P.counters[kCntCont], static_cast<uint32_t>(__popcll(mask)));
+    const uint32_t shard = blockIdx.x & (kContShards - 1);
+    if (lane == leader) base = atomicAdd(&P.cont_cnt[shard * kContCntStride], static_cast<uint32_t>(__popcll(mask)));
     base = __shfl(base, static_cast<int>(leader));
-    const uint32_t slot = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-    if (slot < P.cont_out_cap) {
+    const uint32_t off = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+    if (off < P.cont_out_cap) {
+      const uint32_t slot = shard * P.cont_out_cap + off;
       const uint32_t st = P.cont_out_stride;
       P.cont_out[slot] = wx;
       P.cont_out[st + slot] = wy;
@@ -729,7 +732,12 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* 
   } else if (P.source == kSrcTransit) {
     Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
     const uint32_t pos = P.ci_start + tid;
-    const uint32_t src = P.shuffle ? feistel_bijection(pos, P.cont_in_n, P.shuffle_seed) : pos;
+    const uint32_t logical = P.shuffle ? feistel_bijection(pos, P.cont_in_n, P.shuffle_seed) : pos;
+    uint32_t sh_i = 0u;  // largest shard with seg[shard] <= logical (empty shards repeat their neighbour's start)
+#pragma unroll
+    for (uint32_t step = kContShards / 2; step >= 1u; step >>= 1)
+      if (T.seg[sh_i + step] <= logical) sh_i += step;
+    const uint32_t src = sh_i * P.cont_in_region + (logical - T.seg[sh_i]);
     const uint32_t st = P.cont_in_stride;
     float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
     w = P.cont_in[3u * st + src];
@@ -856,6 +864,8 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     float4* dst = reinterpret_cast<float4*>(T.wl);
     for (uint32_t i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
   }
+  if (P.source == kSrcTransit)
+    for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
   if (!POOL) {
     const float4* src = reinterpret_cast<const float4*>(P.shapes);
     float4* dst = reinterpret_cast<float4*>(&T.shape);
