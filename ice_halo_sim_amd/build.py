@@ -7,8 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhalo_hip.so")
-SOURCES = ["halo_kernels.hip", "halo_backend.cpp", "halo_host.cpp"]
-HEADERS = ["halo_device.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]
+SOURCES = ["halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp", "halo_host.cpp"]
+NO_CONTRACT = {"halo_shapegen.hip"}   # geometry shared with the host: same rounding on both sides
+HEADERS = ["halo_device.h", "halo_geom.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]
 
 
 def hipcc():
@@ -39,7 +40,9 @@ def build(force=False, verbose=False):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
             if os.environ.get("HALO_MIN_WAVES"):
                 cmd.append("-DHALO_MIN_WAVES=" + os.environ["HALO_MIN_WAVES"])
-            if os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast
+            if src in NO_CONTRACT:
+                cmd += ["-ffp-contract=off", "-fno-fast-math"]
+            elif os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast
                 cmd.append("-ffp-contract=" + os.environ["HALO_FP_CONTRACT"])
         else:  # host tables must round like the reference's host build: no FMA contraction
             cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common
@@ -50,7 +53,7 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on " + src)
         if src.endswith(".hip"):
-            with open(os.path.join(bdir, "resource_usage.txt"), "w") as f:
+            with open(os.path.join(bdir, "resource_usage_%s.txt" % src.split(".")[0]), "w") as f:
                 f.write(r.stderr)
         objs.append(obj)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -19,6 +19,7 @@
 
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
+hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
 hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz, int blocks,
                        hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
@@ -69,6 +70,7 @@ struct HaloBackend {
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_mask = 0;      // slots per copy - 1 (power of two >= W*H)
   int blocks_per_cu = 8;
+  int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
 
   // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
@@ -294,6 +296,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "async") b->async = v ? 1 : 0;
+  else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "mono_copies") {
     if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
     int c = 1;
@@ -573,12 +576,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     for (uint64_t off = 0; off < n_ci;) {
       const uint64_t m = chunk_of(n_ci - off, deterministic);
       const uint32_t shape_cnt = deterministic ? 1u : static_cast<uint32_t>((m + b->geom_clock - 1) / b->geom_clock);
-      std::vector<ShapeDev> pool(shape_cnt);
-      for (uint32_t k = 0; k < shape_cnt; k++) {
-        HaloGeomTables g;
-        host::MakeShape(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), g);
-        host::ToShapeDev(g, pool[k]);
-      }
+      const bool host_pool = !deterministic && b->host_shapes;
+      std::vector<ShapeDev> pool(deterministic || host_pool ? shape_cnt : 0u);
+      for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++)
+        host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
+      const uint64_t first_shape = b->shape_count;
       if (!deterministic) b->shape_count += shape_cnt;
       // ---- dispatch slot: tables + zeroed tallies go up in one copy from the pinned mirror ----
       const int k = b->ring_next;
@@ -607,7 +609,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.shapes = &ds->shape;
       } else {
         HIPCHK(b, b->shapes.reserve(shape_cnt));
-        HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        if (host_pool) {
+          HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        } else {  // device generator: one thread per sampled crystal, same stream → ordered before the trace kernel
+          HIPCHK(b, hipMemsetAsync(b->shapes.ptr, 0, static_cast<size_t>(shape_cnt) * sizeof(ShapeDev), b->stream));
+          hipError_t ge = launch_shapegen(b->shapes.ptr, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream);
+          if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
+        }
         P.shapes = b->shapes.ptr;
       }
       P.shape_cnt = shape_cnt;
@@ -635,7 +643,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       HIPCHK(b, hipMemcpyAsync(b->ring_result + 4 * k, ds->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
       HIPCHK(b, hipEventRecord(b->ring_done[k], b->stream));
       b->ring_busy[k] = true;
-      if (!deterministic) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy
+      if (host_pool) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy
       if (P.source == kSrcGen) b->gen_count += m;
       if (P.source == kSrcTransit) b->transit_count += m;
       b->gate_count += m;
@@ -675,6 +683,27 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   add_stats(b->pending, b->layer_acc);
   b->layer_acc = HaloLayerStats{};
   b->cont_in_n = n_cont;  // becomes the next layer's input at Recombine
+  return HALO_OK;
+}
+
+int halo_generate_shapes(halo_handle_t b, const HaloCrystal* crystal, uint64_t first_index, uint32_t n, int on_device, HaloGeomTables* out) {
+  if (!b || !crystal || (!out && n)) return HALO_FATAL;
+  if (crystal->kind != HALO_CRYSTAL_PRISM && crystal->kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
+  std::vector<ShapeDev> pool(n);
+  if (on_device) {
+    HIPCHK(b, hipSetDevice(b->device));
+    DevBuf<ShapeDev> dev;
+    HIPCHK(b, dev.reserve(n));
+    HIPCHK(b, hipMemsetAsync(dev.ptr, 0, static_cast<size_t>(n) * sizeof(ShapeDev), b->stream));
+    hipError_t ge = launch_shapegen(dev.ptr, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream);
+    if (ge == hipSuccess) ge = hipMemcpyAsync(pool.data(), dev.ptr, static_cast<size_t>(n) * sizeof(ShapeDev), hipMemcpyDeviceToHost, b->stream);
+    if (ge == hipSuccess) ge = hipStreamSynchronize(b->stream);
+    dev.release();
+    if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel");
+  } else {
+    for (uint32_t k = 0; k < n; k++) host::MakeShapeDev(b->seed, *crystal, first_index + k, pool[k]);
+  }
+  for (uint32_t k = 0; k < n; k++) host::FromShapeDev(pool[k], out[k]);
   return HALO_OK;
 }
 

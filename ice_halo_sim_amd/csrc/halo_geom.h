@@ -1,0 +1,496 @@
+// halo_geom.h — crystal geometry → kernel tables, written once for host AND device.
+//
+// The same functions build a crystal's ShapeDev on the host (deterministic crystals, parity tests, the C-ABI
+// halo_host_*_geometry exports) and inside halo_shapegen_kernel (stochastic crystals: one thread per sampled shape,
+// SURVEY §8 row f4).  Everything is fixed-size and uses only IEEE basic operations (+ - * / sqrt, fp64 solve, fp32
+// tables), so with contraction off both sides produce bit-identical tables from the same scalars.  The only libm
+// calls are in the scalar sampler (logf / cosf / sinf for Gauss / zigzag / Laplacian draws) and atan2 for the CCW
+// ordering of pyramid face loops, where an ulp moves nothing.
+//
+// Reference: ComputeClosedFormPrism geo3d_closedform.cpp:1318-1407, SolveHexCrossSection :124-302,
+// AdaptClosedFormPrismToCrystalGeom crystal.cpp:109-186, Crystal::PopulateFromCfGeom crystal.cpp:304-347,
+// detail::BuildEntrySubTris simulator.cpp:90-129, FillHexCrystalCoef geo3d.cpp:346-512, SyncGroupSampler
+// simulator.cpp:361-393.
+#ifndef HALO_GEOM_H_
+#define HALO_GEOM_H_
+
+#include <math.h>
+#include <stdint.h>
+
+#include "halo_device.h"
+
+#if defined(__HIPCC__)
+#define HALO_GEOM_HD __host__ __device__ inline
+#else
+#define HALO_GEOM_HD inline
+#endif
+
+namespace halo {
+namespace geom {
+
+constexpr float kGeomFloatEps = 1e-5f;          // math::kFloatEps math.hpp:21
+constexpr float kGeomSqrt3 = 1.73205080757f;    // math::kSqrt3
+constexpr float kGeomDegToRad = 3.14159265359f / 180.0f;
+constexpr double kGeomPiD = 3.14159265358979323846;
+constexpr uint32_t kNonceShape = 0x6A09E667u;   // domain of the shape-scalar stream (ours: the reference draws from mt19937)
+
+// exact 60-degree direction tables (geo3d_closedform.hpp:48-52)
+HALO_GEOM_HD double Cos6(int i) {
+  const double t[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
+  return t[i];
+}
+HALO_GEOM_HD double Sin6(int i) {
+  const double s = 0.86602540378443864676;
+  const double t[6] = {0.0, s, s, 0.0, -s, -s};
+  return t[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// counter-based scalar stream (same hash as the device ray streams, pcg_shared.h:193-197)
+// ---------------------------------------------------------------------------------------------------
+HALO_GEOM_HD uint32_t PcgHash32(uint32_t x) {
+  x = x * 747796405u + 2891336453u;
+  x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+  return (x >> 22u) ^ x;
+}
+
+struct ScalarStream {
+  uint32_t seed, key, slot;
+};
+HALO_GEOM_HD float Uniform(ScalarStream& s) {
+  const uint32_t h = PcgHash32(s.seed ^ PcgHash32(s.key + s.slot));
+  s.slot++;
+  return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
+}
+HALO_GEOM_HD float Gaussian(ScalarStream& s) {
+  const float two_pi = 2.0f * 3.14159265358979323846f;
+  const float u1 = fmaxf(Uniform(s), 1e-7f);
+  const float u2 = Uniform(s);
+  return sqrtf(-2.0f * logf(u1)) * cosf(two_pi * u2);
+}
+// RandomNumberGenerator::Get (math.cpp:418-444) over the PCG stream
+HALO_GEOM_HD float Draw(ScalarStream& s, const HaloDist& d) {
+  const float two_pi = 2.0f * 3.14159265358979323846f;
+  switch (d.type) {
+    case HALO_DIST_UNIFORM: return (Uniform(s) - 0.5f) * d.spread + d.center;
+    case HALO_DIST_GAUSS:
+    case HALO_DIST_GAUSS_LEGACY: return Gaussian(s) * d.spread + d.center;
+    case HALO_DIST_ZIGZAG: return fabsf(d.spread * sinf(Uniform(s) * two_pi) + d.center);
+    case HALO_DIST_LAPLACIAN: {
+      const float u = Uniform(s);
+      const float sgn = (u < 0.5f) ? -1.0f : 1.0f;
+      const float arg = fmaxf(1.0f - 2.0f * fabsf(u - 0.5f), 1e-30f);
+      return d.center - d.spread * sgn * logf(arg);
+    }
+    default: return d.center;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// table emission: compact the present faces and fan-triangulate them (PopulateFromCfGeom + BuildEntrySubTris)
+// ---------------------------------------------------------------------------------------------------
+struct ShapeCursor {
+  int fid = 0, tri = 0;
+};
+
+// Host: zero the record.  Device: the generator's caller clears the whole pool with one memset instead of 3.7 KB of
+// strided stores per thread.
+HALO_GEOM_HD void ClearShape(ShapeDev& s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)s;
+#else
+  uint32_t* w = reinterpret_cast<uint32_t*>(&s);
+  for (uint32_t i = 0; i < sizeof(ShapeDev) / 4u; i++) w[i] = 0u;
+#endif
+}
+
+// one present face: plane = raw coefficients (a, b, c, d), normal = unit outward, loop = CCW corners seen from outside
+HALO_GEOM_HD void EmitFace(ShapeDev& s, ShapeCursor& cur, const float plane[4], const float normal[3], int number,
+                           const float (*loop)[3], int nv) {
+  const int fid = cur.fid;
+  s.face[fid][0] = normal[0];
+  s.face[fid][1] = normal[1];
+  s.face[fid][2] = normal[2];
+  const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
+  s.face[fid][3] = (len > kGeomFloatEps) ? plane[3] / len : 0.0f;
+  s.face_number[fid] = static_cast<uint8_t>(number);
+  for (int k = 1; k + 1 < nv && nv >= 3 && cur.tri < kMaxTris; k++) {
+    const int t = cur.tri;
+    float* v = s.tri_v[t];
+    for (int a = 0; a < 3; a++) {
+      v[a] = loop[0][a];
+      v[3 + a] = loop[k][a];
+      v[6 + a] = loop[k + 1][a];
+    }
+    const float a[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
+    const float b[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+    float nrm[3] = {-b[1] * a[2] + a[1] * b[2], b[0] * a[2] - a[0] * b[2], -b[0] * a[1] + a[0] * b[1]};  // Cross3 math.cpp:36
+    const float mag = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    s.tri_na[t][3] = mag / 2.0f;
+    for (int c = 0; c < 3; c++) s.tri_na[t][c] = (mag > 0.0f) ? nrm[c] / mag : 0.0f;
+    s.tri_face[t] = static_cast<uint8_t>(fid);
+    cur.tri++;
+  }
+  cur.fid++;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prism
+// ---------------------------------------------------------------------------------------------------
+struct Pt2 {
+  double x, y;
+};
+
+// intersection of half-plane boundaries i and j (Cramer, geo3d_closedform.cpp:27-35)
+HALO_GEOM_HD bool Meet(int i, int j, const double r[6], Pt2& out) {
+  const double det = Cos6(i) * Sin6(j) - Sin6(i) * Cos6(j);
+  if (det == 0.0) return false;
+  out.x = (r[i] * Sin6(j) - r[j] * Sin6(i)) / det;
+  out.y = (Cos6(i) * r[j] - Cos6(j) * r[i]) / det;
+  return true;
+}
+
+struct HexSection {
+  Pt2 ring[6];      // CCW corners, one per adjacent pair of present sides
+  int n = 0;
+  bool present[6] = {false, false, false, false, false, false};
+  bool bounded = false;
+};
+
+// 2-D intersection of the six half-planes cos(i*60)x + sin(i*60)y <= r[i] (SolveHexCrossSection,
+// geo3d_closedform.cpp:124-302): enumerate non-parallel pairs, keep feasible corners, dedupe within
+// tol = 5*eps*max|r|, a side is present iff >= 2 corners sit on it, then walk present sides in order.
+HALO_GEOM_HD void SolveHex(const double r[6], HexSection& hs) {
+  double scale = 0.0;
+  for (int i = 0; i < 6; i++) scale = fmax(scale, fabs(r[i]));
+  const double tol = 5.0 * static_cast<double>(kGeomFloatEps) * scale;
+  Pt2 cand[12];
+  int nc = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i + 1; j < 6; j++) {
+      if (j == i + 3) continue;
+      Pt2 q{0.0, 0.0};
+      Meet(i, j, r, q);
+      bool ok = true;
+      for (int m = 0; m < 6 && ok; m++)
+        if (m != i && m != j && Cos6(m) * q.x + Sin6(m) * q.y > r[m] + tol) ok = false;
+      if (!ok) continue;
+      bool dup = false;
+      for (int c = 0; c < nc; c++)
+        if (sqrt((cand[c].x - q.x) * (cand[c].x - q.x) + (cand[c].y - q.y) * (cand[c].y - q.y)) <= tol) {
+          dup = true;
+          break;
+        }
+      if (!dup && nc < 12) cand[nc++] = q;
+    }
+  int sides[6];
+  int n = 0;
+  for (int i = 0; i < 6; i++) {
+    int on = 0;
+    for (int c = 0; c < nc; c++)
+      if (fabs(Cos6(i) * cand[c].x + Sin6(i) * cand[c].y - r[i]) <= tol) on++;
+    hs.present[i] = on >= 2;
+    if (hs.present[i]) sides[n++] = i;
+  }
+  bool opposite_adjacent = false;
+  for (int k = 0; k < n; k++) {
+    const int dlt = sides[k] - sides[(k + 1) % n];
+    if (dlt == 3 || dlt == -3) opposite_adjacent = true;
+  }
+  hs.bounded = n >= 3 && !opposite_adjacent;
+  hs.n = 0;
+  if (!hs.bounded) return;
+  for (int k = 0; k < n; k++) {
+    Pt2 q{0.0, 0.0};
+    Meet(sides[k], sides[(k + 1) % n], r, q);
+    hs.ring[hs.n++] = q;
+  }
+}
+
+// ComputeClosedFormPrism + AdaptClosedFormPrismToCrystalGeom. false = empty crystal (counts stay 0).
+HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], ShapeDev& out) {
+  ClearShape(out);
+  if (!(h > kGeomFloatEps)) return false;
+  const double k_r = kGeomSqrt3 / 4.0, k_d = kGeomSqrt3 / 8.0;
+  double r[6];
+  for (int i = 0; i < 6; i++) r[i] = k_r * static_cast<double>(dist[i]);
+  HexSection hs;
+  SolveHex(r, hs);
+  const int n = hs.n;
+  if (n < 3) return false;  // IsValidClosedFormPrism crystal.cpp:77-79
+  float c[6][2];
+  for (int k = 0; k < n; k++) {
+    c[k][0] = static_cast<float>(hs.ring[k].x);
+    c[k][1] = static_cast<float>(hs.ring[k].y);
+  }
+  const float zt = 0.5f * h, zb = -0.5f * h;
+  ShapeCursor cur;
+  float loop[HALO_MAX_FACE_VTX][3];
+  if (hs.bounded) {  // basal faces (numbers 1, 2)
+    const float plane_t[4] = {0.0f, 0.0f, 1.0f, -zt}, nrm_t[3] = {0.0f, 0.0f, 1.0f};
+    for (int k = 0; k < n; k++) {
+      loop[k][0] = c[k][0];
+      loop[k][1] = c[k][1];
+      loop[k][2] = zt;
+    }
+    EmitFace(out, cur, plane_t, nrm_t, 1, loop, n);
+    const float plane_b[4] = {0.0f, 0.0f, -1.0f, -zt}, nrm_b[3] = {0.0f, 0.0f, -1.0f};
+    for (int k = 0; k < n; k++) {
+      loop[k][0] = c[n - 1 - k][0];
+      loop[k][1] = c[n - 1 - k][1];
+      loop[k][2] = zb;
+    }
+    EmitFace(out, cur, plane_b, nrm_b, 2, loop, n);
+  }
+  // side faces (numbers 3..8): rectangle between ring corners k-1 and k for the k-th present side
+  int k = 0;
+  for (int i = 0; i < 6; i++) {
+    if (!hs.present[i]) continue;
+    const float nrm[3] = {static_cast<float>(Cos6(i)), static_cast<float>(Sin6(i)), 0.0f};
+    const float plane[4] = {0.5f * static_cast<float>(Cos6(i)), 0.5f * static_cast<float>(Sin6(i)), 0.0f,
+                            -static_cast<float>(k_d * static_cast<double>(dist[i]))};
+    const float* a = c[(k - 1 + n) % n];
+    const float* b = c[k];
+    loop[0][0] = a[0]; loop[0][1] = a[1]; loop[0][2] = zb;
+    loop[1][0] = b[0]; loop[1][1] = b[1]; loop[1][2] = zb;
+    loop[2][0] = b[0]; loop[2][1] = b[1]; loop[2][2] = zt;
+    loop[3][0] = a[0]; loop[3][1] = a[1]; loop[3][2] = zt;
+    EmitFace(out, cur, plane, nrm, 3 + i, loop, 4);
+    k++;
+  }
+  out.face_cnt = cur.fid;
+  out.tri_cnt = cur.tri;
+  return out.face_cnt > 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pyramid family (Crystal::CreatePyramid crystal.cpp:379-426).  Plane set, cone slope, wedge legality and the
+// basal cut follow the reference (FillHexCrystalCoef geo3d.cpp:346-512; ComputeClosedFormPyramid
+// geo3d_closedform.cpp:1404-1420); the solid is assembled as a half-space intersection: every feasible
+// concurrence of three planes is a vertex, a face is the CCW-sorted set of vertices on its plane.
+// ---------------------------------------------------------------------------------------------------
+struct Plane3 {
+  double a, b, c, d;
+};
+HALO_GEOM_HD double EvalPlane(const Plane3& p, const double x[3]) { return p.a * x[0] + p.b * x[1] + p.c * x[2] + p.d; }
+
+HALO_GEOM_HD bool Concurrence(const Plane3& p, const Plane3& q, const Plane3& r, double out[3]) {
+  const double det = p.a * (q.b * r.c - q.c * r.b) - p.b * (q.a * r.c - q.c * r.a) + p.c * (q.a * r.b - q.b * r.a);
+  if (fabs(det) < 1e-9) return false;
+  const double dx = -p.d, dy = -q.d, dz = -r.d;
+  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) / det;
+  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) / det;
+  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) / det;
+  return true;
+}
+
+// extreme z over the feasible vertices of one cone's six planes = its natural apex
+HALO_GEOM_HD bool ConeApexZ(const Plane3* cone, double tol, int sign, double& z) {
+  bool found = false;
+  double x[3];
+  for (int i = 0; i < 6; i++)
+    for (int j = i + 1; j < 6; j++)
+      for (int k = j + 1; k < 6; k++) {
+        if (!Concurrence(cone[i], cone[j], cone[k], x)) continue;
+        bool ok = true;
+        for (int m = 0; m < 6 && ok; m++) ok = EvalPlane(cone[m], x) <= tol;
+        if (!ok) continue;
+        if (!found || sign * x[2] > sign * z) z = x[2];
+        found = true;
+      }
+  return found;
+}
+
+constexpr int kPyrMaxVerts = 96;
+
+// cot_u / cot_l = sqrt3/4 / tan(wedge) for a legal wedge, negative = that cone absent (the caller evaluates tan once)
+HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float h2, float h3, const float dist[6], ShapeDev& out) {
+  ClearShape(out);
+  const int number[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
+  const bool upper = h1 > kGeomFloatEps && cot_u >= 0.0;
+  const bool lower = h3 > kGeomFloatEps && cot_l >= 0.0;
+  if (!upper && !lower && h2 < kGeomFloatEps) return false;
+  const double k8 = static_cast<double>(kGeomSqrt3) / 8.0, half = 0.5 * static_cast<double>(h2);
+  const double a1 = upper ? cot_u : -1.0;
+  const double a2 = lower ? cot_l : -1.0;
+  Plane3 raw[20], unit[20];
+  bool active[20];
+  for (int s = 0; s < 20; s++) {
+    active[s] = false;
+    raw[s] = unit[s] = Plane3{0.0, 0.0, 0.0, 0.0};
+  }
+  for (int i = 0; i < 6; i++) {
+    raw[2 + i] = Plane3{0.5 * Cos6(i), 0.5 * Sin6(i), 0.0, -k8 * static_cast<double>(dist[i])};
+    active[2 + i] = true;
+    if (upper) {
+      raw[8 + i] = Plane3{0.5 * a1 * Cos6(i), 0.5 * a1 * Sin6(i), k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
+      active[8 + i] = true;
+    }
+    if (lower) {
+      raw[14 + i] = Plane3{0.5 * a2 * Cos6(i), 0.5 * a2 * Sin6(i), -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
+      active[14 + i] = true;
+    }
+  }
+  double scale = fabs(half);
+  for (int s = 2; s < 20; s++) {
+    if (!active[s]) continue;
+    const double len = sqrt(raw[s].a * raw[s].a + raw[s].b * raw[s].b + raw[s].c * raw[s].c);
+    unit[s] = Plane3{raw[s].a / len, raw[s].b / len, raw[s].c / len, raw[s].d / len};
+    scale = fmax(scale, fabs(unit[s].d));
+  }
+  const double tol = 5.0 * static_cast<double>(kGeomFloatEps) * fmax(scale, 1e-3);
+  double z_top = half, z_bot = -half, apex = 0.0;
+  if (upper) {
+    if (!ConeApexZ(unit + 8, tol, +1, apex)) return false;
+    z_top = half + static_cast<double>(h1) * (apex - half);
+  }
+  if (lower) {
+    if (!ConeApexZ(unit + 14, tol, -1, apex)) return false;
+    z_bot = -half + static_cast<double>(h3) * (apex + half);
+  }
+  raw[0] = unit[0] = Plane3{0.0, 0.0, 1.0, -z_top};
+  raw[1] = unit[1] = Plane3{0.0, 0.0, -1.0, z_bot};
+  active[0] = active[1] = true;
+
+  double verts[kPyrMaxVerts][3];
+  int nv = 0;
+  for (int i = 0; i < 20; i++) {
+    if (!active[i]) continue;
+    for (int j = i + 1; j < 20; j++) {
+      if (!active[j]) continue;
+      for (int k = j + 1; k < 20; k++) {
+        if (!active[k]) continue;
+        double x[3];
+        if (!Concurrence(unit[i], unit[j], unit[k], x)) continue;
+        bool ok = true;
+        for (int m = 0; m < 20 && ok; m++)
+          if (active[m]) ok = EvalPlane(unit[m], x) <= tol;
+        if (!ok) continue;
+        bool dup = false;
+        for (int v = 0; v < nv; v++) {
+          const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
+          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+            dup = true;
+            break;
+          }
+        }
+        if (!dup && nv < kPyrMaxVerts) {
+          verts[nv][0] = x[0];
+          verts[nv][1] = x[1];
+          verts[nv][2] = x[2];
+          nv++;
+        }
+      }
+    }
+  }
+  // a face is present with >= 3 vertices on its plane; the crystal needs >= 4 present faces
+  // (IsValidClosedFormPyramid crystal.cpp:93-101), so the loops are ordered in a first pass and emitted in a second
+  int on[20][HALO_MAX_FACE_VTX];
+  int on_n[20];
+  int present = 0;
+  for (int s = 0; s < 20; s++) {
+    on_n[s] = 0;
+    if (!active[s]) continue;
+    int cnt = 0;
+    for (int v = 0; v < nv; v++)
+      if (fabs(EvalPlane(unit[s], verts[v])) <= 2.0 * tol && cnt < HALO_MAX_FACE_VTX) on[s][cnt++] = v;
+    if (cnt < 3) continue;
+    double c[3] = {0, 0, 0};
+    for (int q = 0; q < cnt; q++)
+      for (int a = 0; a < 3; a++) c[a] += verts[on[s][q]][a] / static_cast<double>(cnt);
+    const double n[3] = {unit[s].a, unit[s].b, unit[s].c};
+    double e1[3] = {verts[on[s][0]][0] - c[0], verts[on[s][0]][1] - c[1], verts[on[s][0]][2] - c[2]};
+    const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    if (l1 <= tol) continue;
+    for (int a = 0; a < 3; a++) e1[a] /= l1;
+    const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+    double ang[HALO_MAX_FACE_VTX];
+    for (int q = 0; q < cnt; q++) {
+      const double r[3] = {verts[on[s][q]][0] - c[0], verts[on[s][q]][1] - c[1], verts[on[s][q]][2] - c[2]};
+      double a = (q == 0) ? 0.0 : atan2(r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2]);
+      if (a < 0.0) a += 2.0 * kGeomPiD;
+      ang[q] = a;
+    }
+    for (int q = 1; q < cnt; q++) {  // stable insertion sort by angle
+      const double ka = ang[q];
+      const int kv = on[s][q];
+      int p = q - 1;
+      while (p >= 0 && ang[p] > ka) {
+        ang[p + 1] = ang[p];
+        on[s][p + 1] = on[s][p];
+        p--;
+      }
+      ang[p + 1] = ka;
+      on[s][p + 1] = kv;
+    }
+    on_n[s] = cnt;
+    present++;
+  }
+  if (present < 4) return false;
+  ShapeCursor cur;
+  float loop[HALO_MAX_FACE_VTX][3];
+  for (int s = 0; s < 20; s++) {
+    if (on_n[s] == 0) continue;
+    const float plane[4] = {static_cast<float>(raw[s].a), static_cast<float>(raw[s].b), static_cast<float>(raw[s].c), static_cast<float>(raw[s].d)};
+    const float nrm[3] = {static_cast<float>(unit[s].a), static_cast<float>(unit[s].b), static_cast<float>(unit[s].c)};
+    for (int q = 0; q < on_n[s]; q++)
+      for (int a = 0; a < 3; a++) loop[q][a] = static_cast<float>(verts[on[s][q]][a]);
+    EmitFace(out, cur, plane, nrm, number[s], loop, on_n[s]);
+  }
+  out.face_cnt = cur.fid;
+  out.tri_cnt = cur.tri;
+  return out.face_cnt > 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one sampled crystal instance (MakeCrystal simulator.cpp:448 with SyncGroupSampler :361-393)
+// ---------------------------------------------------------------------------------------------------
+struct CrystalRecipe {   // HaloCrystal with the wedge trig already evaluated (host, once per dispatch)
+  HaloCrystal c;
+  double cot_u, cot_l;   // sqrt3/4 / tan(wedge); negative = illegal wedge (cone absent)
+};
+
+HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, ShapeDev& out) {
+  const HaloCrystal& c = rc.c;
+  const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
+  const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
+  ScalarStream rng{(hi == 0u) ? (seed ^ kNonceShape) : ((seed ^ kNonceShape) ^ PcgHash32(hi)), lo * 1000003u, 0u};
+  // first member of a sync group draws, later members reuse the raw value
+  int grp[9];
+  float val[9];
+  int cached = 0;
+  float sc[9];
+  const int n_h = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
+  for (int i = 0; i < n_h + 6; i++) {
+    const int slot = (i < n_h) ? i : 3 + (i - n_h);
+    const HaloDist& d = (i < n_h) ? c.height[i] : c.face_dist[i - n_h];
+    const int group = c.sync_group[slot];
+    float v = 0.0f;
+    bool have = false;
+    if (group != 0)
+      for (int q = 0; q < cached; q++)
+        if (grp[q] == group) {
+          v = val[q];
+          have = true;
+          break;
+        }
+    if (!have) {
+      v = Draw(rng, d);
+      if (group != 0) {
+        grp[cached] = group;
+        val[cached] = v;
+        cached++;
+      }
+    }
+    sc[slot] = v;
+  }
+  float dist[6];
+  for (int i = 0; i < 6; i++) dist[i] = sc[3 + i];
+  if (c.kind == HALO_CRYSTAL_PRISM) return BuildPrismShape(fabsf(sc[0]), dist, out);  // heights fold, distances stay signed
+  return BuildPyramidShape(rc.cot_u, rc.cot_l, fabsf(sc[0]), fabsf(sc[1]), fabsf(sc[2]), dist, out);
+}
+
+}  // namespace geom
+}  // namespace halo
+
+#endif

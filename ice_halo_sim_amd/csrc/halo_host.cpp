@@ -10,6 +10,7 @@
 #include <numeric>
 
 #include "cie_tables.inc"
+#include "halo_geom.h"
 
 namespace halo {
 namespace host {
@@ -41,363 +42,64 @@ Mat3 LeftMul(const Mat3& r, const Mat3& m) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
-// RNG
-// ---------------------------------------------------------------------------------------------------
-uint32_t PcgHash(uint32_t x) {  // pcg_shared.h:193-197
-  x = x * 747796405u + 2891336453u;
-  x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
-  return (x >> 22u) ^ x;
-}
-float Pcg::Uniform() {
-  uint32_t h = PcgHash(seed ^ PcgHash(key + slot));
-  slot++;
-  return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
-}
-float Pcg::Gaussian() {
-  const float two_pi = 2.0f * 3.14159265358979323846f;
-  float u1 = std::fmax(Uniform(), 1e-7f);
-  float u2 = Uniform();
-  return std::sqrt(-2.0f * std::log(u1)) * std::cos(two_pi * u2);
-}
-float Pcg::Get(const HaloDist& d) {  // RandomNumberGenerator::Get math.cpp:418-444 over the PCG stream
-  const float two_pi = 2.0f * 3.14159265358979323846f;
-  switch (d.type) {
-    case HALO_DIST_UNIFORM: return (Uniform() - 0.5f) * d.spread + d.center;
-    case HALO_DIST_GAUSS:
-    case HALO_DIST_GAUSS_LEGACY: return Gaussian() * d.spread + d.center;
-    case HALO_DIST_ZIGZAG: return std::fabs(d.spread * std::sin(Uniform() * two_pi) + d.center);
-    case HALO_DIST_LAPLACIAN: {
-      float u = Uniform();
-      float sgn = (u < 0.5f) ? -1.0f : 1.0f;
-      float arg = std::fmax(1.0f - 2.0f * std::fabs(u - 0.5f), 1e-30f);
-      return d.center - d.spread * sgn * std::log(arg);
-    }
-    default: return d.center;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// prism geometry
+// crystal geometry: the builders live in halo_geom.h, shared verbatim with the device generator
+// (halo_shapegen.hip); here they are wrapped into the table layout of the C ABI.
 // ---------------------------------------------------------------------------------------------------
 namespace {
-
 constexpr double kPiD = 3.14159265358979323846;
-// exact 60-degree direction tables (geo3d_closedform.hpp:48-52)
-constexpr double kCos6[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
-constexpr double kS = 0.86602540378443864676;
-constexpr double kSin6[6] = {0.0, kS, kS, 0.0, -kS, -kS};
-
-struct Pt {
-  double x, y;
-};
-
-// intersection of half-plane boundaries i and j (Cramer, geo3d_closedform.cpp:27-35)
-bool Meet(int i, int j, const double r[6], Pt& out) {
-  const double det = kCos6[i] * kSin6[j] - kSin6[i] * kCos6[j];
-  if (det == 0.0) return false;
-  out.x = (r[i] * kSin6[j] - r[j] * kSin6[i]) / det;
-  out.y = (kCos6[i] * r[j] - kCos6[j] * r[i]) / det;
-  return true;
 }
 
-struct HexSection {
-  std::vector<Pt> ring;          // CCW corners, one per adjacent pair of present sides
-  std::array<bool, 6> present{}; // side bounds the polygon
-  bool bounded = false;
-};
+uint32_t PcgHash(uint32_t x) { return geom::PcgHash32(x); }
 
-// 2-D intersection of the six half-planes cos(i*60)x + sin(i*60)y <= r[i] (SolveHexCrossSection,
-// geo3d_closedform.cpp:124-302): enumerate non-parallel pairs, keep feasible corners, dedupe within
-// tol = 5*eps*max|r|, a side is present iff >= 2 corners sit on it, then walk present sides in order.
-HexSection SolveHex(const double r[6]) {
-  HexSection hs;
-  double scale = 0.0;
-  for (int i = 0; i < 6; i++) scale = std::max(scale, std::fabs(r[i]));
-  const double tol = 5.0 * static_cast<double>(kFloatEps) * scale;
-  std::vector<Pt> cand;
-  for (int i = 0; i < 6; i++)
-    for (int j = i + 1; j < 6; j++) {
-      if (j == i + 3) continue;
-      Pt q{};
-      Meet(i, j, r, q);
-      bool ok = true;
-      for (int m = 0; m < 6 && ok; m++)
-        if (m != i && m != j && kCos6[m] * q.x + kSin6[m] * q.y > r[m] + tol) ok = false;
-      if (!ok) continue;
-      bool dup = false;
-      for (const Pt& c : cand)
-        if (std::sqrt((c.x - q.x) * (c.x - q.x) + (c.y - q.y) * (c.y - q.y)) <= tol) {
-          dup = true;
-          break;
-        }
-      if (!dup && cand.size() < 12) cand.push_back(q);
-    }
-  std::vector<int> sides;
-  for (int i = 0; i < 6; i++) {
-    int on = 0;
-    for (const Pt& c : cand)
-      if (std::fabs(kCos6[i] * c.x + kSin6[i] * c.y - r[i]) <= tol) on++;
-    hs.present[i] = on >= 2;
-    if (hs.present[i]) sides.push_back(i);
+void FromShapeDev(const ShapeDev& s, HaloGeomTables& g) {
+  std::memset(&g, 0, sizeof(g));
+  g.face_cnt = s.face_cnt;
+  g.tri_cnt = s.tri_cnt;
+  for (int f = 0; f < s.face_cnt; f++) {
+    g.face_n[f * 3 + 0] = s.face[f][0];
+    g.face_n[f * 3 + 1] = s.face[f][1];
+    g.face_n[f * 3 + 2] = s.face[f][2];
+    g.face_d[f] = s.face[f][3];
+    g.face_number[f] = s.face_number[f];
   }
-  const int n = static_cast<int>(sides.size());
-  bool opposite_adjacent = false;
-  for (int k = 0; k < n; k++)
-    if (std::abs(sides[k] - sides[(k + 1) % n]) == 3) opposite_adjacent = true;
-  hs.bounded = n >= 3 && !opposite_adjacent;
-  if (!hs.bounded) return hs;
-  for (int k = 0; k < n; k++) {
-    Pt q{};
-    Meet(sides[k], sides[(k + 1) % n], r, q);
-    hs.ring.push_back(q);
+  for (int t = 0; t < s.tri_cnt; t++) {
+    std::memcpy(g.tri_v + t * 9, s.tri_v[t], 36);
+    g.tri_n[t * 3 + 0] = s.tri_na[t][0];
+    g.tri_n[t * 3 + 1] = s.tri_na[t][1];
+    g.tri_n[t * 3 + 2] = s.tri_na[t][2];
+    g.tri_area[t] = s.tri_na[t][3];
+    g.tri_face[t] = s.tri_face[t];
   }
-  return hs;
 }
 
-struct FaceLoop {              // one face slot of CrystalGeom (crystal.hpp:78)
-  bool present = false;
-  float plane[4] = {0, 0, 0, 0};
-  float normal[3] = {0, 0, 0};
-  int number = 0;
-  std::vector<std::array<float, 3>> loop;  // CCW corners seen from outside
-};
-
-// Compact the present faces and fan-triangulate them (Crystal::PopulateFromCfGeom crystal.cpp:304-347 +
-// detail::BuildEntrySubTris simulator.cpp:90-129).
-void Tabulate(const std::vector<FaceLoop>& faces, HaloGeomTables& out) {
-  std::memset(&out, 0, sizeof(out));
-  int fid = 0, t = 0;
-  for (const FaceLoop& f : faces) {
-    if (!f.present) continue;
-    std::memcpy(out.face_n + fid * 3, f.normal, sizeof(f.normal));
-    const float len = std::sqrt(f.plane[0] * f.plane[0] + f.plane[1] * f.plane[1] + f.plane[2] * f.plane[2]);
-    out.face_d[fid] = (len > kFloatEps) ? f.plane[3] / len : 0.0f;
-    out.face_number[fid] = f.number;
-    const int nv = static_cast<int>(f.loop.size());
-    for (int k = 1; k + 1 < nv && nv >= 3 && t < kMaxTris; k++) {
-      float* v = out.tri_v + t * 9;
-      std::memcpy(v, f.loop[0].data(), 12);
-      std::memcpy(v + 3, f.loop[k].data(), 12);
-      std::memcpy(v + 6, f.loop[k + 1].data(), 12);
-      const float a[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
-      const float b[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
-      float nrm[3] = {-b[1] * a[2] + a[1] * b[2], b[0] * a[2] - a[0] * b[2], -b[0] * a[1] + a[0] * b[1]};  // Cross3 math.cpp:36
-      const float mag = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-      out.tri_area[t] = mag / 2.0f;
-      for (float& c : nrm) c = (mag > 0.0f) ? c / mag : 0.0f;
-      std::memcpy(out.tri_n + t * 3, nrm, sizeof(nrm));
-      out.tri_face[t] = fid;
-      t++;
-    }
-    fid++;
-  }
-  out.face_cnt = fid;
-  out.tri_cnt = t;
-}
-
-}  // namespace
-
-// ComputeClosedFormPrism (geo3d_closedform.cpp:1318-1407) + AdaptClosedFormPrismToCrystalGeom (crystal.cpp:109-186)
 bool BuildPrism(float h, const float dist[6], HaloGeomTables& out) {
-  std::memset(&out, 0, sizeof(out));
-  if (!(h > kFloatEps)) return false;
-  const double k_r = kSqrt3 / 4.0, k_d = kSqrt3 / 8.0;
-  double r[6];
-  for (int i = 0; i < 6; i++) r[i] = k_r * static_cast<double>(dist[i]);
-  const HexSection hs = SolveHex(r);
-  const int n = static_cast<int>(hs.ring.size());
-  if (n < 3) return false;  // IsValidClosedFormPrism crystal.cpp:77-79
-  std::vector<std::array<float, 2>> c(n);
-  for (int k = 0; k < n; k++) c[k] = {static_cast<float>(hs.ring[k].x), static_cast<float>(hs.ring[k].y)};
-  const float zt = 0.5f * h, zb = -0.5f * h;
-
-  std::vector<FaceLoop> faces(8);
-  for (int s = 0; s < 8; s++) faces[s].number = s + 1;
-  // basal faces
-  faces[0].present = faces[1].present = hs.bounded;
-  faces[0].normal[2] = 1.0f;
-  faces[0].plane[2] = 1.0f;
-  faces[0].plane[3] = -zt;
-  faces[1].normal[2] = -1.0f;
-  faces[1].plane[2] = -1.0f;
-  faces[1].plane[3] = -zt;
-  for (int k = 0; k < n; k++) {
-    faces[0].loop.push_back({c[k][0], c[k][1], zt});
-    faces[1].loop.push_back({c[n - 1 - k][0], c[n - 1 - k][1], zb});
-  }
-  // side faces: rectangle between ring corners k-1 and k for the k-th present side
-  int k = 0;
-  for (int i = 0; i < 6; i++) {
-    FaceLoop& f = faces[2 + i];
-    f.normal[0] = static_cast<float>(kCos6[i]);
-    f.normal[1] = static_cast<float>(kSin6[i]);
-    f.plane[0] = 0.5f * static_cast<float>(kCos6[i]);
-    f.plane[1] = 0.5f * static_cast<float>(kSin6[i]);
-    f.plane[3] = -static_cast<float>(k_d * static_cast<double>(dist[i]));
-    f.present = hs.present[i];
-    if (!f.present) continue;
-    const auto& a = c[(k - 1 + n) % n];
-    const auto& b = c[k];
-    f.loop = {{a[0], a[1], zb}, {b[0], b[1], zb}, {b[0], b[1], zt}, {a[0], a[1], zt}};
-    k++;
-  }
-  Tabulate(faces, out);
-  return out.face_cnt > 0;
+  ShapeDev s;
+  const bool ok = geom::BuildPrismShape(h, dist, s);
+  FromShapeDev(s, out);
+  return ok;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// pyramid family (Crystal::CreatePyramid crystal.cpp:379-426).  Plane set, cone slope, wedge legality and the
-// basal cut follow the reference (FillHexCrystalCoef geo3d.cpp:346-512; ComputeClosedFormPyramid
-// geo3d_closedform.cpp:1404-1420); the solid is assembled as a half-space intersection: every feasible
-// concurrence of three planes is a vertex, a face is the CCW-sorted set of vertices on its plane.
-// ---------------------------------------------------------------------------------------------------
-namespace {
-
-struct Plane {
-  double a = 0, b = 0, c = 0, d = 0;
-  double Eval(const double x[3]) const { return a * x[0] + b * x[1] + c * x[2] + d; }
-};
-
-bool Concurrence(const Plane& p, const Plane& q, const Plane& r, double out[3]) {
-  const double det = p.a * (q.b * r.c - q.c * r.b) - p.b * (q.a * r.c - q.c * r.a) + p.c * (q.a * r.b - q.b * r.a);
-  if (std::fabs(det) < 1e-9) return false;
-  const double dx = -p.d, dy = -q.d, dz = -r.d;
-  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) / det;
-  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) / det;
-  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) / det;
-  return true;
+geom::CrystalRecipe MakeRecipe(const HaloCrystal& c) {
+  geom::CrystalRecipe r{};
+  r.c = c;
+  auto cot = [](float wedge) {  // wedge legality + cone slope (FillHexCrystalCoef geo3d.cpp:346-512)
+    if (!(wedge >= 0.1f && wedge <= 89.9f)) return -1.0;
+    return static_cast<double>(kSqrt3 / 4.0f) / std::tan(static_cast<double>(wedge) * static_cast<double>(kDegToRad));
+  };
+  r.cot_u = cot(c.wedge_upper_deg);
+  r.cot_l = cot(c.wedge_lower_deg);
+  return r;
 }
-
-// extreme z over the feasible vertices of one cone's six planes = its natural apex
-bool ConeApexZ(const Plane* cone, double tol, int sign, double& z) {
-  bool found = false;
-  double x[3];
-  for (int i = 0; i < 6; i++)
-    for (int j = i + 1; j < 6; j++)
-      for (int k = j + 1; k < 6; k++) {
-        if (!Concurrence(cone[i], cone[j], cone[k], x)) continue;
-        bool ok = true;
-        for (int m = 0; m < 6 && ok; m++) ok = cone[m].Eval(x) <= tol;
-        if (!ok) continue;
-        if (!found || sign * x[2] > sign * z) z = x[2];
-        found = true;
-      }
-  return found;
-}
-
-}  // namespace
 
 bool BuildPyramid(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HaloGeomTables& out) {
-  std::memset(&out, 0, sizeof(out));
-  static const int kNumber[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
-  const bool upper = h1 > kFloatEps && wedge_u >= 0.1f && wedge_u <= 89.9f;
-  const bool lower = h3 > kFloatEps && wedge_l >= 0.1f && wedge_l <= 89.9f;
-  if (!upper && !lower && h2 < kFloatEps) return false;
-  const double k8 = static_cast<double>(kSqrt3) / 8.0, half = 0.5 * static_cast<double>(h2);
-  const double a1 = upper ? static_cast<double>(kSqrt3 / 4.0f) / std::tan(static_cast<double>(wedge_u) * static_cast<double>(kDegToRad)) : -1.0;
-  const double a2 = lower ? static_cast<double>(kSqrt3 / 4.0f) / std::tan(static_cast<double>(wedge_l) * static_cast<double>(kDegToRad)) : -1.0;
-  Plane raw[20], unit[20];
-  bool active[20] = {};
-  for (int i = 0; i < 6; i++) {
-    raw[2 + i] = {0.5 * kCos6[i], 0.5 * kSin6[i], 0.0, -k8 * static_cast<double>(dist[i])};
-    active[2 + i] = true;
-    if (upper) {
-      raw[8 + i] = {0.5 * a1 * kCos6[i], 0.5 * a1 * kSin6[i], k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
-      active[8 + i] = true;
-    }
-    if (lower) {
-      raw[14 + i] = {0.5 * a2 * kCos6[i], 0.5 * a2 * kSin6[i], -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
-      active[14 + i] = true;
-    }
-  }
-  double scale = std::fabs(half);
-  for (int s = 2; s < 20; s++) {
-    if (!active[s]) continue;
-    const double len = std::sqrt(raw[s].a * raw[s].a + raw[s].b * raw[s].b + raw[s].c * raw[s].c);
-    unit[s] = {raw[s].a / len, raw[s].b / len, raw[s].c / len, raw[s].d / len};
-    scale = std::fmax(scale, std::fabs(unit[s].d));
-  }
-  const double tol = 5.0 * static_cast<double>(kFloatEps) * std::fmax(scale, 1e-3);
-  double z_top = half, z_bot = -half, apex = 0.0;
-  if (upper) {
-    if (!ConeApexZ(unit + 8, tol, +1, apex)) return false;
-    z_top = half + static_cast<double>(h1) * (apex - half);
-  }
-  if (lower) {
-    if (!ConeApexZ(unit + 14, tol, -1, apex)) return false;
-    z_bot = -half + static_cast<double>(h3) * (apex + half);
-  }
-  raw[0] = unit[0] = {0.0, 0.0, 1.0, -z_top};
-  raw[1] = unit[1] = {0.0, 0.0, -1.0, z_bot};
-  active[0] = active[1] = true;
-
-  std::vector<std::array<double, 3>> verts;
-  for (int i = 0; i < 20; i++) {
-    if (!active[i]) continue;
-    for (int j = i + 1; j < 20; j++) {
-      if (!active[j]) continue;
-      for (int k = j + 1; k < 20; k++) {
-        if (!active[k]) continue;
-        double x[3];
-        if (!Concurrence(unit[i], unit[j], unit[k], x)) continue;
-        bool ok = true;
-        for (int m = 0; m < 20 && ok; m++)
-          if (active[m]) ok = unit[m].Eval(x) <= tol;
-        if (!ok) continue;
-        bool dup = false;
-        for (const auto& v : verts) {
-          const double dx = v[0] - x[0], dy = v[1] - x[1], dz = v[2] - x[2];
-          if (std::sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
-            dup = true;
-            break;
-          }
-        }
-        if (!dup && verts.size() < 96) verts.push_back({x[0], x[1], x[2]});
-      }
-    }
-  }
-  std::vector<FaceLoop> faces(20);
-  int present = 0;
-  for (int s = 0; s < 20; s++) {
-    FaceLoop& f = faces[s];
-    f.number = kNumber[s];
-    if (!active[s]) continue;
-    f.plane[0] = static_cast<float>(raw[s].a);
-    f.plane[1] = static_cast<float>(raw[s].b);
-    f.plane[2] = static_cast<float>(raw[s].c);
-    f.plane[3] = static_cast<float>(raw[s].d);
-    f.normal[0] = static_cast<float>(unit[s].a);
-    f.normal[1] = static_cast<float>(unit[s].b);
-    f.normal[2] = static_cast<float>(unit[s].c);
-    std::vector<int> on;
-    for (size_t v = 0; v < verts.size(); v++)
-      if (std::fabs(unit[s].Eval(verts[v].data())) <= 2.0 * tol && on.size() < HALO_MAX_FACE_VTX) on.push_back(static_cast<int>(v));
-    if (on.size() < 3) continue;
-    double c[3] = {0, 0, 0};
-    for (int v : on)
-      for (int a = 0; a < 3; a++) c[a] += verts[v][a] / static_cast<double>(on.size());
-    const double n[3] = {unit[s].a, unit[s].b, unit[s].c};
-    double e1[3] = {verts[on[0]][0] - c[0], verts[on[0]][1] - c[1], verts[on[0]][2] - c[2]};
-    const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-    if (l1 <= tol) continue;
-    for (double& e : e1) e /= l1;
-    const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
-    std::vector<std::pair<double, int>> order;
-    for (size_t k = 0; k < on.size(); k++) {
-      const double r[3] = {verts[on[k]][0] - c[0], verts[on[k]][1] - c[1], verts[on[k]][2] - c[2]};
-      double ang = (k == 0) ? 0.0 : std::atan2(r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2]);
-      if (ang < 0.0) ang += 2.0 * kPiD;
-      order.emplace_back(ang, on[k]);
-    }
-    std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-    f.present = true;
-    for (const auto& o : order)
-      f.loop.push_back({static_cast<float>(verts[o.second][0]), static_cast<float>(verts[o.second][1]), static_cast<float>(verts[o.second][2])});
-    present++;
-  }
-  if (present < 4) return false;  // IsValidClosedFormPyramid crystal.cpp:93-101
-  Tabulate(faces, out);
-  return out.face_cnt > 0;
+  HaloCrystal c{};
+  c.wedge_upper_deg = wedge_u;
+  c.wedge_lower_deg = wedge_l;
+  const geom::CrystalRecipe r = MakeRecipe(c);
+  ShapeDev s;
+  const bool ok = geom::BuildPyramidShape(r.cot_u, r.cot_l, h1, h2, h3, dist, s);
+  FromShapeDev(s, out);
+  return ok;
 }
 
 void ToShapeDev(const HaloGeomTables& g, ShapeDev& s) {
@@ -547,35 +249,15 @@ bool IsDeterministic(const HaloCrystal& c) {
   return true;
 }
 
+bool MakeShapeDev(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, ShapeDev& out) {
+  return geom::MakeShapeDev(seed, MakeRecipe(c), shape_index, out);
+}
+
 bool MakeShape(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, HaloGeomTables& out) {
-  const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
-  const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
-  Pcg rng{(hi == 0u) ? (seed ^ kNonceShapeHost) : ((seed ^ kNonceShapeHost) ^ PcgHash(hi)), lo * 1000003u, 0u};
-  // SyncGroupSampler (simulator.cpp:361-393): first member of a group draws, later members reuse the raw value
-  int grp[9];
-  float val[9];
-  int cached = 0;
-  auto draw = [&](int group, const HaloDist& d) {
-    if (group == 0) return rng.Get(d);
-    for (int i = 0; i < cached; i++)
-      if (grp[i] == group) return val[i];
-    const float v = rng.Get(d);
-    grp[cached] = group;
-    val[cached] = v;
-    cached++;
-    return v;
-  };
-  float dist[6];
-  if (c.kind == HALO_CRYSTAL_PRISM) {
-    const float h = std::fabs(draw(c.sync_group[0], c.height[0]));  // heights fold, distances stay signed
-    for (int i = 0; i < 6; i++) dist[i] = draw(c.sync_group[3 + i], c.face_dist[i]);
-    return BuildPrism(h, dist, out);
-  }
-  const float h1 = std::fabs(draw(c.sync_group[0], c.height[0]));
-  const float h2 = std::fabs(draw(c.sync_group[1], c.height[1]));
-  const float h3 = std::fabs(draw(c.sync_group[2], c.height[2]));
-  for (int i = 0; i < 6; i++) dist[i] = draw(c.sync_group[3 + i], c.face_dist[i]);
-  return BuildPyramid(c.wedge_upper_deg, c.wedge_lower_deg, h1, h2, h3, dist, out);
+  ShapeDev s;
+  const bool ok = MakeShapeDev(seed, c, shape_index, s);
+  FromShapeDev(s, out);
+  return ok;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "halo_device.h"
+#include "halo_geom.h"
 
 namespace halo {
 namespace host {
@@ -25,6 +26,8 @@ bool BuildPrism(float h, const float dist[6], HaloGeomTables& out);
 bool BuildPyramid(float wedge_u_deg, float wedge_l_deg, float h1, float h2, float h3, const float dist[6],
                   HaloGeomTables& out);
 void ToShapeDev(const HaloGeomTables& g, ShapeDev& out);
+void FromShapeDev(const ShapeDev& s, HaloGeomTables& out);
+geom::CrystalRecipe MakeRecipe(const HaloCrystal& c);   // wedge trig evaluated once, on the host
 
 struct LatLut {
   std::array<float, kLutNodes> theta{}, cdf{}, flip{};
@@ -49,14 +52,8 @@ bool IsDeterministic(const HaloCrystal& c);                 // simulator.cpp:453
 // One sampled crystal instance (MakeCrystal simulator.cpp:448 with SyncGroupSampler :361-393), shape scalars
 // drawn from the host PCG stream (seed, shape_index).
 bool MakeShape(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, HaloGeomTables& out);
+bool MakeShapeDev(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, ShapeDev& out);   // same, device table layout
 
-// tiny counter-based stream used for host-side shape scalars (same hash as the device streams)
-struct Pcg {
-  uint32_t seed, key, slot;
-  float Uniform();
-  float Gaussian();
-  float Get(const HaloDist& d);
-};
 uint32_t PcgHash(uint32_t x);
 
 }  // namespace host

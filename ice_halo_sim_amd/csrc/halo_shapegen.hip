@@ -1,0 +1,33 @@
+// halo_shapegen.hip — device crystal generator: one thread samples one crystal instance and writes
+// its kernel tables.  The geometry code is halo_geom.h, the same functions the host uses, compiled here with
+// -ffp-contract=off so that identical scalars give bit-identical tables on both sides.
+//
+// Replaces, for stochastic crystals, the host loop MakeCrystal (simulator.cpp:448) → closed-form geometry
+// (geo3d_closedform.cpp:124-302,1318-1407) → PopulateFromCfGeom (crystal.cpp:304-347) and the upload of its result;
+// the reference's device counterpart is the per-ray geometry stage of its CUDA backend (cuda_trace_backend.cu:2577-2800).
+// geom_clock consecutive rays share shape k (legacy semantics, simulator.cpp:1244-1275), so the pool has n/geom_clock
+// entries and the trace kernel reads shape tid/geom_clock.
+#include <hip/hip_runtime.h>
+
+#include "halo_geom.h"
+
+namespace halo {
+
+constexpr int kGenBlock = 64;
+
+// `pool` must be zeroed by the caller (an invalid draw leaves face_cnt = 0 = empty crystal).
+__global__ void __launch_bounds__(kGenBlock) halo_shapegen_kernel(ShapeDev* __restrict__ pool, uint32_t n, uint32_t seed,
+                                                                   const geom::CrystalRecipe rc, uint64_t first_index) {
+  const uint32_t k = blockIdx.x * kGenBlock + threadIdx.x;
+  if (k >= n) return;
+  geom::MakeShapeDev(seed, rc, first_index + k, pool[k]);
+}
+
+hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
+                           hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(halo_shapegen_kernel, dim3((n + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, stream, pool, n, seed, rc, first_index);
+  return hipGetLastError();
+}
+
+}  // namespace halo

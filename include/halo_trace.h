@@ -226,6 +226,7 @@ const char* halo_last_error(halo_handle_t h);
  * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
+ * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu". */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
@@ -301,6 +302,13 @@ int halo_host_prism_geometry(float h, const float dist[6], HaloGeomTables* out);
 /* Crystal::CreatePyramid(wedge_u, wedge_l, h1, h2, h3, dist) — crystal.cpp:379-426. */
 int halo_host_pyramid_geometry(float wedge_upper_deg, float wedge_lower_deg, float h1, float h2, float h3,
                                const float dist[6], HaloGeomTables* out);
+/* Sample crystal instances [first_index, first_index + n) of `crystal` from the backend's shape-scalar stream
+ * (MakeCrystal simulator.cpp:448 + SyncGroupSampler :361-393 + closed-form geometry) into `out[n]`:
+ * on_device = 1 runs the device generator the trace path uses for stochastic crystals, 0 the host builder.
+ * Both are the same code (csrc/halo_geom.h); the tables are bit-equal whenever the draws involve no libm call
+ * (fixed / uniform distributions) and equal to float rounding otherwise.  Parity-test hook. */
+int halo_generate_shapes(halo_handle_t h, const HaloCrystal* crystal, uint64_t first_index, uint32_t n, int on_device,
+                         HaloGeomTables* out);
 /* BuildLatLut — lat_lut.cpp:74-204. theta/cdf/flip are HALO_LUT_NODES floats each. */
 int halo_host_build_lat_lut(const HaloDist* latitude, float* theta, float* cdf, float* flip);
 /* BuildProjParams — lens_proj_build.hpp:79-137 → 19 x 4 bytes laid out as lm_proj::ProjParams. */

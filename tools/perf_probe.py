@@ -43,4 +43,15 @@ if "copies" in which:
 if "ms" in which:
     run("config3 multi-scatter 10M", scenes.config3_scene(), rd)
 if "stoch" in which:
+    import time
+    for hs in (0, 1):
+        hb = HipTraceBackend(device=0, seed=42, host_shapes=hs)
+        sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+        rd_s = scenes.render(7, 2048, 1024, el=0, visible=2)
+        run_session(hb, sc_s, rd_s, scenes.wl_discrete(550.0), 1_000_000)
+        hb.sync(); t0 = time.perf_counter()
+        st = run_session(hb, sc_s, rd_s, scenes.wl_discrete(550.0), 16_000_000)
+        hb.sync(); dt = time.perf_counter() - t0
+        print("stochastic prism 16M host_shapes=%d: wall %.1f ms (%.0f M rays/s), trace kernels %.2f ms" % (hs, dt * 1e3, 16 / dt, sum(s.kernel_ms for s in st)), flush=True)
+        hb.close()
     run("stochastic prism 4M", scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8), scenes.render(7, 2048, 1024, el=0, visible=2), n=4_000_000)
