@@ -49,6 +49,27 @@ def cpu_baseline(rays_per_wl_hint, budget_s=12.0):
             "sample": "configs[1] shape, 9 wavelengths x %d rays (%.1f s of CPU work), OpenMP over rays" % (per_wl, dt)}
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per trace-kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_bench_pmc_{fetch,write}_size.txt; counters are collected in their own runs, never inside the timed one).
+    FETCH_SIZE / WRITE_SIZE are in KB; this kernel's traffic is scattered atomics, for which the guide calls the counters
+    uncalibrated — reported as measured, uncorrected."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = 0.0
+    for name, key in (("r01_bench_pmc_fetch_size.txt", "FETCH_SIZE"), ("r01_bench_pmc_write_size.txt", "WRITE_SIZE")):
+        path = os.path.join(here, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        val = None
+        for line in open(path):
+            if "halo_trace_kernel" in line and key in line:
+                val = float(line.split(key)[1].split()[0])
+        if val is None:
+            return None
+        tot += val * 1024.0
+    return tot
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,11 +166,12 @@ def main():
                        "sharding": "root-ray index ranges, 1 RCCL reduce of %d floats per step" % (rd.width * rd.height * 3 + 4),
                        "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
+                         "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)",
                          "kernel": "halo_trace_kernel<0,false,true>", "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "kernel_rays_per_s": (rays_per_rank / max(kernel_ms * 1e-3, 1e-12)),
-                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is ALU/latency/atomic-bound, not HBM-bound (DESIGN.md §4)"},
+                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is VALU-issue-bound, not HBM-bound: SQ_ACTIVE_INST_VALU x4 / SQ_BUSY_CYCLES = 0.987 of VALU issue slots busy, 3321 VALU instructions per wave-ray (profiles/r01_bench_pmc_{cycles,insts}.txt, DESIGN.md §4)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n)

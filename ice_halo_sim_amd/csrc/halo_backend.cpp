@@ -20,8 +20,7 @@
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
 hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz, int blocks,
-                       hipStream_t stream);
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t s_log2, uint32_t copies, float cx, float cy, float cz, hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
@@ -68,7 +67,7 @@ struct HaloBackend {
   int aggregate = 1;
   int mono_enabled = 1;
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
-  uint32_t mono_mask = 0;      // slots per copy - 1 (power of two >= W*H)
+  uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
   int blocks_per_cu = 8;
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
@@ -385,13 +384,13 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->mono_session = b->mono_enabled && wl->illuminant < 0;
   if (b->mono_session) {
     const size_t npix = static_cast<size_t>(render->width) * render->height;
-    size_t slots = 1;
-    while (slots < npix) slots <<= 1;
-    const size_t need = slots * static_cast<size_t>(b->mono_copies);
-    if (b->mono.cap < need || b->mono_mask != slots - 1) {
+    uint32_t s_log2 = 6;  // at least one fold tile of columns
+    while ((static_cast<size_t>(kMonoRows) << s_log2) < npix) s_log2++;
+    const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * static_cast<size_t>(b->mono_copies);
+    if (b->mono.cap < need || b->mono_s_log2 != s_log2) {
       HIPCHK(b, b->mono.reserve(need));
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
-      b->mono_mask = static_cast<uint32_t>(slots - 1);
+      b->mono_s_log2 = s_log2;
     }
     b->mono_cmf[0] = pool[0].cmf_x;
     b->mono_cmf[1] = pool[0].cmf_y;
@@ -408,7 +407,7 @@ static int fold_if_dirty(HaloBackend* b) {
   if (!b->mono_dirty) return HALO_OK;
   HIPCHK(b, hipSetDevice(b->device));
   const uint32_t npix = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
-  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_mask, static_cast<uint32_t>(b->mono_copies), b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->cu_count * 4, b->stream);
+  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_s_log2, static_cast<uint32_t>(b->mono_copies), b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->stream);
   if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   b->mono_dirty = false;
   return HALO_OK;
@@ -557,7 +556,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.counters = b->counters.ptr;
     P.xyz = b->acc;
     P.mono = b->mono.ptr;
-    P.mono_mask = b->mono_mask;
+    P.mono_s_log2 = b->mono_s_log2;
     P.mono_copy_mask = static_cast<uint32_t>(b->mono_copies - 1);
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;

@@ -143,8 +143,8 @@ struct DispatchParams {
   // --- outputs -------------------------------------------------------------------------------
   float* xyz;                  // W*H*3 image
   float* mono;                 // scalar plane(s) for discrete-wavelength sessions, folded into xyz at EndSession:
-                               // mono_copy_mask+1 copies of (mono_mask+1) floats, pixel p at slot (p*kMonoMul)&mono_mask
-  uint32_t mono_mask;
+                               // mono_copy_mask+1 copies of kMonoRows << mono_s_log2 floats, pixel p at MonoSlot(p)
+  uint32_t mono_s_log2;
   uint32_t mono_copy_mask;
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)
@@ -154,9 +154,23 @@ struct DispatchParams {
   const FilterDev* filter;     // nullptr = pass-all
 };
 
-// odd multiplier of the pixel→slot bijection on 2^k slots: neighbouring pixels of a bright feature land on different
-// cache lines, so no line of the plane is hotter than its hottest single pixel
-constexpr uint32_t kMonoMul = 0x9E3779B1u;
+// Pixel → slot map of the mono plane.  The plane is kMonoRows rows of S = 2^s_log2 slots; pixel p sits in row p % kMonoRows
+// at column hash(p / kMonoRows).  Horizontal neighbours are a whole row (>= 8 KB) apart and vertical neighbours are
+// spread by the multiplicative hash, so the pixels of a bright feature never share a cache line and no line of the
+// plane is hotter than its hottest single pixel (same-line atomics serialise at ~12 ns each).  Keeping p % kMonoRows as the
+// row makes the fold a tiled transpose: coalesced on the plane side (consecutive columns) and on the image side
+// (consecutive rows = consecutive pixels).
+constexpr uint32_t kMonoRows = 1024u;
+constexpr uint32_t kMonoMul = 0x9E3779B1u;      // odd: a bijection on any 2^k columns
+constexpr uint32_t kMonoMulInv = 0x0E8B2F51u;   // kMonoMul * kMonoMulInv == 1 (mod 2^32)
+static_assert(static_cast<uint32_t>(kMonoMul * kMonoMulInv) == 1u, "column hash must be invertible");
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t MonoSlot(uint32_t pix, uint32_t s_log2) {
+  const uint32_t col = ((pix / kMonoRows) * kMonoMul) & ((1u << s_log2) - 1u);
+  return ((pix % kMonoRows) << s_log2) + col;
+}
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };
 enum { kSumLanded = 0, kSumExitW = 1, kSumExitN = 2, kSumPixN = 3, kSumNum = 4 };

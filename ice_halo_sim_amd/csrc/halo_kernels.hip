@@ -401,7 +401,7 @@ struct PixCache {
 
 HD float* mono_slot(const DispatchParams& P, uint32_t pix) {
   const uint32_t copy = blockIdx.x & P.mono_copy_mask;
-  return P.mono + static_cast<size_t>(copy) * (static_cast<size_t>(P.mono_mask) + 1u) + ((pix * kMonoMul) & P.mono_mask);
+  return P.mono + (static_cast<size_t>(copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
 }
 
 template <bool MONO>
@@ -561,7 +561,6 @@ template <bool MONO>
 struct LdsTables {
   float lut[3 * kLutNodes];
   WlEntryDev wl[HALO_WL_POOL_MAX];
-  ShapeDev shape;
   PixCache<MONO> cache;
   uint32_t seg[kContShards + 4];
 };
@@ -572,6 +571,15 @@ struct FilterSlot {
 };
 template <>
 struct FilterSlot<false> {
+  uint32_t unused;
+};
+
+template <bool ON, int N = kBlock / 32>
+struct PoolSlots {
+  ShapeDev s[N];
+};
+template <int N>
+struct PoolSlots<false, N> {
   uint32_t unused;
 };
 
@@ -844,6 +852,8 @@ template <int MODE, bool POOL, bool MONO>
 __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
+  __shared__ __attribute__((aligned(16))) PoolSlots<POOL> s_pool;       // stochastic: one shape per half-wave
+  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, 1> s_shape;  // deterministic: the dispatch's one shape
   const FilterDev* filter = nullptr;
   if (MODE != kModePlain && P.filter != nullptr) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.filter);
@@ -866,24 +876,57 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   }
   if (P.source == kSrcTransit)
     for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
-  if (!POOL) {
+  if constexpr (!POOL) {
     const float4* src = reinterpret_cast<const float4*>(P.shapes);
-    float4* dst = reinterpret_cast<float4*>(&T.shape);
+    float4* dst = reinterpret_cast<float4*>(&s_shape.s[0]);
     for (uint32_t i = threadIdx.x; i < sizeof(ShapeDev) / 16u; i += kBlock) dst[i] = src[i];
   }
   __syncthreads();
 
   RaySums sums = {0.0f, 0.0f, 0u, 0u};
   const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t tid = blockIdx.x * kBlock + threadIdx.x; tid < P.n_rays; tid += stride) {
-    if (POOL) {
-      // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275);
-      // a half-wave reads the same rows → broadcast loads served by L1/L2
-      const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-      trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
-    } else {
-      const ShapeDev* sh = &T.shape;  // LDS: ds_read_b128 broadcasts
-      trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
+  bool staged = false;
+  if constexpr (POOL) {
+   if ((P.geom_clock & 31u) == 0u) {
+    staged = true;
+    // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275).  With the
+    // clock a multiple of 32 every half-wave traces ONE shape per pass: its 32 lanes copy the rows that shape uses
+    // (header, face_cnt plane rows, tri_cnt fan rows — 1.3 KB for a prism) from the pool into the half-wave's LDS slot
+    // with coalesced 16-byte loads, and the interaction loop then reads them as LDS broadcasts exactly like the
+    // deterministic path.  LDS operations of one wave retire in order, so no barrier is needed around the copy.
+    ShapeDev* slot = &s_pool.s[threadIdx.x >> 5];
+    const uint32_t l32 = threadIdx.x & 31u;
+    for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
+      const uint32_t tid = base + threadIdx.x;
+      const uint32_t first = base + (threadIdx.x & ~31u);
+      if (first < P.n_rays) {
+        const ShapeDev* g = P.shapes + first / P.geom_clock;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* s4 = reinterpret_cast<float4*>(slot);
+        const uint32_t fc = static_cast<uint32_t>(g->face_cnt), tc = static_cast<uint32_t>(g->tri_cnt);
+        constexpr uint32_t kTriV = offsetof(ShapeDev, tri_v) / 16u, kTriNa = offsetof(ShapeDev, tri_na) / 16u;
+        constexpr uint32_t kTail = offsetof(ShapeDev, tri_face) / 16u, kEnd = sizeof(ShapeDev) / 16u;
+        for (uint32_t i = l32; i < 1u + fc; i += 32u) s4[i] = g4[i];
+        for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) s4[kTriV + i] = g4[kTriV + i];
+        for (uint32_t i = l32; i < tc; i += 32u) s4[kTriNa + i] = g4[kTriNa + i];
+        for (uint32_t i = kTail + l32; i < kEnd; i += 32u) s4[i] = g4[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, filter, static_cast<const ShapeDev*>(slot), tid, sums);
+      __builtin_amdgcn_wave_barrier();
+    }
+   }
+  }
+  if (!staged) {
+    for (uint32_t tid = blockIdx.x * kBlock + threadIdx.x; tid < P.n_rays; tid += stride) {
+      if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
+        const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
+        trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
+      } else {
+        const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
+        trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
+      }
     }
   }
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
@@ -917,27 +960,40 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   }
 }
 
-// xyz[pix] += cmf * sum over copies of mono[slot(pix)]; the slots are zeroed — closes a discrete-wavelength session
-// (see MONO above).
+// xyz[pix] += cmf * sum over copies of mono[MonoSlot(pix)]; the slots are zeroed — closes a discrete-wavelength session
+// (see MONO above).  Tiled transpose through LDS: a block reads a 64-row x 64-column tile of every copy along the columns
+// (coalesced), then walks it along the rows, where consecutive rows are consecutive pixels (coalesced xyz RMW).
+constexpr uint32_t kFoldTile = 64u;
 __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ mono, uint32_t n_pix,
-                                                            uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz) {
-  const uint32_t stride = gridDim.x * kBlock;
-  const size_t plane = static_cast<size_t>(mono_mask) + 1u;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pix; i += stride) {
-    const uint32_t slot = (i * kMonoMul) & mono_mask;
+                                                            uint32_t s_log2, uint32_t copies, float cx, float cy, float cz) {
+  __shared__ float tile[kFoldTile][kFoldTile + 1];
+  const uint32_t tiles_c = (1u << s_log2) / kFoldTile;  // columns per row / tile width (s_log2 >= 6)
+  const uint32_t row0 = (blockIdx.x / tiles_c) * kFoldTile, col0 = (blockIdx.x % tiles_c) * kFoldTile;
+  const size_t plane = static_cast<size_t>(kMonoRows) << s_log2;
+  const uint32_t lo = threadIdx.x & (kFoldTile - 1u), hi = threadIdx.x / kFoldTile;  // hi in [0, 4)
+  for (uint32_t r = hi; r < kFoldTile; r += kBlock / kFoldTile) {
+    float* q = mono + (static_cast<size_t>(row0 + r) << s_log2) + col0 + lo;
     float v = 0.0f;
     for (uint32_t c = 0; c < copies; ++c) {
-      float* q = mono + c * plane + slot;
-      const float x = *q;
+      const float x = q[c * plane];
       if (x != 0.0f) {
-        *q = 0.0f;
+        q[c * plane] = 0.0f;
         v += x;
       }
     }
-    if (v != 0.0f) {
-      xyz[3u * i + 0u] += cx * v;
-      xyz[3u * i + 1u] += cy * v;
-      xyz[3u * i + 2u] += cz * v;
+    tile[r][lo] = v;
+  }
+  __syncthreads();
+  const uint32_t s_mask = (1u << s_log2) - 1u;
+  for (uint32_t c = hi; c < kFoldTile; c += kBlock / kFoldTile) {
+    const float v = tile[lo][c];
+    if (v == 0.0f) continue;
+    const uint32_t a = ((col0 + c) * kMonoMulInv) & s_mask;   // column hash inverted
+    const uint32_t pix = a * kMonoRows + row0 + lo;
+    if (pix < n_pix) {
+      xyz[3u * pix + 0u] += cx * v;
+      xyz[3u * pix + 1u] += cy * v;
+      xyz[3u * pix + 2u] += cz * v;
     }
   }
 }
@@ -1042,9 +1098,9 @@ hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rg
   return hipGetLastError();
 }
 
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t mono_mask, uint32_t copies, float cx, float cy, float cz, int blocks,
-                       hipStream_t stream) {
-  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, mono_mask, copies, cx, cy, cz);
+hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t s_log2, uint32_t copies, float cx, float cy, float cz, hipStream_t stream) {
+  const uint32_t blocks = (kMonoRows / kFoldTile) * ((1u << s_log2) / kFoldTile);
+  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, s_log2, copies, cx, cy, cz);
   return hipGetLastError();
 }
 

@@ -40,6 +40,15 @@ if "copies" in which:
         run("  512x256 mono_copies=%d" % c, sc, scenes.config2_render(512, 256), mono_copies=c)
     run("config2 mono_copies=8, plain atomics", sc, rd, mono_copies=8, aggregate=0)
     run("config2 mono_copies=32, plain atomics", sc, rd, mono_copies=32, aggregate=0)
+if "hits" in which:
+    for mh in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12):
+        sc_h = scenes.config2_scene()
+        sc_h.max_hits = mh
+        run("config2 max_hits=%d" % mh, sc_h, rd)
+    for mh in (1, 4, 7):
+        sc_h = scenes.config2_scene()
+        sc_h.max_hits = mh
+        run("config2 max_hits=%d no-accum" % mh, sc_h, rd, aggregate=2)
 if "ms" in which:
     run("config3 multi-scatter 10M", scenes.config3_scene(), rd)
 if "stoch" in which:
