@@ -20,7 +20,8 @@
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
 hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t s_log2, uint32_t copies, float cx, float cy, float cz, hipStream_t stream);
+hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
+                       hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
@@ -66,6 +67,7 @@ struct HaloBackend {
   uint64_t chunk = 1ull << 26;
   int aggregate = 1;
   int mono_enabled = 1;
+  int lambda_planes = -1;      // illuminant sessions: -1 auto (by batch size), 0 never, 1 always one plane per pool entry
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
   int blocks_per_cu = 8;
@@ -91,10 +93,12 @@ struct HaloBackend {
   int acc_w = 0, acc_h = 0;
   std::vector<HaloFilter> filters;  // table referenced by HaloEntry::filter_id
   DevBuf<FilterDev> filter_dev;
-  DevBuf<float> mono;          // W*H scalar plane for discrete-wavelength sessions
-  bool mono_session = false;
+  DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
+  bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
+  bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
   bool mono_dirty = false;
-  float mono_cmf[3] = {0, 0, 0};
+  uint32_t plane_cnt = 1, plane_copies = 8;
+  std::vector<std::array<float, 3>> plane_coef;  // fold coefficients of the pending planes
   // consumer (RenderConsumer state, server/render.hpp): Neumaier running image + total landed intensity
   DevBuf<float> cons_sum, cons_comp, cons_xyz_out;
   DevBuf<uint8_t> cons_rgb;
@@ -295,6 +299,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "async") b->async = v ? 1 : 0;
+  else if (k == "lambda_planes") b->lambda_planes = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "mono_copies") {
     if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
@@ -351,7 +356,7 @@ int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) 
 
 static int fold_if_dirty(HaloBackend* b);
 
-int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t) {
+int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t ray_num) {
   if (!b || !scene || !render || !wl) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "BeginSession inside a session");
   if (scene->layer_count < 1 || scene->layer_count > HALO_MAX_LAYERS) return fail(b, HALO_FATAL, "layer_count out of range");
@@ -380,21 +385,31 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->wl_pool_size = static_cast<uint32_t>(pool.size());
   if (pool.empty() || pool.size() > HALO_WL_POOL_MAX) return fail(b, HALO_FATAL, "wavelength pool size out of range");
   b->wl_pool_host = pool;  // travels to the device inside each dispatch slot
-  // discrete wavelength → one-channel accumulation, CMF applied once at EndSession
-  b->mono_session = b->mono_enabled && wl->illuminant < 0;
-  if (b->mono_session) {
-    const size_t npix = static_cast<size_t>(render->width) * render->height;
+  // Accumulation planes of this session (kernels never touch the XYZ image; halo_fold_kernel closes the session):
+  //  * discrete wavelength: ONE scalar plane, coefficient = CMF(lambda)            (1 atomic per hit)
+  //  * illuminant, batch >= 8 Mi rays: one scalar plane per pool entry, coefficient = its CMF (1 atomic per hit, fold reads M planes)
+  //  * illuminant, small batch or "mono" = 0: X, Y, Z planes, unit coefficients        (3 atomics per hit, cheap fold)
+  const size_t npix = static_cast<size_t>(render->width) * render->height;
+  if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
+  const bool discrete = wl->illuminant < 0;
+  b->mono_by_wl = b->mono_enabled && !discrete && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
+  b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
+  b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
+  b->plane_copies = b->mono_by_wl ? 1u : static_cast<uint32_t>(b->mono_copies);  // hits already spread over the pool's planes
+  b->plane_coef.clear();
+  for (uint32_t m = 0; m < b->plane_cnt; m++) {
+    if (b->mono_session) b->plane_coef.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
+    else b->plane_coef.push_back({m == 0 ? 1.0f : 0.0f, m == 1 ? 1.0f : 0.0f, m == 2 ? 1.0f : 0.0f});
+  }
+  {
     uint32_t s_log2 = 6;  // at least one fold tile of columns
     while ((static_cast<size_t>(kMonoRows) << s_log2) < npix) s_log2++;
-    const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * static_cast<size_t>(b->mono_copies);
-    if (b->mono.cap < need || b->mono_s_log2 != s_log2) {
+    const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
+    if (b->mono.cap < need) {
       HIPCHK(b, b->mono.reserve(need));
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
-      b->mono_s_log2 = s_log2;
     }
-    b->mono_cmf[0] = pool[0].cmf_x;
-    b->mono_cmf[1] = pool[0].cmf_y;
-    b->mono_cmf[2] = pool[0].cmf_z;
+    b->mono_s_log2 = s_log2;  // planes are all-zero between sessions, so the layout may change freely
   }
   b->in_session = true;
   b->layer_idx = 0;
@@ -407,8 +422,15 @@ static int fold_if_dirty(HaloBackend* b) {
   if (!b->mono_dirty) return HALO_OK;
   HIPCHK(b, hipSetDevice(b->device));
   const uint32_t npix = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
-  hipError_t e = launch_fold(b->acc, b->mono.ptr, npix, b->mono_s_log2, static_cast<uint32_t>(b->mono_copies), b->mono_cmf[0], b->mono_cmf[1], b->mono_cmf[2], b->stream);
-  if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
+  const size_t plane = (static_cast<size_t>(kMonoRows) << b->mono_s_log2) * b->plane_copies;
+  for (uint32_t first = 0; first < b->plane_cnt; first += kFoldGroup) {
+    const uint32_t n = std::min<uint32_t>(kFoldGroup, b->plane_cnt - first);
+    FoldCoef coef{};
+    for (uint32_t m = 0; m < n; m++)
+      for (int a = 0; a < 3; a++) coef.c[m][a] = b->plane_coef[first + m][static_cast<size_t>(a)];
+    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, b->stream);
+    if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
+  }
   b->mono_dirty = false;
   return HALO_OK;
 }
@@ -554,10 +576,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.cont_in_region = b->cont_region[out_slot ^ 1];
     P.cont_cnt = b->cont_cnt.ptr;
     P.counters = b->counters.ptr;
-    P.xyz = b->acc;
     P.mono = b->mono.ptr;
     P.mono_s_log2 = b->mono_s_log2;
-    P.mono_copy_mask = static_cast<uint32_t>(b->mono_copies - 1);
+    P.mono_copy_mask = b->plane_copies - 1u;
+    P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
@@ -636,7 +658,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const int blocks = blocks_of(m);
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
-      b->mono_dirty = b->mono_dirty || b->mono_session;
+      b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));
       HIPCHK(b, hipMemcpyAsync(b->ring_result + 4 * k, ds->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));

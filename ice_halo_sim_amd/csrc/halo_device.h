@@ -141,11 +141,11 @@ struct DispatchParams {
   const float* host_w;
   const uint32_t* host_tf;
   // --- outputs -------------------------------------------------------------------------------
-  float* xyz;                  // W*H*3 image
   float* mono;                 // scalar plane(s) for discrete-wavelength sessions, folded into xyz at EndSession:
                                // mono_copy_mask+1 copies of kMonoRows << mono_s_log2 floats, pixel p at MonoSlot(p)
   uint32_t mono_s_log2;
   uint32_t mono_copy_mask;
+  uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)
   HaloExitRecord* exits;
@@ -161,6 +161,10 @@ struct DispatchParams {
 // row makes the fold a tiled transpose: coalesced on the plane side (consecutive columns) and on the image side
 // (consecutive rows = consecutive pixels).
 constexpr uint32_t kMonoRows = 1024u;
+constexpr uint32_t kFoldGroup = 64u;            // planes folded per halo_fold_kernel launch (coefficients ride in the kernel argument)
+struct FoldCoef {
+  float c[kFoldGroup][3];
+};
 constexpr uint32_t kMonoMul = 0x9E3779B1u;      // odd: a bijection on any 2^k columns
 constexpr uint32_t kMonoMulInv = 0x0E8B2F51u;   // kMonoMul * kMonoMulInv == 1 (mod 2^32)
 static_assert(static_cast<uint32_t>(kMonoMul * kMonoMulInv) == 1u, "column hash must be invertible");

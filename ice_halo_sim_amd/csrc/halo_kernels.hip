@@ -395,21 +395,25 @@ constexpr int kCacheN = 1 << kCacheLog2;
 
 template <bool MONO>
 struct PixCache {
-  uint32_t tag[kCacheN];                 // pixel + 1, 0 = free
+  uint32_t tag[kCacheN];                 // ((plane << 23) | pixel) + 1, 0 = free
   float val[kCacheN * (MONO ? 1 : 3)];
 };
 
-HD float* mono_slot(const DispatchParams& P, uint32_t pix) {
+// Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
+HD float* mono_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) {
   const uint32_t copy = blockIdx.x & P.mono_copy_mask;
-  return P.mono + (static_cast<size_t>(copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
+  return P.mono + (static_cast<size_t>(pl * (P.mono_copy_mask + 1u) + copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
 }
 
+// MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
+// pool entry); the CMF is applied by halo_fold_kernel.  !MONO: X, Y, Z into planes 0..2.
 template <bool MONO>
-HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, float w, float cx, float cy, float cz) {
+HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
   if (P.aggregate == 2u) return;  // diagnostic: trace + project only
+  const uint32_t pl = (MONO && P.mono_by_wl) ? wl_idx : 0u;
   if (P.aggregate == 1u || P.aggregate == 3u) {
-    const uint32_t slot = (pix * 2654435761u) >> (32 - kCacheLog2);
-    const uint32_t key = pix + 1u;
+    const uint32_t key = ((pl << 23) | pix) + 1u;
+    const uint32_t slot = (key * 2654435761u) >> (32 - kCacheLog2);
     const uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
     if (old == 0u || old == key) {
       if (MONO) {
@@ -424,12 +428,11 @@ HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, flo
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
-    atomic_add_f32(mono_slot(P, pix), w);
+    atomic_add_f32(mono_slot(P, pl, pix), w);
   } else {
-    float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
-    atomic_add_f32(dst + 0, cx * w);
-    atomic_add_f32(dst + 1, cy * w);
-    atomic_add_f32(dst + 2, cz * w);
+    atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
+    atomic_add_f32(mono_slot(P, 1u, pix), cy * w);
+    atomic_add_f32(mono_slot(P, 2u, pix), cz * w);
   }
 }
 
@@ -625,14 +628,14 @@ HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, const FilterDe
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
-    accumulate<MONO>(P, cache, pix, w, cmf_x, cmf_y, cmf_z);
+    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
     primary = static_cast<int>(pix);
   }
   if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
-    accumulate<MONO>(P, cache, pix, w, cmf_x, cmf_y, cmf_z);
+    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     sums.pix_n++;
   }
   sums.exit_w += w;
@@ -935,15 +938,14 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     for (int i = threadIdx.x; i < kCacheN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];
       if (key == 0u) continue;
-      const uint32_t pix = key - 1u;
+      const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;
       if (MONO) {
         const float v = T.cache.val[i];
-        if (v != 0.0f) atomic_add_f32(mono_slot(P, pix), v);
+        if (v != 0.0f) atomic_add_f32(mono_slot(P, pl, pix), v);
       } else {
-        float* dst = P.xyz + static_cast<size_t>(pix) * 3u;
-        atomic_add_f32(dst + 0, T.cache.val[i * 3 + 0]);
-        atomic_add_f32(dst + 1, T.cache.val[i * 3 + 1]);
-        atomic_add_f32(dst + 2, T.cache.val[i * 3 + 2]);
+        atomic_add_f32(mono_slot(P, 0u, pix), T.cache.val[i * 3 + 0]);
+        atomic_add_f32(mono_slot(P, 1u, pix), T.cache.val[i * 3 + 1]);
+        atomic_add_f32(mono_slot(P, 2u, pix), T.cache.val[i * 3 + 2]);
       }
     }
   }
@@ -960,40 +962,51 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   }
 }
 
-// xyz[pix] += cmf * sum over copies of mono[MonoSlot(pix)]; the slots are zeroed — closes a discrete-wavelength session
-// (see MONO above).  Tiled transpose through LDS: a block reads a 64-row x 64-column tile of every copy along the columns
-// (coalesced), then walks it along the rows, where consecutive rows are consecutive pixels (coalesced xyz RMW).
+// xyz[pix] += sum over planes of coef[plane] * (sum over copies of plane[MonoSlot(pix)]); the slots are zeroed — closes a
+// session.  Planes: 1 (discrete wavelength, coef = CMF), 3 (X, Y, Z; unit coefs) or one per wavelength-pool entry
+// (coef = that entry's CMF), at most kFoldGroup per launch.  Tiled transpose through LDS: a block reads a 64-row x
+// 64-column tile of every plane copy along the columns (coalesced), then walks it along the rows, where consecutive
+// rows are consecutive pixels (coalesced xyz RMW).
 constexpr uint32_t kFoldTile = 64u;
-__global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ mono, uint32_t n_pix,
-                                                            uint32_t s_log2, uint32_t copies, float cx, float cy, float cz) {
-  __shared__ float tile[kFoldTile][kFoldTile + 1];
+__global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ planes, uint32_t n_pix,
+                                                            uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef coef) {
+  __shared__ float tile[3][kFoldTile][kFoldTile + 1];
   const uint32_t tiles_c = (1u << s_log2) / kFoldTile;  // columns per row / tile width (s_log2 >= 6)
   const uint32_t row0 = (blockIdx.x / tiles_c) * kFoldTile, col0 = (blockIdx.x % tiles_c) * kFoldTile;
   const size_t plane = static_cast<size_t>(kMonoRows) << s_log2;
   const uint32_t lo = threadIdx.x & (kFoldTile - 1u), hi = threadIdx.x / kFoldTile;  // hi in [0, 4)
   for (uint32_t r = hi; r < kFoldTile; r += kBlock / kFoldTile) {
-    float* q = mono + (static_cast<size_t>(row0 + r) << s_log2) + col0 + lo;
-    float v = 0.0f;
-    for (uint32_t c = 0; c < copies; ++c) {
-      const float x = q[c * plane];
-      if (x != 0.0f) {
-        q[c * plane] = 0.0f;
-        v += x;
+    float* q = planes + (static_cast<size_t>(row0 + r) << s_log2) + col0 + lo;
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    for (uint32_t pl = 0; pl < n_planes; ++pl) {
+      float v = 0.0f;
+      for (uint32_t c = 0; c < copies; ++c) {
+        float* a = q + (static_cast<size_t>(pl) * copies + c) * plane;
+        const float t = *a;
+        if (t != 0.0f) {
+          *a = 0.0f;
+          v += t;
+        }
       }
+      x += coef.c[pl][0] * v;
+      y += coef.c[pl][1] * v;
+      z += coef.c[pl][2] * v;
     }
-    tile[r][lo] = v;
+    tile[0][r][lo] = x;
+    tile[1][r][lo] = y;
+    tile[2][r][lo] = z;
   }
   __syncthreads();
   const uint32_t s_mask = (1u << s_log2) - 1u;
   for (uint32_t c = hi; c < kFoldTile; c += kBlock / kFoldTile) {
-    const float v = tile[lo][c];
-    if (v == 0.0f) continue;
+    const float x = tile[0][lo][c], y = tile[1][lo][c], z = tile[2][lo][c];
+    if (x == 0.0f && y == 0.0f && z == 0.0f) continue;
     const uint32_t a = ((col0 + c) * kMonoMulInv) & s_mask;   // column hash inverted
     const uint32_t pix = a * kMonoRows + row0 + lo;
     if (pix < n_pix) {
-      xyz[3u * pix + 0u] += cx * v;
-      xyz[3u * pix + 1u] += cy * v;
-      xyz[3u * pix + 2u] += cz * v;
+      xyz[3u * pix + 0u] += x;
+      xyz[3u * pix + 1u] += y;
+      xyz[3u * pix + 2u] += z;
     }
   }
 }
@@ -1098,9 +1111,11 @@ hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rg
   return hipGetLastError();
 }
 
-hipError_t launch_fold(float* xyz, float* mono, uint32_t n_pix, uint32_t s_log2, uint32_t copies, float cx, float cy, float cz, hipStream_t stream) {
+// `planes` points at the first plane of this group; coef holds n_planes (<= kFoldGroup) coefficient triples
+hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
+                       hipStream_t stream) {
   const uint32_t blocks = (kMonoRows / kFoldTile) * ((1u << s_log2) / kFoldTile);
-  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, mono, n_pix, s_log2, copies, cx, cy, cz);
+  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
   return hipGetLastError();
 }
 

@@ -207,6 +207,20 @@ def test_stochastic_geometry_and_wl_pool_parity():
     assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
 
 
+@pytest.mark.parametrize("planes", [0, 1])
+def test_illuminant_session_plane_modes(planes):
+    """Illuminant (wavelength-pool) sessions accumulate either X/Y/Z planes (3 atomics per hit) or one scalar plane per pool
+    entry with the CMF applied by the fold (1 atomic per hit; auto-selected for >= 8 Mi-ray batches).  Both must equal the
+    oracle's per-exit cmf(lambda)*w accumulation, on a column scene with a hot sun disc and arcs."""
+    sc = scenes.config2_scene()
+    rd = scenes.config2_render(960, 540)
+    r = run_both(sc, rd, scenes.wl_illuminant("D65", 48), 150_000, seed=9, capture=False, lambda_planes=planes)
+    assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
+    assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
+    for ch in range(3):   # colour balance: per-channel energy, not only the luminance-dominated norm
+        assert r["ih"][..., ch].sum() == pytest.approx(r["io"][..., ch].sum(), rel=2e-4)
+
+
 def test_pyramid_crystal_parity():
     """examples/config_example.json crystal id 5 (pyramid, upper Miller (2,0,3)) + a stochastic pyramid entry."""
     p5 = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3)), scenes.axis(zenith=0), 1.0, 5)

@@ -40,6 +40,22 @@ if "copies" in which:
         run("  512x256 mono_copies=%d" % c, sc, scenes.config2_render(512, 256), mono_copies=c)
     run("config2 mono_copies=8, plain atomics", sc, rd, mono_copies=8, aggregate=0)
     run("config2 mono_copies=32, plain atomics", sc, rd, mono_copies=32, aggregate=0)
+if "illum" in which:
+    wl_d65 = scenes.wl_illuminant("D65", 64)
+    def run_wl(label, n, **opts):
+        hb = HipTraceBackend(device=0, seed=42, **opts)
+        best = 1e9
+        for r in range(3):
+            import time
+            hb.sync(); t0 = time.perf_counter()
+            st = run_session(hb, sc, rd, wl_d65, n)
+            hb.sync(); best = min(best, (time.perf_counter() - t0) * 1e3)
+        print("%-46s wall %8.3f ms  kernel %8.3f ms  %8.1f M rays/s (wall)" % (label, best, sum(s.kernel_ms for s in st), n / best / 1e3), flush=True)
+        hb.close()
+    for n in (1_000_000, 10_000_000, 50_000_000):
+        run_wl("D65 n=%dM xyz planes" % (n // 1_000_000), n, lambda_planes=0)
+        run_wl("D65 n=%dM lambda planes" % (n // 1_000_000), n, lambda_planes=1)
+    run_wl("D65 n=10M mono=0 copies=1", 10_000_000, lambda_planes=0, mono_copies=1)
 if "hits" in which:
     for mh in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12):
         sc_h = scenes.config2_scene()
