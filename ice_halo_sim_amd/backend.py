@@ -204,9 +204,9 @@ class HipTraceBackend:
         k = min(n.value, int(max_records))
         return np.frombuffer(buf, dtype=EXIT_DTYPE, count=k).copy()
 
-    def ReadbackXyzAccum(self):
+    def ReadbackXyzAccum(self, width=None, height=None):
         """Returns (xyz[H,W,3] float32, landed_weight float64) and zeroes the device accumulator."""
-        w, h = self._render.width, self._render.height
+        w, h = (width or self._render.width), (height or self._render.height)
         img = np.empty((h, w, 3), np.float32)
         landed = C.c_double()
         self._check(self._L.halo_readback_xyz64(self._h, img.ctypes.data_as(C.POINTER(C.c_float)), w, h, C.byref(landed)))

@@ -471,3 +471,108 @@ def test_stochastic_trace_device_pool_equals_host_pool():
     frac, pix, path = match_exits(res[0][1], res[1][1])
     assert frac == 1.0 and pix == 1.0 and path == 1.0
     assert res[0][2] == pytest.approx(res[1][2], rel=1e-6)
+
+
+# --- edge cases: empty / ragged / limits / error behaviour (reference: test_simulator.cpp PartitionCrystalRayNum zero and
+# ragged cases, e2e configs crystal_sample_count_zero_proportion.json, cpu_trace_backend error paths) ------------------
+def test_edge_empty_and_ragged_batches():
+    sc = scenes.config2_scene()
+    rd = scenes.config2_render(320, 180)
+    hb = hip_backend(seed=11)
+    ob = OracleBackend(seed=11, threads=4)
+    for n in (0, 1, 63, 64, 65, 255, 257, 1000):           # empty, single ray, around wave and workgroup boundaries
+        sh = run_session(hb, sc, rd, scenes.wl_discrete(550.0), n)
+        so = run_session(ob, sc, rd, scenes.wl_discrete(550.0), n)
+        assert sh[0].root_count == n == so[0].root_count
+        assert sh[0].exit_count == so[0].exit_count
+        assert sh[0].exit_w_sum == pytest.approx(so[0].exit_w_sum, rel=1e-5, abs=1e-9)
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    assert lh == pytest.approx(lo, rel=1e-5) and rel_l2(block_mean(ih, 4), block_mean(io, 4)) <= 2e-2
+    img, landed = hb.ReadbackXyzAccum()                    # readback zeroes: a second one is empty
+    assert landed == 0.0 and not img.any()
+    hb.close()
+    ob.close()
+
+
+def test_edge_zero_proportion_and_empty_crystal():
+    """A zero-proportion entry gets no rays; a crystal with h = 0 is empty (Crystal::CreatePrism returns no faces) and its rays
+    contribute nothing — neither exits nor energy — exactly as in the oracle."""
+    e_col = scenes.column_crystal_entry()
+    e_zero = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith=0), 0.0, 6)
+    e_empty = scenes.entry(scenes.prism_crystal(0.0), scenes.axis(zenith=0), 1.0, 7)
+    sc = scenes.scene([(0.0, [e_col, e_zero, e_empty])], max_hits=6)
+    r = run_both(sc, scenes.config2_render(320, 180), scenes.wl_discrete(550.0), 60_000, seed=13)
+    assert r["sh"][0].exit_count == r["so"][0].exit_count > 0
+    assert set(np.unique(r["eh"]["crystal_id"])) == {3} == set(np.unique(r["eo"]["crystal_id"]))   # only the column emits
+    frac, pix, path = match_exits(r["eh"], r["eo"])
+    assert frac >= 0.998 and pix >= 0.995
+    assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
+
+
+@pytest.mark.parametrize("max_hits", [1, 2, 16, 64])
+def test_edge_max_hits_limits(max_hits):
+    """max_hits = 1 (entry reflection only) up to HALO_MAX_HITS = 64; recorded paths saturate at HALO_PATH_CAP = 16 face
+    numbers while path_len keeps counting (ExitFaceSeq semantics)."""
+    sc = scenes.scene([(0.0, [scenes.column_crystal_entry()])], max_hits=max_hits)
+    r = run_both(sc, scenes.config2_render(320, 180), scenes.wl_discrete(550.0), 20_000 if max_hits < 64 else 4_000, seed=17)
+    assert r["sh"][0].exit_count == pytest.approx(r["so"][0].exit_count, rel=2e-3)
+    frac, pix, path = match_exits(r["eh"], r["eo"])
+    assert frac >= 0.995 and path >= 0.999
+    if max_hits == 1:
+        assert (r["eh"]["seq"] == 0).all() and (r["eh"]["path_len"] == 1).all()      # only the external reflection leaves
+    assert int(r["eh"]["seq"].max()) <= 2 * max_hits - 1
+    # energy: what has not left after max_hits interactions is dropped; exits never exceed the injected weight
+    assert r["sh"][0].exit_w_sum <= r["sh"][0].root_count * (1 + 1e-5)
+
+
+def test_edge_layer_and_entry_limits_and_errors():
+    from ice_halo_sim_amd.backend import BackendError
+    hb = hip_backend(seed=19)
+    rd = scenes.config2_render(160, 90)
+    wl = scenes.wl_discrete(550.0)
+    col = scenes.column_crystal_entry()
+    # HALO_MAX_LAYERS layers x HALO_MAX_ENTRIES entries is accepted
+    sc = scenes.scene([(0.3, [col] * abi.HALO_MAX_ENTRIES)] * (abi.HALO_MAX_LAYERS - 1) + [(0.0, [col] * abi.HALO_MAX_ENTRIES)], max_hits=3)
+    st = run_session(hb, sc, rd, wl, 5_000)
+    assert len(st) == abi.HALO_MAX_LAYERS and st[0].continuation_count > 0 and st[-1].continuation_count == 0
+    assert st[1].root_count == st[0].continuation_count
+    # out-of-range scenes are refused with a message, and the backend stays usable
+    bad = scenes.scene([(0.0, [col])], max_hits=3)
+    for field, value in (("max_hits", 0), ("max_hits", abi.HALO_MAX_HITS + 1), ("layer_count", 0), ("layer_count", abi.HALO_MAX_LAYERS + 1)):
+        s2 = type(bad).from_buffer_copy(bytes(bad))
+        setattr(s2, field, value)
+        with pytest.raises(BackendError):
+            hb.BeginSession(s2, rd, wl, 10)
+    with pytest.raises(BackendError):
+        hb.TraceLayer(10)                                   # outside a session
+    hb.BeginSession(bad, rd, wl, 10)
+    with pytest.raises(BackendError):
+        hb.BeginSession(bad, rd, wl, 10)                    # nested session
+    assert hb.TraceLayer(10).root_count == 10
+    assert hb.TraceLayer(7).root_count == 7                 # a session may trace several ragged batches of its layer
+    with pytest.raises(BackendError):
+        hb.Recombine(True) or hb.TraceLayer(0)              # ... but not a layer past the scene's last
+    hb.EndSession()
+    with pytest.raises(BackendError):
+        hb.ReadbackXyzAccum(width=161, height=90)           # size must match the session render
+    img, landed = hb.ReadbackXyzAccum()
+    assert landed > 0.0
+    e_f = type(col).from_buffer_copy(bytes(col))
+    e_f.filter_id = 3                                        # refers past the (empty) filter table
+    with pytest.raises(BackendError):
+        hb.BeginSession(scenes.scene([(0.0, [e_f])], max_hits=3), rd, wl, 10)
+    hb.close()
+
+
+def test_edge_wavelength_pool_limits():
+    """Pool of 1 entry (discrete) up to HALO_WL_POOL_MAX = 255 illuminant entries; every ray's entry index stays in range and
+    the image energy equals sum over entries of landed_m * ybar_m (checked through the oracle image)."""
+    sc = scenes.config2_scene()
+    rd = scenes.config2_render(320, 180)
+    for m in (1, 2, 255):
+        r = run_both(sc, rd, scenes.wl_illuminant("D65", m), 60_000, seed=23)
+        assert int(r["eh"]["wl_idx"].max()) <= m - 1 and int(r["eh"]["wl_idx"].min()) == 0
+        frac, pix, path = match_exits(r["eh"], r["eo"])
+        assert frac >= 0.998
+        assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 5e-3
