@@ -28,16 +28,24 @@ constexpr uint32_t kNonceShapeHost = 0x6A09E667u;
 // One crystal shape as the kernels read it.  Face rows are {nx, ny, nz, d}; triangle rows carry the fan
 // triangle (v0, v1, v2), its raw winding normal, area and compact face id (reference
 // Crystal::PopulateFromCfGeom crystal.cpp:304-347, detail::BuildEntrySubTris simulator.cpp:90-129).
+//
+// Slab table for the next-face search: a convex crystal's faces mostly come in opposite pairs (both basal faces, prism
+// sides i / i+3) whose normals are exact negatives, so one pair of dot products (n.d, n.p) serves both faces and only the
+// face on the side the ray travels towards can be ahead.  slab[k] = {nx, ny, nz, d_plus | d_minus, id_plus, id_minus, -}
+// (ids as int bits); faces without an exact opposite are listed in `single`.
+constexpr int kMaxSlabs = kMaxFaces / 2;
 struct ShapeDev {
   int32_t face_cnt;
   int32_t tri_cnt;
-  int32_t pad0, pad1;
+  int32_t slab_cnt, single_cnt;
   float face[kMaxFaces][4];
+  float slab[kMaxSlabs][8];
   float tri_v[kMaxTris][9];
   float tri_na[kMaxTris][4];          // nx, ny, nz, area
   uint8_t tri_face[kMaxTris];
   uint8_t face_number[kMaxFaces];
-  uint8_t pad2[12];
+  uint8_t single[kMaxFaces];
+  uint8_t pad2[8];
 };
 static_assert(sizeof(ShapeDev) % 16 == 0, "ShapeDev rows are read as float4");
 

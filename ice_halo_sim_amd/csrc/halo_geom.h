@@ -134,6 +134,41 @@ HALO_GEOM_HD void EmitFace(ShapeDev& s, ShapeCursor& cur, const float plane[4], 
   cur.fid++;
 }
 
+// Pair up faces whose unit normals are exact negatives (see ShapeDev::slab); runs once per shape after the last EmitFace.
+HALO_GEOM_HD void FinalizeSlabs(ShapeDev& s, const ShapeCursor& cur) {
+  s.face_cnt = cur.fid;
+  s.tri_cnt = cur.tri;
+  bool used[kMaxFaces];
+  for (int i = 0; i < kMaxFaces; i++) used[i] = false;
+  int ns = 0, n1 = 0;
+  for (int i = 0; i < cur.fid; i++) {
+    if (used[i]) continue;
+    int mate = -1;
+    for (int j = i + 1; j < cur.fid && mate < 0; j++)
+      if (!used[j] && s.face[i][0] == -s.face[j][0] && s.face[i][1] == -s.face[j][1] && s.face[i][2] == -s.face[j][2]) mate = j;
+    if (mate < 0) {
+      s.single[n1++] = static_cast<uint8_t>(i);
+      continue;
+    }
+    used[mate] = true;
+    float* r = s.slab[ns++];
+    r[0] = s.face[i][0];
+    r[1] = s.face[i][1];
+    r[2] = s.face[i][2];
+    r[3] = s.face[i][3];
+    r[4] = s.face[mate][3];
+    int32_t ip = i, im = mate;
+    uint32_t bp, bm;
+    bp = static_cast<uint32_t>(ip);
+    bm = static_cast<uint32_t>(im);
+    reinterpret_cast<uint32_t*>(r)[5] = bp;
+    reinterpret_cast<uint32_t*>(r)[6] = bm;
+    r[7] = 0.0f;
+  }
+  s.slab_cnt = ns;
+  s.single_cnt = n1;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // prism
 // ---------------------------------------------------------------------------------------------------
@@ -258,8 +293,7 @@ HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], ShapeDev& out) {
     EmitFace(out, cur, plane, nrm, 3 + i, loop, 4);
     k++;
   }
-  out.face_cnt = cur.fid;
-  out.tri_cnt = cur.tri;
+  FinalizeSlabs(out, cur);
   return out.face_cnt > 0;
 }
 
@@ -437,8 +471,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
       for (int a = 0; a < 3; a++) loop[q][a] = static_cast<float>(verts[on[s][q]][a]);
     EmitFace(out, cur, plane, nrm, number[s], loop, on_n[s]);
   }
-  out.face_cnt = cur.fid;
-  out.tri_cnt = cur.tri;
+  FinalizeSlabs(out, cur);
   return out.face_cnt > 0;
 }
 

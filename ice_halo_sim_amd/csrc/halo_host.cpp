@@ -121,6 +121,10 @@ void ToShapeDev(const HaloGeomTables& g, ShapeDev& s) {
     s.tri_na[t][3] = g.tri_area[t];
     s.tri_face[t] = static_cast<uint8_t>(g.tri_face[t]);
   }
+  geom::ShapeCursor cur;
+  cur.fid = g.face_cnt;
+  cur.tri = g.tri_cnt;
+  geom::FinalizeSlabs(s, cur);
 }
 
 // ---------------------------------------------------------------------------------------------------

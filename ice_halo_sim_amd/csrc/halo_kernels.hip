@@ -390,6 +390,8 @@ HD void atomic_add_f32(float* addr, float v) {
 //  * a per-workgroup direct-mapped pixel cache in LDS: the first pixel to claim a slot accumulates there with
 //    ds_add_f32 for the rest of the kernel and is flushed once; pixels that lose the claim go straight to HBM.
 //    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 constexpr int kCacheLog2 = 10;
 constexpr int kCacheN = 1 << kCacheLog2;
 
@@ -816,10 +818,29 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* 
     // <=> num_i*den_b < num_b*den_i.  One reciprocal at the end.
     float num_b = 1e30f, den_b = 1.0f;
     int hit = -1;
-    for (int fi = 0; fi < face_cnt; ++fi) {
+    // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain
+    const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
+    const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
+    for (int k = 0; k < slab_cnt; ++k) {
+      // opposite faces +n / -n: den(-n) = -den(+n) and n.p flips sign, so only the face the ray travels towards can be ahead
+      const float4 g = *reinterpret_cast<const float4*>(sh->slab[k]);
+      const float4 e = *reinterpret_cast<const float4*>(sh->slab[k] + 4);
+      const float2v r = X * g.x + Y * g.y + Z * g.z;
+      const bool pos = r.x > 0.0f;
+      const float den = fabsf(r.x);
+      const float num = pos ? -(r.y + g.w) : (r.y - e.x);
+      const int fi = pos ? __float_as_int(e.y) : __float_as_int(e.z);
+      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
+      num_b = better ? num : num_b;
+      den_b = better ? den : den_b;
+      hit = better ? fi : hit;
+    }
+    for (int k = 0; k < single_cnt; ++k) {
+      const int fi = sh->single[k];
       const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
-      const float den = d[0] * g.x + d[1] * g.y + d[2] * g.z;
-      const float num = -(p[0] * g.x + p[1] * g.y + p[2] * g.z + g.w);
+      const float2v r = X * g.x + Y * g.y + Z * g.z;
+      const float den = r.x;
+      const float num = -(r.y + g.w);
       const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
       num_b = better ? num : num_b;
       den_b = better ? den : den_b;
@@ -907,9 +928,11 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
         const float4* g4 = reinterpret_cast<const float4*>(g);
         float4* s4 = reinterpret_cast<float4*>(slot);
         const uint32_t fc = static_cast<uint32_t>(g->face_cnt), tc = static_cast<uint32_t>(g->tri_cnt);
+        constexpr uint32_t kSlab = offsetof(ShapeDev, slab) / 16u;
         constexpr uint32_t kTriV = offsetof(ShapeDev, tri_v) / 16u, kTriNa = offsetof(ShapeDev, tri_na) / 16u;
         constexpr uint32_t kTail = offsetof(ShapeDev, tri_face) / 16u, kEnd = sizeof(ShapeDev) / 16u;
         for (uint32_t i = l32; i < 1u + fc; i += 32u) s4[i] = g4[i];
+        for (uint32_t i = l32; i < 2u * kMaxSlabs; i += 32u) s4[kSlab + i] = g4[kSlab + i];
         for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) s4[kTriV + i] = g4[kTriV + i];
         for (uint32_t i = l32; i < tc; i += 32u) s4[kTriNa + i] = g4[kTriNa + i];
         for (uint32_t i = kTail + l32; i < kEnd; i += 32u) s4[i] = g4[i];
