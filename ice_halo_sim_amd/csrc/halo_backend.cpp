@@ -19,6 +19,7 @@
 
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
+hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
 hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
                        hipStream_t stream);
@@ -67,6 +68,9 @@ struct HaloBackend {
   uint64_t chunk = 1ull << 26;
   int aggregate = 1;
   int mono_enabled = 1;
+  int bin = -1;                // binned accumulation: -1 auto (discrete session, full-sky render, launch >= 4 Mi rays), 0 off, 1 on
+  DevBuf<HitRec> bin_list;
+  DevBuf<uint32_t> bin_cnt;
   int lambda_planes = -1;      // illuminant sessions: -1 auto (by batch size), 0 never, 1 always one plane per pool entry
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
@@ -278,6 +282,8 @@ int halo_destroy(halo_handle_t b) {
   }
   b->shapes.release();
   b->cont_cnt.release();
+  b->bin_list.release();
+  b->bin_cnt.release();
   b->cont[0].release();
   b->cont[1].release();
   b->exits.release();
@@ -300,6 +306,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "async") b->async = v ? 1 : 0;
   else if (k == "lambda_planes") b->lambda_planes = static_cast<int>(v);
+  else if (k == "bin") b->bin = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "mono_copies") {
     if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
@@ -580,6 +587,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.mono_s_log2 = b->mono_s_log2;
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
+    P.bin_list = nullptr;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
@@ -656,10 +664,34 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.host_tf = b->host_u.ptr + off;
       }
       const int blocks = blocks_of(m);
+      // binned accumulation for big one-plane launches (see halo_kernels.hip: HitBuffer)
+      const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> 14);
+      const bool use_bin = b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 256u &&
+                           (b->bin < 0 ? (deterministic && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0);
+      if (use_bin) {
+        // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
+        uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 16);
+        cap = std::min<uint64_t>(cap, (8ull << 30) / (8ull * bin_tiles));
+        HIPCHK(b, b->bin_cnt.reserve(static_cast<size_t>(512) * 16u));
+        HIPCHK(b, hipMemsetAsync(b->bin_cnt.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+        HIPCHK(b, b->bin_list.reserve(cap * bin_tiles));
+        P.bin_list = b->bin_list.ptr;
+        P.bin_cap = static_cast<uint32_t>(cap);
+        P.bin_tiles = bin_tiles;
+        P.bin_cnt = b->bin_cnt.ptr;
+        P.mono_copy_mask = 0u;   // staged hits and their fallbacks address copy 0
+      } else {
+        P.bin_list = nullptr;
+        P.mono_copy_mask = b->plane_copies - 1u;
+      }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
       b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
+      if (use_bin) {
+        hipError_t be = launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
+        if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
+      }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));
       HIPCHK(b, hipMemcpyAsync(b->ring_result + 4 * k, ds->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
       HIPCHK(b, hipEventRecord(b->ring_done[k], b->stream));

@@ -87,6 +87,10 @@ struct FilterDev {
 constexpr int kContShards = 256;
 constexpr int kContCntStride = 16;
 
+struct HitRec {  // one staged pixel hit of the binned accumulation: slot inside plane 0 and the weight's bits
+  uint32_t slot, w_bits;
+};
+
 // Per-dispatch constants and tallies as they sit in HBM: one H2D copy of the whole block per dispatch from a pinned
 // mirror, taken from a ring so a dispatch can be queued while earlier ones still run (no host sync per launch).
 struct DispatchSlot {
@@ -153,6 +157,10 @@ struct DispatchParams {
                                // mono_copy_mask+1 copies of kMonoRows << mono_s_log2 floats, pixel p at MonoSlot(p)
   uint32_t mono_s_log2;
   uint32_t mono_copy_mask;
+  HitRec* bin_list;             // binned accumulation (nullptr = off): bin_tiles lists of bin_cap {slot, weight} records
+  uint32_t bin_cap;
+  uint32_t bin_tiles;
+  uint32_t* bin_cnt;           // list fill counts, kBinCntStride apart
   uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)

@@ -392,13 +392,47 @@ HD void atomic_add_f32(float* addr, float v) {
 //    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-constexpr int kCacheLog2 = 10;
-constexpr int kCacheN = 1 << kCacheLog2;
+template <bool MONO>
+struct CacheGeom {  // 2048 one-channel slots (16 KB) or 1024 three-channel slots (16 KB)
+  static constexpr int kLog2 = MONO ? 11 : 10;
+  static constexpr int kN = 1 << kLog2;
+};
 
 template <bool MONO>
 struct PixCache {
-  uint32_t tag[kCacheN];                 // ((plane << 23) | pixel) + 1, 0 = free
-  float val[kCacheN * (MONO ? 1 : 3)];
+  uint32_t tag[CacheGeom<MONO>::kN];     // ((plane << 23) | pixel) + 1, 0 = free
+  float val[CacheGeom<MONO>::kN * (MONO ? 1 : 3)];
+};
+
+// Binned accumulation (discrete-wavelength sessions, big launches).  A launch of n rays puts tens of hits on EVERY pixel,
+// but no workgroup sees a pixel twice — the reuse only exists chip-wide, and one global atomic per hit caps the kernel at
+// ~21 G hits/s.  So hits are exchanged through per-tile lists in HBM instead: a workgroup stages its hits {slot, w} in LDS,
+// and when the buffer is half full bins them by image tile (16384 slots) — one returning global atomic per tile per
+// flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
+// sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
+// hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
+constexpr int kHitBuf = 2048;                 // staged hits per workgroup (16 KB)
+constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
+constexpr int kBinMaxTiles = 256;
+constexpr int kBinCntStride = 16;              // tile counters 64 B apart
+struct HitBuffer {
+  uint2 h[kHitBuf];
+  uint32_t n;
+  uint32_t hist[kBinMaxTiles];
+  uint32_t base[kBinMaxTiles];
+};
+template <bool ON>
+struct HitSlot {
+  HitBuffer b;
+};
+template <>
+struct HitSlot<false> {
+  uint32_t unused;
+};
+template <bool MONO>
+struct AccCtx {
+  PixCache<MONO>* cache;
+  HitBuffer* hits;   // nullptr = accumulate directly
 };
 
 // Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
@@ -410,13 +444,21 @@ HD float* mono_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) {
 // MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
 // pool entry); the CMF is applied by halo_fold_kernel.  !MONO: X, Y, Z into planes 0..2.
 template <bool MONO>
-HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
+HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
+  PixCache<MONO>& C = *ctx.cache;
   if (P.aggregate == 2u) return;  // diagnostic: trace + project only
   const uint32_t pl = (MONO && P.mono_by_wl) ? wl_idx : 0u;
   if (P.aggregate == 1u || P.aggregate == 3u) {
     const uint32_t key = ((pl << 23) | pix) + 1u;
-    const uint32_t slot = (key * 2654435761u) >> (32 - kCacheLog2);
-    const uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
+    // two-way: a key may live in slot s or s^1.  A hot pixel only misses the cache when BOTH were claimed by other pixels
+    // before its first hit (~0.2 % of workgroups instead of ~5 % one-way) — and every miss of a hot pixel is an atomic on
+    // the same line as all its other misses, chip-wide.
+    uint32_t slot = (key * 2654435761u) >> (32 - CacheGeom<MONO>::kLog2);
+    uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
+    if (old != 0u && old != key) {
+      slot ^= 1u;
+      old = atomicCAS(&C.tag[slot], 0u, key);
+    }
     if (old == 0u || old == key) {
       if (MONO) {
         unsafeAtomicAdd(&C.val[slot], w);
@@ -430,6 +472,20 @@ HD void accumulate(const DispatchParams& P, PixCache<MONO>& C, uint32_t pix, uin
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
+    if (ctx.hits != nullptr) {  // binned mode: stage the hit; the list stores the slot inside plane 0, copy 0
+      // one LDS atomic per wave, not per lane (64 lanes on one address would serialise)
+      const uint64_t mask = __ballot(1);
+      const uint32_t lane = __lane_id();
+      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
+      uint32_t first = 0u;
+      if (lane == leader) first = atomicAdd(&ctx.hits->n, static_cast<uint32_t>(__popcll(mask)));
+      first = __shfl(first, static_cast<int>(leader));
+      const uint32_t pos = first + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+      if (pos < static_cast<uint32_t>(kHitBuf)) {
+        ctx.hits->h[pos] = make_uint2(MonoSlot(pix, P.mono_s_log2), __float_as_uint(w));
+        return;
+      }
+    }
     atomic_add_f32(mono_slot(P, pl, pix), w);
   } else {
     atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
@@ -589,7 +645,7 @@ struct PoolSlots<false, N> {
 };
 
 template <int MODE, bool MONO>
-HD void emit_gate(const DispatchParams& P, PixCache<MONO>& cache, const FilterDev* filter, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
                   const uint8_t* path, uint32_t path_len, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
@@ -709,7 +765,7 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
 }
 
 template <int MODE, bool MONO, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* filter, ShapePtr sh, uint32_t tid, RaySums& sums) {
+HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO>& acc, const FilterDev* filter, ShapePtr sh, uint32_t tid, RaySums& sums) {
   float R[9], d[3], p[3], w;
   int face;
   uint32_t wl_idx = 0u;
@@ -804,7 +860,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* 
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     if (has_exit) {
-      emit_gate<MODE, MONO>(P, T.cache, filter, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+      emit_gate<MODE, MONO>(P, acc, filter, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
                          entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
@@ -849,7 +905,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* 
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO>(P, T.cache, filter, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<MODE, MONO>(P, acc, filter, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];
@@ -863,6 +919,46 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const FilterDev* 
   }
 }
 
+// Bin the staged hits by image tile and append them to the tiles' lists (all kBlock threads call this together).
+// Three sweeps over the staged hits: count per tile; reserve each tile's segment with ONE returning global atomic; place
+// (the position inside the segment comes from a second LDS counter, so nothing has to stay in registers across barriers).
+HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
+  const uint32_t n = min(hb.n, static_cast<uint32_t>(kHitBuf));
+  const uint32_t tmask = P.bin_tiles - 1u;   // tile = low slot bits: the column hash balances the tiles
+  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) hb.hist[t] = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.hist[hb.h[i].x & tmask], 1u);
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) {
+    const uint32_t c = hb.hist[t];
+    hb.base[t] = c ? atomicAdd(&P.bin_cnt[t * kBinCntStride], c) : 0u;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+    const uint2 h = hb.h[i];
+    const uint32_t tile = h.x & tmask;
+    const uint32_t idx = atomicAdd(&hb.base[tile], 1u);
+    if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
+    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (plane 0, copy 0)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) hb.n = 0u;
+  __syncthreads();
+}
+
+// Flush every `every` passes of the ray loop; the interval follows the fill level so that a flush finds the buffer about
+// half full (a pass that overruns the buffer falls back to direct atomics, so a late flush costs speed, not hits).  Every
+// thread of the workgroup reads the same fill count after the barrier, so the new interval is workgroup-uniform.
+HD uint32_t bin_flush_adaptive(const DispatchParams& P, HitBuffer& hb, uint32_t every, uint32_t& since) {
+  __syncthreads();
+  const uint32_t n = hb.n;
+  since = 0u;
+  bin_flush(P, hb);
+  if (n > static_cast<uint32_t>(kHitBuf) * 5u / 8u) return every > 1u ? every - 1u : 1u;
+  if (n < static_cast<uint32_t>(kHitBuf) * 3u / 8u) return every < 64u ? every + 1u : every;
+  return every;
+}
+
 HD float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -872,9 +968,18 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 4
 #endif
-template <int MODE, bool POOL, bool MONO>
+template <int MODE, bool POOL, bool MONO, bool BIN>
 __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
+  static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
+  __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
+  AccCtx<MONO> acc;
+  acc.cache = &T.cache;
+  acc.hits = nullptr;
+  if constexpr (BIN) {
+    acc.hits = &s_hits.b;
+    if (threadIdx.x == 0) s_hits.b.n = 0u;
+  }
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL> s_pool;       // stochastic: one shape per half-wave
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, 1> s_shape;  // deterministic: the dispatch's one shape
@@ -886,8 +991,8 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     filter = reinterpret_cast<const FilterDev*>(&s_filter);
   }
   if (P.aggregate == 1u || P.aggregate == 3u) {
-    for (int i = threadIdx.x; i < kCacheN; i += kBlock) T.cache.tag[i] = 0u;
-    for (int i = threadIdx.x; i < kCacheN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
+    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) T.cache.tag[i] = 0u;
+    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
   }
   // ---- stage the dispatch-constant tables into LDS ----
   if (P.lat_path == kLatLut)
@@ -909,6 +1014,7 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
 
   RaySums sums = {0.0f, 0.0f, 0u, 0u};
   const uint32_t stride = gridDim.x * kBlock;
+  uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
   bool staged = false;
   if constexpr (POOL) {
    if ((P.geom_clock & 31u) == 0u) {
@@ -939,26 +1045,39 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, filter, static_cast<const ShapeDev*>(slot), tid, sums);
+      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, static_cast<const ShapeDev*>(slot), tid, sums);
       __builtin_amdgcn_wave_barrier();
+      if constexpr (BIN) {
+        if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
+      }
     }
    }
   }
   if (!staged) {
-    for (uint32_t tid = blockIdx.x * kBlock + threadIdx.x; tid < P.n_rays; tid += stride) {
-      if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
-        const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-        trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
-      } else {
-        const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-        trace_one<MODE, MONO>(P, T, filter, sh, tid, sums);
+    for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {   // workgroup-uniform trip count
+      const uint32_t tid = base + threadIdx.x;
+      if (tid < P.n_rays) {
+        if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
+          const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
+          trace_one<MODE, MONO>(P, T, acc, filter, sh, tid, sums);
+        } else {
+          const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
+          trace_one<MODE, MONO>(P, T, acc, filter, sh, tid, sums);
+        }
+      }
+      if constexpr (BIN) {
+        if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
       }
     }
+  }
+  if constexpr (BIN) {
+    __syncthreads();
+    bin_flush(P, s_hits.b);
   }
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
   if (P.aggregate == 1u || P.aggregate == 3u) {
     __syncthreads();
-    for (int i = threadIdx.x; i < kCacheN; i += kBlock) {
+    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];
       if (key == 0u) continue;
       const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;
@@ -983,6 +1102,46 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
     if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
   }
+}
+
+// kBinSplit workgroups per image tile: each sums its share of the tile's hit list in a 64 KB LDS tile (8 independent
+// loads in flight per thread — the loop is load-latency-bound otherwise) and adds the non-zero slots to the plane.
+constexpr int kBinBlock = 1024;
+constexpr uint32_t kBinSplit = 2u;
+__global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
+                                                                         const uint32_t* __restrict__ cnt, uint32_t tiles_log2) {
+  __shared__ float acc[1u << kBinTileLog2];
+  const uint32_t tile = blockIdx.x / kBinSplit, part = blockIdx.x % kBinSplit;
+  const uint32_t n = min(cnt[tile * kBinCntStride], cap);
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kBinSplit);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kBinSplit);
+  if (hi <= lo) return;
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0f;
+  __syncthreads();
+  const uint2* src = list + static_cast<size_t>(tile) * cap;
+  constexpr uint32_t kU = 8u;
+  uint32_t i = lo + threadIdx.x;
+  for (; i + (kU - 1u) * kBinBlock < hi; i += kU * kBinBlock) {
+    uint2 h[kU];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x >> tiles_log2], __uint_as_float(h[u].y));
+  }
+  for (; i < hi; i += kBinBlock) {
+    const uint2 h = src[i];
+    unsafeAtomicAdd(&acc[h.x >> tiles_log2], __uint_as_float(h.y));
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) {
+    const float v = acc[j];
+    if (v != 0.0f) atomic_add_f32(plane + ((static_cast<size_t>(j) << tiles_log2) | tile), v);
+  }
+}
+
+hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_bin_accumulate_kernel, dim3(tiles * kBinSplit), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list), cap, cnt, static_cast<uint32_t>(__builtin_ctz(tiles)));
+  return hipGetLastError();
 }
 
 // xyz[pix] += sum over planes of coef[plane] * (sum over copies of plane[MonoSlot(pix)]); the slots are zeroed — closes a
@@ -1145,8 +1304,9 @@ hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log
 // host-callable launcher (halo_backend.cpp is plain C++ and never sees <<<>>>)
 template <int MODE, bool POOL>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, false>), grid, block, 0, stream, P);
+  if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, true>), grid, block, 0, stream, P);
+  else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, false>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, false, false>), grid, block, 0, stream, P);
 }
 
 template <int MODE>

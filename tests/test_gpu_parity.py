@@ -576,3 +576,27 @@ def test_edge_wavelength_pool_limits():
         frac, pix, path = match_exits(r["eh"], r["eo"])
         assert frac >= 0.998
         assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 5e-3
+
+
+def test_binned_accumulation_equals_direct_and_oracle():
+    """Binned accumulation (hits staged in LDS, binned by image tile into HBM lists, summed per tile by
+    halo_bin_accumulate_kernel) is only a different route to the same sums: image equal to the direct-atomic route to float
+    rounding and to the oracle within the usual bound; tiny per-tile lists force the overflow fallback as well."""
+    sc = scenes.config2_scene()
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 1024, 512, visible=abi.VISIBLE_FULL, overlap=0.0872)   # every exit lands, some twice
+    n = 400_000
+    imgs = {}
+    for mode in (0, 1):
+        hb = hip_backend(seed=31, bin=mode)
+        st = run_session(hb, sc, rd, scenes.wl_discrete(550.0), n)
+        imgs[mode] = hb.ReadbackXyzAccum() + (st[0].pixel_hits,)
+        hb.close()
+    assert imgs[0][2] == imgs[1][2] > 4 * n
+    assert imgs[0][1] == pytest.approx(imgs[1][1], rel=1e-6)
+    assert rel_l2(imgs[0][0], imgs[1][0]) <= 2e-5            # different summation order per pixel, same addends
+    ob = OracleBackend(seed=31, threads=8)
+    run_session(ob, sc, rd, scenes.wl_discrete(550.0), n)
+    io, lo = ob.ReadbackXyzAccum()
+    ob.close()
+    assert abs(imgs[1][1] - lo) <= 1e-4 * lo
+    assert rel_l2(block_mean(imgs[1][0]), block_mean(io)) <= 3e-3

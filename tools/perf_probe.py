@@ -40,6 +40,16 @@ if "copies" in which:
         run("  512x256 mono_copies=%d" % c, sc, scenes.config2_render(512, 256), mono_copies=c)
     run("config2 mono_copies=8, plain atomics", sc, rd, mono_copies=8, aggregate=0)
     run("config2 mono_copies=32, plain atomics", sc, rd, mono_copies=32, aggregate=0)
+if "bin" in which:
+    full = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 2048, 1024, visible=abi.VISIBLE_FULL)
+    sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+    rd_s = scenes.render(7, 2048, 1024, el=0, visible=2)
+    for b in (0, 1):
+        run("config2 10M bin=%d" % b, sc, rd, bin=b)
+        run("config2 50M bin=%d" % b, sc, rd, n=50_000_000, reps=2, bin=b)
+        run("config2 dual-fisheye full sky 2048x1024 10M bin=%d" % b, sc, full, bin=b)
+        run("config2 dual-fisheye full sky 2048x1024 50M bin=%d" % b, sc, full, n=50_000_000, reps=2, bin=b)
+        run("stochastic prism rect full sky 4M bin=%d" % b, sc_s, rd_s, n=4_000_000, bin=b)
 if "illum" in which:
     wl_d65 = scenes.wl_illuminant("D65", 64)
     def run_wl(label, n, **opts):
