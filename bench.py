@@ -49,25 +49,36 @@ def cpu_baseline(rays_per_wl_hint, budget_s=12.0):
             "sample": "configs[1] shape, 9 wavelengths x %d rays (%.1f s of CPU work), OpenMP over rays" % (per_wl, dt)}
 
 
+def _pmc_mean(name, key):
+    """mean-per-dispatch value of counter `key` for the trace kernel in a committed rocprofv3 PMC summary (tools/rocpd_summary.py)"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    if not os.path.exists(path):
+        return None
+    val = None
+    for line in open(path):
+        if "halo_trace_kernel" in line and (" " + key + " ") in line:
+            val = float(line.split(" " + key + " ")[1].split()[0])
+    return val
+
+
 def pmc_traffic_per_launch():
     """HBM-side bytes per trace-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_bench_pmc_{fetch,write}_size.txt; counters are collected in their own runs, never inside the timed one).
     FETCH_SIZE / WRITE_SIZE are in KB; this kernel's traffic is scattered atomics, for which the guide calls the counters
     uncalibrated — reported as measured, uncorrected."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    tot = 0.0
-    for name, key in (("r01_bench_pmc_fetch_size.txt", "FETCH_SIZE"), ("r01_bench_pmc_write_size.txt", "WRITE_SIZE")):
-        path = os.path.join(here, "profiles", name)
-        if not os.path.exists(path):
-            return None
-        val = None
-        for line in open(path):
-            if "halo_trace_kernel" in line and key in line:
-                val = float(line.split(key)[1].split()[0])
-        if val is None:
-            return None
-        tot += val * 1024.0
-    return tot
+    f, w = _pmc_mean("r01_bench_pmc_fetch_size.txt", "FETCH_SIZE"), _pmc_mean("r01_bench_pmc_write_size.txt", "WRITE_SIZE")
+    return None if f is None or w is None else (f + w) * 1024.0
+
+
+def pmc_valu(rays_per_launch):
+    """VALU issue utilisation and instructions per 64-ray wave pass of the trace kernel, from the committed PMC passes
+    (per-dispatch means are per counter instance: one instance = 32 SIMDs; SQ_ACTIVE_INST_VALU counts quad-cycles)."""
+    act, busy = _pmc_mean("r01_bench_pmc_cycles.txt", "SQ_ACTIVE_INST_VALU"), _pmc_mean("r01_bench_pmc_cycles.txt", "SQ_BUSY_CYCLES")
+    insts = _pmc_mean("r01_bench_pmc_insts.txt", "SQ_INSTS_VALU")
+    if not act or not busy or not insts:
+        return None
+    return {"valu_busy_frac": act * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
+            "source": "profiles/r01_bench_pmc_{cycles,insts}.txt"}
 
 
 def main():
@@ -168,10 +179,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                          "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)",
-                         "kernel": "halo_trace_kernel<0,false,true>", "launches": launches,
+                         "kernel": "halo_trace_kernel<0,false,true,false>", "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "kernel_rays_per_s": (rays_per_rank / max(kernel_ms * 1e-3, 1e-12)),
-                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is VALU-issue-bound, not HBM-bound: SQ_ACTIVE_INST_VALU x4 / SQ_BUSY_CYCLES = 0.987 of VALU issue slots busy, 3321 VALU instructions per wave-ray (profiles/r01_bench_pmc_{cycles,insts}.txt, DESIGN.md §4)"},
+                         "valu": pmc_valu(n),
+                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n)
