@@ -34,7 +34,7 @@ class HaloCrystal(C.Structure):
 
 class HaloEntry(C.Structure):
     _fields_ = [("crystal", HaloCrystal), ("axis", HaloAxis), ("proportion", C.c_float),
-                ("crystal_config_id", C.c_int32), ("filter_id", C.c_int32), ("reserved", C.c_int32)]
+                ("crystal_config_id", C.c_int32), ("filter_id", C.c_int32), ("color_id", C.c_int32)]
 
 
 FILTER_MAX_OR, FILTER_MAX_TERMS = 8, 16
@@ -51,6 +51,21 @@ class HaloFilterTerm(C.Structure):
 class HaloFilter(C.Structure):
     _fields_ = [("action", C.c_int32), ("symmetry", C.c_int32), ("is_complex", C.c_int32), ("or_count", C.c_int32),
                 ("and_counts", C.c_int32 * FILTER_MAX_OR), ("terms", HaloFilterTerm * FILTER_MAX_TERMS)]
+
+
+COLOR_MAX_TERMS, COLOR_MAX_CLASSES = 16, 16
+
+
+class HaloColorTerm(C.Structure):
+    _fields_ = [("predicate", HaloFilterTerm), ("symmetry", C.c_int32), ("bit", C.c_int32)]
+
+
+class HaloColorSet(C.Structure):
+    _fields_ = [("term_count", C.c_int32), ("reserved", C.c_int32), ("terms", HaloColorTerm * COLOR_MAX_TERMS)]
+
+
+class HaloColorClass(C.Structure):
+    _fields_ = [("bits", C.c_uint64), ("combine_all", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HaloLayer(C.Structure):
@@ -86,7 +101,7 @@ class HaloLayerStats(C.Structure):
 class HaloExitRecord(C.Structure):
     _fields_ = [("dir", C.c_float * 3), ("weight", C.c_float), ("root", C.c_uint32), ("seq", C.c_uint16),
                 ("layer", C.c_uint8), ("path_len", C.c_uint8), ("path", C.c_uint8 * PATH_CAP),
-                ("pixel", C.c_int32), ("crystal_id", C.c_uint16), ("wl_idx", C.c_uint16)]
+                ("pixel", C.c_int32), ("crystal_id", C.c_uint16), ("wl_idx", C.c_uint16), ("color_mask", C.c_uint64)]
 
 
 class HaloGeomTables(C.Structure):

@@ -55,6 +55,8 @@ def load_library():
         "halo_readback_xyz": (C.c_int, [H, f32p, C.c_int, C.c_int, f32p]),
         "halo_readback_xyz64": (C.c_int, [H, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "halo_sync": (C.c_int, [H]),
+        "halo_set_color": (C.c_int, [H, C.POINTER(abi.HaloColorSet), C.c_int, C.POINTER(abi.HaloColorClass), C.c_int]),
+        "halo_readback_class_lanes": (C.c_int, [H, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]),
         "halo_generate_shapes": (C.c_int, [H, C.POINTER(abi.HaloCrystal), C.c_uint64, C.c_uint32, C.c_int, C.POINTER(abi.HaloGeomTables)]),
         "halo_collect_stats": (C.c_int, [H, C.POINTER(abi.HaloLayerStats)]),
         "halo_take_landed": (C.c_int, [H, C.POINTER(C.c_double)]),
@@ -80,7 +82,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath",
 ]
@@ -134,6 +136,21 @@ class HipTraceBackend:
         """Filter table referenced by HaloEntry.filter_id (1-based; 0 = none)."""
         arr = (abi.HaloFilter * max(1, len(filters)))(*filters)
         self._check(self._L.halo_set_filters(self._h, arr, len(filters)))
+
+    def set_color(self, sets, classes):
+        """Raypath-colour tables: `sets` referenced by HaloEntry.color_id (1-based), `classes` define the Y lanes."""
+        sa = (abi.HaloColorSet * max(1, len(sets)))(*sets)
+        ca = (abi.HaloColorClass * max(1, len(classes)))(*classes)
+        self._check(self._L.halo_set_color(self._h, sa, len(sets), ca, len(classes)))
+        self._n_classes = len(classes)
+
+    def ReadbackClassLanes(self):
+        """TraceBackend::ReadbackClassLanes: (class_count, H, W) float32 Y lanes; zeroes the device lanes."""
+        w, h, n = self._render.width, self._render.height, getattr(self, "_n_classes", 0)
+        out = np.zeros((n, h, w), np.float32)
+        if n:
+            self._check(self._L.halo_readback_class_lanes(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), w, h, n))
+        return out
 
     def bind_accumulator(self, device_ptr, n_floats):
         self._check(self._L.halo_bind_accumulator(self._h, C.c_void_p(device_ptr), int(n_floats)))
@@ -237,5 +254,5 @@ class HipTraceBackend:
 
 EXIT_DTYPE = np.dtype([("dir", np.float32, 3), ("weight", np.float32), ("root", np.uint32), ("seq", np.uint16),
                        ("layer", np.uint8), ("path_len", np.uint8), ("path", np.uint8, abi.PATH_CAP),
-                       ("pixel", np.int32), ("crystal_id", np.uint16), ("wl_idx", np.uint16)])
+                       ("pixel", np.int32), ("crystal_id", np.uint16), ("wl_idx", np.uint16), ("color_mask", np.uint64)])
 assert EXIT_DTYPE.itemsize == C.sizeof(abi.HaloExitRecord)

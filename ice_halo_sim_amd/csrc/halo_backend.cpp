@@ -96,6 +96,10 @@ struct HaloBackend {
   uint64_t acc_floats = 0;
   int acc_w = 0, acc_h = 0;
   std::vector<HaloFilter> filters;  // table referenced by HaloEntry::filter_id
+  std::vector<HaloColorSet> color_sets;      // table referenced by HaloEntry::color_id
+  std::vector<HaloColorClass> color_classes; // raypath-colour classes (Y lanes)
+  DevBuf<float> lanes;                       // class_count x W x H
+  int lanes_w = 0, lanes_h = 0;
   DevBuf<FilterDev> filter_dev;
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
@@ -282,6 +286,7 @@ int halo_destroy(halo_handle_t b) {
   }
   b->shapes.release();
   b->cont_cnt.release();
+  b->lanes.release();
   b->bin_list.release();
   b->bin_cnt.release();
   b->cont[0].release();
@@ -375,6 +380,8 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     for (int e = 0; e < scene->layers[l].entry_count; e++) {
       const int fid = scene->layers[l].entries[e].filter_id;
       if (fid < 0 || fid > static_cast<int>(b->filters.size())) return fail(b, HALO_FATAL, "entry refers to a filter_id outside the table");
+      const int cid = scene->layers[l].entries[e].color_id;
+      if (cid < 0 || cid > static_cast<int>(b->color_sets.size())) return fail(b, HALO_FATAL, "entry refers to a color_id outside the table");
       const int kind = scene->layers[l].entries[e].crystal.kind;
       if (kind != HALO_CRYSTAL_PRISM && kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
     }
@@ -417,6 +424,15 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
     }
     b->mono_s_log2 = s_log2;  // planes are all-zero between sessions, so the layout may change freely
+  }
+  if (!b->color_classes.empty()) {  // Y lanes persist like the accumulator, until halo_readback_class_lanes
+    const size_t need = b->color_classes.size() * npix;
+    if (b->lanes.cap < need || b->lanes_w != render->width || b->lanes_h != render->height) {
+      HIPCHK(b, b->lanes.reserve(need));
+      HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(float), b->stream));
+      b->lanes_w = render->width;
+      b->lanes_h = render->height;
+    }
   }
   b->in_session = true;
   b->layer_idx = 0;
@@ -498,7 +514,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     region = (region + 63) & ~63ull;
     const uint64_t stride = region * kContShards;
     if (stride > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "continuation pool would exceed 2^32 rays; split the batch");
-    HIPCHK(b, b->cont[out_slot].reserve(stride * 5));
+    HIPCHK(b, b->cont[out_slot].reserve(stride * (b->color_classes.empty() ? 5 : 7)));  // + mask lo/hi planes with raypath colour
     b->cont_stride[out_slot] = static_cast<uint32_t>(stride);
     b->cont_region[out_slot] = static_cast<uint32_t>(region);
     out_cap = static_cast<uint32_t>(region);
@@ -600,6 +616,32 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       use_filter = fd.is_complex || fd.terms[0].type != HALO_FILTER_NONE || fd.action != 0;
     }
 
+    // raypath colour: this entry's predicates (canonicalised like filter terms, each with its own symmetry) + the classes
+    ColorDev cd{};
+    const bool use_color = !b->color_classes.empty();
+    if (use_color) {
+      cd.class_cnt = static_cast<uint32_t>(b->color_classes.size());
+      for (uint32_t c = 0; c < cd.class_cnt; c++) {
+        cd.class_bits[c] = b->color_classes[c].bits;
+        cd.class_all[c] = b->color_classes[c].combine_all ? 1 : 0;
+      }
+      if (E.color_id > 0) {
+        const HaloColorSet& cs = b->color_sets[static_cast<size_t>(E.color_id - 1)];
+        cd.term_cnt = static_cast<uint32_t>(std::min(cs.term_count, HALO_COLOR_MAX_TERMS));
+        for (uint32_t k = 0; k < cd.term_cnt; k++) {
+          HaloFilter one{};
+          one.symmetry = cs.terms[k].symmetry;
+          one.terms[0] = cs.terms[k].predicate;
+          const FilterDev f1 = host::BuildFilter(one, E.axis);
+          cd.terms[k].t = f1.terms[0];
+          cd.terms[k].symmetry = f1.symmetry;
+          cd.terms[k].d_applicable = f1.d_applicable;
+          cd.terms[k].sigma_a = f1.sigma_a;
+          cd.terms[k].bit = static_cast<uint8_t>(cs.terms[k].bit & 0xFF);
+        }
+      }
+    }
+
     const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
     for (uint64_t off = 0; off < n_ci;) {
@@ -626,12 +668,16 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       std::copy(b->wl_pool_host.begin(), b->wl_pool_host.end(), hs.wl);
       if (deterministic) hs.shape = pool[0];
       if (use_filter) hs.filter = fd;
+      if (use_color) hs.color = cd;
       for (double& v : hs.sums) v = 0.0;
       if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
       HIPCHK(b, hipMemcpyAsync(ds, &hs, sizeof(DispatchSlot), hipMemcpyHostToDevice, b->stream));
       P.lut = ds->lut;
       P.wl_pool = ds->wl;
       P.filter = use_filter ? &ds->filter : nullptr;
+      P.color = use_color ? &ds->color : nullptr;
+      P.lanes = b->lanes.ptr;
+      P.lane_stride = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
       P.sums = ds->sums;
       P.cont_in_seg = ds->seg;
       if (deterministic) {
@@ -757,6 +803,32 @@ int halo_generate_shapes(halo_handle_t b, const HaloCrystal* crystal, uint64_t f
     for (uint32_t k = 0; k < n; k++) host::MakeShapeDev(b->seed, *crystal, first_index + k, pool[k]);
   }
   for (uint32_t k = 0; k < n; k++) host::FromShapeDev(pool[k], out[k]);
+  return HALO_OK;
+}
+
+int halo_set_color(halo_handle_t b, const HaloColorSet* sets, int n_sets, const HaloColorClass* classes, int n_classes) {
+  if (!b || n_sets < 0 || n_classes < 0 || (n_sets && !sets) || (n_classes && !classes)) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "halo_set_color inside a session");
+  if (n_classes > HALO_COLOR_MAX_CLASSES) return fail(b, HALO_FATAL, "more than HALO_COLOR_MAX_CLASSES colour classes");
+  for (int i = 0; i < n_sets; i++) {
+    if (sets[i].term_count < 0 || sets[i].term_count > HALO_COLOR_MAX_TERMS) return fail(b, HALO_FATAL, "colour set term_count out of range");
+    for (int k = 0; k < sets[i].term_count; k++)
+      if (sets[i].terms[k].bit < 0 || sets[i].terms[k].bit > 63) return fail(b, HALO_FATAL, "colour bit outside 0..63");
+  }
+  b->color_sets.assign(sets, sets + n_sets);
+  b->color_classes.assign(classes, classes + n_classes);
+  return HALO_OK;
+}
+
+int halo_readback_class_lanes(halo_handle_t b, float* lanes, int width, int height, int class_count) {
+  if (!b || !lanes) return HALO_FATAL;
+  if (class_count != static_cast<int>(b->color_classes.size()) || width != b->lanes_w || height != b->lanes_h || !b->lanes.ptr)
+    return fail(b, HALO_FATAL, "class lanes: size does not match the session (classes x width x height)");
+  HIPCHK(b, hipSetDevice(b->device));
+  const size_t n = static_cast<size_t>(class_count) * width * height;
+  HIPCHK(b, hipMemcpyAsync(lanes, b->lanes.ptr, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, n * sizeof(float), b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
   return HALO_OK;
 }
 
@@ -953,6 +1025,9 @@ uint64_t halo_abi_sizeof(int which) {
     case 4: return sizeof(HaloGeomTables);
     case 5: return sizeof(HaloLayerStats);
     case 6: return sizeof(HaloEntry);
+    case 7: return sizeof(HaloColorSet);
+    case 8: return sizeof(HaloColorClass);
+    case 9: return sizeof(HaloFilter);
     default: return 0;
   }
 }

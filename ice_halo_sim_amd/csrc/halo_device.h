@@ -80,6 +80,20 @@ struct FilterDev {
   FilterTermDev terms[HALO_FILTER_MAX_TERMS];
 };
 
+// Raypath-colour tables of one dispatch (see halo_trace.h HaloColorSet / HaloColorClass): predicates are canonicalised on
+// the host like filter terms, each with its own symmetry.
+struct ColorTermDev {
+  FilterTermDev t;
+  uint8_t symmetry, d_applicable, bit, pad;
+  int32_t sigma_a;
+};
+struct ColorDev {
+  uint32_t term_cnt, class_cnt;
+  uint64_t class_bits[HALO_COLOR_MAX_CLASSES];
+  uint8_t class_all[HALO_COLOR_MAX_CLASSES];
+  ColorTermDev terms[HALO_COLOR_MAX_TERMS];
+};
+
 // Continuation pool sharding.  One device counter saturates at ~88 M returning atomics/s (measured, MI355X), and every
 // wave appends once per emit site — so the pool is cut into kContShards regions, block b appends to region b % kContShards
 // through that region's own counter (64 B apart: same-line atomics serialise), and the next layer reads logical index j
@@ -100,6 +114,7 @@ struct DispatchSlot {
   alignas(16) FilterDev filter;
   alignas(16) double sums[4];
   alignas(16) uint32_t seg[kContShards + 4];
+  alignas(16) ColorDev color;
 };
 
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
@@ -168,6 +183,9 @@ struct DispatchParams {
   uint32_t exit_cap;
   uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
   const FilterDev* filter;     // nullptr = pass-all
+  const ColorDev* color;       // nullptr = no raypath colour: no masks carried, no lanes
+  float* lanes;                // class_cnt x lane_stride Y lanes
+  uint32_t lane_stride;        // W*H
 };
 
 // Pixel → slot map of the mono plane.  The plane is kMonoRows rows of S = 2^s_log2 slots; pixel p sits in row p % kMonoRows

@@ -566,14 +566,14 @@ HD void reduce_buffer(uint8_t* data, uint32_t size, uint8_t symmetry, int32_t si
   }
 }
 
-HD bool filter_match_term(const FilterDev& f, const FilterTermDev& t, const uint8_t* path, uint32_t len, float wx, float wy, float wz,
-                          uint32_t crystal_id) {  // DeviceFilterMatchSimple :238-257
+HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, const FilterTermDev& t, const uint8_t* path, uint32_t len, float wx,
+                          float wy, float wz, uint32_t crystal_id) {  // DeviceFilterMatchSimple :238-257
   if (t.type == HALO_FILTER_NONE) return true;
   if (t.type == HALO_FILTER_RAYPATH) {  // :156-178
     if (len != t.canonical_len) return false;
     uint8_t buf[kFilterPathCap];
     for (uint32_t i = 0; i < len; ++i) buf[i] = path[i];
-    reduce_buffer(buf, len, f.symmetry, f.sigma_a, f.d_applicable != 0u);
+    reduce_buffer(buf, len, symmetry, sigma_a, d_applicable);
     for (uint32_t i = 0; i < len; ++i)
       if (buf[i] != t.canonical[i]) return false;
     return true;
@@ -586,8 +586,8 @@ HD bool filter_match_term(const FilterDev& f, const FilterTermDev& t, const uint
     uint32_t n = 0u;
     if (t.has_entry) ee[n++] = path[0];
     if (t.has_exit) ee[n++] = path[len - 1u];
-    reduce_buffer(ee, n, f.symmetry, f.sigma_a, f.d_applicable != 0u);
-    if (f.symmetry != 0u && n != t.canonical_len) return false;
+    reduce_buffer(ee, n, symmetry, sigma_a, d_applicable);
+    if (symmetry != 0u && n != t.canonical_len) return false;
     for (uint32_t i = 0; i < n; ++i)
       if (ee[i] != t.canonical[i]) return false;
     return true;
@@ -600,19 +600,42 @@ HD bool filter_match_term(const FilterDev& f, const FilterTermDev& t, const uint
 HD bool filter_check(const FilterDev& f, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
   bool m;
   if (!f.is_complex) {
-    m = filter_match_term(f, f.terms[0], path, len, wx, wy, wz, crystal_id);
+    m = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[0], path, len, wx, wy, wz, crystal_id);
   } else {  // OR over AND-clauses; an empty complex filter matches nothing (:263-291)
     m = false;
     uint32_t idx = 0u;
     for (uint32_t o = 0u; o < f.or_count && !m; ++o) {
       const uint32_t n = f.and_counts[o];
       bool all = true;
-      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f, f.terms[idx + a], path, len, wx, wy, wz, crystal_id);
+      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[idx + a], path, len, wx, wy, wz, crystal_id);
       idx += n;
       m = all;
     }
   }
   return (f.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+}
+
+// Raypath colour (ApplyLayerColorBits cu:498-527): OR into the carried mask the bit of every predicate of this crystal
+// entry that matches the exit.  Non-destructive: runs beside the physical filter, never drops a ray.
+HD uint64_t color_bits(const ColorDev& c, uint64_t carried, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
+  uint64_t m = carried;
+  for (uint32_t k = 0u; k < c.term_cnt; ++k) {
+    const ColorTermDev& ct = c.terms[k];
+    if (ct.bit < 64u && filter_match_term(ct.symmetry, ct.sigma_a, ct.d_applicable != 0u, ct.t, path, len, wx, wy, wz, crystal_id))
+      m |= 1ull << ct.bit;
+  }
+  return m;
+}
+
+// FanColorClassLanes cu:535-556: the exit's Y goes to every class whose rule its mask satisfies (primary AND overlap hits)
+HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uint32_t pix, float y_val) {
+  for (uint32_t k = 0u; k < c.class_cnt; ++k) {
+    const uint64_t bits = c.class_bits[k];
+    if (bits == 0ull) continue;
+    const uint64_t matched = mask & bits;
+    const bool ok = c.class_all[k] ? (matched == bits) : (matched != 0ull);
+    if (ok) atomic_add_f32(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, y_val);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -634,6 +657,14 @@ template <>
 struct FilterSlot<false> {
   uint32_t unused;
 };
+template <bool ON>
+struct ColorSlot {
+  ColorDev c;
+};
+template <>
+struct ColorSlot<false> {
+  uint32_t unused;
+};
 
 template <bool ON, int N = kBlock / 32>
 struct PoolSlots {
@@ -645,7 +676,7 @@ struct PoolSlots<false, N> {
 };
 
 template <int MODE, bool MONO>
-HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
                   const uint8_t* path, uint32_t path_len, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
@@ -656,6 +687,8 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
   if (MODE != kModePlain && filter != nullptr) {
     if (!filter_check(*filter, path, path_len, wx, wy, wz, P.crystal_id)) return;
   }
+  uint64_t cmask = carried;
+  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, path, path_len, wx, wy, wz, P.crystal_id);
   // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
   // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
   bool pass = false;
@@ -679,6 +712,10 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
       P.cont_out[2u * st + slot] = wz;
       P.cont_out[3u * st + slot] = w;
       reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
+      if (MODE != kModePlain && color != nullptr) {  // the mask rides with the continuation (cu:922,1129)
+        reinterpret_cast<uint32_t*>(P.cont_out)[5u * st + slot] = static_cast<uint32_t>(cmask);
+        reinterpret_cast<uint32_t*>(P.cont_out)[6u * st + slot] = static_cast<uint32_t>(cmask >> 32);
+      }
     }
     return;
   }
@@ -687,6 +724,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
     accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
+    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
     primary = static_cast<int>(pix);
@@ -694,6 +732,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
   if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
     accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
+    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.pix_n++;
   }
   sums.exit_w += w;
@@ -714,6 +753,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
       rec.pixel = primary;
       rec.crystal_id = static_cast<uint16_t>(P.crystal_id);
       rec.wl_idx = static_cast<uint16_t>(wl_idx);
+      rec.color_mask = cmask;
       P.exits[slot] = rec;
     }
   }
@@ -765,7 +805,9 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
 }
 
 template <int MODE, bool MONO, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO>& acc, const FilterDev* filter, ShapePtr sh, uint32_t tid, RaySums& sums) {
+HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
+                  uint32_t tid, RaySums& sums) {
+  uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
   int face;
   uint32_t wl_idx = 0u;
@@ -811,6 +853,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
     w = P.cont_in[3u * st + src];
     wl_idx = reinterpret_cast<const uint32_t*>(P.cont_in)[4u * st + src];
+    if (MODE != kModePlain && color != nullptr)
+      carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[5u * st + src]) |
+                (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[6u * st + src]) << 32);
     float lon, lat, roll;
     sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
     build_crystal_rotation(lon, lat, roll, R);
@@ -860,7 +905,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     if (has_exit) {
-      emit_gate<MODE, MONO>(P, acc, filter, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
                          entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
@@ -905,7 +950,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO>(P, acc, filter, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];
@@ -983,6 +1028,14 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL> s_pool;       // stochastic: one shape per half-wave
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, 1> s_shape;  // deterministic: the dispatch's one shape
+  __shared__ __attribute__((aligned(16))) ColorSlot<MODE != kModePlain> s_color;
+  const ColorDev* color = nullptr;
+  if (MODE != kModePlain && P.color != nullptr) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.color);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_color);
+    for (uint32_t i = threadIdx.x; i < sizeof(ColorDev) / 4u; i += kBlock) dst[i] = src[i];
+    color = reinterpret_cast<const ColorDev*>(&s_color);
+  }
   const FilterDev* filter = nullptr;
   if (MODE != kModePlain && P.filter != nullptr) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.filter);
@@ -1045,7 +1098,7 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, static_cast<const ShapeDev*>(slot), tid, sums);
+      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const ShapeDev*>(slot), tid, sums);
       __builtin_amdgcn_wave_barrier();
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
@@ -1059,10 +1112,10 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
           const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-          trace_one<MODE, MONO>(P, T, acc, filter, sh, tid, sums);
+          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO>(P, T, acc, filter, sh, tid, sums);
+          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
         }
       }
       if constexpr (BIN) {
@@ -1318,7 +1371,7 @@ static void launch_pool(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono) {
   dim3 grid(blocks), block(kBlock);
   if (capture) launch_pool<kModeCapture>(P, grid, block, stream, pool, mono);
-  else if (P.filter != nullptr) launch_pool<kModeFilter>(P, grid, block, stream, pool, mono);
+  else if (P.filter != nullptr || P.color != nullptr) launch_pool<kModeFilter>(P, grid, block, stream, pool, mono);
   else launch_pool<kModePlain>(P, grid, block, stream, pool, mono);
   return hipGetLastError();
 }

@@ -57,8 +57,9 @@ def axis(zenith=None, azimuth=None, roll=None):
     return a
 
 
-def entry(crystal, axis_dist, proportion=1.0, crystal_config_id=1, filter_id=0):
+def entry(crystal, axis_dist, proportion=1.0, crystal_config_id=1, filter_id=0, color_id=0):
     e = abi.HaloEntry()
+    e.color_id = int(color_id)
     e.crystal = crystal
     e.axis = axis_dist
     e.proportion = float(proportion)
@@ -81,6 +82,30 @@ def filter_term(kind="none", raypath=None, entry=None, exit=None, min_len=1, max
     t.min_len, t.max_len = int(min_len), 0 if max_len is None else int(max_len)
     t.az, t.el, t.radii, t.crystal_id = float(az), float(el), float(radii), int(crystal_id)
     return t
+
+
+def _sym(symmetry):
+    return sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+
+
+def color_set(terms):
+    """terms: list of (HaloFilterTerm predicate, symmetry string, bit) — one crystal entry's raypath-colour predicates
+    (reference ColorGatePlacement, src/config/color_gate_table.hpp:62-81)."""
+    cs = abi.HaloColorSet()
+    cs.term_count = len(terms)
+    for k, (pred, symmetry, bit) in enumerate(terms):
+        cs.terms[k].predicate = pred
+        cs.terms[k].symmetry = _sym(symmetry)
+        cs.terms[k].bit = int(bit)
+    return cs
+
+
+def color_class(bits, combine="any"):
+    """bits: iterable of bit numbers; combine 'any' | 'all' (ColorGateParams::color_class_bits / _combine)."""
+    c = abi.HaloColorClass()
+    c.bits = sum(1 << int(b) for b in bits)
+    c.combine_all = 1 if combine == "all" else 0
+    return c
 
 
 def simple_filter(term, symmetry="", action="filter_in"):

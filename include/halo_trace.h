@@ -89,7 +89,7 @@ typedef struct HaloEntry {
   float proportion;
   int32_t crystal_config_id;
   int32_t filter_id;  /* 0 = no filter (pass-all); k > 0 = filters[k-1] of the table given to halo_set_filters */
-  int32_t reserved;
+  int32_t color_id;   /* 0 = no raypath-colour predicates; k > 0 = colour set k-1 of the table given to halo_set_color */
 } HaloEntry;
 
 /* Emit-gate filters — FilterConfig (src/config/filter_config.hpp:20-86) as the device matcher consumes it
@@ -116,6 +116,29 @@ typedef struct HaloFilter {
   int32_t and_counts[HALO_FILTER_MAX_OR];
   HaloFilterTerm terms[HALO_FILTER_MAX_TERMS]; /* simple filter: terms[0] */
 } HaloFilter;
+
+/* Raypath colour (reference "Design 2", src/config/color_gate_table.hpp:25-81, cuda_trace_backend.cu:498-556): every
+ * emitted exit carries a 64-bit component mask; a crystal entry's colour set lists predicates (SimpleFilterParam + P/B/D
+ * symmetry) and the mask bit each sets when it matches the exit's raypath / direction / crystal; masks accumulate across
+ * scattering layers (they ride with the continuation).  A colour CLASS is a bit set with an any/all rule; each in-frame
+ * pixel hit of an exit whose mask satisfies class c adds cmf_y*w to lane c (class_count x W x H floats). */
+#define HALO_COLOR_MAX_TERMS 16    /* predicates per crystal entry (ColorGatePlacement) */
+#define HALO_COLOR_MAX_CLASSES 16
+typedef struct HaloColorTerm { /* ColorGateEntry: predicate_, symmetry_, bit_ */
+  HaloFilterTerm predicate;
+  int32_t symmetry; /* HALO_SYM_* bitmask */
+  int32_t bit;      /* 0..63 */
+} HaloColorTerm;
+typedef struct HaloColorSet {
+  int32_t term_count;
+  int32_t reserved;
+  HaloColorTerm terms[HALO_COLOR_MAX_TERMS];
+} HaloColorSet;
+typedef struct HaloColorClass { /* ColorGateParams::color_class_bits / color_class_combine */
+  uint64_t bits;
+  int32_t combine_all; /* 0 = any bit of `bits` set, 1 = all of them */
+  int32_t reserved;
+} HaloColorClass;
 
 typedef struct HaloLayer {
   float prob; /* MsInfo::prob_ — continuation probability to the next layer */
@@ -208,6 +231,7 @@ typedef struct HaloExitRecord {
   int32_t pixel;    /* flat pixel index of the primary hit, -1 = culled / out of frame */
   uint16_t crystal_id;
   uint16_t wl_idx;
+  uint64_t color_mask; /* raypath-colour component mask of the exit (0 without halo_set_color) */
 } HaloExitRecord;
 
 typedef struct HaloBackend* halo_handle_t;
@@ -261,6 +285,12 @@ int halo_end(halo_handle_t h);
 int halo_readback_xyz(halo_handle_t h, float* xyz, int width, int height, float* landed_weight);
 /* Same, but returns landed weight in double and does not add. */
 int halo_readback_xyz64(halo_handle_t h, float* xyz, int width, int height, double* landed_weight);
+/* Raypath colour tables: `sets` is referenced by HaloEntry.color_id (1-based), `classes` defines the Y lanes.
+ * n_sets = n_classes = 0 switches colour off (the default; the production kernels then carry no mask at all). */
+int halo_set_color(halo_handle_t h, const HaloColorSet* sets, int n_sets, const HaloColorClass* classes, int n_classes);
+/* TraceBackend::ReadbackClassLanes — trace_backend.hpp:471-493: copies class_count*W*H floats (lane c at
+ * lanes[c*W*H + py*W + px]) and zeroes the device lanes.  Call after halo_readback_xyz's sync point or halo_sync. */
+int halo_readback_class_lanes(halo_handle_t h, float* lanes, int width, int height, int class_count);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
  * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the

@@ -1291,6 +1291,7 @@ int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* pa
 /* whole path: the backend state machine of include/halo_trace.h on the CPU                  */
 /* ======================================================================================== */
 typedef struct { float n_idx, spd_weight, cmf[3]; } HoWlEntry; /* wl_pool.hpp:29-35 */
+#define HO_CONT_STRIDE 7 /* dx dy dz w wl_idx | colour mask (2 x 32 bit) */
 
 /* Stream nonces — cuda_trace_backend.cu:259-278, pcg_shared.h:119-120 */
 #define NONCE_TRANSIT 0xA5A5A5A5u
@@ -1324,6 +1325,12 @@ struct HoBackend {
   int cont_shuffle;
   HaloFilter* filters;
   int filter_count;
+  HaloColorSet* color_sets;
+  int color_set_count;
+  HaloColorClass color_classes[HALO_COLOR_MAX_CLASSES];
+  int color_class_count;
+  float* lanes; /* class_count x W x H */
+  int lanes_w, lanes_h;
   /* consumer: RenderConsumer::internal_xyz_ / comp_xyz_ / total_intensity_ (server/render.hpp) */
   float* cons_sum;
   float* cons_comp;
@@ -1350,6 +1357,8 @@ void ho_destroy(HoBackend* b) {
   free(b->cons_sum);
   free(b->cons_comp);
   free(b->filters);
+  free(b->color_sets);
+  free(b->lanes);
   free(b);
 }
 int ho_set_option(HoBackend* b, const char* key, int64_t v) {
@@ -1395,6 +1404,29 @@ int ho_set_filters(HoBackend* b, const HaloFilter* filters, int32_t count) {
   return HALO_OK;
 }
 
+int ho_set_color(HoBackend* b, const HaloColorSet* sets, int32_t n_sets, const HaloColorClass* classes, int32_t n_classes) {
+  if (n_classes > HALO_COLOR_MAX_CLASSES) return HALO_FATAL;
+  free(b->color_sets);
+  b->color_sets = NULL;
+  b->color_set_count = n_sets;
+  if (n_sets > 0) {
+    b->color_sets = (HaloColorSet*)malloc((size_t)n_sets * sizeof(HaloColorSet));
+    memcpy(b->color_sets, sets, (size_t)n_sets * sizeof(HaloColorSet));
+  }
+  b->color_class_count = n_classes;
+  if (n_classes > 0) memcpy(b->color_classes, classes, (size_t)n_classes * sizeof(HaloColorClass));
+  return HALO_OK;
+}
+
+/* TraceBackend::ReadbackClassLanes trace_backend.hpp:471-493: copy + zero */
+int ho_readback_class_lanes(HoBackend* b, float* lanes, int width, int height, int class_count) {
+  if (class_count != b->color_class_count || width != b->lanes_w || height != b->lanes_h || !b->lanes) return HALO_FATAL;
+  size_t n = (size_t)class_count * width * height;
+  memcpy(lanes, b->lanes, n * sizeof(float));
+  memset(b->lanes, 0, n * sizeof(float));
+  return HALO_OK;
+}
+
 int ho_begin(HoBackend* b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t hint) {
   (void)hint;
   if (b->in_session) return HALO_FATAL;
@@ -1409,6 +1441,12 @@ int ho_begin(HoBackend* b, const HaloScene* scene, const HaloRender* render, con
     b->acc_h = render->height;
     b->xyz = (float*)calloc((size_t)b->acc_w * b->acc_h * 3, sizeof(float));
     b->landed = 0.0;
+  }
+  if (b->color_class_count > 0 && (!b->lanes || b->lanes_w != render->width || b->lanes_h != render->height)) {
+    free(b->lanes);
+    b->lanes_w = render->width;
+    b->lanes_h = render->height;
+    b->lanes = (float*)calloc((size_t)b->color_class_count * b->lanes_w * b->lanes_h, sizeof(float));
   }
   b->in_session = 1;
   b->layer_idx = 0;
@@ -1449,6 +1487,7 @@ typedef struct {
   int crystal_id;
   const HaloFilter* filter; /* NULL = pass-all */
   const HaloAxis* axis;
+  const HaloColorSet* color; /* NULL = this entry sets no colour bits */
 } HoCiCtx;
 
 typedef struct { /* per-thread output sink */
@@ -1459,7 +1498,7 @@ typedef struct { /* per-thread output sink */
   uint64_t pixel_hits;
 } HoSink;
 
-static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const float exit_world[3], float w, int32_t* primary_pix) {
+static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const float exit_world[3], float w, uint64_t cmask, int32_t* primary_pix) {
   /* EmitToDeviceXyz cuda_trace_backend.cu:433-480 == ScatterOutgoingToXyz scatter_accum.hpp:47-110 */
   HoProjResult r = ho_project_exit_to_pixel(&b->proj, exit_world[0], exit_world[1], exit_world[2]);
   *primary_pix = -1;
@@ -1481,6 +1520,21 @@ static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const f
       dst[1] += a1;
       dst[2] += a2;
 #endif
+      /* FanColorClassLanes cu:535-556: primary AND overlap hits feed every class the mask satisfies */
+      for (int k = 0; k < b->color_class_count; k++) {
+        uint64_t bits = b->color_classes[k].bits;
+        if (bits == 0) continue;
+        uint64_t matched = cmask & bits;
+        int ok = b->color_classes[k].combine_all ? (matched == bits) : (matched != 0);
+        if (ok) {
+          float* lane = b->lanes + (size_t)k * (size_t)b->proj.img_w * (size_t)b->proj.img_h + pix;
+          float yv = wle->cmf[1] * w;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+          *lane += yv;
+        }
+      }
       sink->pixel_hits++;
       if (r.hits[hi].bump_landed) {
         sink->landed += (double)w;
@@ -1495,12 +1549,23 @@ typedef struct { float d[3], p[3], w; int face; int depth; } HoSeg;
 /* Emit gate for one outgoing candidate — CollectData simulator.cpp:665-762 (no filter: pass-all). */
 static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const float rot[9], const HoWlEntry* wle,
                       uint32_t wl_idx, const float d_local[3], float w, uint32_t root, int seq, const uint8_t* path,
-                      int path_len) {
+                      int path_len, uint64_t carried) {
   HoBackend* b = sink->b;
   float exit_world[3];
   ho_apply_mat9(rot, d_local, exit_world);
   /* physical filter: fail = the ray terminates (CollectData simulator.cpp:689,725-728) */
   if (c->filter && !ho_filter_check(c->filter, c->axis, path, path_len, exit_world, c->crystal_id)) return;
+  /* raypath colour, non-destructive, after the physical filter (ApplyLayerColorBits cu:498-527) */
+  uint64_t cmask = carried;
+  if (c->color) {
+    int dap = ho_is_d_applicable(c->axis);
+    int sigma_a = dap ? ho_compute_sigma_a(c->axis->roll.center) : 0;
+    for (int k = 0; k < c->color->term_count; k++) {
+      const HaloColorTerm* ct = &c->color->terms[k];
+      if (ct->bit >= 0 && ct->bit < 64 && filter_match_term(&ct->predicate, ct->symmetry, sigma_a, dap, path, path_len, exit_world, c->crystal_id))
+        cmask |= 1ull << ct->bit;
+    }
+  }
   int pass_prob = 0;
   if (c->prob > 0.0f) pass_prob = (c->prob >= 1.0f) ? 1 : (ho_pcg_uniform(gate) < c->prob); /* rng.GetUniform() < prob_ :719 */
   if (pass_prob) {
@@ -1511,13 +1576,14 @@ static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const floa
 #endif
     slot = b->cont_n++;
     if (slot < b->cont_cap) {
-      float* o = b->cont + slot * 5;
+      float* o = b->cont + slot * HO_CONT_STRIDE;
       o[0] = exit_world[0]; o[1] = exit_world[1]; o[2] = exit_world[2]; o[3] = w; o[4] = (float)wl_idx;
+      memcpy(o + 5, &cmask, 8); /* the colour mask rides with the continuation (cu:922,1129) */
     }
     return;
   }
   int32_t pix = -1;
-  emit_pixel(b, sink, wle, exit_world, w, &pix);
+  emit_pixel(b, sink, wle, exit_world, w, cmask, &pix);
   sink->exit_count++;
   sink->exit_w_sum += (double)w;
   if (b->capture) {
@@ -1539,6 +1605,7 @@ static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const floa
       rec->pixel = pix;
       rec->crystal_id = (uint16_t)c->crystal_id;
       rec->wl_idx = (uint16_t)wl_idx;
+      rec->color_mask = cmask;
     }
   }
 }
@@ -1566,7 +1633,7 @@ static int propagate_slab(const HaloGeomTables* g, const float d[3], const float
  * (TraceRayBasicInfo :585, HitSurface optics.cpp:18-53, CollectData :665). Generic two-children form. */
 static void trace_root(const HoCiCtx* c, HoSink* sink, const HaloGeomTables* g, const float rot[9], float n_idx,
                        const HoWlEntry* wle, uint32_t wl_idx, const float d0[3], const float p0[3], float w0, int face0,
-                       uint32_t root, HoStream* gate) {
+                       uint32_t root, HoStream* gate, uint64_t carried) {
   if (face0 < 0 || face0 >= g->face_cnt) return; /* HitSurface kInvalidId guard optics.cpp:27-32 */
   HoSeg cur[2], nxt[4];
   uint8_t path_cur[2][HALO_MAX_HITS + 2], path_nxt[4][HALO_MAX_HITS + 2];
@@ -1601,7 +1668,7 @@ static void trace_root(const HoCiCtx* c, HoSink* sink, const HaloGeomTables* g, 
         float p_new[3];
         int f_new = propagate_slab(g, dirs[ch], s->p, s->face, p_new);
         if (f_new < 0) { /* outgoing candidate */
-          emit_gate(c, sink, gate, rot, wle, wl_idx, dirs[ch], ws[ch], root, 2 * i + ch, path_cur[k], plen_cur[k]);
+          emit_gate(c, sink, gate, rot, wle, wl_idx, dirs[ch], ws[ch], root, 2 * i + ch, path_cur[k], plen_cur[k], carried);
         } else if (n_nxt < 4) {
           HoSeg* o = &nxt[n_nxt];
           memcpy(o->d, dirs[ch], 12);
@@ -1643,6 +1710,7 @@ static void run_ray(const HoCiCtx* c, HoSink* sink, uint32_t tid) {
   float rot[9], d_crystal[3], p[3], w;
   int face;
   uint32_t wl_idx = 0;
+  uint64_t carried = 0; /* colour mask inherited from earlier scattering layers */
   const HaloGeomTables* g = &c->shapes[(c->shape_cnt > 1) ? (tid / c->geom_clock) : 0];
   HoStream gate;
   {
@@ -1681,7 +1749,8 @@ static void run_ray(const HoCiCtx* c, HoSink* sink, uint32_t tid) {
     uint32_t mixed = ho_pcg_seed_with_high(c->transit_seed, ho_pcg_advance_hi(lo, hi, tid));
     uint64_t pos = c->ci_start + tid;
     uint64_t src = c->shuffle ? ho_feistel_bijection((uint32_t)pos, (uint32_t)c->cont_in_n, c->shuffle_seed) : pos;
-    const float* in = c->cont_in + src * 5;
+    const float* in = c->cont_in + src * HO_CONT_STRIDE;
+    memcpy(&carried, in + 5, 8);
     HoStream s = {mixed, gidx, 0};
     float lon, lat, roll;
     ho_sample_lat_lon_roll(&s, &c->gp, c->lut_theta, c->lut_cdf, c->lut_flip, &lon, &lat, &roll);
@@ -1693,7 +1762,7 @@ static void run_ray(const HoCiCtx* c, HoSink* sink, uint32_t tid) {
     if (face < 0) w = 0.0f;
   }
   const HoWlEntry* wle = &b->pool[wl_idx];
-  trace_root(c, sink, g, rot, wle->n_idx, wle, wl_idx, d_crystal, p, w, face, (uint32_t)(c->ci_start + tid), &gate);
+  trace_root(c, sink, g, rot, wle->n_idx, wle, wl_idx, d_crystal, p, w, face, (uint32_t)(c->ci_start + tid), &gate, carried);
 }
 
 /* shape scalars: SamplePrismShapeScalars simulator.cpp:405-412 + SyncGroupSampler :361-393, host PCG stream */
@@ -1751,7 +1820,7 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     uint64_t need = n * (uint64_t)b->scene.max_hits;
     if (need > b->cont_cap) {
       free(b->cont);
-      b->cont = (float*)malloc((size_t)(need ? need : 1) * 5 * sizeof(float));
+      b->cont = (float*)malloc((size_t)(need ? need : 1) * HO_CONT_STRIDE * sizeof(float));
       b->cont_cap = need;
     }
   }
@@ -1787,6 +1856,7 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     c->max_hits = b->scene.max_hits;
     c->crystal_id = E->crystal_config_id;
     c->filter = (E->filter_id > 0 && E->filter_id <= b->filter_count) ? &b->filters[E->filter_id - 1] : NULL;
+    c->color = (b->color_class_count > 0 && E->color_id > 0 && E->color_id <= b->color_set_count) ? &b->color_sets[E->color_id - 1] : NULL;
     c->axis = &E->axis;
     /* BuildTransitGpParams / BuildGenGpParams cuda_trace_backend.cu:342-399 */
     c->gp.lat_path = ho_select_lat_path(&E->axis);
@@ -1885,7 +1955,8 @@ int ho_recombine(HoBackend* b, int shuffle, uint64_t* continuation_count) {
 
 uint64_t ho_continuation_dump(HoBackend* b, float* out5, uint64_t cap) {
   uint64_t n = b->cont_n < cap ? b->cont_n : cap;
-  if (out5 && b->cont) memcpy(out5, b->cont, (size_t)n * 5 * sizeof(float));
+  if (out5 && b->cont)
+    for (uint64_t i = 0; i < n; i++) memcpy(out5 + i * 5, b->cont + i * HO_CONT_STRIDE, 5 * sizeof(float));
   return b->cont_n;
 }
 

@@ -112,6 +112,8 @@ int ho_compute_sigma_a(float roll_mean_deg);
 int ho_is_d_applicable(const HaloAxis* axis);
 int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id);
 int ho_set_filters(HoBackend* b, const HaloFilter* filters, int32_t count);
+int ho_set_color(HoBackend* b, const HaloColorSet* sets, int32_t n_sets, const HaloColorClass* classes, int32_t n_classes);
+int ho_readback_class_lanes(HoBackend* b, float* lanes, int width, int height, int class_count);
 /* consumer (server/render.cpp:96-201,465-578; util/color_space.cpp) */
 void ho_neumaier_add(float* sum, float* comp, float delta);
 void ho_gamut_clip_xyz(const float xyz[3], float clipped[3]);

@@ -107,6 +107,8 @@ def oracle():
     L.ho_filter_check.restype = C.c_int
     L.ho_filter_check.argtypes = [C.POINTER(abi.HaloFilter), C.POINTER(abi.HaloAxis), u8p, C.c_int, f32p, C.c_int]
     L.ho_set_filters.restype = C.c_int; L.ho_set_filters.argtypes = [C.c_void_p, C.POINTER(abi.HaloFilter), C.c_int32]
+    L.ho_set_color.restype = C.c_int; L.ho_set_color.argtypes = [C.c_void_p, C.POINTER(abi.HaloColorSet), C.c_int32, C.POINTER(abi.HaloColorClass), C.c_int32]
+    L.ho_readback_class_lanes.restype = C.c_int; L.ho_readback_class_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]
     L.ho_neumaier_add.restype = None; L.ho_neumaier_add.argtypes = [f32p, f32p, C.c_float]
     L.ho_gamut_clip_xyz.restype = None; L.ho_gamut_clip_xyz.argtypes = [f32p, f32p]
     L.ho_xyz_to_linear_rgb.restype = None; L.ho_xyz_to_linear_rgb.argtypes = [f32p, f32p]

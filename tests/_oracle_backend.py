@@ -35,6 +35,19 @@ class OracleBackend:
         arr = (abi.HaloFilter * max(1, len(filters)))(*filters)
         assert self._L.ho_set_filters(self._h, arr, len(filters)) == 0
 
+    def set_color(self, sets, classes):
+        sa = (abi.HaloColorSet * max(1, len(sets)))(*sets)
+        ca = (abi.HaloColorClass * max(1, len(classes)))(*classes)
+        assert self._L.ho_set_color(self._h, sa, len(sets), ca, len(classes)) == 0
+        self._n_classes = len(classes)
+
+    def ReadbackClassLanes(self):
+        w, h, n = self._render.width, self._render.height, getattr(self, "_n_classes", 0)
+        out = np.zeros((n, h, w), np.float32)
+        if n:
+            assert self._L.ho_readback_class_lanes(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), w, h, n) == 0
+        return out
+
     def BeginSession(self, scene, render, wl, ray_num=0):
         self._render, self._scene = render, scene
         assert self._L.ho_begin(self._h, C.byref(scene), C.byref(render), C.byref(wl), int(ray_num)) == 0
