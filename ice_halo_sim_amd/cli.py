@@ -29,6 +29,8 @@ def run_job(job, render_id=None, seed=42, device=0, max_rays=None, progress=None
     if job.geom_clock:
         be.set_option("geom_clock", job.geom_clock)
     be.set_filters(job.filters)
+    if job.color_classes:
+        be.set_color(job.color_sets, job.color_classes)
     total = job.ray_num if job.ray_num is not None else (max_rays or 0)
     if max_rays is not None:
         total = min(total, max_rays)

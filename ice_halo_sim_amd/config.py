@@ -239,6 +239,7 @@ class TraceJob:
         self.ray_num = 0           # total root rays requested (None = "infinite")
         self.geom_clock = None
         self.filters = []          # HaloFilter table; HaloEntry.filter_id is a 1-based index into it
+        self.color_sets, self.color_classes, self.color_meta, self.color_mode = [], [], [], "painter"   # raypath_color
 
     def per_wavelength_ray_num(self):
         """ceil(ray_num / N_wl) — server/ray_num_semantics.hpp:13-17."""
@@ -315,5 +316,62 @@ def load_config(source):
     job.scene = scenes.scene(layers, max_hits=max_hits, sun_altitude=float(ls["altitude"]),
                              sun_azimuth=float(ls.get("azimuth", 0.0)), sun_diameter=float(ls.get("diameter", 0.0)))
     if "raypath_color" in doc and doc["raypath_color"]:
-        raise UnsupportedConfig("raypath_color classes are not implemented by this backend")
+        parse_raypath_color(doc["raypath_color"], layers, job)
     return job
+
+
+def parse_raypath_color(jrc, layers, job):
+    """raypath_color → the backend's colour sets + classes.  Restates from_json(RaypathColorConfig)
+    (raypath_color_config.cpp:84-101), BuildColorGateTable (color_gate_table.cpp:57-103: one bit per unique
+    (layer, crystal_id, predicate, symmetry) in class/match order, placement must be unambiguous) and BuildColorClassTable
+    (color_class_table.cpp:34-87: class bits = OR of its refs' bits, combine any|all).  Class colours / visibility / the
+    composite mode are display-side and kept on the job for a compositor."""
+    jclasses = jrc["classes"] if isinstance(jrc, dict) else jrc
+    job.color_mode = jrc.get("mode", "painter") if isinstance(jrc, dict) else "painter"
+    gate = []          # [(layer, crystal_id, key, term, symmetry, bit)]
+    job.color_meta = []
+    classes = []
+    for jc in jclasses:
+        combine = jc.get("combine", "any")
+        if combine not in ("any", "all"):
+            raise ConfigError('raypath_color: unknown combine "%s" (expected "any" or "all")' % combine)
+        bits = []
+        for ref in jc["match"]:
+            layer, cid = int(ref["layer"]), int(ref["crystal"])
+            if layer >= len(layers):
+                raise ConfigError("raypath_color: layer index out of range (layer=%d, crystal_id=%d)" % (layer, cid))
+            n_match = sum(1 for e in layers[layer][1] if e.crystal_config_id == cid)
+            if n_match == 0:
+                raise ConfigError("raypath_color: no scattering setting with crystal_id %d on layer %d" % (cid, layer))
+            if n_match >= 2:
+                raise ConfigError("raypath_color: crystal_id %d matches %d scattering settings on layer %d" % (cid, n_match, layer))
+            pred = {k: v for k, v in ref.items() if k not in ("layer", "crystal", "symmetry")}
+            sym = "".join(sorted(ref.get("symmetry", "")))
+            key = (layer, cid, json.dumps(pred, sort_keys=True), sym)
+            found = next((g for g in gate if g[:2] + (g[2],) + (g[4],) == key[:3] + (sym,)), None)
+            if found is None:
+                bit = len(gate) if len(gate) < 64 else None      # ComponentTable::kMaxBits; overflow = kNoBit
+                found = (layer, cid, key[2], _parse_simple_filter(pred), sym, bit)
+                gate.append(found)
+            if found[5] is not None:
+                bits.append(found[5])
+        classes.append(scenes.color_class(bits, combine))
+        job.color_meta.append({"color": [float(v) for v in jc["color"]], "visible": bool(jc.get("visible", True)),
+                               "solo": bool(jc.get("solo", False))})
+    if len(classes) > abi.COLOR_MAX_CLASSES:
+        raise UnsupportedConfig("more raypath_color classes than the backend's cap")
+    job.color_classes = classes
+    job.color_sets = []
+    for li, (_, entries) in enumerate(layers):
+        for e in entries:
+            terms = [(g[3], g[4], g[5]) for g in gate if g[0] == li and g[1] == e.crystal_config_id and g[5] is not None]
+            if not terms:
+                continue
+            if len(terms) > abi.COLOR_MAX_TERMS:
+                raise UnsupportedConfig("more raypath_color predicates on one placement than the backend's cap")
+            job.color_sets.append(scenes.color_set(terms))
+            e.color_id = len(job.color_sets)
+    # entries were copied into the scene struct before this pass: write the ids through
+    for li, (_, entries) in enumerate(layers):
+        for ei, e in enumerate(entries):
+            job.scene.layers[li].entries[ei].color_id = e.color_id

@@ -103,7 +103,9 @@ def color_set(terms):
 def color_class(bits, combine="any"):
     """bits: iterable of bit numbers; combine 'any' | 'all' (ColorGateParams::color_class_bits / _combine)."""
     c = abi.HaloColorClass()
-    c.bits = sum(1 << int(b) for b in bits)
+    c.bits = 0
+    for b in bits:
+        c.bits |= 1 << int(b)
     c.combine_all = 1 if combine == "all" else 0
     return c
 

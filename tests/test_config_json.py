@@ -94,8 +94,8 @@ def test_illuminant_and_rejections():
     with pytest.raises(config.ConfigError, match="max_hits"):
         config.load_config(bad)
     rc = copy.deepcopy(DOC)
-    rc["raypath_color"] = [{"name": "x"}]
-    with pytest.raises(config.UnsupportedConfig):
+    rc["raypath_color"] = [{"color": [1, 0, 0], "match": [{"layer": 0, "crystal": 99}]}]
+    with pytest.raises(config.ConfigError, match="no scattering setting with crystal_id 99"):
         config.load_config(rc)
 
 
@@ -148,3 +148,48 @@ def test_cli_benchmark_line(tmp_path):
     rec = json.loads(line[len("[BENCHMARK] "):])
     assert rec["rays"] == 9_000_000 and rec["rays_per_sec"] > 1e7 and rec["rate_basis"] in ("steady", "active_short")
     assert (tmp_path / "o.ppm").stat().st_size > 1920 * 1080 * 3
+
+
+def test_raypath_color_maps_onto_color_sets_and_classes():
+    """raypath_color (doc shape of test/e2e/configs/raypath_color_multi_layer.json): bits are assigned per unique
+    (layer, crystal, predicate, symmetry) in class/match order; class bits OR their refs; placements must be unambiguous."""
+    import json
+    doc = copy.deepcopy(DOC)
+    doc.pop("filter")
+    doc["crystal"] = [{"id": i, "type": "prism", "shape": {"height": 1.0 + 0.1 * i}} for i in (1, 2, 3, 4, 5)]
+    doc["scene"]["scattering"] = [{"prob": 0.9, "entries": [{"crystal": 1, "proportion": 30}, {"crystal": 4, "proportion": 10}, {"crystal": 5, "proportion": 10}]},
+                                  {"prob": 0.0, "entries": [{"crystal": 2, "proportion": 10}, {"crystal": 3, "proportion": 10}]}]
+    doc["raypath_color"] = {"mode": "dominant", "classes": [
+        {"color": [1.0, 0.0, 1.0], "combine": "all", "match": [{"layer": 0, "crystal": 1}, {"layer": 1, "crystal": 2}]},
+        {"color": [1.0, 0.55, 0.0], "match": [{"layer": 1, "crystal": 3}]},
+        {"color": [1.0, 0.0, 0.0], "match": [{"layer": 0, "crystal": 4}]},
+        {"color": [0.0, 1.0, 0.0], "combine": "any", "match": [{"layer": 0, "crystal": 5, "type": "entry_exit", "min_len": 2, "max_len": 2},
+                                                                 {"layer": 0, "crystal": 5, "type": "entry_exit", "min_len": 3},
+                                                                 {"layer": 0, "crystal": 5, "type": "entry_exit", "min_len": 2, "max_len": 2}]},
+        {"color": [0.0, 0.0, 1.0], "match": [{"layer": 0, "crystal": 1, "type": "raypath", "raypath": [3, 5], "symmetry": "PBD"},
+                                             {"layer": 0, "crystal": 1}]}]}
+    job = config.load_config(doc)
+    assert job.color_mode == "dominant" and len(job.color_classes) == 5 and len(job.color_sets) == 5
+    bits = [c.bits for c in job.color_classes]
+    assert bits == [0b11, 0b100, 0b1000, 0b110000, 0b1000001]           # duplicate refs reuse their bit; new predicate gets bit 6
+    assert [c.combine_all for c in job.color_classes] == [1, 0, 0, 0, 0]
+    ids = [[e.color_id for e in job.scene.layers[l].entries[:job.scene.layers[l].entry_count]] for l in (0, 1)]
+    assert ids == [[1, 2, 3], [4, 5]]
+    s1 = job.color_sets[0]                                               # crystal 1 on layer 0: the `none` predicate and the symmetric raypath
+    assert s1.term_count == 2 and [s1.terms[k].bit for k in range(2)] == [0, 6]
+    assert s1.terms[0].predicate.type == abi.FILTER_NONE and s1.terms[1].predicate.type == abi.FILTER_RAYPATH and s1.terms[1].symmetry == 7
+    s5 = job.color_sets[2]
+    assert s5.term_count == 2 and s5.terms[0].predicate.max_len == 2 and s5.terms[1].predicate.min_len == 3
+    # ambiguity and range errors follow the reference's messages
+    bad = json.loads(json.dumps(doc))
+    bad["scene"]["scattering"][0]["entries"].append({"crystal": 1, "proportion": 1})
+    with pytest.raises(config.ConfigError, match="matches 2 scattering settings"):
+        config.load_config(bad)
+    bad = json.loads(json.dumps(doc))
+    bad["raypath_color"]["classes"][0]["match"][0]["layer"] = 7
+    with pytest.raises(config.ConfigError, match="layer index out of range"):
+        config.load_config(bad)
+    bad = json.loads(json.dumps(doc))
+    bad["raypath_color"]["classes"][1]["combine"] = "xor"
+    with pytest.raises(config.ConfigError, match="unknown combine"):
+        config.load_config(bad)
