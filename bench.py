@@ -103,10 +103,17 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
+    # HALO_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box); default RCCL
+    dist_backend = os.environ.get("HALO_BENCH_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=dist_backend)
 
     from ice_halo_sim_amd import scenes
     from ice_halo_sim_amd.backend import HipTraceBackend

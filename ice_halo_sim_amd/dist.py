@@ -24,9 +24,13 @@ def reduce_accumulators(acc, landed, group=None, dst=0):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return acc, landed
     rank = dist.get_rank(group)
-    dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     lt = torch.tensor([landed], dtype=torch.float64, device=acc.device)
-    dist.reduce(lt, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if acc.is_cuda and dist.get_backend(group) == "gloo":   # gloo reduces CUDA tensors only as all_reduce
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce(lt, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if rank != dst:
         acc.zero_()
         return acc, 0.0
