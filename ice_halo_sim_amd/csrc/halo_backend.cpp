@@ -492,7 +492,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     return m;
   };
   auto blocks_of = [&](uint64_t m) {
-    return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, static_cast<uint64_t>(max_blocks)));
+    // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch: below 8 Mi rays half as many
+    // persistent workgroups (4 per CU) finish sooner — measured 0.27 -> 0.20 ms at 1 M rays, equal from 16 M up
+    const uint64_t cap = (m < (8ull << 20) && b->blocks_per_cu > 4) ? static_cast<uint64_t>(b->cu_count) * 4u : static_cast<uint64_t>(max_blocks);
+    return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, cap));
   };
 
   // continuation output pool: kContShards regions; a region must hold everything its blocks can emit over the layer's
