@@ -644,7 +644,6 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
 template <bool MONO>
 struct LdsTables {
   float lut[3 * kLutNodes];
-  WlEntryDev wl[HALO_WL_POOL_MAX];
   PixCache<MONO> cache;
   uint32_t seg[kContShards + 4];
 };
@@ -839,7 +838,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     float dwz = P.s_lat * x + P.c_lat * z;
     apply_inverse(R, dwx, dwy, dwz, d);
     face = sample_entry(s, sh, sh->tri_cnt, d, p);
-    w = T.wl[wl_idx].spd_weight;
+    w = (P.wl_pool_size == 1u) ? P.wl_pool[0].spd_weight : P.wl_pool[wl_idx].spd_weight;
   } else if (P.source == kSrcTransit) {
     Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
     const uint32_t pos = P.ci_start + tid;
@@ -874,9 +873,14 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
   }
   if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
 
-  const float n_idx = T.wl[wl_idx].n_idx;
+  // the wavelength pool (<= 8 KB) is read where it lies: one entry for a discrete session (a scalar load), a couple of
+  // L1-resident reads per ray otherwise — staging it cost every workgroup 8 KB of LDS
+  WlEntryDev wle;
+  if (P.wl_pool_size == 1u) wle = P.wl_pool[0];   // uniform address: one scalar load per ray pass
+  else wle = P.wl_pool[wl_idx];
+  const float n_idx = wle.n_idx;
   const float inv_n = 1.0f / n_idx;  // once per ray, IEEE like the reference
-  const float cmf_x = T.wl[wl_idx].cmf_x, cmf_y = T.wl[wl_idx].cmf_y, cmf_z = T.wl[wl_idx].cmf_z;
+  const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
 
   uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
   uint32_t path_len = 0u;
@@ -1050,12 +1054,6 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
   // ---- stage the dispatch-constant tables into LDS ----
   if (P.lat_path == kLatLut)
     for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
-  {
-    const uint32_t n4 = P.wl_pool_size * (sizeof(WlEntryDev) / 16u);
-    const float4* src = reinterpret_cast<const float4*>(P.wl_pool);
-    float4* dst = reinterpret_cast<float4*>(T.wl);
-    for (uint32_t i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
-  }
   if (P.source == kSrcTransit)
     for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
   if constexpr (!POOL) {
