@@ -7,9 +7,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhalo_hip.so")
-SOURCES = ["halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp", "halo_host.cpp"]
+SOURCES = ["halo_trace_m0.hip", "halo_trace_m1.hip", "halo_trace_m2.hip", "halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp",
+           "halo_host.cpp"]
 NO_CONTRACT = {"halo_shapegen.hip"}   # geometry shared with the host: same rounding on both sides
-HEADERS = ["halo_device.h", "halo_geom.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]
+HEADERS = ["halo_device.h", "halo_trace.inl", "halo_geom.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]
 
 
 def hipcc():
@@ -30,11 +31,11 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cc = hipcc()
-    objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     common = ["-std=c++17", "-fPIC", "-I", os.path.join(HERE, "..", "include")]
-    for src in SOURCES:
+
+    def compile_one(src):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
@@ -48,13 +49,21 @@ def build(force=False, verbose=False):
             cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if src.endswith(".hip") and r.returncode == 0:
+            with open(os.path.join(bdir, "resource_usage_%s.txt" % src.split(".")[0]), "w") as f:
+                f.write(r.stderr)
+        return src, obj, r
+
+    # the translation units are independent: compile them side by side (the three halo_trace_m*.hip dominate)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    objs = []
+    for src, obj, r in results:
         if verbose or r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on " + src)
-        if src.endswith(".hip"):
-            with open(os.path.join(bdir, "resource_usage_%s.txt" % src.split(".")[0]), "w") as f:
-                f.write(r.stderr)
         objs.append(obj)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,1159 +1,9 @@
-// halo_kernels.hip — gfx950 (CDNA4 / MI355X) kernels of the ice-halo trace hot path.
-//
-// One fused kernel per (scattering layer, crystal entry) dispatch:
-//     root generation | layer hop  →  entry Fresnel  →  ≤ max_hits-1 interior interactions
-//     →  emit gate  →  lens projection  →  CIE-XYZ accumulation  |  continuation append
-// Ray state lives in VGPRs for its whole life; the crystal plane/fan tables, the latitude LUT and the
-// wavelength pool are staged once per workgroup into LDS and read back as wave-wide broadcasts
-// (ds_read_b128, conflict-free); HBM sees only the accumulator atomics and — for multi-scatter layers —
-// the 20-byte SoA continuation record, appended with wave64 ballot compaction (one atomic per wave per
-// emit site) and gathered by the next layer through the Feistel permutation, so neither the reference's
-// 80 B/ray root buffers nor its separate gen / transit / shuffle kernels exist here.
-//
-// What each block restates (reference /root/reference, file:line):
-//   PCG streams, orientation, sun cone, entry pick   src/core/shared/pcg_shared.h:193-624,
-//                                                     cuda_trace_backend.cu:1417-1616 (gen), :1220-1403 (transit)
-//   Fresnel split / refraction                        src/core/optics.cpp:18-53, shared/optics_shared.h:17-24
-//   convex slab traversal                             src/core/optics.cpp:64-158, shared/traversal_shared.h:61-71
-//   hit loop + emit gate (legacy semantics)           src/core/simulator.cpp:585-762, 1308-1336
-//   projection (11 lenses)                            src/core/shared/projection_shared.h:42-375
-//   XYZ accumulation + landed weight                  shared/accum_shared.h:40-47, cuda_trace_backend.cu:433-480
-//   continuation permutation                          pcg_shared.h:550-603, cuda_trace_backend.cu:1633-1657
-#include <hip/hip_runtime.h>
-
-#include "halo_device.h"
+// halo_kernels.hip — the kernels around the trace kernel (binned-accumulation pass, plane fold, device consumer) and
+// the launch dispatcher.  The trace kernel itself is a template in halo_trace.inl, instantiated per MODE in
+// halo_trace_m{0,1,2}.hip.
+#include "halo_trace.inl"
 
 namespace halo {
-
-#define HD __device__ __forceinline__
-
-constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
-constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
-constexpr float kSlabEps = 1e-5f;                 // traversal_shared.h:46
-
-// Separately-rounded multiply / add that the compiler cannot re-fuse into an FMA (the backend fuses any
-// fmul+fadd pair under -ffp-contract=fast, whatever the source says).  Used only where the reference's formula
-// cancels catastrophically and a fused product would move the result by orders of magnitude more than an ulp.
-HD float mul_rn(float a, float b) {
-  float r;
-  asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-HD float add_rn(float a, float b) {
-  float r;
-  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the inner-loop quotients whose last bit does
-// not steer a discrete decision; IEEE division costs ~10 VALU ops here and the loop had nine of them per hit.
-HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-// sin and cos together for |x| below a few turns (every angle on this path is): two-term Cody-Waite reduction by
-// pi/2 with FMAs, then the classic degree-7 / degree-8 minimax kernels on [-pi/4, pi/4].  ~1 ulp; replaces the
-// library sincosf whose general-argument reduction dominated root generation.
-HD void sincos_small(float x, float* sn, float* cs) {
-  const float k = rintf(x * 0.6366197466850281f);
-  float r = fmaf(k, -1.5707963705062866f, x);
-  r = fmaf(k, 4.371138828673793e-08f, r);
-  const int q = static_cast<int>(k);
-  const float z = r * r;
-  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
-                        fmaf(-0.5f, z, 1.0f));
-  const bool swap = (q & 1) != 0;
-  float so = swap ? cp : sp;
-  float co = swap ? sp : cp;
-  so = (q & 2) ? -so : so;
-  co = ((q + 1) & 2) ? -co : co;
-  *sn = so;
-  *cs = co;
-}
-
-// ------------------------------------------------------------------------------------------------
-// counter-based RNG (pcg_shared.h:193-274)
-// ------------------------------------------------------------------------------------------------
-HD uint32_t pcg_hash(uint32_t x) {
-  x = x * 747796405u + 2891336453u;
-  x = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
-  return (x >> 22u) ^ x;
-}
-
-struct Stream {
-  uint32_t seed;
-  uint32_t key;   // global_idx * 1000003u, hoisted
-  uint32_t slot;
-};
-
-HD Stream make_stream(uint32_t seed, uint32_t lo, uint32_t hi, uint32_t tid) {
-  // pcg_advance_hi + pcg_seed_with_high (pcg_shared.h:257-268): the 64-bit ray index = hi:lo + tid
-  uint32_t g = lo + tid;
-  uint32_t h = hi + ((g < lo) ? 1u : 0u);
-  Stream s;
-  s.seed = (h == 0u) ? seed : (seed ^ pcg_hash(h));
-  s.key = g * 1000003u;
-  s.slot = 0u;
-  return s;
-}
-
-HD float uniform(Stream& s) {
-  uint32_t h = pcg_hash(s.seed ^ pcg_hash(s.key + s.slot));
-  s.slot++;
-  return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
-}
-
-HD float gaussian(Stream& s) {  // Box-Muller, pcg_shared.h:277-281
-  float u1 = fmaxf(uniform(s), 1e-7f);
-  float u2 = uniform(s);
-  return sqrtf(-2.0f * logf(u1)) * cosf(2.0f * kPiF * u2);
-}
-
-HD float get_dist(Stream& s, uint32_t dtype, float mean, float spread) {  // pcg_shared.h:290-308
-  if (dtype == HALO_DIST_NONE) return mean;
-  if (dtype == HALO_DIST_UNIFORM) return (uniform(s) - 0.5f) * spread + mean;
-  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return gaussian(s) * spread + mean;
-  if (dtype == HALO_DIST_ZIGZAG) return fabsf(spread * sinf(uniform(s) * 2.0f * kPiF) + mean);
-  float u = uniform(s);
-  float sgn = (u < 0.5f) ? -1.0f : 1.0f;
-  float arg = fmaxf(1.0f - 2.0f * fabsf(u - 0.5f), 1e-30f);
-  return mean - spread * sgn * logf(arg);
-}
-
-// 4-round balanced Feistel + cycle walk on [0, n)  (pcg_shared.h:550-603)
-HD uint32_t feistel_bijection(uint32_t i, uint32_t n, uint32_t seed) {
-  if (n <= 1u) return i;
-  if (n == 2u) return i ^ 1u;
-  uint32_t bits = 32u - __clz(n - 1u);  // smallest b with 2^b >= n (n >= 3)
-  if (bits > 30u) bits = 30u;
-  if (bits & 1u) bits++;
-  const uint32_t half_bits = bits >> 1u;
-  const uint32_t hm = (1u << half_bits) - 1u;
-  uint32_t cur = i;
-  for (uint32_t guard = 0u; guard < 64u; guard++) {
-    uint32_t L = (cur >> half_bits) & hm;
-    uint32_t R = cur & hm;
-    const uint32_t rc[4] = {0x9E3779B9u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t f = pcg_hash(seed ^ R ^ rc[k]) & hm;
-      uint32_t nr = L ^ f;
-      L = R;
-      R = nr;
-    }
-    uint32_t out = (L << half_bits) | R;
-    if (out < n) return out;
-    cur = out;
-  }
-  return cur % n;
-}
-
-// ------------------------------------------------------------------------------------------------
-// orientation (pcg_shared.h:311-483)
-// ------------------------------------------------------------------------------------------------
-HD void normalize_latitude(float phi, float& phi_out, bool& flip) {
-  float theta = kPi2F - phi;
-  theta = fmodf(theta, 2.0f * kPiF);
-  if (theta < 0.0f) theta += 2.0f * kPiF;
-  flip = theta > kPiF;
-  if (flip) theta = 2.0f * kPiF - theta;
-  phi_out = kPi2F - theta;
-}
-
-// LUT in LDS: [0..256] theta, [257..513] cdf, [514..770] flip
-HD float invert_lat_lut(float xi, const float* lut) {
-  const float* th = lut;
-  const float* cdf = lut + kLutNodes;
-  xi = fminf(fmaxf(xi, cdf[0]), cdf[kLutNodes - 1]);
-  uint32_t lo = 0u, hi = kLutNodes - 1u;
-#pragma unroll
-  for (int it = 0; it < 8; it++) {  // 256 intervals → exactly 8 halvings, wave-uniform trip count
-    uint32_t mid = (lo + hi) >> 1u;
-    bool le = cdf[mid] <= xi;
-    lo = le ? mid : lo;
-    hi = le ? hi : mid;
-  }
-  float c0 = cdf[lo], c1 = cdf[lo + 1u];
-  float denom = c1 - c0;
-  float w = denom > 0.0f ? (xi - c0) * fast_rcp(denom) : 0.0f;
-  return th[lo] + w * (th[lo + 1u] - th[lo]);
-}
-
-HD uint32_t lat_lut_bin(float theta, const float* lut) {
-  float span = lut[kLutNodes - 1] - lut[0];
-  float t = span > 0.0f ? (theta - lut[0]) / span : 0.0f;
-  int idx = static_cast<int>(t * static_cast<float>(kLutNodes - 1));
-  idx = idx < 0 ? 0 : idx;
-  idx = idx > kLutNodes - 2 ? kLutNodes - 2 : idx;
-  return static_cast<uint32_t>(idx);
-}
-
-HD void sample_lat_lon_roll(Stream& s, const DispatchParams& P, const float* lut, float& lon, float& lat, float& roll) {
-  float phi = 0.0f;
-  bool flip = false;
-  lon = 0.0f;
-  if (P.lat_path == kLatFullSphere) {
-    float u = uniform(s) * 2.0f - 1.0f;
-    u = fminf(fmaxf(u, -1.0f), 1.0f);
-    phi = asinf(u);
-    lon = uniform(s) * 2.0f * kPiF;
-  } else if (P.lat_path == kLatNoRandom) {
-    phi = P.lat_mean_rad;
-  } else if (P.lat_path == kLatGaussLegacy) {
-    float raw = get_dist(s, HALO_DIST_GAUSS_LEGACY, P.lat_mean_rad, P.lat_std_rad);
-    normalize_latitude(raw, phi, flip);
-  } else {  // kLatLut
-    float xi = uniform(s);
-    float colat = invert_lat_lut(xi, lut);
-    phi = kPi2F - colat;
-    uint32_t bin = lat_lut_bin(colat, lut);
-    flip = uniform(s) < lut[2 * kLutNodes + bin];
-  }
-  if (P.lat_path != kLatFullSphere) lon = get_dist(s, P.az_type, P.az_mean_rad, P.az_std_rad);
-  roll = get_dist(s, P.roll_type, P.roll_mean_rad, P.roll_std_rad);
-  if (flip) {
-    lon += kPiF;
-    roll += kPiF;
-  }
-  lat = phi;
-}
-
-// R = Rz(lon - pi) * Ry(lat - pi/2) * Rz(roll), row-major (pcg_shared.h:441-483).  Evaluated in the sparse
-// form the dense axis-angle / 3x3 chain reduces to; `k = (1 - c) + c` keeps the reference's diagonal term.
-HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
-  float s1, c1, s2, c2, s3, c3;
-  sincos_small(roll, &s1, &c1);
-  sincos_small(lat - kPi2F, &s2, &c2);
-  sincos_small(lon - kPiF, &s3, &c3);
-  float k1 = (1.0f - c1) + c1, k2 = (1.0f - c2) + c2, k3 = (1.0f - c3) + c3;
-  // t = Ry * Rz(roll)
-  float t00 = c2 * c1, t01 = c2 * (-s1), t02 = s2 * k1;
-  float t10 = k2 * s1, t11 = k2 * c1;  // t12 = 0
-  float t20 = (-s2) * c1, t21 = (-s2) * (-s1), t22 = c2 * k1;
-  R[0] = c3 * t00 + (-s3) * t10;
-  R[1] = c3 * t01 + (-s3) * t11;
-  R[2] = c3 * t02;
-  R[3] = s3 * t00 + c3 * t10;
-  R[4] = s3 * t01 + c3 * t11;
-  R[5] = s3 * t02;
-  R[6] = k3 * t20;
-  R[7] = k3 * t21;
-  R[8] = k3 * t22;
-}
-
-HD void apply_inverse(const float* R, float x, float y, float z, float* o) {  // o = R^T v
-  o[0] = R[0] * x + R[3] * y + R[6] * z;
-  o[1] = R[1] * x + R[4] * y + R[7] * z;
-  o[2] = R[2] * x + R[5] * y + R[8] * z;
-}
-
-// ------------------------------------------------------------------------------------------------
-// projection (projection_shared.h:42-375); proj_type is dispatch-uniform → scalar branches
-// ------------------------------------------------------------------------------------------------
-struct XY {
-  float x, y;
-  bool valid;
-};
-
-HD XY fisheye_equal_area(float dx, float dy, float dz, float rs) {
-  float k = rs / sqrtf(1.0f + fminf(fmaxf(dz, -1.0f + 1e-6f), 1.0f));
-  return {k * dx, k * dy, true};
-}
-HD XY fisheye_equidistant(float dx, float dy, float dz, float rs) {
-  float rho = sqrtf(dx * dx + dy * dy);
-  if (rho < 1e-10f) return {0.0f, 0.0f, true};
-  float theta = acosf(fminf(fmaxf(dz, -1.0f), 1.0f));
-  float sc = rs * theta / (kPi2F * rho);
-  return {sc * dx, sc * dy, true};
-}
-HD XY fisheye_stereographic(float dx, float dy, float dz, float rs) {
-  float rho = sqrtf(dx * dx + dy * dy);
-  if (rho < 1e-10f) return {0.0f, 0.0f, true};
-  float theta = acosf(fminf(fmaxf(dz, -1.0f), 1.0f));
-  float sc = rs * tanf(theta / 2.0f) / rho;
-  return {sc * dx, sc * dy, true};
-}
-HD XY fisheye_orthographic(float dx, float dy, float dz, float rs) {
-  if (dz < 0.0f) return {0.0f, 0.0f, false};
-  return {rs * dx, rs * dy, true};
-}
-HD XY dual_forward(int t, float sx, float sy, float z, float rs) {
-  if (t == HALO_LENS_DUAL_FISHEYE_EQUAL_AREA) return fisheye_equal_area(sx, sy, z, rs);
-  if (t == HALO_LENS_DUAL_FISHEYE_EQUIDISTANT) return fisheye_equidistant(sx, sy, z, rs);
-  if (t == HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC) return fisheye_stereographic(sx, sy, z, rs);
-  return fisheye_orthographic(sx, sy, z, rs);
-}
-HD void dual_to_pixel(float xn, float yn, bool upper, int w, int h, float& fx, float& fy) {
-  int half_w = w / 2;
-  int short_res = half_w < h ? half_w : h;
-  float r = static_cast<float>(short_res) / 2.0f;
-  float cy = static_cast<float>(h) / 2.0f;
-  float cx = upper ? static_cast<float>(w) / 2.0f - r : static_cast<float>(w) / 2.0f + r;
-  fx = (upper ? -yn : yn) * r + cx;
-  fy = xn * r + cy;
-}
-
-struct Hits {
-  int px0, py0, px1, py1;
-  int count;
-};
-
-HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz) {
-  Hits r;
-  r.count = 0;
-  r.px0 = r.py0 = r.px1 = r.py1 = 0;
-  const int t = p.proj_type;
-  if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT ||
-      t == HALO_LENS_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
-    if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
-    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
-    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
-    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
-    XY xy;
-    if (t == HALO_LENS_LINEAR) {
-      if (cz <= 0.0f) return r;
-      xy = {cx / cz, cy / cz, true};
-    } else {
-      if (cz <= 0.0f) return r;
-      if (t == HALO_LENS_FISHEYE_EQUAL_AREA) xy = fisheye_equal_area(cx, cy, cz, 1.0f);
-      else if (t == HALO_LENS_FISHEYE_EQUIDISTANT) xy = fisheye_equidistant(cx, cy, cz, 1.0f);
-      else if (t == HALO_LENS_FISHEYE_STEREOGRAPHIC) xy = fisheye_stereographic(cx, cy, cz, 1.0f);
-      else xy = fisheye_orthographic(cx, cy, cz, 1.0f);
-    }
-    if (!xy.valid) return r;
-    xy.x = -xy.x;
-    r.px0 = static_cast<int>(floorf(xy.x * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
-    r.py0 = static_cast<int>(floorf(xy.y * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
-    r.count = 1;
-    return r;
-  }
-  if (t == HALO_LENS_RECTANGULAR) {
-    float lon = atan2f(-wy, -wx) - p.az0;
-    float lat = asinf(fminf(fmaxf(-wz, -1.0f), 1.0f));
-    while (lon < -kPiF) lon += 2.0f * kPiF;
-    while (lon > kPiF) lon -= 2.0f * kPiF;
-    int raw_x = static_cast<int>(floorf(lon * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f));
-    r.px0 = ((raw_x % p.img_w) + p.img_w) % p.img_w;
-    r.py0 = static_cast<int>(floorf(-lat * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f));
-    r.count = 1;
-    return r;
-  }
-  if (t == HALO_LENS_DUAL_FISHEYE_EQUAL_AREA || t == HALO_LENS_DUAL_FISHEYE_EQUIDISTANT ||
-      t == HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_DUAL_FISHEYE_ORTHOGRAPHIC) {
-    float sx = -wx, sy = -wy, sz = -wz;
-    bool upper = (sz >= 0.0f);
-    float z_hemi = upper ? sz : -sz;
-    XY xy = dual_forward(t, sx, sy, z_hemi, p.r_scale);
-    float fx, fy;
-    dual_to_pixel(xy.x, xy.y, upper, p.img_w, p.img_h, fx, fy);
-    r.px0 = static_cast<int>(floorf(fx + 0.5f));
-    r.py0 = static_cast<int>(floorf(fy + 0.5f));
-    r.count = 1;
-    if (p.max_abs_dz > 0.0f && fabsf(sz) < p.max_abs_dz) {
-      XY xy2 = dual_forward(t, sx, sy, -z_hemi, p.r_scale);
-      dual_to_pixel(xy2.x, xy2.y, !upper, p.img_w, p.img_h, fx, fy);
-      r.px1 = static_cast<int>(floorf(fx + 0.5f));
-      r.py1 = static_cast<int>(floorf(fy + 0.5f));
-      r.count = 2;
-    }
-    return r;
-  }
-  if (t == HALO_LENS_GLOBE) {
-    const float kGlobeCameraD = 4.0f;
-    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
-    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
-    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
-    if (cz >= -1.0f / kGlobeCameraD) return r;
-    float denom = kGlobeCameraD + cz;
-    r.px0 = static_cast<int>(floorf(-cx / denom * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
-    r.py0 = static_cast<int>(floorf(cy / denom * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
-    r.count = 1;
-    return r;
-  }
-  return r;
-}
-
-// ------------------------------------------------------------------------------------------------
-// accumulation
-// ------------------------------------------------------------------------------------------------
-HD void atomic_add_f32(float* addr, float v) {
-  // hardware global_atomic_add_f32 (no CAS loop); the accumulator is ordinary coarse-grained device memory
-  unsafeAtomicAdd(addr, v);
-}
-
-// Measured on MI355X (tools/atomic_bench.hip): scattered fp32 atomics retire at ~20.7 G/s whatever the scope or
-// buffer size, but same-cache-line atomics serialize — and a third of all exits land on the ~20 pixels of the
-// sun disc (rays crossing two parallel faces keep their direction).  Two measures keep that off the fabric:
-//  * MONO: in a discrete-wavelength session every exit's XYZ is cmf(lambda)*w, so the kernel accumulates the
-//    scalar w into a one-channel plane (1 atomic per hit, not 3) and halo_fold_kernel applies the CMF once per
-//    session (AccumXyzToPixel accum_shared.h:40-47 distributes over the sum);
-//  * a per-workgroup direct-mapped pixel cache in LDS: the first pixel to claim a slot accumulates there with
-//    ds_add_f32 for the rest of the kernel and is flushed once; pixels that lose the claim go straight to HBM.
-//    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
-typedef float float2v __attribute__((ext_vector_type(2)));
-
-template <bool MONO>
-struct CacheGeom {  // 2048 one-channel slots (16 KB) or 1024 three-channel slots (16 KB)
-  static constexpr int kLog2 = MONO ? 11 : 10;
-  static constexpr int kN = 1 << kLog2;
-};
-
-template <bool MONO>
-struct PixCache {
-  uint32_t tag[CacheGeom<MONO>::kN];     // ((plane << 23) | pixel) + 1, 0 = free
-  float val[CacheGeom<MONO>::kN * (MONO ? 1 : 3)];
-};
-
-// Binned accumulation (discrete-wavelength sessions, big launches).  A launch of n rays puts tens of hits on EVERY pixel,
-// but no workgroup sees a pixel twice — the reuse only exists chip-wide, and one global atomic per hit caps the kernel at
-// ~21 G hits/s.  So hits are exchanged through per-tile lists in HBM instead: a workgroup stages its hits {slot, w} in LDS,
-// and when the buffer is half full bins them by image tile (16384 slots) — one returning global atomic per tile per
-// flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
-// sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
-// hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
-constexpr int kHitBuf = 2048;                 // staged hits per workgroup (16 KB)
-constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
-constexpr int kBinMaxTiles = 256;
-constexpr int kBinCntStride = 16;              // tile counters 64 B apart
-struct HitBuffer {
-  uint2 h[kHitBuf];
-  uint32_t n;
-  uint32_t hist[kBinMaxTiles];
-  uint32_t base[kBinMaxTiles];
-};
-template <bool ON>
-struct HitSlot {
-  HitBuffer b;
-};
-template <>
-struct HitSlot<false> {
-  uint32_t unused;
-};
-template <bool MONO>
-struct AccCtx {
-  PixCache<MONO>* cache;
-  HitBuffer* hits;   // nullptr = accumulate directly
-};
-
-// Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
-HD float* mono_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) {
-  const uint32_t copy = blockIdx.x & P.mono_copy_mask;
-  return P.mono + (static_cast<size_t>(pl * (P.mono_copy_mask + 1u) + copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
-}
-
-// MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
-// pool entry); the CMF is applied by halo_fold_kernel.  !MONO: X, Y, Z into planes 0..2.
-template <bool MONO>
-HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
-  PixCache<MONO>& C = *ctx.cache;
-  if (P.aggregate == 2u) return;  // diagnostic: trace + project only
-  const uint32_t pl = (MONO && P.mono_by_wl) ? wl_idx : 0u;
-  if (P.aggregate == 1u || P.aggregate == 3u) {
-    const uint32_t key = ((pl << 23) | pix) + 1u;
-    // two-way: a key may live in slot s or s^1.  A hot pixel only misses the cache when BOTH were claimed by other pixels
-    // before its first hit (~0.2 % of workgroups instead of ~5 % one-way) — and every miss of a hot pixel is an atomic on
-    // the same line as all its other misses, chip-wide.
-    uint32_t slot = (key * 2654435761u) >> (32 - CacheGeom<MONO>::kLog2);
-    uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
-    if (old != 0u && old != key) {
-      slot ^= 1u;
-      old = atomicCAS(&C.tag[slot], 0u, key);
-    }
-    if (old == 0u || old == key) {
-      if (MONO) {
-        unsafeAtomicAdd(&C.val[slot], w);
-      } else {
-        unsafeAtomicAdd(&C.val[slot * 3 + 0], cx * w);
-        unsafeAtomicAdd(&C.val[slot * 3 + 1], cy * w);
-        unsafeAtomicAdd(&C.val[slot * 3 + 2], cz * w);
-      }
-      return;
-    }
-    if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
-  }
-  if (MONO) {
-    if (ctx.hits != nullptr) {  // binned mode: stage the hit; the list stores the slot inside plane 0, copy 0
-      // one LDS atomic per wave, not per lane (64 lanes on one address would serialise)
-      const uint64_t mask = __ballot(1);
-      const uint32_t lane = __lane_id();
-      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
-      uint32_t first = 0u;
-      if (lane == leader) first = atomicAdd(&ctx.hits->n, static_cast<uint32_t>(__popcll(mask)));
-      first = __shfl(first, static_cast<int>(leader));
-      const uint32_t pos = first + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-      if (pos < static_cast<uint32_t>(kHitBuf)) {
-        ctx.hits->h[pos] = make_uint2(MonoSlot(pix, P.mono_s_log2), __float_as_uint(w));
-        return;
-      }
-    }
-    atomic_add_f32(mono_slot(P, pl, pix), w);
-  } else {
-    atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
-    atomic_add_f32(mono_slot(P, 1u, pix), cy * w);
-    atomic_add_f32(mono_slot(P, 2u, pix), cz * w);
-  }
-}
-
-struct RaySums {
-  float landed;
-  float exit_w;
-  uint32_t exit_n;
-  uint32_t pix_n;
-};
-
-// ------------------------------------------------------------------------------------------------
-// emit-gate filters (shared/filter_shared.h:53-315).  Paths are crystal face NUMBERS already, so the reference's
-// ApplyGetFn remap (poly index → face number) is the identity here.
-// ------------------------------------------------------------------------------------------------
-HD void p_canonical_shift(uint8_t* data, uint32_t size) {  // filter_shared.h:53-68
-  int first_pri = -1;
-  for (uint32_t i = 0; i < size; ++i) {
-    const uint8_t x = data[i];
-    if (x < 3u) continue;
-    const uint32_t pyr = x / 10u;
-    int pri = static_cast<int>(x % 10u);
-    if (first_pri < 0) first_pri = pri;
-    pri = (pri + 6 - first_pri) % 6 + 3;
-    data[i] = static_cast<uint8_t>(pyr * 10u + static_cast<uint32_t>(pri));
-  }
-}
-
-HD bool lex_less(const uint8_t* a, const uint8_t* b, uint32_t size) {
-  for (uint32_t i = 0; i < size; ++i)
-    if (a[i] != b[i]) return a[i] < b[i];
-  return false;
-}
-
-HD void reduce_buffer(uint8_t* data, uint32_t size, uint8_t symmetry, int32_t sigma_a, bool d_applicable) {  // :79-132
-  if (symmetry == 0u) return;
-  if (symmetry & HALO_SYM_P) p_canonical_shift(data, size);
-  uint8_t scratch[kFilterPathCap];
-  if ((symmetry & HALO_SYM_D) && d_applicable) {
-    for (uint32_t i = 0; i < size; ++i) {
-      const uint8_t x = data[i];
-      if (x < 3u) {
-        scratch[i] = x;
-        continue;
-      }
-      const uint32_t pyr = x / 10u;
-      const int pri0 = static_cast<int>(x % 10u) - 3;
-      const int np = ((sigma_a - pri0) % 6 + 6) % 6;
-      scratch[i] = static_cast<uint8_t>(pyr * 10u + static_cast<uint32_t>(np + 3));
-    }
-    if (symmetry & HALO_SYM_P) p_canonical_shift(scratch, size);
-    if (lex_less(scratch, data, size))
-      for (uint32_t i = 0; i < size; ++i) data[i] = scratch[i];
-  }
-  if (symmetry & HALO_SYM_B) {
-    bool changed = false;
-    for (uint32_t i = 0; i < size; ++i) {
-      const uint8_t x = data[i];
-      if (x <= 2u) {
-        scratch[i] = static_cast<uint8_t>(3u - x);
-        changed = true;
-      } else if (x >= 13u && x <= 18u) {
-        scratch[i] = static_cast<uint8_t>(x + 10u);
-        changed = true;
-      } else if (x >= 23u && x <= 28u) {
-        scratch[i] = static_cast<uint8_t>(x - 10u);
-        changed = true;
-      } else {
-        scratch[i] = x;
-      }
-    }
-    if (changed && lex_less(scratch, data, size))
-      for (uint32_t i = 0; i < size; ++i) data[i] = scratch[i];
-  }
-}
-
-HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, const FilterTermDev& t, const uint8_t* path, uint32_t len, float wx,
-                          float wy, float wz, uint32_t crystal_id) {  // DeviceFilterMatchSimple :238-257
-  if (t.type == HALO_FILTER_NONE) return true;
-  if (t.type == HALO_FILTER_RAYPATH) {  // :156-178
-    if (len != t.canonical_len) return false;
-    uint8_t buf[kFilterPathCap];
-    for (uint32_t i = 0; i < len; ++i) buf[i] = path[i];
-    reduce_buffer(buf, len, symmetry, sigma_a, d_applicable);
-    for (uint32_t i = 0; i < len; ++i)
-      if (buf[i] != t.canonical[i]) return false;
-    return true;
-  }
-  if (t.type == HALO_FILTER_ENTRY_EXIT) {  // :180-224
-    if (len == 0u || len < t.min_len) return false;
-    if (t.max_len != 0u && len > t.max_len) return false;
-    if (!t.has_entry && !t.has_exit) return true;
-    uint8_t ee[2];
-    uint32_t n = 0u;
-    if (t.has_entry) ee[n++] = path[0];
-    if (t.has_exit) ee[n++] = path[len - 1u];
-    reduce_buffer(ee, n, symmetry, sigma_a, d_applicable);
-    if (symmetry != 0u && n != t.canonical_len) return false;
-    for (uint32_t i = 0; i < n; ++i)
-      if (ee[i] != t.canonical[i]) return false;
-    return true;
-  }
-  if (t.type == HALO_FILTER_DIRECTION) return t.dir[0] * wx + t.dir[1] * wy + t.dir[2] * wz > t.radii_c;  // :226-229
-  if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;                                    // :231-233
-  return false;
-}
-
-HD bool filter_check(const FilterDev& f, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
-  bool m;
-  if (!f.is_complex) {
-    m = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[0], path, len, wx, wy, wz, crystal_id);
-  } else {  // OR over AND-clauses; an empty complex filter matches nothing (:263-291)
-    m = false;
-    uint32_t idx = 0u;
-    for (uint32_t o = 0u; o < f.or_count && !m; ++o) {
-      const uint32_t n = f.and_counts[o];
-      bool all = true;
-      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[idx + a], path, len, wx, wy, wz, crystal_id);
-      idx += n;
-      m = all;
-    }
-  }
-  return (f.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
-}
-
-// Raypath colour (ApplyLayerColorBits cu:498-527): OR into the carried mask the bit of every predicate of this crystal
-// entry that matches the exit.  Non-destructive: runs beside the physical filter, never drops a ray.
-HD uint64_t color_bits(const ColorDev& c, uint64_t carried, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
-  uint64_t m = carried;
-  for (uint32_t k = 0u; k < c.term_cnt; ++k) {
-    const ColorTermDev& ct = c.terms[k];
-    if (ct.bit < 64u && filter_match_term(ct.symmetry, ct.sigma_a, ct.d_applicable != 0u, ct.t, path, len, wx, wy, wz, crystal_id))
-      m |= 1ull << ct.bit;
-  }
-  return m;
-}
-
-// FanColorClassLanes cu:535-556: the exit's Y goes to every class whose rule its mask satisfies (primary AND overlap hits)
-HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uint32_t pix, float y_val) {
-  for (uint32_t k = 0u; k < c.class_cnt; ++k) {
-    const uint64_t bits = c.class_bits[k];
-    if (bits == 0ull) continue;
-    const uint64_t matched = mask & bits;
-    const bool ok = c.class_all[k] ? (matched == bits) : (matched != 0ull);
-    if (ok) atomic_add_f32(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, y_val);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// the fused kernel.  MODE: 0 = production, 1 = + raypath recording and emit-gate filter, 2 = + exit capture (tests)
-// ------------------------------------------------------------------------------------------------
-template <bool MONO>
-struct LdsTables {
-  float lut[3 * kLutNodes];
-  PixCache<MONO> cache;
-  uint32_t seg[kContShards + 4];
-};
-constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
-template <bool ON>
-struct FilterSlot {
-  FilterDev f;
-};
-template <>
-struct FilterSlot<false> {
-  uint32_t unused;
-};
-template <bool ON>
-struct ColorSlot {
-  ColorDev c;
-};
-template <>
-struct ColorSlot<false> {
-  uint32_t unused;
-};
-
-template <bool ON, int N = kBlock / 32>
-struct PoolSlots {
-  ShapeDev s[N];
-};
-template <int N>
-struct PoolSlots<false, N> {
-  uint32_t unused;
-};
-
-template <int MODE, bool MONO>
-HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
-                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const uint8_t* path, uint32_t path_len, RaySums& sums) {
-  // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
-  float wx = R[0] * lx + R[1] * ly + R[2] * lz;
-  float wy = R[3] * lx + R[4] * ly + R[5] * lz;
-  float wz = R[6] * lx + R[7] * ly + R[8] * lz;
-  // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
-  if (MODE != kModePlain && filter != nullptr) {
-    if (!filter_check(*filter, path, path_len, wx, wy, wz, P.crystal_id)) return;
-  }
-  uint64_t cmask = carried;
-  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, path, path_len, wx, wy, wz, P.crystal_id);
-  // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
-  // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
-  bool pass = false;
-  if (P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
-  if (pass) {
-    if (P.final_layer) return;  // "continue" with no next layer is dropped (simulator.cpp:719-722)
-    // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
-    const uint64_t mask = __ballot(1);
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
-    uint32_t base = 0u;
-    const uint32_t shard = blockIdx.x & (kContShards - 1);
-    if (lane == leader) base = atomicAdd(&P.cont_cnt[shard * kContCntStride], static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, static_cast<int>(leader));
-    const uint32_t off = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-    if (off < P.cont_out_cap) {
-      const uint32_t slot = shard * P.cont_out_cap + off;
-      const uint32_t st = P.cont_out_stride;
-      P.cont_out[slot] = wx;
-      P.cont_out[st + slot] = wy;
-      P.cont_out[2u * st + slot] = wz;
-      P.cont_out[3u * st + slot] = w;
-      reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
-      if (MODE != kModePlain && color != nullptr) {  // the mask rides with the continuation (cu:922,1129)
-        reinterpret_cast<uint32_t*>(P.cont_out)[5u * st + slot] = static_cast<uint32_t>(cmask);
-        reinterpret_cast<uint32_t*>(P.cont_out)[6u * st + slot] = static_cast<uint32_t>(cmask >> 32);
-      }
-    }
-    return;
-  }
-  Hits h = project_exit(P.proj, wx, wy, wz);
-  int primary = -1;
-  if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
-    uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
-    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
-    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
-    sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
-    sums.pix_n++;
-    primary = static_cast<int>(pix);
-  }
-  if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
-    uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
-    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
-    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
-    sums.pix_n++;
-  }
-  sums.exit_w += w;
-  sums.exit_n++;
-  if (MODE == kModeCapture) {
-    uint32_t slot = atomicAdd(&P.counters[kCntExit], 1u);
-    if (slot < P.exit_cap) {
-      HaloExitRecord rec;
-      rec.dir[0] = wx;
-      rec.dir[1] = wy;
-      rec.dir[2] = wz;
-      rec.weight = w;
-      rec.root = root;
-      rec.seq = static_cast<uint16_t>(seq);
-      rec.layer = static_cast<uint8_t>(P.layer);
-      rec.path_len = static_cast<uint8_t>(path_len < HALO_PATH_CAP ? path_len : HALO_PATH_CAP);
-      for (int k = 0; k < HALO_PATH_CAP; k++) rec.path[k] = (static_cast<uint32_t>(k) < path_len) ? path[k] : 0;
-      rec.pixel = primary;
-      rec.crystal_id = static_cast<uint16_t>(P.crystal_id);
-      rec.wl_idx = static_cast<uint16_t>(wl_idx);
-      rec.color_mask = cmask;
-      P.exits[slot] = rec;
-    }
-  }
-}
-
-// Projected-area categorical entry pick + uniform point (InitRay_p_fid simulator.cpp:133-192 in its device form
-// gen_root_kernel cu:1556-1597).  Two passes over the fan table instead of a 64-float private array.
-template <typename ShapePtr>
-HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* p) {
-  const float u_cat = uniform(s);
-  if (tri_cnt == 0) {
-    p[0] = p[1] = p[2] = 0.0f;
-    return -1;
-  }
-  float total = 0.0f;
-  for (int t = 0; t < tri_cnt; ++t) {
-    const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
-    float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
-    total += fmaxf(-dot * na.w, 0.0f);
-  }
-  int tri = 0;
-  if (total > 0.0f) {
-    const float target = u_cat * total;
-    float cum = 0.0f;
-    tri = tri_cnt - 1;
-    for (int t = 0; t < tri_cnt; ++t) {
-      const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
-      float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
-      cum += fmaxf(-dot * na.w, 0.0f);
-      if (cum > target) {
-        tri = t;
-        break;
-      }
-    }
-  }
-  float u = uniform(s);
-  float v = uniform(s);
-  if (u + v > 1.0f) {
-    u = 1.0f - u;
-    v = 1.0f - v;
-  }
-  const float* vt = sh->tri_v[tri];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    float a = vt[k], b = vt[3 + k], c = vt[6 + k];
-    p[k] = u * (b - a) + v * (c - a) + a;
-  }
-  return static_cast<int>(sh->tri_face[tri]);
-}
-
-template <int MODE, bool MONO, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  uint32_t tid, RaySums& sums) {
-  uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
-  float R[9], d[3], p[3], w;
-  int face;
-  uint32_t wl_idx = 0u;
-  const int face_cnt = sh->face_cnt;
-  Stream gate = make_stream(P.gate_seed, P.gate_lo, P.gate_hi, tid);
-
-  if (P.source == kSrcGen) {
-    Stream s = make_stream(P.gen_seed, P.gen_lo, P.gen_hi, tid);
-    // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
-    Stream wls = s;
-    wls.seed ^= kNonceWl;
-    wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(P.wl_pool_size));
-    if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
-    float lon, lat, roll;
-    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
-    build_crystal_rotation(lon, lat, roll, R);
-    // sun cone (sample_sph_cap pcg_shared.h:514-529; trig of the fixed sun angles is host-evaluated)
-    float u = uniform(s);
-    float x = add_rn(u, mul_rn(1.0f - u, P.c_cap));  // separately rounded: see the note on r below
-    // x is within 1e-5 of 1: `1 - x*x` cancels catastrophically, so keep the product separately rounded like the
-    // reference's host evaluation (a contracted fma here moves r by up to ~2e-4 for rays near the cone axis)
-    float r = sqrtf(fmaxf(add_rn(1.0f, -mul_rn(x, x)), 0.0f));
-    float phi = uniform(s) * 2.0f * kPiF;
-    float sp, cp;
-    sincos_small(phi, &sp, &cp);
-    float y = cp * r, z = sp * r;
-    float dwx = P.c_lon * P.c_lat * x - P.s_lon * y - P.c_lon * P.s_lat * z;
-    float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
-    float dwz = P.s_lat * x + P.c_lat * z;
-    apply_inverse(R, dwx, dwy, dwz, d);
-    face = sample_entry(s, sh, sh->tri_cnt, d, p);
-    w = (P.wl_pool_size == 1u) ? P.wl_pool[0].spd_weight : P.wl_pool[wl_idx].spd_weight;
-  } else if (P.source == kSrcTransit) {
-    Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
-    const uint32_t pos = P.ci_start + tid;
-    const uint32_t logical = P.shuffle ? feistel_bijection(pos, P.cont_in_n, P.shuffle_seed) : pos;
-    uint32_t sh_i = 0u;  // largest shard with seg[shard] <= logical (empty shards repeat their neighbour's start)
-#pragma unroll
-    for (uint32_t step = kContShards / 2; step >= 1u; step >>= 1)
-      if (T.seg[sh_i + step] <= logical) sh_i += step;
-    const uint32_t src = sh_i * P.cont_in_region + (logical - T.seg[sh_i]);
-    const uint32_t st = P.cont_in_stride;
-    float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
-    w = P.cont_in[3u * st + src];
-    wl_idx = reinterpret_cast<const uint32_t*>(P.cont_in)[4u * st + src];
-    if (MODE != kModePlain && color != nullptr)
-      carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[5u * st + src]) |
-                (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[6u * st + src]) << 32);
-    float lon, lat, roll;
-    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
-    build_crystal_rotation(lon, lat, roll, R);
-    apply_inverse(R, dwx, dwy, dwz, d);
-    face = sample_entry(s, sh, sh->tri_cnt, d, p);
-  } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)
-    R[0] = R[4] = R[8] = 1.0f;
-    R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      d[k] = P.host_d[static_cast<size_t>(tid) * 3 + k];
-      p[k] = P.host_p[static_cast<size_t>(tid) * 3 + k];
-    }
-    w = P.host_w[tid];
-    face = static_cast<int>(P.host_tf[tid]);
-  }
-  if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
-
-  // the wavelength pool (<= 8 KB) is read where it lies: one entry for a discrete session (a scalar load), a couple of
-  // L1-resident reads per ray otherwise — staging it cost every workgroup 8 KB of LDS
-  WlEntryDev wle;
-  if (P.wl_pool_size == 1u) wle = P.wl_pool[0];   // uniform address: one scalar load per ray pass
-  else wle = P.wl_pool[wl_idx];
-  const float n_idx = wle.n_idx;
-  const float inv_n = 1.0f / n_idx;  // once per ray, IEEE like the reference
-  const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
-
-  uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
-  uint32_t path_len = 0u;
-  if (MODE != kModePlain) path[path_len++] = sh->face_number[face];
-
-  for (uint32_t i = 0u; i < P.max_hits; ++i) {
-    // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
-    const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
-    const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
-    const float rr = cos_t > 0.0f ? n_idx : inv_n;
-    const float dd = (1.0f - rr * rr) * fast_rcp(cos_t * cos_t) + rr * rr;
-    const bool tir = dd <= 0.0f;
-    const float sq = fast_sqrt(fmaxf(dd, 0.0f));
-    float Rs = (rr - sq) * fast_rcp(rr + sq);
-    Rs *= Rs;
-    float Rp = (1.0f - rr * sq) * fast_rcp(1.0f + rr * sq);
-    Rp *= Rp;
-    const float w_refl = (Rs + Rp) * 0.5f * w;
-    const float w_refr = w - w_refl;
-    const float k_refl = 2.0f * cos_t;
-    const float k_refr = (rr - sq) * cos_t;
-    const float rlx = d[0] - k_refl * fn.x, rly = d[1] - k_refl * fn.y, rlz = d[2] - k_refl * fn.z;
-    const float rfx = rr * d[0] - k_refr * fn.x, rfy = rr * d[1] - k_refr * fn.y, rfz = rr * d[2] - k_refr * fn.z;
-    // On a convex body exactly one child stays inside: the refracted one when entering (cos<0), the reflected
-    // one otherwise; the other child leaves through `face` and is the outgoing candidate.
-    const bool entering = cos_t < 0.0f;
-    const bool has_exit = entering || !tir;
-    if (has_exit) {
-      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
-                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
-    }
-    if (i + 1u == P.max_hits) break;
-    const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
-    d[0] = entering ? rfx : rlx;
-    d[1] = entering ? rfy : rly;
-    d[2] = entering ? rfz : rlz;
-    w = entering ? w_refr : w_refl;
-    // --- next face on the convex body (PropagateSlab optics.cpp:64-158) ---
-    // min over candidate faces of t = num/den (den > eps > 0) without dividing: num_i/den_i < num_b/den_b
-    // <=> num_i*den_b < num_b*den_i.  One reciprocal at the end.
-    float num_b = 1e30f, den_b = 1.0f;
-    int hit = -1;
-    // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain
-    const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
-    const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
-    for (int k = 0; k < slab_cnt; ++k) {
-      // opposite faces +n / -n: den(-n) = -den(+n) and n.p flips sign, so only the face the ray travels towards can be ahead
-      const float4 g = *reinterpret_cast<const float4*>(sh->slab[k]);
-      const float4 e = *reinterpret_cast<const float4*>(sh->slab[k] + 4);
-      const float2v r = X * g.x + Y * g.y + Z * g.z;
-      const bool pos = r.x > 0.0f;
-      const float den = fabsf(r.x);
-      const float num = pos ? -(r.y + g.w) : (r.y - e.x);
-      const int fi = pos ? __float_as_int(e.y) : __float_as_int(e.z);
-      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
-      num_b = better ? num : num_b;
-      den_b = better ? den : den_b;
-      hit = better ? fi : hit;
-    }
-    for (int k = 0; k < single_cnt; ++k) {
-      const int fi = sh->single[k];
-      const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
-      const float2v r = X * g.x + Y * g.y + Z * g.z;
-      const float den = r.x;
-      const float num = -(r.y + g.w);
-      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
-      num_b = better ? num : num_b;
-      den_b = better ? den : den_b;
-      hit = better ? fi : hit;
-    }
-    const float t_best = num_b * fast_rcp(den_b);
-    if (hit < 0 || t_best <= -kSlabEps) {
-      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
-      break;
-    }
-    p[0] += t_best * d[0];
-    p[1] += t_best * d[1];
-    p[2] += t_best * d[2];
-    face = hit;
-    if (MODE != kModePlain) {
-      if (path_len < kFilterPathCap) path[path_len] = sh->face_number[face];
-      path_len++;
-    }
-  }
-}
-
-// Bin the staged hits by image tile and append them to the tiles' lists (all kBlock threads call this together).
-// Three sweeps over the staged hits: count per tile; reserve each tile's segment with ONE returning global atomic; place
-// (the position inside the segment comes from a second LDS counter, so nothing has to stay in registers across barriers).
-HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
-  const uint32_t n = min(hb.n, static_cast<uint32_t>(kHitBuf));
-  const uint32_t tmask = P.bin_tiles - 1u;   // tile = low slot bits: the column hash balances the tiles
-  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) hb.hist[t] = 0u;
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.hist[hb.h[i].x & tmask], 1u);
-  __syncthreads();
-  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) {
-    const uint32_t c = hb.hist[t];
-    hb.base[t] = c ? atomicAdd(&P.bin_cnt[t * kBinCntStride], c) : 0u;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-    const uint2 h = hb.h[i];
-    const uint32_t tile = h.x & tmask;
-    const uint32_t idx = atomicAdd(&hb.base[tile], 1u);
-    if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
-    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (plane 0, copy 0)
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) hb.n = 0u;
-  __syncthreads();
-}
-
-// Flush every `every` passes of the ray loop; the interval follows the fill level so that a flush finds the buffer about
-// half full (a pass that overruns the buffer falls back to direct atomics, so a late flush costs speed, not hits).  Every
-// thread of the workgroup reads the same fill count after the barrier, so the new interval is workgroup-uniform.
-HD uint32_t bin_flush_adaptive(const DispatchParams& P, HitBuffer& hb, uint32_t every, uint32_t& since) {
-  __syncthreads();
-  const uint32_t n = hb.n;
-  since = 0u;
-  bin_flush(P, hb);
-  if (n > static_cast<uint32_t>(kHitBuf) * 5u / 8u) return every > 1u ? every - 1u : 1u;
-  if (n < static_cast<uint32_t>(kHitBuf) * 3u / 8u) return every < 64u ? every + 1u : every;
-  return every;
-}
-
-HD float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return v;
-}
-
-#ifndef HALO_MIN_WAVES
-#define HALO_MIN_WAVES 4
-#endif
-template <int MODE, bool POOL, bool MONO, bool BIN>
-__global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
-  static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
-  __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
-  __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
-  AccCtx<MONO> acc;
-  acc.cache = &T.cache;
-  acc.hits = nullptr;
-  if constexpr (BIN) {
-    acc.hits = &s_hits.b;
-    if (threadIdx.x == 0) s_hits.b.n = 0u;
-  }
-  __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
-  __shared__ __attribute__((aligned(16))) PoolSlots<POOL> s_pool;       // stochastic: one shape per half-wave
-  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, 1> s_shape;  // deterministic: the dispatch's one shape
-  __shared__ __attribute__((aligned(16))) ColorSlot<MODE != kModePlain> s_color;
-  const ColorDev* color = nullptr;
-  if (MODE != kModePlain && P.color != nullptr) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.color);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_color);
-    for (uint32_t i = threadIdx.x; i < sizeof(ColorDev) / 4u; i += kBlock) dst[i] = src[i];
-    color = reinterpret_cast<const ColorDev*>(&s_color);
-  }
-  const FilterDev* filter = nullptr;
-  if (MODE != kModePlain && P.filter != nullptr) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.filter);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_filter);
-    for (uint32_t i = threadIdx.x; i < sizeof(FilterDev) / 4u; i += kBlock) dst[i] = src[i];
-    filter = reinterpret_cast<const FilterDev*>(&s_filter);
-  }
-  if (P.aggregate == 1u || P.aggregate == 3u) {
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) T.cache.tag[i] = 0u;
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
-  }
-  // ---- stage the dispatch-constant tables into LDS ----
-  if (P.lat_path == kLatLut)
-    for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
-  if (P.source == kSrcTransit)
-    for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
-  if constexpr (!POOL) {
-    const float4* src = reinterpret_cast<const float4*>(P.shapes);
-    float4* dst = reinterpret_cast<float4*>(&s_shape.s[0]);
-    for (uint32_t i = threadIdx.x; i < sizeof(ShapeDev) / 16u; i += kBlock) dst[i] = src[i];
-  }
-  __syncthreads();
-
-  RaySums sums = {0.0f, 0.0f, 0u, 0u};
-  const uint32_t stride = gridDim.x * kBlock;
-  uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
-  bool staged = false;
-  if constexpr (POOL) {
-   if ((P.geom_clock & 31u) == 0u) {
-    staged = true;
-    // stochastic geometry: geom_clock consecutive rays share one sampled shape (simulator.cpp:1244-1275).  With the
-    // clock a multiple of 32 every half-wave traces ONE shape per pass: its 32 lanes copy the rows that shape uses
-    // (header, face_cnt plane rows, tri_cnt fan rows — 1.3 KB for a prism) from the pool into the half-wave's LDS slot
-    // with coalesced 16-byte loads, and the interaction loop then reads them as LDS broadcasts exactly like the
-    // deterministic path.  LDS operations of one wave retire in order, so no barrier is needed around the copy.
-    ShapeDev* slot = &s_pool.s[threadIdx.x >> 5];
-    const uint32_t l32 = threadIdx.x & 31u;
-    for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
-      const uint32_t tid = base + threadIdx.x;
-      const uint32_t first = base + (threadIdx.x & ~31u);
-      if (first < P.n_rays) {
-        const ShapeDev* g = P.shapes + first / P.geom_clock;
-        const float4* g4 = reinterpret_cast<const float4*>(g);
-        float4* s4 = reinterpret_cast<float4*>(slot);
-        const uint32_t fc = static_cast<uint32_t>(g->face_cnt), tc = static_cast<uint32_t>(g->tri_cnt);
-        constexpr uint32_t kSlab = offsetof(ShapeDev, slab) / 16u;
-        constexpr uint32_t kTriV = offsetof(ShapeDev, tri_v) / 16u, kTriNa = offsetof(ShapeDev, tri_na) / 16u;
-        constexpr uint32_t kTail = offsetof(ShapeDev, tri_face) / 16u, kEnd = sizeof(ShapeDev) / 16u;
-        for (uint32_t i = l32; i < 1u + fc; i += 32u) s4[i] = g4[i];
-        for (uint32_t i = l32; i < 2u * kMaxSlabs; i += 32u) s4[kSlab + i] = g4[kSlab + i];
-        for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) s4[kTriV + i] = g4[kTriV + i];
-        for (uint32_t i = l32; i < tc; i += 32u) s4[kTriNa + i] = g4[kTriNa + i];
-        for (uint32_t i = kTail + l32; i < kEnd; i += 32u) s4[i] = g4[i];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const ShapeDev*>(slot), tid, sums);
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (BIN) {
-        if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
-      }
-    }
-   }
-  }
-  if (!staged) {
-    for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {   // workgroup-uniform trip count
-      const uint32_t tid = base + threadIdx.x;
-      if (tid < P.n_rays) {
-        if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
-          const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
-          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
-        } else {
-          const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
-        }
-      }
-      if constexpr (BIN) {
-        if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
-      }
-    }
-  }
-  if constexpr (BIN) {
-    __syncthreads();
-    bin_flush(P, s_hits.b);
-  }
-  // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
-  if (P.aggregate == 1u || P.aggregate == 3u) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) {
-      const uint32_t key = T.cache.tag[i];
-      if (key == 0u) continue;
-      const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;
-      if (MONO) {
-        const float v = T.cache.val[i];
-        if (v != 0.0f) atomic_add_f32(mono_slot(P, pl, pix), v);
-      } else {
-        atomic_add_f32(mono_slot(P, 0u, pix), T.cache.val[i * 3 + 0]);
-        atomic_add_f32(mono_slot(P, 1u, pix), T.cache.val[i * 3 + 1]);
-        atomic_add_f32(mono_slot(P, 2u, pix), T.cache.val[i * 3 + 2]);
-      }
-    }
-  }
-  // ---- per-wave reduction of the scalar tallies: one fp64 atomic per wave, not per exit ----
-  float landed = wave_sum(sums.landed);
-  float exit_w = wave_sum(sums.exit_w);
-  float exit_n = wave_sum(static_cast<float>(sums.exit_n));
-  float pix_n = wave_sum(static_cast<float>(sums.pix_n));
-  if ((threadIdx.x & 63) == 0) {
-    if (pix_n != 0.0f) atomicAdd(&P.sums[kSumPixN], static_cast<double>(pix_n));
-    if (landed != 0.0f) atomicAdd(P.landed, static_cast<double>(landed));
-    if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
-    if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
-  }
-}
 
 // kBinSplit workgroups per image tile: each sums its share of the tile's hit list in a 64 KB LDS tile (8 independent
 // loads in flight per thread — the loop is load-latency-bound otherwise) and adds the non-zero slots to the plane.
@@ -1352,26 +202,15 @@ hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log
   return hipGetLastError();
 }
 
-// host-callable launcher (halo_backend.cpp is plain C++ and never sees <<<>>>)
-template <int MODE, bool POOL>
-static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, true>), grid, block, 0, stream, P);
-  else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, false>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, false, false>), grid, block, 0, stream, P);
-}
+hipError_t launch_trace_m0(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
+hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
+hipError_t launch_trace_m2(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
 
-template <int MODE>
-static void launch_pool(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool pool, bool mono) {
-  if (pool) launch_mono<MODE, true>(P, grid, block, stream, mono);
-  else launch_mono<MODE, false>(P, grid, block, stream, mono);
-}
-
+// MODE: capture (tests) > filter / raypath colour (path recorded) > plain
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono) {
-  dim3 grid(blocks), block(kBlock);
-  if (capture) launch_pool<kModeCapture>(P, grid, block, stream, pool, mono);
-  else if (P.filter != nullptr || P.color != nullptr) launch_pool<kModeFilter>(P, grid, block, stream, pool, mono);
-  else launch_pool<kModePlain>(P, grid, block, stream, pool, mono);
-  return hipGetLastError();
+  if (capture) return launch_trace_m2(P, blocks, stream, pool, mono);
+  if (P.filter != nullptr || P.color != nullptr) return launch_trace_m1(P, blocks, stream, pool, mono);
+  return launch_trace_m0(P, blocks, stream, pool, mono);
 }
 
 }  // namespace halo

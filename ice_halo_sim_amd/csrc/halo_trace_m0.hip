@@ -1,0 +1,8 @@
+// halo_trace_m0.hip — the kModePlain instantiations of halo_trace_kernel (see halo_trace.inl).
+#include "halo_trace.inl"
+
+namespace halo {
+hipError_t launch_trace_m0(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono) {
+  return launch_mode<kModePlain>(P, blocks, stream, pool, mono);
+}
+}  // namespace halo
