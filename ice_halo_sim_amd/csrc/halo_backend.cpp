@@ -1,5 +1,5 @@
 // halo_backend.cpp — the C ABI of include/halo_trace.h: session state machine, per-(layer, entry) dispatch,
-// device memory, streams/events.  Host C++ only; kernels live in halo_kernels.hip.
+// device memory, streams/events.  Host C++ only; kernels live in halo_trace.inl (+ halo_trace_m*.hip) and halo_kernels.hip.
 //
 // State machine (reference trace_backend.hpp:91-116):
 //   halo_begin → (halo_trace_layer → halo_recombine)* → halo_trace_layer → halo_end ; halo_readback_xyz any time.
@@ -18,7 +18,7 @@
 #include "halo_host.hpp"
 
 namespace halo {
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono);
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
 hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -488,7 +488,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   const int max_blocks = b->cu_count * b->blocks_per_cu;
   auto chunk_of = [&](uint64_t left, bool deterministic) {
     uint64_t m = std::min<uint64_t>(left, b->chunk);
-    if (!deterministic) m = std::min<uint64_t>(m, 1ull << 22);
+    // stochastic geometry: the shape pool costs 4.1 KB per geom_clock rays — 2 GB per 16 Mi rays when the device generator
+    // writes it, while host-built pools (pageable staging + H2D) stay at 4 Mi rays
+    if (!deterministic) m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : (1ull << 24));
     return m;
   };
   auto blocks_of = [&](uint64_t m) {
@@ -713,10 +715,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.host_tf = b->host_u.ptr + off;
       }
       const int blocks = blocks_of(m);
-      // binned accumulation for big one-plane launches (see halo_kernels.hip: HitBuffer)
+      // binned accumulation for big one-plane launches (see halo_trace.inl: HitBuffer)
       const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> 14);
       const bool use_bin = b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 256u &&
-                           (b->bin < 0 ? (deterministic && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0);
+                           (b->bin < 0 ? ((deterministic || E.crystal.kind == HALO_CRYSTAL_PRISM) && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0);
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
         uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 16);
@@ -734,7 +736,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
-      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, !deterministic, b->mono_session);
+      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, deterministic ? 0 : (E.crystal.kind == HALO_CRYSTAL_PRISM ? 2 : 1), b->mono_session);
       b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_bin) {

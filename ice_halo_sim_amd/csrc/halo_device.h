@@ -1,5 +1,5 @@
 // halo_device.h — POD parameter blocks shared by the host orchestration (halo_backend.cpp) and the
-// gfx950 kernels (halo_kernels.hip).  gfx950 only; no other backend is supported or dispatched.
+// gfx950 kernels (halo_trace.inl, halo_kernels.hip).  gfx950 only; no other backend is supported or dispatched.
 #ifndef HALO_DEVICE_H_
 #define HALO_DEVICE_H_
 

@@ -202,15 +202,16 @@ hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log
   return hipGetLastError();
 }
 
-hipError_t launch_trace_m0(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
-hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
-hipError_t launch_trace_m2(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono);
+hipError_t launch_trace_m0(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
+hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
+hipError_t launch_trace_m2(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
 
 // MODE: capture (tests) > filter / raypath colour (path recorded) > plain
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, bool pool, bool mono) {
-  if (capture) return launch_trace_m2(P, blocks, stream, pool, mono);
-  if (P.filter != nullptr || P.color != nullptr) return launch_trace_m1(P, blocks, stream, pool, mono);
-  return launch_trace_m0(P, blocks, stream, pool, mono);
+// geom: 0 = one shape per dispatch, 1 = shape pool, 2 = shape pool of prisms (compact LDS slots)
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono) {
+  if (capture) return launch_trace_m2(P, blocks, stream, geom, mono);
+  if (P.filter != nullptr || P.color != nullptr) return launch_trace_m1(P, blocks, stream, geom, mono);
+  return launch_trace_m0(P, blocks, stream, geom, mono);
 }
 
 }  // namespace halo

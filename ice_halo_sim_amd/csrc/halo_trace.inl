@@ -666,14 +666,74 @@ struct ColorSlot<false> {
   uint32_t unused;
 };
 
-template <bool ON, int N = kBlock / 32>
-struct PoolSlots {
-  ShapeDev s[N];
+// A sampled prism never has more than 8 faces, 4 opposite-face slabs and 20 fan triangles: its LDS copy is a third of
+// a ShapeDev (same member names, so the trace code is generic over the two).
+struct ShapePrismLds {
+  int32_t face_cnt, tri_cnt, slab_cnt, single_cnt;
+  float face[8][4];
+  float slab[4][8];
+  float tri_v[20][9];
+  float tri_na[20][4];
+  uint8_t tri_face[20];
+  uint8_t face_number[8];
+  uint8_t single[8];
+  uint8_t pad[12];
 };
-template <int N>
-struct PoolSlots<false, N> {
+static_assert(sizeof(ShapePrismLds) % 16 == 0 && offsetof(ShapePrismLds, tri_v) % 16 == 0 && offsetof(ShapePrismLds, tri_na) % 16 == 0 &&
+              offsetof(ShapePrismLds, tri_face) % 4 == 0 && offsetof(ShapePrismLds, face_number) % 4 == 0 && offsetof(ShapePrismLds, single) % 4 == 0,
+              "rows are copied as float4 / dwords");
+static_assert(offsetof(ShapeDev, tri_v) % 16 == 0 && offsetof(ShapeDev, tri_na) % 16 == 0 && offsetof(ShapeDev, slab) % 16 == 0 &&
+              offsetof(ShapeDev, tri_face) % 4 == 0 && offsetof(ShapeDev, face_number) % 4 == 0 && offsetof(ShapeDev, single) % 4 == 0,
+              "rows are copied as float4 / dwords");
+
+constexpr int kGeomOne = 0, kGeomPool = 1, kGeomPoolPrism = 2;   // GEOM: one shape per dispatch | pool, generic slots | pool, prism slots
+template <int GEOM>
+struct PoolSlotType {
+  typedef ShapeDev type;
+};
+template <>
+struct PoolSlotType<kGeomPoolPrism> {
+  typedef ShapePrismLds type;
+};
+template <bool ON, typename SlotT, int N = kBlock / 32>
+struct PoolSlots {
+  SlotT s[N];
+};
+template <typename SlotT, int N>
+struct PoolSlots<false, SlotT, N> {
   uint32_t unused;
 };
+
+// 32 lanes copy the rows one pool shape uses into their half-wave's LDS slot (coalesced 16-byte loads)
+template <typename SlotT>
+HD void stage_shape(SlotT* slot, const ShapeDev* g, uint32_t l32) {
+  constexpr uint32_t kF = sizeof(slot->face) / 16u, kS = sizeof(slot->slab) / 32u, kT = sizeof(slot->tri_na) / 16u, kN = sizeof(slot->single);
+  const uint32_t fc = min(static_cast<uint32_t>(g->face_cnt), kF), tc = min(static_cast<uint32_t>(g->tri_cnt), kT);
+  const uint32_t sc = min(static_cast<uint32_t>(g->slab_cnt), kS), n1 = min(static_cast<uint32_t>(g->single_cnt), kN);
+  if (l32 == 0u) {
+    slot->face_cnt = static_cast<int32_t>(fc);
+    slot->tri_cnt = static_cast<int32_t>(tc);
+    slot->slab_cnt = static_cast<int32_t>(sc);
+    slot->single_cnt = static_cast<int32_t>(n1);
+  }
+  const float4* gf = reinterpret_cast<const float4*>(g->face);
+  float4* sf = reinterpret_cast<float4*>(slot->face);
+  for (uint32_t i = l32; i < fc; i += 32u) sf[i] = gf[i];
+  const float4* gs = reinterpret_cast<const float4*>(g->slab);
+  float4* ss = reinterpret_cast<float4*>(slot->slab);
+  for (uint32_t i = l32; i < 2u * sc; i += 32u) ss[i] = gs[i];
+  const float4* gv = reinterpret_cast<const float4*>(g->tri_v);
+  float4* sv = reinterpret_cast<float4*>(slot->tri_v);
+  for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) sv[i] = gv[i];
+  const float4* gn = reinterpret_cast<const float4*>(g->tri_na);
+  float4* sn = reinterpret_cast<float4*>(slot->tri_na);
+  for (uint32_t i = l32; i < tc; i += 32u) sn[i] = gn[i];
+  const uint32_t* gb = reinterpret_cast<const uint32_t*>(g->tri_face);
+  uint32_t* sb = reinterpret_cast<uint32_t*>(slot->tri_face);
+  for (uint32_t i = l32; i < (tc + 3u) / 4u; i += 32u) sb[i] = gb[i];
+  if (l32 < (fc + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->face_number)[l32] = reinterpret_cast<const uint32_t*>(g->face_number)[l32];
+  if (l32 < (n1 + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->single)[l32] = reinterpret_cast<const uint32_t*>(g->single)[l32];
+}
 
 template <int MODE, bool MONO>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
@@ -1018,7 +1078,7 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 4
 #endif
-template <int MODE, bool POOL, bool MONO, bool BIN>
+template <int MODE, int GEOM, bool MONO, bool BIN>
 __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
@@ -1031,8 +1091,10 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     if (threadIdx.x == 0) s_hits.b.n = 0u;
   }
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
-  __shared__ __attribute__((aligned(16))) PoolSlots<POOL> s_pool;       // stochastic: one shape per half-wave
-  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, 1> s_shape;  // deterministic: the dispatch's one shape
+  constexpr bool POOL = GEOM != kGeomOne;
+  typedef typename PoolSlotType<GEOM>::type PoolSlot;
+  __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
+  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, ShapeDev, 1> s_shape;  // deterministic: the dispatch's one shape
   __shared__ __attribute__((aligned(16))) ColorSlot<MODE != kModePlain> s_color;
   const ColorDev* color = nullptr;
   if (MODE != kModePlain && P.color != nullptr) {
@@ -1076,28 +1138,15 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     // (header, face_cnt plane rows, tri_cnt fan rows — 1.3 KB for a prism) from the pool into the half-wave's LDS slot
     // with coalesced 16-byte loads, and the interaction loop then reads them as LDS broadcasts exactly like the
     // deterministic path.  LDS operations of one wave retire in order, so no barrier is needed around the copy.
-    ShapeDev* slot = &s_pool.s[threadIdx.x >> 5];
+    PoolSlot* slot = &s_pool.s[threadIdx.x >> 5];
     const uint32_t l32 = threadIdx.x & 31u;
     for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
       const uint32_t tid = base + threadIdx.x;
       const uint32_t first = base + (threadIdx.x & ~31u);
-      if (first < P.n_rays) {
-        const ShapeDev* g = P.shapes + first / P.geom_clock;
-        const float4* g4 = reinterpret_cast<const float4*>(g);
-        float4* s4 = reinterpret_cast<float4*>(slot);
-        const uint32_t fc = static_cast<uint32_t>(g->face_cnt), tc = static_cast<uint32_t>(g->tri_cnt);
-        constexpr uint32_t kSlab = offsetof(ShapeDev, slab) / 16u;
-        constexpr uint32_t kTriV = offsetof(ShapeDev, tri_v) / 16u, kTriNa = offsetof(ShapeDev, tri_na) / 16u;
-        constexpr uint32_t kTail = offsetof(ShapeDev, tri_face) / 16u, kEnd = sizeof(ShapeDev) / 16u;
-        for (uint32_t i = l32; i < 1u + fc; i += 32u) s4[i] = g4[i];
-        for (uint32_t i = l32; i < 2u * kMaxSlabs; i += 32u) s4[kSlab + i] = g4[kSlab + i];
-        for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) s4[kTriV + i] = g4[kTriV + i];
-        for (uint32_t i = l32; i < tc; i += 32u) s4[kTriNa + i] = g4[kTriNa + i];
-        for (uint32_t i = kTail + l32; i < kEnd; i += 32u) s4[i] = g4[i];
-      }
+      if (first < P.n_rays) stage_shape(slot, P.shapes + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const ShapeDev*>(slot), tid, sums);
+      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums);
       __builtin_amdgcn_wave_barrier();
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
@@ -1158,18 +1207,19 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
 
 // host-callable launcher pieces: each halo_trace_m<MODE>.hip translation unit instantiates the kernels of one MODE
 // (the 18 instantiations compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
-template <int MODE, bool POOL>
+template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, true>), grid, block, 0, stream, P);
-  else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, true, false>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((halo_trace_kernel<MODE, POOL, false, false>), grid, block, 0, stream, P);
+  if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, true>), grid, block, 0, stream, P);
+  else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, false>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, false>), grid, block, 0, stream, P);
 }
 
 template <int MODE>
-static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono) {
+static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
   dim3 grid(blocks), block(kBlock);
-  if (pool) launch_mono<MODE, true>(P, grid, block, stream, mono);
-  else launch_mono<MODE, false>(P, grid, block, stream, mono);
+  if (geom == kGeomPoolPrism) launch_mono<MODE, kGeomPoolPrism>(P, grid, block, stream, mono);
+  else if (geom == kGeomPool) launch_mono<MODE, kGeomPool>(P, grid, block, stream, mono);
+  else launch_mono<MODE, kGeomOne>(P, grid, block, stream, mono);
   return hipGetLastError();
 }
 

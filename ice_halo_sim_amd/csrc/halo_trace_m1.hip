@@ -2,7 +2,7 @@
 #include "halo_trace.inl"
 
 namespace halo {
-hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, bool pool, bool mono) {
-  return launch_mode<kModeFilter>(P, blocks, stream, pool, mono);
+hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
+  return launch_mode<kModeFilter>(P, blocks, stream, geom, mono);
 }
 }  // namespace halo

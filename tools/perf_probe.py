@@ -50,6 +50,7 @@ if "bin" in which:
         run("config2 dual-fisheye full sky 2048x1024 10M bin=%d" % b, sc, full, bin=b)
         run("config2 dual-fisheye full sky 2048x1024 50M bin=%d" % b, sc, full, n=50_000_000, reps=2, bin=b)
         run("stochastic prism rect full sky 4M bin=%d" % b, sc_s, rd_s, n=4_000_000, bin=b)
+        run("stochastic prism rect full sky 16M bin=%d" % b, sc_s, rd_s, n=16_000_000, bin=b)
 if "illum" in which:
     wl_d65 = scenes.wl_illuminant("D65", 64)
     def run_wl(label, n, **opts):
