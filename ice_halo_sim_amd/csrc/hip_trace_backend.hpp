@@ -84,6 +84,37 @@ class HipTraceBackend {
     Check(halo_readback_xyz(h_, xyz.data, xyz.width, xyz.height, &landed_weight));
   }
   void EndSession() { Check(halo_end(h_)); }
+
+  // --- beyond the reference's virtuals: tables the reference hands over inside SessionSpec, and the deferred tallies ---
+  // physical filters referenced by HaloEntry::filter_id (reference: FilterSpec per scattering setting, filter_spec.hpp)
+  void SetFilters(const std::vector<HaloFilter>& filters) {
+    Check(halo_set_filters(h_, filters.empty() ? nullptr : filters.data(), static_cast<int32_t>(filters.size())));
+  }
+  // raypath colour (reference: SessionSpec::raypath_color → ColorGateTable / ColorClassTable)
+  void SetColor(const std::vector<HaloColorSet>& sets, const std::vector<HaloColorClass>& classes) {
+    Check(halo_set_color(h_, sets.empty() ? nullptr : sets.data(), static_cast<int>(sets.size()), classes.empty() ? nullptr : classes.data(),
+                         static_cast<int>(classes.size())));
+    class_count_ = classes.size();
+  }
+  // TraceBackend::ReadbackClassLanes (trace_backend.hpp:471-493): lane c at lane_data[c*W*H + py*W + px]; zeroes the device
+  void ReadbackClassLanes(std::vector<float>& lane_data, size_t& class_count) {
+    class_count = class_count_;
+    lane_data.assign(class_count_ * static_cast<size_t>(width_) * static_cast<size_t>(height_), 0.0f);
+    if (class_count_) Check(halo_readback_class_lanes(h_, lane_data.data(), width_, height_, static_cast<int>(class_count_)));
+  }
+  // option "async" = 1: final-layer TraceLayer only queues; the summed LayerStats of everything traced since the last call
+  HaloLayerStats CollectStats() {
+    HaloLayerStats st{};
+    Check(halo_collect_stats(h_, &st));
+    return st;
+  }
+  // RenderConsumer on the device (server/render.cpp:138-330)
+  void ConsumeDeviceFused() { Check(halo_consumer_fold(h_)); }
+  double Snapshot(const HaloDisplay& display, uint8_t* rgb_out, float* xyz_out = nullptr) {
+    double total = 0.0;
+    Check(halo_consumer_snapshot(h_, &display, rgb_out, xyz_out, &total));
+    return total;
+  }
   bool IsCompatible(const HaloRender& render) const { return render.width > 0 && render.height > 0; }
 
  private:
@@ -95,6 +126,7 @@ class HipTraceBackend {
   }
   halo_handle_t h_ = nullptr;
   int width_ = 0, height_ = 0;
+  size_t class_count_ = 0;
 };
 
 }  // namespace halo

@@ -51,6 +51,56 @@ int main() {
     std::printf("roots %llu exits %llu landed %.3f sumY %.3f drained %zu\n", (unsigned long long)lh.stats.root_count,
                 (unsigned long long)lh.stats.exit_count, landed, y, drained);
     bool ok = lh.stats.root_count == n && drained == 0 && landed > 0.4f * n && landed < n && std::fabs(y / (0.995 * landed) - 1.0) < 0.02;
+
+    // second session: filter + raypath colour + deferred tallies + device consumer, through the adapter only
+    HaloFilter f;
+    std::memset(&f, 0, sizeof(f));
+    f.symmetry = HALO_SYM_P;
+    f.terms[0].type = HALO_FILTER_RAYPATH;
+    f.terms[0].raypath_len = 2;
+    f.terms[0].raypath[0] = 3;
+    f.terms[0].raypath[1] = 5;
+    be.SetFilters({f});
+    HaloColorSet cs;
+    std::memset(&cs, 0, sizeof(cs));
+    cs.term_count = 1;
+    cs.terms[0].predicate = f.terms[0];
+    cs.terms[0].symmetry = HALO_SYM_P;
+    cs.terms[0].bit = 2;
+    HaloColorClass cc = {1ull << 2, 0, 0};
+    be.SetColor({cs}, {cc});
+    be.SetOption("async", 1);
+    (void)be.CollectStats();                          // start a fresh tally window (the first session is in it)
+    sc.layers[0].entries[0].filter_id = 1;
+    sc.layers[0].entries[0].color_id = 1;
+    be.BeginSession(sc, rd, wl, n);
+    halo::LayerHandle lq = be.TraceLayer(n);          // queued: tallies arrive through CollectStats
+    be.EndSession();
+    HaloLayerStats st = be.CollectStats();
+    std::vector<float> lanes;
+    size_t classes = 0;
+    float landed2 = 0.0f;
+    be.ReadbackXyzAccum(xyz, landed2);
+    be.ReadbackClassLanes(lanes, classes);
+    double lane_sum = 0.0, y2 = 0.0;
+    for (float v : lanes) lane_sum += v;
+    for (size_t i = 1; i < img.size(); i += 3) y2 += img[i];
+    std::printf("filtered: queued exits %llu collected exits %llu landed %.3f lane %.3f sumY %.3f\n", (unsigned long long)lq.stats.exit_count,
+                (unsigned long long)st.exit_count, landed2, lane_sum, y2);
+    // every surviving exit is a 3-5 path, so it sets bit 2 and the single class lane equals the image's Y
+    ok = ok && lq.stats.exit_count == 0 && st.root_count == n && st.exit_count > 0 && st.exit_count < lh.stats.exit_count && classes == 1 &&
+         landed2 > 0.0f && std::fabs(lane_sum / y2 - 1.0) < 1e-3;
+    be.BeginSession(sc, rd, wl, n);
+    be.TraceLayer(n);
+    be.EndSession();
+    be.ConsumeDeviceFused();
+    std::vector<uint8_t> rgb(static_cast<size_t>(rd.width) * rd.height * 3);
+    HaloDisplay disp = {1.0f, {-1.0f, -1.0f, -1.0f}, {0.0f, 0.0f, 0.0f}};
+    double total = be.Snapshot(disp, rgb.data());
+    unsigned mx = 0;
+    for (uint8_t v : rgb) mx = v > mx ? v : mx;
+    std::printf("consumer: total intensity %.3f max rgb %u\n", total, mx);
+    ok = ok && total > 0.0 && mx > 0;
     return ok ? 0 : 1;
   } catch (const halo::BackendUnavailableError& e) {
     std::printf("BackendUnavailableError: %s\n", e.what());
