@@ -28,7 +28,6 @@ def test_adapter_compiles_and_reports_unavailable_without_gpu():
 
 @pytest.mark.gpu
 def test_adapter_runs_a_session_on_the_gpu():
-    if not os.path.exists(EXE):
-        _build()
+    _build()   # always: a binary that travelled with the snapshot may predate the header
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
