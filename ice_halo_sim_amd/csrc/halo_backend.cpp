@@ -20,7 +20,8 @@
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
-hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index, hipStream_t stream);
+hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
+                           hipStream_t stream);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
                        hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
@@ -653,6 +654,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint64_t m = chunk_of(n_ci - off, deterministic);
       const uint32_t shape_cnt = deterministic ? 1u : static_cast<uint32_t>((m + b->geom_clock - 1) / b->geom_clock);
       const bool host_pool = !deterministic && b->host_shapes;
+      // 0 = one shape per dispatch, 1 = pool of ShapeDev records, 2 = pool of ShapePrism records (device-generated prisms)
+      const int geom = deterministic ? 0 : ((E.crystal.kind == HALO_CRYSTAL_PRISM && !host_pool) ? 2 : 1);
       std::vector<ShapeDev> pool(deterministic || host_pool ? shape_cnt : 0u);
       for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++)
         host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
@@ -688,12 +691,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       if (deterministic) {
         P.shapes = &ds->shape;
       } else {
-        HIPCHK(b, b->shapes.reserve(shape_cnt));
+        HIPCHK(b, b->shapes.reserve(shape_cnt));   // sized for ShapeDev records; prism pools use the front third
         if (host_pool) {
           HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
         } else {  // device generator: one thread per sampled crystal, same stream → ordered before the trace kernel
-          HIPCHK(b, hipMemsetAsync(b->shapes.ptr, 0, static_cast<size_t>(shape_cnt) * sizeof(ShapeDev), b->stream));
-          hipError_t ge = launch_shapegen(b->shapes.ptr, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream);
+          hipError_t ge = launch_shapegen(b->shapes.ptr, geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream);
           if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
         }
         P.shapes = b->shapes.ptr;
@@ -736,7 +738,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
-      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, deterministic ? 0 : (E.crystal.kind == HALO_CRYSTAL_PRISM ? 2 : 1), b->mono_session);
+      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, geom, b->mono_session);
       b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_bin) {
@@ -798,8 +800,7 @@ int halo_generate_shapes(halo_handle_t b, const HaloCrystal* crystal, uint64_t f
     HIPCHK(b, hipSetDevice(b->device));
     DevBuf<ShapeDev> dev;
     HIPCHK(b, dev.reserve(n));
-    HIPCHK(b, hipMemsetAsync(dev.ptr, 0, static_cast<size_t>(n) * sizeof(ShapeDev), b->stream));
-    hipError_t ge = launch_shapegen(dev.ptr, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream);
+    hipError_t ge = launch_shapegen(dev.ptr, false, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream);
     if (ge == hipSuccess) ge = hipMemcpyAsync(pool.data(), dev.ptr, static_cast<size_t>(n) * sizeof(ShapeDev), hipMemcpyDeviceToHost, b->stream);
     if (ge == hipSuccess) ge = hipStreamSynchronize(b->stream);
     dev.release();

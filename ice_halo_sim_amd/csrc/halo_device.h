@@ -49,6 +49,21 @@ struct ShapeDev {
 };
 static_assert(sizeof(ShapeDev) % 16 == 0, "ShapeDev rows are read as float4");
 
+// A hexagonal prism never has more than 8 faces, 4 opposite-face slabs and 20 fan triangles: stochastic prism pools and
+// their LDS copies use this third-size record (same member names, so geometry and trace code are generic over the two).
+struct ShapePrism {
+  int32_t face_cnt, tri_cnt, slab_cnt, single_cnt;
+  float face[8][4];
+  float slab[4][8];
+  float tri_v[20][9];
+  float tri_na[20][4];
+  uint8_t tri_face[20];
+  uint8_t face_number[8];
+  uint8_t single[8];
+  uint8_t pad[12];
+};
+static_assert(sizeof(ShapePrism) % 16 == 0, "ShapePrism rows are read as float4");
+
 struct WlEntryDev {  // reference WlEntry, src/core/backend/wl_pool.hpp:29-35 (+pad to 32 B)
   float n_idx, spd_weight, cmf_x, cmf_y, cmf_z, pad0, pad1, pad2;
 };

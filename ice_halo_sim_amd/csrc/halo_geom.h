@@ -95,17 +95,19 @@ struct ShapeCursor {
 
 // Host: zero the record.  Device: the generator's caller clears the whole pool with one memset instead of 3.7 KB of
 // strided stores per thread.
-HALO_GEOM_HD void ClearShape(ShapeDev& s) {
+template <class S>
+HALO_GEOM_HD void ClearShape(S& s) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  (void)s;
+  s.face_cnt = s.tri_cnt = s.slab_cnt = s.single_cnt = 0;   // rows beyond the counts are never read
 #else
   uint32_t* w = reinterpret_cast<uint32_t*>(&s);
-  for (uint32_t i = 0; i < sizeof(ShapeDev) / 4u; i++) w[i] = 0u;
+  for (uint32_t i = 0; i < sizeof(S) / 4u; i++) w[i] = 0u;
 #endif
 }
 
 // one present face: plane = raw coefficients (a, b, c, d), normal = unit outward, loop = CCW corners seen from outside
-HALO_GEOM_HD void EmitFace(ShapeDev& s, ShapeCursor& cur, const float plane[4], const float normal[3], int number,
+template <class S>
+HALO_GEOM_HD void EmitFace(S& s, ShapeCursor& cur, const float plane[4], const float normal[3], int number,
                            const float (*loop)[3], int nv) {
   const int fid = cur.fid;
   s.face[fid][0] = normal[0];
@@ -114,7 +116,7 @@ HALO_GEOM_HD void EmitFace(ShapeDev& s, ShapeCursor& cur, const float plane[4], 
   const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
   s.face[fid][3] = (len > kGeomFloatEps) ? plane[3] / len : 0.0f;
   s.face_number[fid] = static_cast<uint8_t>(number);
-  for (int k = 1; k + 1 < nv && nv >= 3 && cur.tri < kMaxTris; k++) {
+  for (int k = 1; k + 1 < nv && nv >= 3 && cur.tri < static_cast<int>(sizeof(s.tri_na) / 16u); k++) {
     const int t = cur.tri;
     float* v = s.tri_v[t];
     for (int a = 0; a < 3; a++) {
@@ -135,7 +137,8 @@ HALO_GEOM_HD void EmitFace(ShapeDev& s, ShapeCursor& cur, const float plane[4], 
 }
 
 // Pair up faces whose unit normals are exact negatives (see ShapeDev::slab); runs once per shape after the last EmitFace.
-HALO_GEOM_HD void FinalizeSlabs(ShapeDev& s, const ShapeCursor& cur) {
+template <class S>
+HALO_GEOM_HD void FinalizeSlabs(S& s, const ShapeCursor& cur) {
   s.face_cnt = cur.fid;
   s.tri_cnt = cur.tri;
   bool used[kMaxFaces];
@@ -243,7 +246,8 @@ HALO_GEOM_HD void SolveHex(const double r[6], HexSection& hs) {
 }
 
 // ComputeClosedFormPrism + AdaptClosedFormPrismToCrystalGeom. false = empty crystal (counts stay 0).
-HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], ShapeDev& out) {
+template <class S>
+HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], S& out) {
   ClearShape(out);
   if (!(h > kGeomFloatEps)) return false;
   const double k_r = kGeomSqrt3 / 4.0, k_d = kGeomSqrt3 / 8.0;
@@ -483,7 +487,17 @@ struct CrystalRecipe {   // HaloCrystal with the wedge trig already evaluated (h
   double cot_u, cot_l;   // sqrt3/4 / tan(wedge); negative = illegal wedge (cone absent)
 };
 
-HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, ShapeDev& out) {
+HALO_GEOM_HD bool BuildPyramidDispatch(const CrystalRecipe& rc, const float sc[9], const float dist[6], ShapeDev& out) {
+  return BuildPyramidShape(rc.cot_u, rc.cot_l, fabsf(sc[0]), fabsf(sc[1]), fabsf(sc[2]), dist, out);
+}
+HALO_GEOM_HD bool BuildPyramidDispatch(const CrystalRecipe&, const float*, const float*, ShapePrism& out) {
+  ClearShape(out);
+  return false;
+}
+
+// S = ShapeDev (any crystal) or ShapePrism (prisms only: a pyramid recipe yields the empty shape)
+template <class S>
+HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, S& out) {
   const HaloCrystal& c = rc.c;
   const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
   const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
@@ -520,7 +534,7 @@ HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t 
   float dist[6];
   for (int i = 0; i < 6; i++) dist[i] = sc[3 + i];
   if (c.kind == HALO_CRYSTAL_PRISM) return BuildPrismShape(fabsf(sc[0]), dist, out);  // heights fold, distances stay signed
-  return BuildPyramidShape(rc.cot_u, rc.cot_l, fabsf(sc[0]), fabsf(sc[1]), fabsf(sc[2]), dist, out);
+  return BuildPyramidDispatch(rc, sc, dist, out);
 }
 
 }  // namespace geom

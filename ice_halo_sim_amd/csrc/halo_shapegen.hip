@@ -15,18 +15,23 @@ namespace halo {
 
 constexpr int kGenBlock = 64;
 
-// `pool` must be zeroed by the caller (an invalid draw leaves face_cnt = 0 = empty crystal).
-__global__ void __launch_bounds__(kGenBlock) halo_shapegen_kernel(ShapeDev* __restrict__ pool, uint32_t n, uint32_t seed,
-                                                                   const geom::CrystalRecipe rc, uint64_t first_index) {
+// S = ShapeDev (any crystal; 4.1 KB records) or ShapePrism (prism pools; 1.4 KB records).  Every record gets its counts
+// written (an invalid draw leaves them 0 = empty crystal) and rows beyond the counts are never read, so the pool needs no
+// clearing.
+template <class S>
+__global__ void __launch_bounds__(kGenBlock) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
+                                                                   uint64_t first_index) {
   const uint32_t k = blockIdx.x * kGenBlock + threadIdx.x;
   if (k >= n) return;
   geom::MakeShapeDev(seed, rc, first_index + k, pool[k]);
 }
 
-hipError_t launch_shapegen(ShapeDev* pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
+hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(halo_shapegen_kernel, dim3((n + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, stream, pool, n, seed, rc, first_index);
+  const dim3 grid((n + kGenBlock - 1) / kGenBlock), block(kGenBlock);
+  if (prism_records) hipLaunchKernelGGL(halo_shapegen_kernel<ShapePrism>, grid, block, 0, stream, static_cast<ShapePrism*>(pool), n, seed, rc, first_index);
+  else hipLaunchKernelGGL(halo_shapegen_kernel<ShapeDev>, grid, block, 0, stream, static_cast<ShapeDev*>(pool), n, seed, rc, first_index);
   return hipGetLastError();
 }
 

@@ -666,34 +666,21 @@ struct ColorSlot<false> {
   uint32_t unused;
 };
 
-// A sampled prism never has more than 8 faces, 4 opposite-face slabs and 20 fan triangles: its LDS copy is a third of
-// a ShapeDev (same member names, so the trace code is generic over the two).
-struct ShapePrismLds {
-  int32_t face_cnt, tri_cnt, slab_cnt, single_cnt;
-  float face[8][4];
-  float slab[4][8];
-  float tri_v[20][9];
-  float tri_na[20][4];
-  uint8_t tri_face[20];
-  uint8_t face_number[8];
-  uint8_t single[8];
-  uint8_t pad[12];
-};
-static_assert(sizeof(ShapePrismLds) % 16 == 0 && offsetof(ShapePrismLds, tri_v) % 16 == 0 && offsetof(ShapePrismLds, tri_na) % 16 == 0 &&
-              offsetof(ShapePrismLds, tri_face) % 4 == 0 && offsetof(ShapePrismLds, face_number) % 4 == 0 && offsetof(ShapePrismLds, single) % 4 == 0,
+static_assert(offsetof(ShapePrism, tri_v) % 16 == 0 && offsetof(ShapePrism, tri_na) % 16 == 0 && offsetof(ShapePrism, slab) % 16 == 0 &&
+              offsetof(ShapePrism, tri_face) % 4 == 0 && offsetof(ShapePrism, face_number) % 4 == 0 && offsetof(ShapePrism, single) % 4 == 0,
               "rows are copied as float4 / dwords");
 static_assert(offsetof(ShapeDev, tri_v) % 16 == 0 && offsetof(ShapeDev, tri_na) % 16 == 0 && offsetof(ShapeDev, slab) % 16 == 0 &&
               offsetof(ShapeDev, tri_face) % 4 == 0 && offsetof(ShapeDev, face_number) % 4 == 0 && offsetof(ShapeDev, single) % 4 == 0,
               "rows are copied as float4 / dwords");
 
-constexpr int kGeomOne = 0, kGeomPool = 1, kGeomPoolPrism = 2;   // GEOM: one shape per dispatch | pool, generic slots | pool, prism slots
+constexpr int kGeomOne = 0, kGeomPool = 1, kGeomPoolPrism = 2;   // GEOM: one shape per dispatch | pool of ShapeDev | pool of ShapePrism (HBM records and LDS slots)
 template <int GEOM>
 struct PoolSlotType {
   typedef ShapeDev type;
 };
 template <>
 struct PoolSlotType<kGeomPoolPrism> {
-  typedef ShapePrismLds type;
+  typedef ShapePrism type;
 };
 template <bool ON, typename SlotT, int N = kBlock / 32>
 struct PoolSlots {
@@ -706,7 +693,7 @@ struct PoolSlots<false, SlotT, N> {
 
 // 32 lanes copy the rows one pool shape uses into their half-wave's LDS slot (coalesced 16-byte loads)
 template <typename SlotT>
-HD void stage_shape(SlotT* slot, const ShapeDev* g, uint32_t l32) {
+HD void stage_shape(SlotT* slot, const SlotT* g, uint32_t l32) {
   constexpr uint32_t kF = sizeof(slot->face) / 16u, kS = sizeof(slot->slab) / 32u, kT = sizeof(slot->tri_na) / 16u, kN = sizeof(slot->single);
   const uint32_t fc = min(static_cast<uint32_t>(g->face_cnt), kF), tc = min(static_cast<uint32_t>(g->tri_cnt), kT);
   const uint32_t sc = min(static_cast<uint32_t>(g->slab_cnt), kS), n1 = min(static_cast<uint32_t>(g->single_cnt), kN);
@@ -1143,7 +1130,7 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
     for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
       const uint32_t tid = base + threadIdx.x;
       const uint32_t first = base + (threadIdx.x & ~31u);
-      if (first < P.n_rays) stage_shape(slot, P.shapes + first / P.geom_clock, l32);
+      if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolSlot*>(P.shapes) + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums);
@@ -1159,7 +1146,7 @@ __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(cons
       const uint32_t tid = base + threadIdx.x;
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
-          const ShapeDev* sh = P.shapes + (tid / P.geom_clock);
+          const PoolSlot* sh = reinterpret_cast<const PoolSlot*>(P.shapes) + (tid / P.geom_clock);
           trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
