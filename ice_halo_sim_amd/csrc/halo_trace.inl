@@ -209,7 +209,12 @@ HD void sample_lat_lon_roll(Stream& s, const DispatchParams& P, const float* lut
     float colat = invert_lat_lut(xi, lut);
     phi = kPi2F - colat;
     uint32_t bin = lat_lut_bin(colat, lut);
-    flip = uniform(s) < lut[2 * kLutNodes + bin];
+    const float p_flip = lut[2 * kLutNodes + bin];
+    if (p_flip > 0.0f) {
+      flip = uniform(s) < p_flip;
+    } else {
+      s.slot++;  // u < 0 is false for every u: keep the stream aligned, skip the two hashes
+    }
   }
   if (P.lat_path != kLatFullSphere) lon = get_dist(s, P.az_type, P.az_mean_rad, P.az_std_rad);
   roll = get_dist(s, P.roll_type, P.roll_mean_rad, P.roll_std_rad);
@@ -868,8 +873,10 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
     Stream wls = s;
     wls.seed ^= kNonceWl;
-    wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(P.wl_pool_size));
-    if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
+    if (P.wl_pool_size > 1u) {  // a one-entry pool needs no draw: floor(u * 1) is 0 for every u in [0, 1) (own stream, nothing to keep aligned)
+      wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(P.wl_pool_size));
+      if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
+    }
     float lon, lat, roll;
     sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
     build_crystal_rotation(lon, lat, roll, R);
