@@ -55,6 +55,7 @@ def load_library():
         "halo_readback_xyz": (C.c_int, [H, f32p, C.c_int, C.c_int, f32p]),
         "halo_readback_xyz64": (C.c_int, [H, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "halo_sync": (C.c_int, [H]),
+        "halo_last_sample_counts": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "halo_set_color": (C.c_int, [H, C.POINTER(abi.HaloColorSet), C.c_int, C.POINTER(abi.HaloColorClass), C.c_int]),
         "halo_readback_class_lanes": (C.c_int, [H, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]),
         "halo_generate_shapes": (C.c_int, [H, C.POINTER(abi.HaloCrystal), C.c_uint64, C.c_uint32, C.c_int, C.POINTER(abi.HaloGeomTables)]),
@@ -82,7 +83,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath",
 ]
@@ -163,6 +164,12 @@ class HipTraceBackend:
         out = (abi.HaloGeomTables * n)()
         self._check(self._L.halo_generate_shapes(self._h, C.byref(crystal), int(first_index), int(n), 1 if on_device else 0, out))
         return out
+
+    def last_sample_counts(self):
+        """(stochastic crystal instances sampled, rays whose orientation was drawn) in the session traced last."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._L.halo_last_sample_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def collect_stats(self):
         """Summed tallies of every layer traced since the previous call (waits for the stream); the only source of

@@ -142,6 +142,7 @@ struct HaloBackend {
   uint64_t exits_pending = 0;
   DevBuf<float> host_f;        // injected rays: d | p | w
   DevBuf<uint32_t> host_u;
+  uint64_t sess_crystal_samples = 0, sess_orient_samples = 0;  // this session's stochastic draws (halo_last_sample_counts)
   double landed_host = 0.0;    // landed weight already folded from `sums` (kept in fp64 on the host)
 };
 
@@ -435,6 +436,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       b->lanes_h = render->height;
     }
   }
+  b->sess_crystal_samples = b->sess_orient_samples = 0;
   b->in_session = true;
   b->layer_idx = 0;
   b->cont_in_n = 0;
@@ -660,7 +662,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++)
         host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
       const uint64_t first_shape = b->shape_count;
-      if (!deterministic) b->shape_count += shape_cnt;
+      if (!deterministic) {
+        b->shape_count += shape_cnt;
+        b->sess_crystal_samples += shape_cnt;
+      }
+      if (rays == nullptr && (E.axis.azimuth.type != HALO_DIST_NONE || E.axis.latitude.type != HALO_DIST_NONE || E.axis.roll.type != HALO_DIST_NONE))
+        b->sess_orient_samples += m;   // AxisDistribution::IsAxisDeterministic is false: one orientation per ray
       // ---- dispatch slot: tables + zeroed tallies go up in one copy from the pinned mirror ----
       const int k = b->ring_next;
       b->ring_next = (k + 1) % HaloBackend::kRing;
@@ -835,6 +842,13 @@ int halo_readback_class_lanes(halo_handle_t b, float* lanes, int width, int heig
   HIPCHK(b, hipMemcpyAsync(lanes, b->lanes.ptr, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, n * sizeof(float), b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));
+  return HALO_OK;
+}
+
+int halo_last_sample_counts(halo_handle_t b, uint64_t* crystal_samples, uint64_t* orientation_samples) {
+  if (!b) return HALO_FATAL;
+  if (crystal_samples) *crystal_samples = b->sess_crystal_samples;
+  if (orientation_samples) *orientation_samples = b->sess_orient_samples;
   return HALO_OK;
 }
 

@@ -115,6 +115,17 @@ class HipTraceBackend {
     Check(halo_consumer_snapshot(h_, &display, rgb_out, xyz_out, &total));
     return total;
   }
+  // trace_backend.hpp:587,625 — real counts of the last session's stochastic draws (never stand-ins)
+  size_t GetLastBatchStochasticCrystalSampleCount() const {
+    uint64_t c = 0, o = 0;
+    (void)halo_last_sample_counts(h_, &c, &o);
+    return static_cast<size_t>(c);
+  }
+  size_t GetLastBatchStochasticOrientationSampleCount() const {
+    uint64_t c = 0, o = 0;
+    (void)halo_last_sample_counts(h_, &c, &o);
+    return static_cast<size_t>(o);
+  }
   bool IsCompatible(const HaloRender& render) const { return render.width > 0 && render.height > 0; }
 
  private:

@@ -291,6 +291,11 @@ int halo_set_color(halo_handle_t h, const HaloColorSet* sets, int n_sets, const 
 /* TraceBackend::ReadbackClassLanes — trace_backend.hpp:471-493: copies class_count*W*H floats (lane c at
  * lanes[c*W*H + py*W + px]) and zeroes the device lanes.  Call after halo_readback_xyz's sync point or halo_sync. */
 int halo_readback_class_lanes(halo_handle_t h, float* lanes, int width, int height, int class_count);
+/* TraceBackend::GetLastBatchStochasticCrystalSampleCount / ...OrientationSampleCount (trace_backend.hpp:587,625), for the
+ * session traced last (counters reset at halo_begin): crystal instances actually sampled (one per geom_clock rays of every
+ * crystal entry that is not IsDeterministic; 0 for fixed shapes) and rays whose orientation was drawn (every ray of an entry
+ * whose axis has a non-fixed distribution).  Real counts of what the kernels did, not estimates. */
+int halo_last_sample_counts(halo_handle_t h, uint64_t* crystal_samples, uint64_t* orientation_samples);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
  * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the

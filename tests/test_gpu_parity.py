@@ -452,6 +452,26 @@ def test_device_crystal_generator_equals_host_builder():
     hb.close()
 
 
+def test_sample_count_getters_report_real_draws():
+    """GetLastBatchStochastic{Crystal,Orientation}SampleCount (trace_backend.hpp:587,625): one crystal per geom_clock rays of
+    a stochastic entry, none for a fixed shape; one orientation per ray of an entry with a non-fixed axis."""
+    u = lambda m, s: {"type": "uniform", "mean": m, "std": s}
+    fixed_axis = scenes.entry(scenes.prism_crystal(1.0), scenes.axis(), 1.0, 1)                                   # nothing random
+    stoch = scenes.entry(scenes.prism_crystal(u(1.0, 0.5)), scenes.axis(zenith=u(90, 360), azimuth=u(0, 360)), 3.0, 2)
+    sc = scenes.scene([(0.0, [fixed_axis, stoch])], max_hits=4)
+    hb = hip_backend(seed=3)
+    run_session(hb, sc, scenes.config2_render(160, 90), scenes.wl_discrete(550.0), 40_000)
+    crystals, orients = hb.last_sample_counts()
+    assert orients == 30_000 and crystals == (30_000 + 31) // 32
+    hb.set_option("geom_clock", 64)
+    run_session(hb, sc, scenes.config2_render(160, 90), scenes.wl_discrete(550.0), 40_000)
+    assert hb.last_sample_counts() == ((30_000 + 63) // 64, 30_000)
+    sc2 = scenes.scene([(0.0, [fixed_axis])], max_hits=4)
+    run_session(hb, sc2, scenes.config2_render(160, 90), scenes.wl_discrete(550.0), 1000)
+    assert hb.last_sample_counts() == (0, 0)
+    hb.close()
+
+
 def test_stochastic_trace_device_pool_equals_host_pool():
     """Tracing with device-generated shape pools gives the same rays as with host-built pools (uniform draws: same bits)."""
     u = lambda m, s: {"type": "uniform", "mean": m, "std": s}
