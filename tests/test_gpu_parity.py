@@ -370,6 +370,41 @@ def test_full_size_properties():
     hb.close()
 
 
+def test_full_size_image_l2_vs_oracle():
+    """north_star: "outputs must match the reference CPU backend's fixed-seed image within a stated per-pixel L2 tolerance".
+    configs[1] at 1920x1080, one wavelength, 20 M rays on both sides (same streams): per-PIXEL (no block averaging) relative
+    L2 <= 1e-3, also with the sun disc masked out so the bound is not carried by its few bright pixels."""
+    sc, rd = scenes.config2_scene(), scenes.config2_render()
+    n, drains = 20_000_000, 20
+    import os
+    hb = hip_backend(seed=2024)
+    ob = OracleBackend(seed=2024, threads=min(os.cpu_count() or 1, 128))
+    sh = run_session(hb, sc, rd, scenes.wl_discrete(570.0), n)
+    ih, lh = hb.ReadbackXyzAccum()
+    # The oracle adds every hit into a float32 pixel one by one: in ONE 20 M-ray session the sun-disc pixels pass 5e5 and
+    # hits lighter than half an ulp (0.016) vanish — it reads 0.37 % low there.  Drain it every 1 M rays into float64
+    # (ray counters are monotone across sessions, so these are the same 20 M rays).
+    io, lo, exits_o = np.zeros((rd.height, rd.width, 3), np.float64), 0.0, 0
+    for _ in range(drains):
+        so = run_session(ob, sc, rd, scenes.wl_discrete(570.0), n // drains)
+        part, l = ob.ReadbackXyzAccum()
+        io += part
+        lo += l
+        exits_o += so[0].exit_count
+    hb.close()
+    ob.close()
+    so = [type("S", (), {"exit_count": exits_o})()]
+    assert sh[0].exit_count == pytest.approx(so[0].exit_count, rel=1e-5)
+    assert lh == pytest.approx(lo, rel=1e-6)
+    io = io.astype(np.float32)
+    full = rel_l2(ih, io)
+    y = io[..., 1]
+    dim = y < np.partition(y.ravel(), -64)[-64]        # everything but the 64 brightest pixels
+    halo = rel_l2(ih[dim], io[dim])
+    print("per-pixel rel L2: full %.3e, without the 64 brightest pixels %.3e" % (full, halo))
+    assert full <= 1e-3 and halo <= 1e-3
+
+
 def test_async_dispatch_equals_synchronous():
     """Option async=1 queues final-layer dispatches without a host sync; image, landed weight and the collected tallies must
     equal the synchronous run's bit for bit (same launches, same streams)."""
