@@ -421,7 +421,7 @@ struct PixCache {
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
 constexpr int kHitBuf = 2048;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
-constexpr int kBinMaxTiles = 256;
+constexpr int kBinMaxTiles = 512;
 constexpr int kBinCntStride = 16;              // tile counters 64 B apart
 struct HitBuffer {
   uint2 h[kHitBuf];
@@ -447,6 +447,31 @@ struct AccCtx {
 HD float* mono_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) {
   const uint32_t copy = blockIdx.x & P.mono_copy_mask;
   return P.mono + (static_cast<size_t>(pl * (P.mono_copy_mask + 1u) + copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
+}
+
+// X/Y/Z-binned route (illuminant sessions, full-sky renders): the planes are X, Y, Z; a scalar hit of pool entry `wl`
+// that cannot be staged (cache flush, full buffer or list, or a launch too small to bin) is added with its CMF directly.
+HD void add_xyz_direct(const DispatchParams& P, uint32_t wl, uint32_t slot_in_plane, float v) {
+  const WlEntryDev e = P.wl_pool[wl];
+  const size_t plane = static_cast<size_t>(P.mono_copy_mask + 1u) << (P.mono_s_log2 + 10u);   // copies == 1 on this route
+  atomic_add_f32(P.mono + slot_in_plane, e.cmf_x * v);
+  atomic_add_f32(P.mono + plane + slot_in_plane, e.cmf_y * v);
+  atomic_add_f32(P.mono + 2u * plane + slot_in_plane, e.cmf_z * v);
+}
+
+// Stage one hit record in the workgroup's buffer; false = buffer full (the caller adds the hit directly).
+HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
+  // one LDS atomic per wave, not per lane (64 lanes on one address would serialise)
+  const uint64_t mask = __ballot(1);
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
+  uint32_t first = 0u;
+  if (lane == leader) first = atomicAdd(&hb->n, static_cast<uint32_t>(__popcll(mask)));
+  first = __shfl(first, static_cast<int>(leader));
+  const uint32_t pos = first + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+  if (pos >= static_cast<uint32_t>(kHitBuf)) return false;
+  hb->h[pos] = make_uint2(key, __float_as_uint(w));
+  return true;
 }
 
 // MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
@@ -480,22 +505,11 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pi
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
-    if (ctx.hits != nullptr) {  // binned mode: stage the hit; the list stores the slot inside plane 0, copy 0
-      // one LDS atomic per wave, not per lane (64 lanes on one address would serialise)
-      const uint64_t mask = __ballot(1);
-      const uint32_t lane = __lane_id();
-      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
-      uint32_t first = 0u;
-      if (lane == leader) first = atomicAdd(&ctx.hits->n, static_cast<uint32_t>(__popcll(mask)));
-      first = __shfl(first, static_cast<int>(leader));
-      const uint32_t pos = first + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-      if (pos < static_cast<uint32_t>(kHitBuf)) {
-        ctx.hits->h[pos] = make_uint2(MonoSlot(pix, P.mono_s_log2), __float_as_uint(w));
-        return;
-      }
-    }
+    if (ctx.hits != nullptr && stage_hit(ctx.hits, MonoSlot(pix, P.mono_s_log2), w)) return;   // binned: {slot in plane 0, w}
     atomic_add_f32(mono_slot(P, pl, pix), w);
   } else {
+    // X/Y/Z planes.  Binned (illuminant, full sky): {slot | pool entry << 23, w}; the accumulate pass applies the CMF
+    if (ctx.hits != nullptr && stage_hit(ctx.hits, MonoSlot(pix, P.mono_s_log2) | (wl_idx << 23), w)) return;
     atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
     atomic_add_f32(mono_slot(P, 1u, pix), cy * w);
     atomic_add_f32(mono_slot(P, 2u, pix), cz * w);
@@ -1045,7 +1059,8 @@ HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
     const uint32_t tile = h.x & tmask;
     const uint32_t idx = atomicAdd(&hb.base[tile], 1u);
     if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
-    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (plane 0, copy 0)
+    else if (P.bin_xyz) add_xyz_direct(P, h.x >> 23, h.x & 0x7FFFFFu, __uint_as_float(h.y));   // list full: direct
+    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));                                      // (plane 0, copy 0)
   }
   __syncthreads();
   if (threadIdx.x == 0) hb.n = 0u;
@@ -1076,7 +1091,6 @@ HD float wave_sum(float v) {
 #endif
 template <int MODE, int GEOM, bool MONO, bool BIN>
 __global__ void __launch_bounds__(kBlock, HALO_MIN_WAVES) halo_trace_kernel(const DispatchParams P) {
-  static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
   AccCtx<MONO> acc;
@@ -1207,6 +1221,7 @@ template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
   if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, true>), grid, block, 0, stream, P);
   else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, false>), grid, block, 0, stream, P);
+  else if (P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, true>), grid, block, 0, stream, P);
   else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, false>), grid, block, 0, stream, P);
 }
 

@@ -40,6 +40,21 @@ if "copies" in which:
         run("  512x256 mono_copies=%d" % c, sc, scenes.config2_render(512, 256), mono_copies=c)
     run("config2 mono_copies=8, plain atomics", sc, rd, mono_copies=8, aggregate=0)
     run("config2 mono_copies=32, plain atomics", sc, rd, mono_copies=32, aggregate=0)
+if "stochd65" in which:
+    # examples/bench_config_stoch.json: stochastic prism, D65, rectangular 2048x1024 full sky, max_hits 8, 10 M rays
+    import time
+    sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+    rd_s = scenes.render(7, 2048, 1024, el=0, visible=2)
+    for opts in ({}, {"lambda_planes": 0}, {"lambda_planes": 1}):
+        hb = HipTraceBackend(device=0, seed=42, **opts)
+        for n in (10_000_000, 50_000_000):
+            best = 1e9
+            for r in range(3):
+                hb.sync(); t0 = time.perf_counter()
+                st = run_session(hb, sc_s, rd_s, scenes.wl_illuminant("D65", 64), n)
+                hb.sync(); best = min(best, (time.perf_counter() - t0) * 1e3)
+            print("bench_config_stoch shape %s n=%dM: wall %.2f ms (%.0f M rays/s), kernels %.2f ms" % (opts, n // 1_000_000, best, n / best / 1e3, sum(s.kernel_ms for s in st)), flush=True)
+        hb.close()
 if "bin" in which:
     full = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 2048, 1024, visible=abi.VISIBLE_FULL)
     sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
