@@ -186,7 +186,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
                          "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)",
-                         "kernel": "halo_trace_kernel<0,false,true,false>", "launches": launches,
+                         "kernel": "halo_trace_kernel<0,0,true,false>", "launches": launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "kernel_rays_per_s": (rays_per_rank / max(kernel_ms * 1e-3, 1e-12)),
                          "valu": pmc_valu(n),
