@@ -77,7 +77,7 @@ struct HaloBackend {
   int lambda_planes = -1;      // illuminant sessions: -1 auto (by batch size), 0 never, 1 always one plane per pool entry
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
-  int blocks_per_cu = 8;
+  int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
 
@@ -325,7 +325,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     if (c != b->mono_copies) b->mono.release();
     b->mono_copies = c;
   }
-  else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 16));
+  else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 64));
   else if (k == "rank") {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
     const uint64_t base = static_cast<uint64_t>(v) << 40;
@@ -505,9 +505,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     return m;
   };
   auto blocks_of = [&](uint64_t m) {
-    // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch: below 8 Mi rays half as many
-    // persistent workgroups (4 per CU) finish sooner — measured 0.27 -> 0.20 ms at 1 M rays, equal from 16 M up
-    const uint64_t cap = (m < (8ull << 20) && b->blocks_per_cu > 4) ? static_cast<uint64_t>(b->cu_count) * 4u : static_cast<uint64_t>(max_blocks);
+    // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch, a long tail is paid per
+    // round of resident workgroups: aim at >= 32 passes of the ray loop per workgroup, between 4 and blocks_per_cu per CU
+    // (measured: 1 M rays 0.27 -> 0.20 ms at 4/CU; 50 M rays 4.02 -> 3.67 ms at 24/CU instead of 8/CU)
+    const uint64_t want = m / (static_cast<uint64_t>(kBlock) * 32u);
+    const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, 4));
+    const uint64_t cap = std::min<uint64_t>(static_cast<uint64_t>(max_blocks), std::max<uint64_t>(lo_cap, want));
     return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, cap));
   };
 
