@@ -71,14 +71,22 @@ def pmc_traffic_per_launch():
 
 
 def pmc_valu(rays_per_launch):
-    """VALU issue utilisation and instructions per 64-ray wave pass of the trace kernel, from the committed PMC passes
-    (per-dispatch means are per counter instance: one instance = 32 SIMDs; SQ_ACTIVE_INST_VALU counts quad-cycles)."""
-    act, busy = _pmc_mean("r01_bench_pmc_cycles.txt", "SQ_ACTIVE_INST_VALU"), _pmc_mean("r01_bench_pmc_cycles.txt", "SQ_BUSY_CYCLES")
+    """VALU issue utilisation and instructions per 64-ray wave pass of the trace kernel, from the committed PMC pass
+    (profiles/r01_bench_pmc_insts.txt: per-dispatch means are per counter instance = 32 SIMDs).  Issue fraction =
+    VALU wave-instructions per SIMD x 4 cycles (a wave64 VALU instruction occupies a SIMD for 4 cycles) / kernel duration
+    of that same pass at the nominal 2.4 GHz."""
     insts = _pmc_mean("r01_bench_pmc_insts.txt", "SQ_INSTS_VALU")
-    if not act or not busy or not insts:
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_insts.txt")
+    avg_us = None
+    if os.path.exists(path):
+        for line in open(path):
+            if "halo_trace_kernel" in line and "SQ_" not in line:
+                avg_us = float(line.split()[-4])          # calls total_us avg_us min_us max_us pct
+                break
+    if not insts or not avg_us:
         return None
-    return {"valu_busy_frac": act * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
-            "source": "profiles/r01_bench_pmc_{cycles,insts}.txt"}
+    return {"valu_issue_frac": (insts / 32.0) * 4.0 / (avg_us * 1e-6 * 2.4e9), "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
+            "assumes": "4 cycles per wave64 VALU instruction, 2.4 GHz", "source": "profiles/r01_bench_pmc_insts.txt"}
 
 
 def main():
