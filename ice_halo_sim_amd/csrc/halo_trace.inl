@@ -3,12 +3,13 @@
 // One fused kernel per (scattering layer, crystal entry) dispatch:
 //     root generation | layer hop  →  entry Fresnel  →  ≤ max_hits-1 interior interactions
 //     →  emit gate  →  lens projection  →  CIE-XYZ accumulation  |  continuation append
-// Ray state lives in VGPRs for its whole life; the crystal plane/fan tables, the latitude LUT and the
-// wavelength pool are staged once per workgroup into LDS and read back as wave-wide broadcasts
-// (ds_read_b128, conflict-free); HBM sees only the accumulator atomics and — for multi-scatter layers —
-// the 20-byte SoA continuation record, appended with wave64 ballot compaction (one atomic per wave per
-// emit site) and gathered by the next layer through the Feistel permutation, so neither the reference's
-// 80 B/ray root buffers nor its separate gen / transit / shuffle kernels exist here.
+// Ray state lives in VGPRs for its whole life; the crystal plane/slab/fan tables and the latitude LUT are
+// staged once per workgroup (or, for sampled crystals, once per half-wave pass) into LDS and read back as
+// wave-wide broadcasts (ds_read_b128, conflict-free); HBM sees only the accumulation traffic (atomics on
+// line-decorrelated planes, or binned hit lists) and — for multi-scatter layers — the 20-byte SoA
+// continuation record, appended with wave64 ballot compaction into sharded regions and gathered by the next
+// layer through the Feistel permutation, so neither the reference's 80 B/ray root buffers nor its separate
+// gen / transit / shuffle kernels exist here.
 //
 // What each block restates (reference /root/reference, file:line):
 //   PCG streams, orientation, sun cone, entry pick   src/core/shared/pcg_shared.h:193-624,
@@ -391,11 +392,12 @@ HD void atomic_add_f32(float* addr, float v) {
 
 // Measured on MI355X (tools/atomic_bench.hip): scattered fp32 atomics retire at ~20.7 G/s whatever the scope or
 // buffer size, but same-cache-line atomics serialize — and a third of all exits land on the ~20 pixels of the
-// sun disc (rays crossing two parallel faces keep their direction).  Two measures keep that off the fabric:
+// sun disc (rays crossing two parallel faces keep their direction).  What keeps that off the fabric (the plane
+// layout that decorrelates lines is MonoSlot in halo_device.h):
 //  * MONO: in a discrete-wavelength session every exit's XYZ is cmf(lambda)*w, so the kernel accumulates the
 //    scalar w into a one-channel plane (1 atomic per hit, not 3) and halo_fold_kernel applies the CMF once per
 //    session (AccumXyzToPixel accum_shared.h:40-47 distributes over the sum);
-//  * a per-workgroup direct-mapped pixel cache in LDS: the first pixel to claim a slot accumulates there with
+//  * a per-workgroup two-way pixel cache in LDS: the first pixel to claim a slot accumulates there with
 //    ds_add_f32 for the rest of the kernel and is flushed once; pixels that lose the claim go straight to HBM.
 //    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
 typedef float float2v __attribute__((ext_vector_type(2)));
