@@ -19,8 +19,6 @@
 
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono);
-hipError_t launch_bin_accumulate_xyz(float* planes, size_t plane_stride, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles,
-                                     const WlEntryDev* wl_pool, uint32_t wl_n, hipStream_t stream);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream);
@@ -106,7 +104,6 @@ struct HaloBackend {
   DevBuf<FilterDev> filter_dev;
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
-  bool bin_xyz = false;        // illuminant session on the binned route: records carry the pool entry, planes are X, Y, Z
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
   bool mono_dirty = false;
   uint32_t plane_cnt = 1, plane_copies = 8;
@@ -411,15 +408,10 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   const size_t npix = static_cast<size_t>(render->width) * render->height;
   if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
   const bool discrete = wl->illuminant < 0;
-  // illuminant + full-sky render: hits can be binned as {slot | entry, w} records with the CMF applied in the accumulate
-  // pass (planes X, Y, Z).  Measured no faster than one-plane-per-entry direct atomics — the pass needs three LDS atomics
-  // per hit and runs at the LDS atomic rate (88 M hits: 1.6 ms) — so it is opt-in ("bin" = 1), never automatic.
-  b->bin_xyz = b->mono_enabled && !discrete && b->aggregate == 1 && !b->capture && render->visible == HALO_VISIBLE_FULL && b->bin > 0;
-  b->mono_by_wl = !b->bin_xyz && b->mono_enabled && !discrete && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
-  b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);   // the X/Y/Z-binned route runs the three-plane kernel
+  b->mono_by_wl = b->mono_enabled && !discrete && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
+  b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
-  // one copy where hits are already spread (per-entry planes) or exchanged through lists (X/Y/Z-binned route)
-  b->plane_copies = (b->mono_by_wl || b->bin_xyz) ? 1u : static_cast<uint32_t>(b->mono_copies);
+  b->plane_copies = b->mono_by_wl ? 1u : static_cast<uint32_t>(b->mono_copies);  // hits already spread over the pool's planes
   b->plane_coef.clear();
   for (uint32_t m = 0; m < b->plane_cnt; m++) {
     if (b->mono_session) b->plane_coef.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
@@ -622,7 +614,6 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.mono_s_log2 = b->mono_s_log2;
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
-    P.bin_xyz = b->bin_xyz ? 1u : 0u;
     P.bin_list = nullptr;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
@@ -737,13 +728,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       const int blocks = blocks_of(m);
       // binned accumulation for big one-plane launches (see halo_trace.inl: HitBuffer)
-      // discrete: 16384-slot tiles of one plane; illuminant (X/Y/Z route): 4096-slot tiles x 3 channels
-      const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> (b->bin_xyz ? 12 : 14));
+      const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> 14);   // 16384-slot tiles
       const bool bin_geom_ok = deterministic || E.crystal.kind == HALO_CRYSTAL_PRISM;
-      const bool use_bin = (b->bin_xyz || (b->mono_session && !b->mono_by_wl)) && b->aggregate == 1 && !b->capture && bin_tiles >= 8u &&
-                           bin_tiles <= 512u &&
-                           (b->bin_xyz ? (bin_geom_ok && (b->bin > 0 || m >= (4ull << 20)))
-                                       : (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0));
+      const bool use_bin = b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 256u &&
+                           (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0);
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
         uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 16);
@@ -765,9 +753,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_bin) {
-        hipError_t be = b->bin_xyz ? launch_bin_accumulate_xyz(b->mono.ptr, static_cast<size_t>(kMonoRows) << b->mono_s_log2, b->bin_list.ptr, P.bin_cap,
-                                                               b->bin_cnt.ptr, bin_tiles, P.wl_pool, b->wl_pool_size, b->stream)
-                                   : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
+        hipError_t be = launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));

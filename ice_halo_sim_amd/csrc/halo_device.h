@@ -191,7 +191,6 @@ struct DispatchParams {
   uint32_t bin_cap;
   uint32_t bin_tiles;
   uint32_t* bin_cnt;           // list fill counts, kBinCntStride apart
-  uint32_t bin_xyz;            // 1: illuminant session on the binned route — hit records carry the pool entry, planes are X, Y, Z
   uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)

@@ -40,65 +40,6 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* _
   }
 }
 
-// X/Y/Z variant (illuminant sessions): records carry the wavelength-pool entry in bits 23..30 of the key; a tile is 4096
-// slots x 3 channels (48 KB), the CMF is applied here, and the tile goes to the X, Y, Z planes.
-constexpr uint32_t kBinXyzTileLog2 = 12u;
-__global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_xyz_kernel(float* __restrict__ planes, size_t plane_stride, const uint2* __restrict__ list,
-                                                                             uint32_t cap, const uint32_t* __restrict__ cnt, uint32_t tiles_log2,
-                                                                             const WlEntryDev* __restrict__ wl_pool, uint32_t wl_n) {
-  __shared__ float acc[3][1u << kBinXyzTileLog2];
-  __shared__ float cmf[HALO_WL_POOL_MAX + 1][3];
-  const uint32_t tile = blockIdx.x / kBinSplit, part = blockIdx.x % kBinSplit;
-  const uint32_t n = min(cnt[tile * kBinCntStride], cap);
-  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kBinSplit);
-  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kBinSplit);
-  if (hi <= lo) return;
-  for (uint32_t j = threadIdx.x; j < 3u << kBinXyzTileLog2; j += kBinBlock) (&acc[0][0])[j] = 0.0f;
-  for (uint32_t j = threadIdx.x; j < wl_n; j += kBinBlock) {
-    cmf[j][0] = wl_pool[j].cmf_x;
-    cmf[j][1] = wl_pool[j].cmf_y;
-    cmf[j][2] = wl_pool[j].cmf_z;
-  }
-  __syncthreads();
-  const uint2* src = list + static_cast<size_t>(tile) * cap;
-  constexpr uint32_t kU = 8u;
-  uint32_t i = lo + threadIdx.x;
-  for (; i + (kU - 1u) * kBinBlock < hi; i += kU * kBinBlock) {
-    uint2 h[kU];
-#pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
-#pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) {
-      const uint32_t wl = h[u].x >> 23, j = (h[u].x & 0x7FFFFFu) >> tiles_log2;
-      const float v = __uint_as_float(h[u].y);
-      unsafeAtomicAdd(&acc[0][j], cmf[wl][0] * v);
-      unsafeAtomicAdd(&acc[1][j], cmf[wl][1] * v);
-      unsafeAtomicAdd(&acc[2][j], cmf[wl][2] * v);
-    }
-  }
-  for (; i < hi; i += kBinBlock) {
-    const uint2 h = src[i];
-    const uint32_t wl = h.x >> 23, j = (h.x & 0x7FFFFFu) >> tiles_log2;
-    const float v = __uint_as_float(h.y);
-    unsafeAtomicAdd(&acc[0][j], cmf[wl][0] * v);
-    unsafeAtomicAdd(&acc[1][j], cmf[wl][1] * v);
-    unsafeAtomicAdd(&acc[2][j], cmf[wl][2] * v);
-  }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < 3u << kBinXyzTileLog2; j += kBinBlock) {
-    const uint32_t ch = j >> kBinXyzTileLog2, k = j & ((1u << kBinXyzTileLog2) - 1u);
-    const float v = acc[ch][k];
-    if (v != 0.0f) atomic_add_f32(planes + ch * plane_stride + ((static_cast<size_t>(k) << tiles_log2) | tile), v);
-  }
-}
-
-hipError_t launch_bin_accumulate_xyz(float* planes, size_t plane_stride, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles,
-                                     const WlEntryDev* wl_pool, uint32_t wl_n, hipStream_t stream) {
-  hipLaunchKernelGGL(halo_bin_accumulate_xyz_kernel, dim3(tiles * kBinSplit), dim3(kBinBlock), 0, stream, planes, plane_stride,
-                     reinterpret_cast<const uint2*>(list), cap, cnt, static_cast<uint32_t>(__builtin_ctz(tiles)), wl_pool, wl_n);
-  return hipGetLastError();
-}
-
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream) {
   hipLaunchKernelGGL(halo_bin_accumulate_kernel, dim3(tiles * kBinSplit), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list), cap, cnt, static_cast<uint32_t>(__builtin_ctz(tiles)));
   return hipGetLastError();

@@ -421,9 +421,9 @@ struct PixCache {
 // flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
 // sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
-constexpr int kHitBuf = 2048;                 // staged hits per workgroup (16 KB)
+constexpr int kHitBuf = 1536;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
-constexpr int kBinMaxTiles = 512;
+constexpr int kBinMaxTiles = 256;
 constexpr int kBinCntStride = 16;              // tile counters 64 B apart
 struct HitBuffer {
   uint2 h[kHitBuf];
@@ -449,16 +449,6 @@ struct AccCtx {
 HD float* mono_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) {
   const uint32_t copy = blockIdx.x & P.mono_copy_mask;
   return P.mono + (static_cast<size_t>(pl * (P.mono_copy_mask + 1u) + copy) << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2);
-}
-
-// X/Y/Z-binned route (illuminant sessions, full-sky renders): the planes are X, Y, Z; a scalar hit of pool entry `wl`
-// that cannot be staged (cache flush, full buffer or list, or a launch too small to bin) is added with its CMF directly.
-HD void add_xyz_direct(const DispatchParams& P, uint32_t wl, uint32_t slot_in_plane, float v) {
-  const WlEntryDev e = P.wl_pool[wl];
-  const size_t plane = static_cast<size_t>(P.mono_copy_mask + 1u) << (P.mono_s_log2 + 10u);   // copies == 1 on this route
-  atomic_add_f32(P.mono + slot_in_plane, e.cmf_x * v);
-  atomic_add_f32(P.mono + plane + slot_in_plane, e.cmf_y * v);
-  atomic_add_f32(P.mono + 2u * plane + slot_in_plane, e.cmf_z * v);
 }
 
 // Stage one hit record in the workgroup's buffer; false = buffer full (the caller adds the hit directly).
@@ -510,8 +500,6 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pi
     if (ctx.hits != nullptr && stage_hit(ctx.hits, MonoSlot(pix, P.mono_s_log2), w)) return;   // binned: {slot in plane 0, w}
     atomic_add_f32(mono_slot(P, pl, pix), w);
   } else {
-    // X/Y/Z planes.  Binned (illuminant, full sky): {slot | pool entry << 23, w}; the accumulate pass applies the CMF
-    if (ctx.hits != nullptr && stage_hit(ctx.hits, MonoSlot(pix, P.mono_s_log2) | (wl_idx << 23), w)) return;
     atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
     atomic_add_f32(mono_slot(P, 1u, pix), cy * w);
     atomic_add_f32(mono_slot(P, 2u, pix), cz * w);
@@ -1061,8 +1049,7 @@ HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
     const uint32_t tile = h.x & tmask;
     const uint32_t idx = atomicAdd(&hb.base[tile], 1u);
     if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
-    else if (P.bin_xyz) add_xyz_direct(P, h.x >> 23, h.x & 0x7FFFFFu, __uint_as_float(h.y));   // list full: direct
-    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));                                      // (plane 0, copy 0)
+    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (plane 0, copy 0)
   }
   __syncthreads();
   if (threadIdx.x == 0) hb.n = 0u;
@@ -1094,7 +1081,8 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES 5
 #endif
 template <int MODE, int GEOM, bool MONO, bool BIN>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? HALO_MIN_WAVES : 4)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : 4)) halo_trace_kernel(const DispatchParams P) {
+  static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
   AccCtx<MONO> acc;
@@ -1225,7 +1213,6 @@ template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
   if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, true>), grid, block, 0, stream, P);
   else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, false>), grid, block, 0, stream, P);
-  else if (P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, true>), grid, block, 0, stream, P);
   else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, false>), grid, block, 0, stream, P);
 }
 

@@ -221,34 +221,6 @@ def test_illuminant_session_plane_modes(planes):
         assert r["ih"][..., ch].sum() == pytest.approx(r["io"][..., ch].sum(), rel=2e-4)
 
 
-def test_illuminant_full_sky_binned_route():
-    """Illuminant session on a full-sky render: hits are binned as {slot | pool entry, w} records and the CMF is applied by the
-    accumulate pass into X/Y/Z planes.  Same image as the direct route and as the oracle; a stochastic prism pool on top."""
-    col = scenes.column_crystal_entry()
-    sto = scenes.stochastic_prism_entry()
-    sc = scenes.scene([(0.0, [col, sto])], max_hits=7)
-    rd = scenes.render(abi.LENS_RECTANGULAR, 1024, 512, el=0.0, visible=abi.VISIBLE_FULL)
-    wl = scenes.wl_illuminant("D65", 40)
-    n = 300_000
-    res = {}
-    for mode in (0, 1):
-        hb = hip_backend(seed=55, bin=mode)
-        st = run_session(hb, sc, rd, wl, n)
-        res[mode] = hb.ReadbackXyzAccum() + (st[0].pixel_hits,)
-        hb.close()
-    assert res[0][2] == res[1][2] > 4 * n
-    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)
-    assert rel_l2(res[0][0], res[1][0]) <= 3e-5
-    for ch in range(3):
-        assert res[0][0][..., ch].sum() == pytest.approx(res[1][0][..., ch].sum(), rel=1e-5)
-    ob = OracleBackend(seed=55, threads=8)
-    run_session(ob, sc, rd, wl, n)
-    io, lo = ob.ReadbackXyzAccum()
-    ob.close()
-    assert abs(res[1][1] - lo) <= 1e-4 * lo
-    assert rel_l2(block_mean(res[1][0]), block_mean(io)) <= 3e-3
-
-
 def test_pyramid_crystal_parity():
     """examples/config_example.json crystal id 5 (pyramid, upper Miller (2,0,3)) + a stochastic pyramid entry."""
     p5 = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3)), scenes.axis(zenith=0), 1.0, 5)
