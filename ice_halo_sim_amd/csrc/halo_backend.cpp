@@ -731,7 +731,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> 14);   // 16384-slot tiles
       const bool bin_geom_ok = deterministic || E.crystal.kind == HALO_CRYSTAL_PRISM;
       const bool use_bin = b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 256u &&
-                           (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (4ull << 20)) : b->bin != 0);
+                           (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
         uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 16);

@@ -402,16 +402,18 @@ HD void atomic_add_f32(float* addr, float v) {
 //    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-template <bool MONO>
-struct CacheGeom {  // 2048 one-channel slots (16 KB) or 1024 three-channel slots (16 KB)
-  static constexpr int kLog2 = MONO ? 11 : 10;
+// SMALLC: binned kernels of shape-pool dispatches halve the one-channel cache (their LDS also holds the pool slots and the
+// hit buffer; misses are cheap there) to stay at 4 workgroups per CU
+template <bool MONO, bool SMALLC>
+struct CacheGeom {  // 2048 one-channel slots (16 KB; 1024 with SMALLC) or 1024 three-channel slots (16 KB)
+  static constexpr int kLog2 = (MONO && !SMALLC) ? 11 : 10;
   static constexpr int kN = 1 << kLog2;
 };
 
-template <bool MONO>
+template <bool MONO, bool SMALLC>
 struct PixCache {
-  uint32_t tag[CacheGeom<MONO>::kN];     // ((plane << 23) | pixel) + 1, 0 = free
-  float val[CacheGeom<MONO>::kN * (MONO ? 1 : 3)];
+  uint32_t tag[CacheGeom<MONO, SMALLC>::kN];     // ((plane << 23) | pixel) + 1, 0 = free
+  float val[CacheGeom<MONO, SMALLC>::kN * (MONO ? 1 : 3)];
 };
 
 // Binned accumulation (discrete-wavelength sessions, big launches).  A launch of n rays puts tens of hits on EVERY pixel,
@@ -439,9 +441,9 @@ template <>
 struct HitSlot<false> {
   uint32_t unused;
 };
-template <bool MONO>
+template <bool MONO, bool SMALLC>
 struct AccCtx {
-  PixCache<MONO>* cache;
+  PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
 };
 
@@ -468,9 +470,9 @@ HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
 
 // MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
 // pool entry); the CMF is applied by halo_fold_kernel.  !MONO: X, Y, Z into planes 0..2.
-template <bool MONO>
-HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
-  PixCache<MONO>& C = *ctx.cache;
+template <bool MONO, bool SMALLC>
+HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uint32_t pix, uint32_t wl_idx, float w, float cx, float cy, float cz) {
+  PixCache<MONO, SMALLC>& C = *ctx.cache;
   if (P.aggregate == 2u) return;  // diagnostic: trace + project only
   const uint32_t pl = (MONO && P.mono_by_wl) ? wl_idx : 0u;
   if (P.aggregate == 1u || P.aggregate == 3u) {
@@ -478,7 +480,7 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO>& ctx, uint32_t pi
     // two-way: a key may live in slot s or s^1.  A hot pixel only misses the cache when BOTH were claimed by other pixels
     // before its first hit (~0.2 % of workgroups instead of ~5 % one-way) — and every miss of a hot pixel is an atomic on
     // the same line as all its other misses, chip-wide.
-    uint32_t slot = (key * 2654435761u) >> (32 - CacheGeom<MONO>::kLog2);
+    uint32_t slot = (key * 2654435761u) >> (32 - CacheGeom<MONO, SMALLC>::kLog2);
     uint32_t old = atomicCAS(&C.tag[slot], 0u, key);
     if (old != 0u && old != key) {
       slot ^= 1u;
@@ -653,10 +655,10 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
 // ------------------------------------------------------------------------------------------------
 // the fused kernel.  MODE: 0 = production, 1 = + raypath recording and emit-gate filter, 2 = + exit capture (tests)
 // ------------------------------------------------------------------------------------------------
-template <bool MONO>
+template <bool MONO, bool SMALLC>
 struct LdsTables {
   float lut[3 * kLutNodes];
-  PixCache<MONO> cache;
+  PixCache<MONO, SMALLC> cache;
   uint32_t seg[kContShards + 4];
 };
 constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
@@ -733,8 +735,8 @@ HD void stage_shape(SlotT* slot, const SlotT* g, uint32_t l32) {
   if (l32 < (n1 + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->single)[l32] = reinterpret_cast<const uint32_t*>(g->single)[l32];
 }
 
-template <int MODE, bool MONO>
-HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
+template <int MODE, bool MONO, bool SMALLC>
+HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
                   const uint8_t* path, uint32_t path_len, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
@@ -781,7 +783,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
-    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
+    accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
@@ -789,7 +791,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO>& cache, const Filt
   }
   if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
-    accumulate<MONO>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
+    accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.pix_n++;
   }
@@ -862,8 +864,8 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
   return static_cast<int>(sh->tri_face[tri]);
 }
 
-template <int MODE, bool MONO, typename ShapePtr>
-HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
+template <int MODE, bool MONO, bool SMALLC, typename ShapePtr>
+HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
                   uint32_t tid, RaySums& sums) {
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
@@ -970,7 +972,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     if (has_exit) {
-      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
+      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
                          entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
     }
     if (i + 1u == P.max_hits) break;
@@ -1015,7 +1017,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO>& T, const AccCtx<MONO
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
       break;
     }
     p[0] += t_best * d[0];
@@ -1083,9 +1085,10 @@ HD float wave_sum(float v) {
 template <int MODE, int GEOM, bool MONO, bool BIN>
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : 4)) halo_trace_kernel(const DispatchParams P) {
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
-  __shared__ __attribute__((aligned(16))) LdsTables<MONO> T;
+  constexpr bool SMALLC = BIN && GEOM != kGeomOne;
+  __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
-  AccCtx<MONO> acc;
+  AccCtx<MONO, SMALLC> acc;
   acc.cache = &T.cache;
   acc.hits = nullptr;
   if constexpr (BIN) {
@@ -1113,8 +1116,8 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
     filter = reinterpret_cast<const FilterDev*>(&s_filter);
   }
   if (P.aggregate == 1u || P.aggregate == 3u) {
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) T.cache.tag[i] = 0u;
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
+    for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) T.cache.tag[i] = 0u;
+    for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
   }
   // ---- stage the dispatch-constant tables into LDS ----
   if (P.lat_path == kLatLut)
@@ -1148,7 +1151,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolSlot*>(P.shapes) + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums);
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums);
       __builtin_amdgcn_wave_barrier();
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
@@ -1162,10 +1165,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
           const PoolSlot* sh = reinterpret_cast<const PoolSlot*>(P.shapes) + (tid / P.geom_clock);
-          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
+          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO>(P, T, acc, filter, color, sh, tid, sums);
+          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums);
         }
       }
       if constexpr (BIN) {
@@ -1180,7 +1183,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
   if (P.aggregate == 1u || P.aggregate == 3u) {
     __syncthreads();
-    for (int i = threadIdx.x; i < CacheGeom<MONO>::kN; i += kBlock) {
+    for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];
       if (key == 0u) continue;
       const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;

@@ -251,7 +251,7 @@ const char* halo_last_error(halo_handle_t h);
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
  * "bin" (binned accumulation through per-tile hit lists: -1 [default] = for full-sky renders of discrete-wavelength sessions
- * with launches >= 4 Mi rays, 0 = never, 1 = always when applicable),
+ * with launches >= 2 Mi rays, 0 = never, 1 = always when applicable),
  * "lambda_planes" (illuminant sessions: -1 [default] = one accumulation plane per wavelength-pool entry when the batch
  * has >= 8 Mi rays, else X/Y/Z planes; 0 = never; 1 = always),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
