@@ -55,6 +55,24 @@ if "stochd65" in which:
                 hb.sync(); best = min(best, (time.perf_counter() - t0) * 1e3)
             print("bench_config_stoch shape %s n=%dM: wall %.2f ms (%.0f M rays/s), kernels %.2f ms" % (opts, n // 1_000_000, best, n / best / 1e3, sum(s.kernel_ms for s in st)), flush=True)
         hb.close()
+if "light" in which:
+    # the reference's published GPU scene `bench_light_single_ms` (doc/performance-testing.md:465,501): prism h=1.2, random
+    # orientation, D65, max_hits 7, dual fisheye equal area, resolution sweep — 130.5 M rays/s at 512x256 on its CUDA backend (RTX 4060 Ti)
+    import time
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    sc_l = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.2), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)])], max_hits=7)
+    for (w, h) in ((256, 128), (512, 256), (1024, 512), (2048, 1024)):
+        rd_l = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, w, h, visible=abi.VISIBLE_FULL)
+        hb = HipTraceBackend(device=0, seed=42, **{"async": 1})
+        n, reps = 50_000_000, 4
+        for r in range(2):
+            hb.sync(); t0 = time.perf_counter()
+            for k in range(reps):
+                run_session(hb, sc_l, rd_l, scenes.wl_illuminant("D65", 64), n)
+            hb.sync(); dt = time.perf_counter() - t0
+        st = hb.collect_stats()
+        print("bench_light_single_ms shape %dx%d: %.1f M rays/s wall (%d x %d M rays), kernels %.2f ms per session" % (w, h, reps * n / dt / 1e6, reps, n // 1_000_000, st.kernel_ms / (2 * reps)), flush=True)
+        hb.close()
 if "bin" in which:
     full = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 2048, 1024, visible=abi.VISIBLE_FULL)
     sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
