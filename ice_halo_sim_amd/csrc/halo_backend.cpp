@@ -728,9 +728,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       const int blocks = blocks_of(m);
       // binned accumulation for big one-plane launches (see halo_trace.inl: HitBuffer)
-      const uint32_t bin_tiles = static_cast<uint32_t>((static_cast<size_t>(kMonoRows) << b->mono_s_log2) >> 14);   // 16384-slot tiles
+      // 16384-slot tiles over the session's planes taken as one array (1 plane, or the per-entry planes of a small image)
+      const uint64_t bin_slots = (static_cast<uint64_t>(kMonoRows) << b->mono_s_log2) * (b->mono_by_wl ? b->plane_cnt : 1u);
+      const uint32_t bin_tiles = static_cast<uint32_t>(bin_slots >> 14);
       const bool bin_geom_ok = deterministic || E.crystal.kind == HALO_CRYSTAL_PRISM;
-      const bool use_bin = b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 256u &&
+      const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 512u &&
+                           (bin_tiles & (bin_tiles - 1u)) == 0u && bin_slots <= (1ull << 31) &&
                            (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics

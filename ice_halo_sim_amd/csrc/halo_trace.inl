@@ -425,13 +425,12 @@ struct PixCache {
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
 constexpr int kHitBuf = 1536;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
-constexpr int kBinMaxTiles = 256;
+constexpr int kBinMaxTiles = 512;
 constexpr int kBinCntStride = 16;              // tile counters 64 B apart
 struct HitBuffer {
   uint2 h[kHitBuf];
   uint32_t n;
-  uint32_t hist[kBinMaxTiles];
-  uint32_t base[kBinMaxTiles];
+  uint32_t cur[kBinMaxTiles];   // per tile: hit count of this flush, then the write cursor inside the tile's reserved segment
 };
 template <bool ON>
 struct HitSlot {
@@ -499,7 +498,8 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (MONO) {
-    if (ctx.hits != nullptr && stage_hit(ctx.hits, MonoSlot(pix, P.mono_s_log2), w)) return;   // binned: {slot in plane 0, w}
+    // binned: {slot, w}; the planes of a per-entry-plane session lie back to back, so `slot` addresses them as one array
+    if (ctx.hits != nullptr && stage_hit(ctx.hits, (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2), w)) return;
     atomic_add_f32(mono_slot(P, pl, pix), w);
   } else {
     atomic_add_f32(mono_slot(P, 0u, pix), cx * w);
@@ -1037,21 +1037,21 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
   const uint32_t n = min(hb.n, static_cast<uint32_t>(kHitBuf));
   const uint32_t tmask = P.bin_tiles - 1u;   // tile = low slot bits: the column hash balances the tiles
-  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) hb.hist[t] = 0u;
+  for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) hb.cur[t] = 0u;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.hist[hb.h[i].x & tmask], 1u);
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.cur[hb.h[i].x & tmask], 1u);
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) {
-    const uint32_t c = hb.hist[t];
-    hb.base[t] = c ? atomicAdd(&P.bin_cnt[t * kBinCntStride], c) : 0u;
+    const uint32_t c = hb.cur[t];
+    hb.cur[t] = c ? atomicAdd(&P.bin_cnt[t * kBinCntStride], c) : 0u;   // count -> start of the reserved segment
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
     const uint2 h = hb.h[i];
     const uint32_t tile = h.x & tmask;
-    const uint32_t idx = atomicAdd(&hb.base[tile], 1u);
+    const uint32_t idx = atomicAdd(&hb.cur[tile], 1u);
     if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
-    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (plane 0, copy 0)
+    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (copy 0)
   }
   __syncthreads();
   if (threadIdx.x == 0) hb.n = 0u;

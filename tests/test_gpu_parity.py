@@ -221,6 +221,34 @@ def test_illuminant_session_plane_modes(planes):
         assert r["ih"][..., ch].sum() == pytest.approx(r["io"][..., ch].sum(), rel=2e-4)
 
 
+def test_illuminant_small_image_binned_over_entry_planes():
+    """Illuminant session, full-sky render, image small enough that pool entries x plane slots fit 512 tiles (the reference's
+    own GPU benchmark shape: D65, dual fisheye 512x256): the per-entry planes are binned as one array.  Same image as the
+    direct route and as the oracle."""
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.2), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)])], max_hits=7)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    wl = scenes.wl_illuminant("D65", 64)
+    n = 300_000
+    res = {}
+    for mode in (0, 1):
+        hb = hip_backend(seed=61, bin=mode, lambda_planes=1)
+        st = run_session(hb, sc, rd, wl, n)
+        res[mode] = hb.ReadbackXyzAccum() + (st[0].pixel_hits,)
+        hb.close()
+    assert res[0][2] == res[1][2] > 4 * n
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)
+    assert rel_l2(res[0][0], res[1][0]) <= 3e-5
+    ob = OracleBackend(seed=61, threads=8)
+    run_session(ob, sc, rd, wl, n)
+    io, lo = ob.ReadbackXyzAccum()
+    ob.close()
+    assert abs(res[1][1] - lo) <= 1e-4 * lo
+    assert rel_l2(block_mean(res[1][0]), block_mean(io)) <= 3e-3
+    for ch in range(3):
+        assert res[1][0][..., ch].sum() == pytest.approx(io[..., ch].sum(), rel=2e-4)
+
+
 def test_pyramid_crystal_parity():
     """examples/config_example.json crystal id 5 (pyramid, upper Miller (2,0,3)) + a stochastic pyramid entry."""
     p5 = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3)), scenes.axis(zenith=0), 1.0, 5)
