@@ -80,6 +80,7 @@ def main(argv=None):
     ap.add_argument("--benchmark", action="store_true", help="print the [BENCHMARK] JSON line")
     ap.add_argument("--out-rgb", default=None, help="write the sRGB image as binary PPM")
     ap.add_argument("--out-xyz", default=None, help="write the raw XYZ snapshot as .npy")
+    ap.add_argument("--out-lanes", default=None, help="raypath_color configs: write the per-class Y lanes (classes, H, W) as .npy")
     args = ap.parse_args(argv)
     try:
         job = config.load_config(args.config)
@@ -101,6 +102,8 @@ def main(argv=None):
         write_ppm(args.out_rgb, rgb)
     if args.out_xyz:
         np.save(args.out_xyz, xyz)
+    if args.out_lanes and job.color_classes:
+        np.save(args.out_lanes, be.ReadbackClassLanes())
     if args.benchmark:
         active = res["active_sec"]
         basis = "steady" if active >= 0.05 else "active_short"
