@@ -41,6 +41,8 @@ def run_job(job, render_id=None, seed=42, device=0, max_rays=None, progress=None
     be.TraceLayer(1024)
     be.EndSession()
     be.ReadbackXyzAccum()
+    if job.color_classes:
+        be.ReadbackClassLanes()   # the warm-up rays must not stay in the lanes
     setup = time.perf_counter() - t0
     t1 = time.perf_counter()
     rays = 0
