@@ -423,7 +423,7 @@ def test_full_size_image_l2_vs_oracle():
     ob.close()
     so = [type("S", (), {"exit_count": exits_o})()]
     assert sh[0].exit_count == pytest.approx(so[0].exit_count, rel=1e-5)
-    assert lh == pytest.approx(lo, rel=1e-6)
+    assert lh == pytest.approx(lo, rel=5e-6)          # per-thread fp32 partial sums of 2e7 weights vs the oracle's fp64
     io = io.astype(np.float32)
     full = rel_l2(ih, io)
     y = io[..., 1]
