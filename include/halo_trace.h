@@ -255,21 +255,24 @@ const char* halo_last_error(halo_handle_t h);
  * "lambda_planes" (illuminant sessions: -1 [default] = one accumulation plane per wavelength-pool entry when the batch
  * has >= 8 Mi rays, else X/Y/Z planes; 0 = never; 1 = always),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
- * "blocks_per_cu". */
+ * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
+ * workgroup below that cap). */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
 int halo_set_stream(halo_handle_t h, void* hip_stream);
 /* Bind an externally-owned device accumulator of width*height*3+4 floats (e.g. a torch tensor, so
- * torch.distributed can reduce it in place).  NULL = backend-owned.  Layout: xyz image then
- * [landed_lo, landed_hi, 0, 0] (landed weight kept as a float pair). */
+ * torch.distributed can reduce it in place).  NULL = backend-owned.  Layout: the xyz image, then 4 reserved floats
+ * (kept zero; the landed-weight tally is a separate fp64 scalar read with halo_take_landed / halo_readback_xyz64). */
 int halo_bind_accumulator(halo_handle_t h, void* device_ptr, uint64_t n_floats);
 /* The filter table HaloEntry::filter_id indexes (ConfigManager::filters_, config_manager.cpp:184-215). Copied; stays in
  * force until replaced.  A filter-failing exit is dropped: neither emitted nor continued (CollectData simulator.cpp:725). */
 int halo_set_filters(halo_handle_t h, const HaloFilter* filters, int32_t count);
 
 /* --- session ------------------------------------------------------------------------------ */
-/* TraceBackend::BeginSession(SessionSpec) — trace_backend.hpp:374-378. scene/render are COPIED. */
-int halo_begin(halo_handle_t h, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t ray_num_hint);
+/* TraceBackend::BeginSession(SessionSpec) — trace_backend.hpp:374-378. scene/render are COPIED.  ray_num (SessionSpec::ray_num)
+ * is the number of roots the session is going to trace; it only selects the accumulation layout of illuminant sessions
+ * (see "lambda_planes"), results do not depend on it. */
+int halo_begin(halo_handle_t h, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t ray_num);
 /* TraceBackend::TraceLayer(RootRaySource) — trace_backend.hpp:380-389.  First call of a session:
  * host mode, `count` roots self-generated on device (rays == NULL) or injected (rays != NULL).
  * Later calls: device mode, consumes the continuation produced by halo_recombine (count ignored). */
