@@ -288,3 +288,53 @@ def test_reduce_raypath_orbit_invariant_and_product_agreement():
         if (sym & 4) and dap:  # D: sigma reflection
             ref = [x if x < 3 else (x // 10) * 10 + ((sa - (x % 10 - 3)) % 6) + 3 for x in rp]
             assert _reduce(O.ho_reduce_raypath, ref, sym, sa, dap) == base
+
+
+# ---------------------------------------------------------------- raypath colour (oracle side, no GPU)
+def test_oracle_color_masks_follow_the_predicates_and_lanes_follow_the_masks():
+    """Reference semantics of the colour pass (cuda_trace_backend.cu:498-556, color_gate_table.hpp): bit k is set iff predicate
+    k matches the exit (after the physical filter, which here drops nothing); an entry without a colour set sets no bits;
+    lane c collects cmf_y*w of every in-frame hit whose mask satisfies class c (any / all); readback zeroes the lanes."""
+    from tests._oracle_backend import OracleBackend, run_session
+    sets = [scenes.color_set([(scenes.filter_term("raypath", raypath=[3, 5]), "P", 0),
+                              (scenes.filter_term("entry_exit", entry=1, min_len=2), "B", 7),
+                              (scenes.filter_term("crystal", crystal_id=3), "", 9)])]
+    classes = [scenes.color_class([0]), scenes.color_class([0, 7], "any"), scenes.color_class([0, 9], "all"), scenes.color_class([7, 0], "all")]
+    col = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 0.3}, roll={"type": "uniform", "mean": 0, "std": 360}), 1.0, 3, color_id=1)
+    plain = scenes.entry(scenes.prism_crystal(0.4), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 1.0}), 1.0, 6)
+    sc = scenes.scene([(0.0, [col, plain])], max_hits=6)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 256, 128, visible=abi.VISIBLE_FULL)
+    ob = OracleBackend(seed=5, capture_exits=1, threads=2)
+    ob.set_color(sets, classes)
+    run_session(ob, sc, rd, scenes.wl_discrete(550.0), 6000)
+    ex = ob.DrainExits()
+    img, landed = ob.ReadbackXyzAccum()
+    lanes = ob.ReadbackClassLanes()
+    assert not ob.ReadbackClassLanes().any()
+    ob.close()
+    O = _libs.oracle()
+    m = ex["color_mask"]
+    assert set(np.unique(m[ex["crystal_id"] == 6])) == {0}
+    c3 = ex[ex["crystal_id"] == 3]
+    assert ((c3["color_mask"] >> np.uint64(9)) & np.uint64(1)).all()                  # crystal predicate: every exit of crystal 3
+    for rec in c3[:1500]:
+        n = int(rec["path_len"])
+        red = (C.c_uint8 * n)()
+        path = (C.c_uint8 * n)(*rec["path"][:n])
+        O.ho_reduce_raypath(path, n, abi.SYM_P, 0, 0, red)
+        want0 = n == 2 and list(red) == [3, 5]
+        want7 = n >= 2 and int(rec["path"][0]) in (1, 2)                               # entry face 1 under B = {1, 2}
+        assert bool(int(rec["color_mask"]) & 1) == want0 and bool((int(rec["color_mask"]) >> 7) & 1) == want7
+    assert (m & np.uint64(1)).any() and ((m >> np.uint64(7)) & np.uint64(1)).any()
+    # lanes from masks: primary hits only (this render has no overlap ring)
+    ybar = img[..., 1].sum() / landed
+    ok = ex["pixel"] >= 0
+    for k, cls in enumerate(classes):
+        bits = np.uint64(cls.bits)
+        mm = m & bits
+        sel = ok & ((mm == bits) if cls.combine_all else (mm != 0))
+        want = np.zeros(256 * 128)
+        np.add.at(want, ex["pixel"][sel], ex["weight"][sel].astype(np.float64))
+        assert np.allclose(lanes[k].ravel(), want * ybar, rtol=2e-4, atol=1e-6), k
+    assert np.array_equal(lanes[2], lanes[0])                                          # bit 9 is always set on crystal 3, so {0 and 9} == {0}
+    assert lanes[3].sum() == 0.0                                                       # a 3-5 path never enters through a basal face
