@@ -338,3 +338,29 @@ def test_oracle_color_masks_follow_the_predicates_and_lanes_follow_the_masks():
         assert np.allclose(lanes[k].ravel(), want * ybar, rtol=2e-4, atol=1e-6), k
     assert np.array_equal(lanes[2], lanes[0])                                          # bit 9 is always set on crystal 3, so {0 and 9} == {0}
     assert lanes[3].sum() == 0.0                                                       # a 3-5 path never enters through a basal face
+
+
+def test_oracle_filters_partition_the_exits():
+    """FilterSpec::Check = Match XOR filter_out (filter_shared.h:308-315): with the same rays, filter_in and filter_out of one
+    predicate split the unfiltered exits exactly; complex OR-of-ANDs equals the union of its clauses; `none` passes all."""
+    col = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 0.3}, roll={"type": "uniform", "mean": 0, "std": 360}), 1.0, 3)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 128, 64, visible=abi.VISIBLE_FULL)
+    t_rp = scenes.filter_term("raypath", raypath=[3, 5])
+    t_ee = scenes.filter_term("entry_exit", entry=1, min_len=2, max_len=4)
+    table = [scenes.simple_filter(t_rp, "P"), scenes.simple_filter(t_rp, "P", "filter_out"), scenes.simple_filter(scenes.filter_term("none")),
+             scenes.simple_filter(t_ee, "B"), scenes.complex_filter([[t_rp], [t_ee]], "PB")]
+
+    def keys(fid):
+        e = type(col).from_buffer_copy(bytes(col))
+        e.filter_id = fid
+        ob = OracleBackend(seed=8, capture_exits=1, threads=2)
+        ob.set_filters(table)
+        run_session(ob, scenes.scene([(0.0, [e])], max_hits=6), rd, scenes.wl_discrete(550.0), 5000)
+        ex = ob.DrainExits()
+        ob.close()
+        return set(zip(ex["root"].tolist(), ex["seq"].tolist()))
+
+    allx, fin, fout, none, ee, cx = keys(0), keys(1), keys(2), keys(3), keys(4), keys(5)
+    assert none == allx and len(allx) > 20000
+    assert fin and fout and fin.isdisjoint(fout) and (fin | fout) == allx
+    assert ee and cx >= fin and cx >= ee            # symmetry PB of the complex filter only widens each clause
