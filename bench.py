@@ -169,8 +169,8 @@ def main():
     launches, kernel_ms, pixel_hits, exits = int(st.launches), float(st.kernel_ms), int(st.pixel_hits), int(st.exit_count)
     assert int(st.root_count) == rays_per_rank
 
+    img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
     if rank == 0:
-        img, landed = tracer.readback()
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         alg_bytes_per_launch = pixel_hits * 24.0 / max(launches, 1)   # 3 ch x 4 B x (read + write) per in-frame pixel hit
         achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9

@@ -37,6 +37,35 @@ def reduce_accumulators(acc, landed, group=None, dst=0):
     return acc, float(lt.item())
 
 
+def reduce_image(acc, group=None, dst=0):
+    """Sum-reduce the accumulator tensors onto `dst` and drain the other ranks.  Stream-ordered: nothing waits on the host
+    (the backend launches on torch's current stream, the collective is enqueued behind it)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return acc
+    if acc.is_cuda and dist.get_backend(group) == "gloo":   # gloo reduces CUDA tensors only as all_reduce
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if dist.get_rank(group) != dst:
+        acc.zero_()
+    return acc
+
+
+def reduce_scalar(value, device, group=None, dst=0):
+    """Sum of one float64 per rank, valid on `dst` (0.0 elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) if dist.get_rank(group) == dst else 0.0
+
+
 class ShardedTracer:
     """One rank's slice of a trace job on one MI355X."""
 
@@ -68,12 +97,9 @@ class ShardedTracer:
         return st
 
     def reduce_to_root(self):
-        self.landed += self.backend.take_landed()
-        self.acc, self.landed = reduce_accumulators(self.acc, self.landed)
-        if self.world > 1:
-            # the collective (and the drain of non-root ranks) is stream-ordered inside torch only; the backend
-            # launches on its own stream, so fence on the host before the next trace touches the accumulator
-            self.torch.cuda.synchronize(self.device)
+        """The drain-point collective: ONE sum-reduce of the image accumulator, enqueued on the stream behind this rank's
+        trace kernels; non-root ranks are drained.  The landed-weight scalars stay on their devices until readback()."""
+        self.acc = reduce_image(self.acc)
 
     def zero(self):
         self.backend.take_landed()
@@ -82,7 +108,9 @@ class ShardedTracer:
         self.torch.cuda.synchronize(self.device)
 
     def readback(self):
-        self.landed += self.backend.take_landed()
+        """COLLECTIVE (every rank calls it): the root gets the reduced image and the summed landed weight; all ranks are
+        left drained."""
+        self.landed = reduce_scalar(self.landed + self.backend.take_landed(), self.device)
         w, h = self.render.width, self.render.height
         img = self.acc[: w * h * 3].cpu().numpy().reshape(h, w, 3).copy()
         landed = self.landed

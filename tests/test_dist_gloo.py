@@ -36,14 +36,18 @@ def _trace_shard(rank, world, n_total):
 def _worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
-    from ice_halo_sim_amd.dist import reduce_accumulators
+    from ice_halo_sim_amd.dist import reduce_accumulators, reduce_image, reduce_scalar
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     img, landed = _trace_shard(rank, world, N)
     acc = torch.zeros(W * H * 3 + 4, dtype=torch.float32)
     acc[: W * H * 3] = torch.from_numpy(img.ravel())
+    # the two-step form bench.py uses (image every step, landed scalar once at readback) must give the same result
+    acc2 = reduce_image(acc.clone())
+    landed2 = reduce_scalar(landed, acc.device)
     acc, landed = reduce_accumulators(acc, landed)
+    assert torch.equal(acc, acc2) and landed == landed2
     np.save(os.path.join(out_dir, "acc%d.npy" % rank), acc.numpy())
     np.save(os.path.join(out_dir, "landed%d.npy" % rank), np.array([landed]))
     dist.barrier()
