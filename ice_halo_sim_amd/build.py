@@ -39,8 +39,9 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
-            if os.environ.get("HALO_MIN_WAVES"):
-                cmd.append("-DHALO_MIN_WAVES=" + os.environ["HALO_MIN_WAVES"])
+            for knob in ("HALO_MIN_WAVES", "HALO_MIN_WAVES_FILTER"):
+                if os.environ.get(knob):
+                    cmd.append("-D%s=%s" % (knob, os.environ[knob]))
             if src in NO_CONTRACT:
                 cmd += ["-ffp-contract=off", "-fno-fast-math"]
             elif os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast

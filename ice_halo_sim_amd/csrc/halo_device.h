@@ -86,6 +86,9 @@ struct FilterTermDev {
   float radii_c;
   uint32_t crystal_id;
   uint8_t canonical[kFilterPathCap];
+  // the same canonical sequence packed big-endian and left-aligned into 128 bits (element 0 in the top byte) when it has
+  // at most 16 elements: equal-length sequences then compare lexicographically as unsigned integers, in registers
+  uint64_t canon_hi, canon_lo;
 };
 struct FilterDev {
   uint8_t is_complex, action, symmetry, d_applicable;

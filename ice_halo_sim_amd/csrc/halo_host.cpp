@@ -229,6 +229,12 @@ FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis) {
       const std::vector<uint8_t> canon = ReduceRaypath(rp, d.symmetry, d.sigma_a, dap);
       o.canonical_len = static_cast<uint8_t>(canon.size());
       std::copy(canon.begin(), canon.end(), o.canonical);
+      if (canon.size() <= 16) {  // packed form for the register path of the device filter
+        uint64_t w[2] = {0, 0};
+        for (size_t i = 0; i < canon.size(); i++) w[i / 8] |= static_cast<uint64_t>(canon[i]) << (8 * (7 - i % 8));
+        o.canon_hi = w[0];
+        o.canon_lo = w[1];
+      }
     }
   };
   if (!f.is_complex) {

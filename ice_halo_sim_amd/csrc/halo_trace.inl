@@ -519,6 +519,110 @@ struct RaySums {
 // emit-gate filters (shared/filter_shared.h:53-315).  Paths are crystal face NUMBERS already, so the reference's
 // ApplyGetFn remap (poly index → face number) is the identity here.
 // ------------------------------------------------------------------------------------------------
+//
+// A path of at most 16 faces is ALSO kept as a 128-bit shift register (one byte per face, newest in the low byte), and the
+// symmetry reduction then runs on packed values in registers: a sequence is held left-aligned (element 0 in the top byte),
+// every transform streams the bytes out of the top of one register pair into the bottom of another, and "lexicographically
+// smaller" is an unsigned compare.  The byte-array versions below remain for longer paths (max_hits up to 64).
+struct Pk128 {
+  uint64_t hi, lo;
+};
+struct PathView {
+  const uint8_t* bytes;   // face numbers of interactions 16 .. kFilterPathCap-1 (the array is only written past the register)
+  uint32_t len;           // interactions recorded (may exceed the capacity of both)
+  Pk128 reg;              // shift register of the first min(len, 16) interactions, newest in the low byte
+};
+HD Pk128 pk_shl8(Pk128 v) { return {(v.hi << 8) | (v.lo >> 56), v.lo << 8}; }
+HD Pk128 pk_shl_bytes(Pk128 v, uint32_t n) {  // n in [0, 16]
+  const uint32_t b = n * 8u;
+  if (b == 0u) return v;
+  if (b >= 128u) return {0ull, 0ull};
+  if (b >= 64u) return {v.lo << (b - 64u), 0ull};
+  return {(v.hi << b) | (v.lo >> (64u - b)), v.lo << b};
+}
+HD bool pk_less(Pk128 a, Pk128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+HD bool pk_eq(Pk128 a, Pk128 b) { return a.hi == b.hi && a.lo == b.lo; }
+HD uint32_t pk_byte(Pk128 v, uint32_t pos) {  // byte `pos` counted from the low end
+  return static_cast<uint32_t>((pos < 8u ? v.lo >> (8u * pos) : v.hi >> (8u * (pos - 8u))) & 0xFFull);
+}
+
+HD uint8_t path_at(const PathView& pv, uint32_t i) {  // interaction i of a path of any recorded length
+  const uint32_t held = pv.len < 16u ? pv.len : 16u;
+  return i < 16u ? static_cast<uint8_t>(pk_byte(pv.reg, held - 1u - i)) : pv.bytes[i];
+}
+
+HD Pk128 pk_p_shift(Pk128 in, uint32_t len) {  // p_canonical_shift on a left-aligned sequence
+  Pk128 out = {0ull, 0ull};
+  int first_pri = -1;
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t x = static_cast<uint32_t>(in.hi >> 56);
+    in = pk_shl8(in);
+    if (x >= 3u) {
+      const uint32_t pyr = x / 10u;
+      int pri = static_cast<int>(x % 10u);
+      if (first_pri < 0) first_pri = pri;
+      pri = (pri + 6 - first_pri) % 6 + 3;
+      x = pyr * 10u + static_cast<uint32_t>(pri);
+    }
+    out = pk_shl8(out);
+    out.lo |= x;
+  }
+  return pk_shl_bytes(out, 16u - len);
+}
+HD Pk128 pk_d_image(Pk128 in, uint32_t len, int32_t sigma_a) {
+  Pk128 out = {0ull, 0ull};
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t x = static_cast<uint32_t>(in.hi >> 56);
+    in = pk_shl8(in);
+    if (x >= 3u) {
+      const uint32_t pyr = x / 10u;
+      const int pri0 = static_cast<int>(x % 10u) - 3;
+      const int np = ((sigma_a - pri0) % 6 + 6) % 6;
+      x = pyr * 10u + static_cast<uint32_t>(np + 3);
+    }
+    out = pk_shl8(out);
+    out.lo |= x;
+  }
+  return pk_shl_bytes(out, 16u - len);
+}
+HD Pk128 pk_b_image(Pk128 in, uint32_t len, bool& changed) {
+  Pk128 out = {0ull, 0ull};
+  changed = false;
+  for (uint32_t i = 0; i < len; ++i) {
+    uint32_t x = static_cast<uint32_t>(in.hi >> 56);
+    in = pk_shl8(in);
+    if (x <= 2u) {
+      x = 3u - x;
+      changed = true;
+    } else if (x >= 13u && x <= 18u) {
+      x += 10u;
+      changed = true;
+    } else if (x >= 23u && x <= 28u) {
+      x -= 10u;
+      changed = true;
+    }
+    out = pk_shl8(out);
+    out.lo |= x;
+  }
+  return pk_shl_bytes(out, 16u - len);
+}
+// reduce_buffer (below) on a left-aligned packed sequence of len <= 16
+HD Pk128 pk_reduce(Pk128 data, uint32_t len, uint8_t symmetry, int32_t sigma_a, bool d_applicable) {
+  if (symmetry == 0u) return data;
+  if (symmetry & HALO_SYM_P) data = pk_p_shift(data, len);
+  if ((symmetry & HALO_SYM_D) && d_applicable) {
+    Pk128 img = pk_d_image(data, len, sigma_a);
+    if (symmetry & HALO_SYM_P) img = pk_p_shift(img, len);
+    if (pk_less(img, data)) data = img;
+  }
+  if (symmetry & HALO_SYM_B) {
+    bool changed;
+    const Pk128 img = pk_b_image(data, len, changed);
+    if (changed && pk_less(img, data)) data = img;
+  }
+  return data;
+}
+
 HD void p_canonical_shift(uint8_t* data, uint32_t size) {  // filter_shared.h:53-68
   int first_pri = -1;
   for (uint32_t i = 0; i < size; ++i) {
@@ -580,13 +684,21 @@ HD void reduce_buffer(uint8_t* data, uint32_t size, uint8_t symmetry, int32_t si
   }
 }
 
-HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, const FilterTermDev& t, const uint8_t* path, uint32_t len, float wx,
+// NOT inlined: the emit gate sits at three places of the trace loop and each one evaluates up to 16 filter terms and 16
+// colour terms; inlined, one filter kernel grew to 555 KB of code (the plain kernel is 96 KB) and ran out of the
+// instruction cache.  One shared copy is called instead; the tables are reached through generic pointers.
+__device__ __attribute__((noinline)) bool filter_match_path(uint8_t symmetry, int32_t sigma_a, bool d_applicable, const FilterTermDev& t, const PathView& pv, float wx,
                           float wy, float wz, uint32_t crystal_id) {  // DeviceFilterMatchSimple :238-257
+  const uint32_t len = pv.len;
   if (t.type == HALO_FILTER_NONE) return true;
   if (t.type == HALO_FILTER_RAYPATH) {  // :156-178
     if (len != t.canonical_len) return false;
+    if (len <= 16u) {  // register path
+      const Pk128 red = pk_reduce(pk_shl_bytes(pv.reg, 16u - len), len, symmetry, sigma_a, d_applicable);
+      return pk_eq(red, Pk128{t.canon_hi, t.canon_lo});
+    }
     uint8_t buf[kFilterPathCap];
-    for (uint32_t i = 0; i < len; ++i) buf[i] = path[i];
+    for (uint32_t i = 0; i < len; ++i) buf[i] = path_at(pv, i);
     reduce_buffer(buf, len, symmetry, sigma_a, d_applicable);
     for (uint32_t i = 0; i < len; ++i)
       if (buf[i] != t.canonical[i]) return false;
@@ -596,10 +708,20 @@ HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, 
     if (len == 0u || len < t.min_len) return false;
     if (t.max_len != 0u && len > t.max_len) return false;
     if (!t.has_entry && !t.has_exit) return true;
+    if (len <= 16u) {  // register path: the (entry, exit) pair as a packed sequence of one or two faces
+      const uint32_t first = pk_byte(pv.reg, len - 1u), last = static_cast<uint32_t>(pv.reg.lo & 0xFFull);
+      uint32_t n2 = 0u;
+      uint64_t top = 0ull;
+      if (t.has_entry) top |= static_cast<uint64_t>(first) << (56u - 8u * n2++);
+      if (t.has_exit) top |= static_cast<uint64_t>(last) << (56u - 8u * n2++);
+      const Pk128 red = pk_reduce(Pk128{top, 0ull}, n2, symmetry, sigma_a, d_applicable);
+      if (symmetry != 0u && n2 != t.canonical_len) return false;
+      return pk_eq(red, Pk128{t.canon_hi, t.canon_lo});
+    }
     uint8_t ee[2];
     uint32_t n = 0u;
-    if (t.has_entry) ee[n++] = path[0];
-    if (t.has_exit) ee[n++] = path[len - 1u];
+    if (t.has_entry) ee[n++] = path_at(pv, 0u);
+    if (t.has_exit) ee[n++] = path_at(pv, (len < kFilterPathCap ? len : kFilterPathCap) - 1u);
     reduce_buffer(ee, n, symmetry, sigma_a, d_applicable);
     if (symmetry != 0u && n != t.canonical_len) return false;
     for (uint32_t i = 0; i < n; ++i)
@@ -611,17 +733,26 @@ HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, 
   return false;
 }
 
-HD bool filter_check(const FilterDev& f, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
+// the predicates that never look at the path stay inline; only the two path predicates pay for the call
+HD bool filter_match_term(uint8_t symmetry, int32_t sigma_a, bool d_applicable, const FilterTermDev& t, const PathView& pv, float wx,
+                          float wy, float wz, uint32_t crystal_id) {
+  if (t.type == HALO_FILTER_NONE) return true;
+  if (t.type == HALO_FILTER_DIRECTION) return t.dir[0] * wx + t.dir[1] * wy + t.dir[2] * wz > t.radii_c;  // :226-229
+  if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;                                    // :231-233
+  return filter_match_path(symmetry, sigma_a, d_applicable, t, pv, wx, wy, wz, crystal_id);
+}
+
+HD bool filter_check(const FilterDev& f, const PathView& pv, float wx, float wy, float wz, uint32_t crystal_id) {
   bool m;
   if (!f.is_complex) {
-    m = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[0], path, len, wx, wy, wz, crystal_id);
+    m = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[0], pv, wx, wy, wz, crystal_id);
   } else {  // OR over AND-clauses; an empty complex filter matches nothing (:263-291)
     m = false;
     uint32_t idx = 0u;
     for (uint32_t o = 0u; o < f.or_count && !m; ++o) {
       const uint32_t n = f.and_counts[o];
       bool all = true;
-      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[idx + a], path, len, wx, wy, wz, crystal_id);
+      for (uint32_t a = 0u; a < n && all; ++a) all = filter_match_term(f.symmetry, f.sigma_a, f.d_applicable != 0u, f.terms[idx + a], pv, wx, wy, wz, crystal_id);
       idx += n;
       m = all;
     }
@@ -631,11 +762,11 @@ HD bool filter_check(const FilterDev& f, const uint8_t* path, uint32_t len, floa
 
 // Raypath colour (ApplyLayerColorBits cu:498-527): OR into the carried mask the bit of every predicate of this crystal
 // entry that matches the exit.  Non-destructive: runs beside the physical filter, never drops a ray.
-HD uint64_t color_bits(const ColorDev& c, uint64_t carried, const uint8_t* path, uint32_t len, float wx, float wy, float wz, uint32_t crystal_id) {
+HD uint64_t color_bits(const ColorDev& c, uint64_t carried, const PathView& pv, float wx, float wy, float wz, uint32_t crystal_id) {
   uint64_t m = carried;
   for (uint32_t k = 0u; k < c.term_cnt; ++k) {
     const ColorTermDev& ct = c.terms[k];
-    if (ct.bit < 64u && filter_match_term(ct.symmetry, ct.sigma_a, ct.d_applicable != 0u, ct.t, path, len, wx, wy, wz, crystal_id))
+    if (ct.bit < 64u && filter_match_term(ct.symmetry, ct.sigma_a, ct.d_applicable != 0u, ct.t, pv, wx, wy, wz, crystal_id))
       m |= 1ull << ct.bit;
   }
   return m;
@@ -738,17 +869,17 @@ HD void stage_shape(SlotT* slot, const SlotT* g, uint32_t l32) {
 template <int MODE, bool MONO, bool SMALLC>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const uint8_t* path, uint32_t path_len, RaySums& sums) {
+                  const PathView& pv, RaySums& sums) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
   float wx = R[0] * lx + R[1] * ly + R[2] * lz;
   float wy = R[3] * lx + R[4] * ly + R[5] * lz;
   float wz = R[6] * lx + R[7] * ly + R[8] * lz;
   // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
   if (MODE != kModePlain && filter != nullptr) {
-    if (!filter_check(*filter, path, path_len, wx, wy, wz, P.crystal_id)) return;
+    if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
   }
   uint64_t cmask = carried;
-  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, path, path_len, wx, wy, wz, P.crystal_id);
+  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
   // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
   // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
   bool pass = false;
@@ -808,8 +939,8 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
       rec.root = root;
       rec.seq = static_cast<uint16_t>(seq);
       rec.layer = static_cast<uint8_t>(P.layer);
-      rec.path_len = static_cast<uint8_t>(path_len < HALO_PATH_CAP ? path_len : HALO_PATH_CAP);
-      for (int k = 0; k < HALO_PATH_CAP; k++) rec.path[k] = (static_cast<uint32_t>(k) < path_len) ? path[k] : 0;
+      rec.path_len = static_cast<uint8_t>(pv.len < HALO_PATH_CAP ? pv.len : HALO_PATH_CAP);
+      for (int k = 0; k < HALO_PATH_CAP; k++) rec.path[k] = (static_cast<uint32_t>(k) < pv.len) ? path_at(pv, static_cast<uint32_t>(k)) : 0;
       rec.pixel = primary;
       rec.crystal_id = static_cast<uint16_t>(P.crystal_id);
       rec.wl_idx = static_cast<uint16_t>(wl_idx);
@@ -946,8 +1077,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
 
   uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
-  uint32_t path_len = 0u;
-  if (MODE != kModePlain) path[path_len++] = sh->face_number[face];
+  PathView pv = {path, 0u, {0ull, 0ull}};
+  if (MODE != kModePlain) {
+    pv.reg.lo = sh->face_number[face];
+    pv.len = 1u;
+  }
 
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
@@ -973,7 +1107,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const bool has_exit = entering || !tir;
     if (has_exit) {
       emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
-                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), path, path_len, sums);
+                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), pv, sums);
     }
     if (i + 1u == P.max_hits) break;
     const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
@@ -1017,7 +1151,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
       // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, path, path_len, sums);
+      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, pv, sums);
       break;
     }
     p[0] += t_best * d[0];
@@ -1025,8 +1159,14 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     p[2] += t_best * d[2];
     face = hit;
     if (MODE != kModePlain) {
-      if (path_len < kFilterPathCap) path[path_len] = sh->face_number[face];
-      path_len++;
+      const uint8_t fn = sh->face_number[face];
+      if (pv.len < 16u) {
+        pv.reg = pk_shl8(pv.reg);
+        pv.reg.lo |= fn;
+      } else if (pv.len < kFilterPathCap) {
+        path[pv.len] = fn;
+      }
+      pv.len++;
     }
   }
 }
@@ -1078,12 +1218,16 @@ HD float wave_sum(float v) {
 }
 
 // waves per SIMD the register allocator must leave room for: 5 for the production kernels (96 VGPRs, measured 4.5 % faster
-// than 4), 4 where the path record of filter / capture modes would spill
+// than 4); the filter / capture kernels carry the path register, the predicate tables' addressing and the colour mask on
+// top, and are built for HALO_MIN_WAVES_FILTER (measured below)
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 5
 #endif
+#ifndef HALO_MIN_WAVES_FILTER
+#define HALO_MIN_WAVES_FILTER 3
+#endif
 template <int MODE, int GEOM, bool MONO, bool BIN>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : 4)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   constexpr bool SMALLC = BIN && GEOM != kGeomOne;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;

@@ -289,10 +289,13 @@ def _filter_table():
                                [scenes.filter_term("raypath", raypath=[3, 1, 5, 7, 4])]], "PBD"),             # 4: complex OR of ANDs
         scenes.simple_filter(scenes.filter_term("none")),                                                      # 5
         scenes.simple_filter(scenes.filter_term("raypath", raypath=[13, 25]), "PB"),                           # 6: pyramidal faces
+        scenes.complex_filter([[scenes.filter_term("entry_exit", entry=3, min_len=17)],                        # 7: paths past the 16 faces
+                               [scenes.filter_term("raypath", raypath=[3] + [1, 2] * 8 + [5])],               #    the kernel keeps in registers
+                               [scenes.filter_term("entry_exit", entry=1, exit=4, min_len=12, max_len=16)]], "PBD"),
     ]
 
 
-@pytest.mark.parametrize("case", ["raypath_P", "entry_exit_PBD_d_applicable", "direction_out", "complex", "multi_scatter_gate", "pyramid_PB"])
+@pytest.mark.parametrize("case", ["raypath_P", "entry_exit_PBD_d_applicable", "direction_out", "complex", "multi_scatter_gate", "pyramid_PB", "long_paths"])
 def test_emit_gate_filter_parity(case):
     """Emit-gate filters (reference filter_shared.h / filter_spec.cpp): same per-ray survivors, paths and image as the oracle."""
     col = scenes.column_crystal_entry()
@@ -308,9 +311,10 @@ def test_emit_gate_filter_parity(case):
         "complex": [(0.0, [_with(col, 4), _with(plate, 4)])],
         "multi_scatter_gate": [(0.6, [_with(plate, 2)]), (0.0, [_with(col, 1)])],
         "pyramid_PB": [(0.0, [_with(pyr, 6), _with(col, 5)])],
+        "long_paths": [(0.0, [_with(col, 7), _with(plate, 7)])],
     }[case]
-    sc = scenes.scene(layers, max_hits=7)
-    n = 80_000
+    sc = scenes.scene(layers, max_hits=24 if case == "long_paths" else 7)
+    n = 400_000 if case == "long_paths" else 80_000
     hb = hip_backend(seed=21, capture_exits=1)
     ob = OracleBackend(seed=21, capture_exits=1, threads=8)
     for b in (hb, ob):
@@ -336,6 +340,8 @@ def test_emit_gate_filter_parity(case):
     if case == "raypath_P":
         c3 = eh[eh["crystal_id"] == 3]
         assert (c3["path_len"] == 2).all() and set(map(tuple, np.unique(c3["path"][:, :2], axis=0))) <= {(3, 5), (4, 6), (5, 7), (6, 8), (7, 3), (8, 4)}
+    if case == "long_paths":
+        assert (eh["path_len"] >= 12).all() and (eh["path_len"] == 16).sum() > 50   # records keep the first 16 faces
     if case == "direction_out":
         sun = np.array([np.cos(np.deg2rad(20)) * np.cos(np.pi), np.cos(np.deg2rad(20)) * np.sin(np.pi), np.sin(np.deg2rad(20))], np.float32)
         assert (eh["dir"] @ sun <= np.cos(np.deg2rad(2.0)) + 1e-6).all()

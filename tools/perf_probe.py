@@ -55,6 +55,26 @@ if "stochd65" in which:
                 hb.sync(); best = min(best, (time.perf_counter() - t0) * 1e3)
             print("bench_config_stoch shape %s n=%dM: wall %.2f ms (%.0f M rays/s), kernels %.2f ms" % (opts, n // 1_000_000, best, n / best / 1e3, sum(s.kernel_ms for s in st)), flush=True)
         hb.close()
+if "filter" in which:
+    col = scenes.column_crystal_entry()
+    def with_f(fid):
+        e = type(col).from_buffer_copy(bytes(col)); e.filter_id = fid; return e
+    table = [scenes.simple_filter(scenes.filter_term("raypath", raypath=[3, 5]), "P"),
+             scenes.simple_filter(scenes.filter_term("entry_exit", entry=3, exit=5, min_len=2, max_len=4), "PBD"),
+             scenes.simple_filter(scenes.filter_term("direction", az=180, el=20, radii=2.0), "", "filter_out"),
+             scenes.complex_filter([[scenes.filter_term("raypath", raypath=[1, 3, 2])], [scenes.filter_term("entry_exit", entry=1), scenes.filter_term("crystal", crystal_id=3)],
+                                    [scenes.filter_term("raypath", raypath=[3, 1, 5, 7, 4])]], "PBD"),
+             scenes.simple_filter(scenes.filter_term("crystal", crystal_id=99), "", "filter_out")]
+    for fid, name in ((0, "no filter (MODE 0)"), (1, "raypath P"), (2, "entry_exit PBD"), (3, "direction out"), (4, "complex PBD"), (5, "crystal 99 out (all pass)")):
+        hb = HipTraceBackend(device=0, seed=42)
+        hb.set_filters(table)
+        sc_f = scenes.scene([(0.0, [with_f(fid)])], max_hits=7)
+        best = 1e9
+        for r in range(3):
+            st = run_session(hb, sc_f, rd, scenes.wl_discrete(550.0), 10_000_000)
+            best = min(best, st[0].kernel_ms)
+        print("filter %-22s kernel %.3f ms  %.0f M rays/s  exits/root %.3f" % (name, best, 1e4 / best, st[0].exit_count / 1e7), flush=True)
+        hb.close()
 if "light" in which:
     # the reference's published GPU scene `bench_light_single_ms` (doc/performance-testing.md:465,501): prism h=1.2, random
     # orientation, D65, max_hits 7, dual fisheye equal area, resolution sweep — 130.5 M rays/s at 512x256 on its CUDA backend (RTX 4060 Ti)
