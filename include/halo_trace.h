@@ -277,7 +277,10 @@ int halo_begin(halo_handle_t h, const HaloScene* scene, const HaloRender* render
  * host mode, `count` roots self-generated on device (rays == NULL) or injected (rays != NULL).
  * Later calls: device mode, consumes the continuation produced by halo_recombine (count ignored). */
 int halo_trace_layer(halo_handle_t h, uint64_t count, const HaloHostRays* rays, HaloLayerStats* stats);
-/* TraceBackend::Recombine(handle, RecombineSpec{shuffle}) — trace_backend.hpp:391-395. */
+/* TraceBackend::Recombine(handle, RecombineSpec{shuffle}) — trace_backend.hpp:391-395.  No data moves: the pools swap
+ * roles and the next layer reads its roots through a Feistel bijection of the pool positions.  The bijection permutes
+ * chunks of 32 consecutive pool entries (32 different parent rays), not single entries like the reference's CUDA
+ * shuffle_cont_kernel (cu:1633-1657): same decorrelation of position ranges, coalesced reads. */
 int halo_recombine(halo_handle_t h, int shuffle, uint64_t* continuation_count);
 /* TraceBackend::DrainExits — trace_backend.hpp:430-448 (only with "capture_exits"). */
 int halo_drain_exits(halo_handle_t h, HaloExitRecord* out, uint64_t cap, uint64_t* count);
