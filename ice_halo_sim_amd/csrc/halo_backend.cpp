@@ -20,6 +20,8 @@
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
+hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -67,11 +69,12 @@ struct HaloBackend {
   int capture = 0;
   uint32_t geom_clock = 32;  // simulator.hpp:144 (rays per sampled shape)
   uint64_t chunk = 1ull << 26;
+  uint64_t stoch_chunk = 1ull << 24;   // rays per dispatch with device-generated crystal pools
   int aggregate = 1;
   int mono_enabled = 1;
   int bin = -1;                // binned accumulation: -1 auto (discrete session, full-sky render, launch >= 4 Mi rays), 0 off, 1 on
-  DevBuf<HitRec> bin_list;
-  DevBuf<uint32_t> bin_cnt;
+  DevBuf<HitRec> bin_list, bin_list2;   // one-level tile lists / coarse lists; tile lists of the two-level route
+  DevBuf<uint32_t> bin_cnt, bin_cnt2;
   int lambda_planes = -1;      // illuminant sessions: -1 auto (by batch size), 0 never, 1 always one plane per pool entry
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
@@ -291,6 +294,8 @@ int halo_destroy(halo_handle_t b) {
   b->lanes.release();
   b->bin_list.release();
   b->bin_cnt.release();
+  b->bin_list2.release();
+  b->bin_cnt2.release();
   b->cont[0].release();
   b->cont[1].release();
   b->exits.release();
@@ -309,6 +314,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (k == "capture_exits") b->capture = v ? 1 : 0;
   else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
   else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
+  else if (k == "stoch_chunk") b->stoch_chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 24));
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "async") b->async = v ? 1 : 0;
@@ -493,7 +499,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     uint64_t m = std::min<uint64_t>(left, b->chunk);
     // stochastic geometry: the shape pool costs 4.1 KB per geom_clock rays — 2 GB per 16 Mi rays when the device generator
     // writes it, while host-built pools (pageable staging + H2D) stay at 4 Mi rays
-    if (!deterministic) m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : (1ull << 24));
+    if (!deterministic) m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : b->stoch_chunk);
     return m;
   };
   auto blocks_of = [&](uint64_t m) {
@@ -615,6 +621,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.bin_list = nullptr;
+    P.bin_shift = 0u;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
@@ -732,21 +739,38 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint64_t bin_slots = (static_cast<uint64_t>(kMonoRows) << b->mono_s_log2) * (b->mono_by_wl ? b->plane_cnt : 1u);
       const uint32_t bin_tiles = static_cast<uint32_t>(bin_slots >> 14);
       const bool bin_geom_ok = deterministic || E.crystal.kind == HALO_CRYSTAL_PRISM;
-      const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_tiles >= 8u && bin_tiles <= 512u &&
-                           (bin_tiles & (bin_tiles - 1u)) == 0u && bin_slots <= (1ull << 31) &&
+      // up to 512 tiles: one level (interleaved tiles).  More (per-wavelength planes of a large image): two levels — the
+      // trace kernel fills coarse lists of `fan` consecutive tiles each, a split pass deals them out to the tiles.
+      uint32_t fan_log2 = 0u;
+      while (((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) > 512u) fan_log2++;
+      const bool two_level = bin_tiles > 512u;
+      const bool bin_shape_ok = two_level ? (fan_log2 <= 6u && (bin_slots & 16383ull) == 0ull)
+                                          : (bin_tiles >= 8u && (bin_tiles & (bin_tiles - 1u)) == 0u);
+      const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_shape_ok && bin_slots <= (1ull << 31) &&
                            (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
+      const uint32_t lists1 = two_level ? ((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) : bin_tiles;
+      uint32_t cap2 = 0u;
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
-        uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 16);
-        cap = std::min<uint64_t>(cap, (8ull << 30) / (8ull * bin_tiles));
+        uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / lists1, 1ull << 16);
+        cap = std::min<uint64_t>(cap, (8ull << 30) / (8ull * lists1));
         HIPCHK(b, b->bin_cnt.reserve(static_cast<size_t>(512) * 16u));
-        HIPCHK(b, hipMemsetAsync(b->bin_cnt.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
-        HIPCHK(b, b->bin_list.reserve(cap * bin_tiles));
+        HIPCHK(b, hipMemsetAsync(b->bin_cnt.ptr, 0, static_cast<size_t>(two_level ? 512u : bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+        HIPCHK(b, b->bin_list.reserve(cap * lists1));
         P.bin_list = b->bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
-        P.bin_tiles = bin_tiles;
+        P.bin_tiles = two_level ? 512u : bin_tiles;
+        P.bin_shift = two_level ? 14u + fan_log2 : 0u;
         P.bin_cnt = b->bin_cnt.ptr;
         P.mono_copy_mask = 0u;   // staged hits and their fallbacks address copy 0
+        if (two_level) {
+          uint64_t c2 = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 12);
+          c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * bin_tiles));
+          cap2 = static_cast<uint32_t>(c2);
+          HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(bin_tiles) * 16u));
+          HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+          HIPCHK(b, b->bin_list2.reserve(c2 * bin_tiles));
+        }
       } else {
         P.bin_list = nullptr;
         P.mono_copy_mask = b->plane_copies - 1u;
@@ -756,7 +780,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->mono_dirty = true;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_bin) {
-        hipError_t be = launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
+        hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
+                                                         bin_tiles, fan_log2, b->stream)
+                                  : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));

@@ -193,6 +193,7 @@ struct DispatchParams {
   HitRec* bin_list;             // binned accumulation (nullptr = off): bin_tiles lists of bin_cap {slot, weight} records
   uint32_t bin_cap;
   uint32_t bin_tiles;
+  uint32_t bin_shift;          // list of a hit = (slot >> bin_shift) & (bin_tiles - 1): 0 = interleaved tiles, > 0 = contiguous slot ranges (two-level binning)
   uint32_t* bin_cnt;           // list fill counts, kBinCntStride apart
   uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)

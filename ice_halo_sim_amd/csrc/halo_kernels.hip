@@ -45,6 +45,106 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
   return hipGetLastError();
 }
 
+// ---- two-level binning: accumulators of more than 512 tiles (per-wavelength planes: 64 planes x 2 Mi slots = 8192 tiles) ----
+// The trace kernel can feed at most 512 lists from its 1536-record LDS buffer (fewer than ~3 records per list and flush and
+// the appends stop coalescing).  For larger accumulators its lists are COARSE — list l1 holds the hits of `fan` consecutive
+// tiles (bin_shift = 14 + fan_log2) — and this kernel deals each coarse list out to its `fan` tile lists: a workgroup takes
+// 2048 records at a time, ranks them per tile with LDS counters, reserves the `fan` segments with one returning atomic each
+// and places the records.  Everything moves as 8-byte records, coalesced on the read side and in runs per tile on the
+// write side; a tile list that overflows falls back to direct atomics on the plane.
+constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 64u;
+__global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
+                                                                     const uint32_t* __restrict__ cnt1, uint2* __restrict__ list2, uint32_t cap2,
+                                                                     uint32_t* __restrict__ cnt2, uint32_t fan_log2) {
+  __shared__ uint32_t s_cnt[kSplitFanMax], s_base[kSplitFanMax];
+  const uint32_t l1 = blockIdx.x / kSplitParts, part = blockIdx.x % kSplitParts;
+  const uint32_t n = min(cnt1[l1 * kBinCntStride], cap1);
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kSplitParts);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kSplitParts);
+  const uint32_t fan = 1u << fan_log2, fmask = fan - 1u;
+  const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
+  for (uint32_t b0 = lo; b0 < hi; b0 += kSplitBlock * kSplitPer) {   // workgroup-uniform trip count
+    if (threadIdx.x < fan) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint2 h[kSplitPer];
+    uint32_t rank[kSplitPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kSplitPer; ++u) {
+      const uint32_t i = b0 + u * kSplitBlock + threadIdx.x;
+      h[u] = i < hi ? src[i] : make_uint2(0xFFFFFFFFu, 0u);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kSplitPer; ++u)
+      rank[u] = h[u].x != 0xFFFFFFFFu ? atomicAdd(&s_cnt[(h[u].x >> kBinTileLog2) & fmask], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < fan) {
+      const uint32_t c = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = c ? atomicAdd(&cnt2[static_cast<size_t>((l1 << fan_log2) + threadIdx.x) * kBinCntStride], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kSplitPer; ++u) {
+      if (h[u].x == 0xFFFFFFFFu) continue;
+      const uint32_t tile = h[u].x >> kBinTileLog2;
+      const uint32_t pos = s_base[tile & fmask] + rank[u];
+      if (pos < cap2) list2[static_cast<size_t>(tile) * cap2 + pos] = h[u];
+      else atomic_add_f32(plane + h[u].x, __uint_as_float(h[u].y));
+    }
+    __syncthreads();
+  }
+}
+
+// One workgroup per tile of 16 Ki CONSECUTIVE slots: sums the tile's list in LDS and adds the tile to the plane with plain
+// coalesced float4 read-modify-writes — the workgroup is the only writer of those slots while this kernel runs (direct
+// atomics of the trace / split kernels are ordered before it on the stream).
+__global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
+                                                                               const uint32_t* __restrict__ cnt) {
+  __shared__ __attribute__((aligned(16))) float acc[1u << kBinTileLog2];
+  const uint32_t tile = blockIdx.x;
+  const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
+  if (n == 0u) return;
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0f;
+  __syncthreads();
+  const uint2* src = list + static_cast<size_t>(tile) * cap;
+  constexpr uint32_t kU = 4u, kMask = (1u << kBinTileLog2) - 1u;
+  uint32_t i = threadIdx.x;
+  for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
+    uint2 h[kU];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & kMask], __uint_as_float(h[u].y));
+  }
+  for (; i < n; i += kBinBlock) {
+    const uint2 h = src[i];
+    unsafeAtomicAdd(&acc[h.x & kMask], __uint_as_float(h.y));
+  }
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << kBinTileLog2));
+  const float4* a4 = reinterpret_cast<const float4*>(acc);
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2) / 4u; j += kBinBlock) {
+    const float4 v = a4[j];
+    if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
+      float4 q = dst[j];
+      q.x += v.x;
+      q.y += v.y;
+      q.z += v.z;
+      q.w += v.w;
+      dst[j] = q;
+    }
+  }
+}
+
+hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_bin_split_kernel, dim3(lists1 * kSplitParts), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
+                     cnt1, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
+  return hipGetLastError();
+}
+
 // xyz[pix] += sum over planes of coef[plane] * (sum over copies of plane[MonoSlot(pix)]); the slots are zeroed — closes a
 // session.  Planes: 1 (discrete wavelength, coef = CMF), 3 (X, Y, Z; unit coefs) or one per wavelength-pool entry
 // (coef = that entry's CMF), at most kFoldGroup per launch.  Tiled transpose through LDS: a block reads a 64-row x

@@ -1188,10 +1188,10 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 // (the position inside the segment comes from a second LDS counter, so nothing has to stay in registers across barriers).
 HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
   const uint32_t n = min(hb.n, static_cast<uint32_t>(kHitBuf));
-  const uint32_t tmask = P.bin_tiles - 1u;   // tile = low slot bits: the column hash balances the tiles
+  const uint32_t tmask = P.bin_tiles - 1u;   // one level: list = low slot bits (the column hash balances the lists); two levels: a contiguous slot range
   for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) hb.cur[t] = 0u;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.cur[hb.h[i].x & tmask], 1u);
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hb.cur[(hb.h[i].x >> P.bin_shift) & tmask], 1u);
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < P.bin_tiles; t += kBlock) {
     const uint32_t c = hb.cur[t];
@@ -1200,7 +1200,7 @@ HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
     const uint2 h = hb.h[i];
-    const uint32_t tile = h.x & tmask;
+    const uint32_t tile = (h.x >> P.bin_shift) & tmask;
     const uint32_t idx = atomicAdd(&hb.cur[tile], 1u);
     if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
     else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (copy 0)

@@ -45,7 +45,8 @@ if "stochd65" in which:
     import time
     sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
     rd_s = scenes.render(7, 2048, 1024, el=0, visible=2)
-    for opts in ({}, {"lambda_planes": 0}, {"aggregate": 2}):
+    import json
+    for opts in json.loads(os.environ.get("STOCH_OPTS", '[{}, {"bin": 0}, {"aggregate": 2}]')):
         hb = HipTraceBackend(device=0, seed=42, **opts)
         for n in (10_000_000, 50_000_000):
             best = 1e9
