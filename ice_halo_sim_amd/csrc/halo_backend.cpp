@@ -69,7 +69,8 @@ struct HaloBackend {
   int capture = 0;
   uint32_t geom_clock = 32;  // simulator.hpp:144 (rays per sampled shape)
   uint64_t chunk = 1ull << 26;
-  uint64_t stoch_chunk = 1ull << 24;   // rays per dispatch with device-generated crystal pools
+  uint64_t stoch_chunk = 0;            // rays per dispatch with device-generated crystal pools (0 = by record size, see chunk_of)
+  uint32_t bin_l1 = 128u;              // coarse lists of the two-level binned route (measured: 512 -> 128 lists 6 % faster, 64 slower)
   int aggregate = 1;
   int mono_enabled = 1;
   int bin = -1;                // binned accumulation: -1 auto (discrete session, full-sky render, launch >= 4 Mi rays), 0 off, 1 on
@@ -314,7 +315,8 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (k == "capture_exits") b->capture = v ? 1 : 0;
   else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
   else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
-  else if (k == "stoch_chunk") b->stoch_chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 24));
+  else if (k == "bin_l1") b->bin_l1 = static_cast<uint32_t>(v >= 8 && v <= 512 ? v : 128);
+  else if (k == "stoch_chunk") b->stoch_chunk = static_cast<uint64_t>(v > 0 ? v : 0);
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
   else if (k == "async") b->async = v ? 1 : 0;
@@ -495,11 +497,15 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   }
   // launch plan: chunking bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
   const int max_blocks = b->cu_count * b->blocks_per_cu;
-  auto chunk_of = [&](uint64_t left, bool deterministic) {
+  auto chunk_of = [&](uint64_t left, const HaloCrystal& crystal) {
     uint64_t m = std::min<uint64_t>(left, b->chunk);
-    // stochastic geometry: the shape pool costs 4.1 KB per geom_clock rays — 2 GB per 16 Mi rays when the device generator
-    // writes it, while host-built pools (pageable staging + H2D) stay at 4 Mi rays
-    if (!deterministic) m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : b->stoch_chunk);
+    // stochastic geometry: one pool record per geom_clock rays.  Device-generated prisms are 1360 B records (2.9 GB per
+    // 64 Mi rays), other device-generated shapes 4.1 KB (2 GB per 16 Mi rays); host-built pools (pageable staging + H2D)
+    // stay at 4 Mi rays
+    if (!host::IsDeterministic(crystal)) {
+      const uint64_t dev = b->stoch_chunk ? b->stoch_chunk : (crystal.kind == HALO_CRYSTAL_PRISM ? (1ull << 26) : (1ull << 24));
+      m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : dev);
+    }
     return m;
   };
   auto blocks_of = [&](uint64_t m) {
@@ -521,7 +527,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     for (int ci = 0; ci < L.entry_count; ci++) {
       const bool det = host::IsDeterministic(L.entries[ci].crystal);
       for (uint64_t off = 0; off < per_ci[ci];) {
-        const uint64_t m = chunk_of(per_ci[ci] - off, det);
+        const uint64_t m = chunk_of(per_ci[ci] - off, L.entries[ci].crystal);
         const uint64_t nb = static_cast<uint64_t>(blocks_of(m));
         const uint64_t per_block = (m + nb * kBlock - 1) / (nb * kBlock) * kBlock;   // grid-stride share, rounded up
         region += (nb + kContShards - 1) / kContShards * per_block * static_cast<uint64_t>(b->scene.max_hits);
@@ -663,7 +669,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
     for (uint64_t off = 0; off < n_ci;) {
-      const uint64_t m = chunk_of(n_ci - off, deterministic);
+      const uint64_t m = chunk_of(n_ci - off, E.crystal);
       const uint32_t shape_cnt = deterministic ? 1u : static_cast<uint32_t>((m + b->geom_clock - 1) / b->geom_clock);
       const bool host_pool = !deterministic && b->host_shapes;
       // 0 = one shape per dispatch, 1 = pool of ShapeDev records, 2 = pool of ShapePrism records (device-generated prisms)
@@ -742,9 +748,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // up to 512 tiles: one level (interleaved tiles).  More (per-wavelength planes of a large image): two levels — the
       // trace kernel fills coarse lists of `fan` consecutive tiles each, a split pass deals them out to the tiles.
       uint32_t fan_log2 = 0u;
-      while (((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) > 512u) fan_log2++;
+      while (((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) > b->bin_l1) fan_log2++;
       const bool two_level = bin_tiles > 512u;
-      const bool bin_shape_ok = two_level ? (fan_log2 <= 6u && (bin_slots & 16383ull) == 0ull)
+      const bool bin_shape_ok = two_level ? (fan_log2 <= 7u && (bin_slots & 16383ull) == 0ull)
                                           : (bin_tiles >= 8u && (bin_tiles & (bin_tiles - 1u)) == 0u);
       const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_shape_ok && bin_slots <= (1ull << 31) &&
                            (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
@@ -752,19 +758,22 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       uint32_t cap2 = 0u;
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
-        uint64_t cap = std::max<uint64_t>(4ull * 6ull * m / lists1, 1ull << 16);
+        // (the coarse and tile lists of the two-level route are slot ranges interleaved over the image — rows p % 1024 — and
+        // stay balanced whatever the image shows: 2x there)
+        const uint64_t slack = two_level ? 2ull : 4ull;
+        uint64_t cap = std::max<uint64_t>(slack * 6ull * m / lists1, 1ull << 16);
         cap = std::min<uint64_t>(cap, (8ull << 30) / (8ull * lists1));
         HIPCHK(b, b->bin_cnt.reserve(static_cast<size_t>(512) * 16u));
         HIPCHK(b, hipMemsetAsync(b->bin_cnt.ptr, 0, static_cast<size_t>(two_level ? 512u : bin_tiles) * 16u * sizeof(uint32_t), b->stream));
         HIPCHK(b, b->bin_list.reserve(cap * lists1));
         P.bin_list = b->bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
-        P.bin_tiles = two_level ? 512u : bin_tiles;
+        P.bin_tiles = two_level ? b->bin_l1 : bin_tiles;
         P.bin_shift = two_level ? 14u + fan_log2 : 0u;
         P.bin_cnt = b->bin_cnt.ptr;
         P.mono_copy_mask = 0u;   // staged hits and their fallbacks address copy 0
         if (two_level) {
-          uint64_t c2 = std::max<uint64_t>(4ull * 6ull * m / bin_tiles, 1ull << 12);
+          uint64_t c2 = std::max<uint64_t>(slack * 6ull * m / bin_tiles, 1ull << 12);
           c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * bin_tiles));
           cap2 = static_cast<uint32_t>(c2);
           HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(bin_tiles) * 16u));

@@ -11,13 +11,16 @@ constexpr int kBinBlock = 1024;
 constexpr uint32_t kBinSplit = 2u;
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
                                                                          const uint32_t* __restrict__ cnt, uint32_t tiles_log2) {
-  __shared__ float acc[1u << kBinTileLog2];
+  // fp64 sums, and not for precision: on gfx950 ds_add_f32 retires ~0.3 lanes per clock per CU (200 G adds/s chip-wide) while
+  // ds_add_f64 runs at 1500 G/s and ds_add_u32 at 4600 G/s (tools/lds_atomic_bench.hip) — the fp32 LDS atomic is the slow one,
+  // and this pass is one LDS add per hit.  128 KB of the CU's 160 KB: one workgroup of 16 waves per CU.
+  __shared__ double acc[1u << kBinTileLog2];
   const uint32_t tile = blockIdx.x / kBinSplit, part = blockIdx.x % kBinSplit;
   const uint32_t n = min(cnt[tile * kBinCntStride], cap);
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kBinSplit);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kBinSplit);
   if (hi <= lo) return;
-  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0f;
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
   constexpr uint32_t kU = 8u;
@@ -27,15 +30,15 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* _
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x >> tiles_log2], __uint_as_float(h[u].y));
+    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x >> tiles_log2], static_cast<double>(__uint_as_float(h[u].y)));
   }
   for (; i < hi; i += kBinBlock) {
     const uint2 h = src[i];
-    unsafeAtomicAdd(&acc[h.x >> tiles_log2], __uint_as_float(h.y));
+    unsafeAtomicAdd(&acc[h.x >> tiles_log2], static_cast<double>(__uint_as_float(h.y)));
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) {
-    const float v = acc[j];
+    const float v = static_cast<float>(acc[j]);
     if (v != 0.0f) atomic_add_f32(plane + ((static_cast<size_t>(j) << tiles_log2) | tile), v);
   }
 }
@@ -52,7 +55,7 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 // 2048 records at a time, ranks them per tile with LDS counters, reserves the `fan` segments with one returning atomic each
 // and places the records.  Everything moves as 8-byte records, coalesced on the read side and in runs per tile on the
 // write side; a tile list that overflows falls back to direct atomics on the plane.
-constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 64u;
+constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 128u;
 __global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                      const uint32_t* __restrict__ cnt1, uint2* __restrict__ list2, uint32_t cap2,
                                                                      uint32_t* __restrict__ cnt2, uint32_t fan_log2) {
@@ -99,11 +102,11 @@ __global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __re
 // atomics of the trace / split kernels are ordered before it on the stream).
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
                                                                                const uint32_t* __restrict__ cnt) {
-  __shared__ __attribute__((aligned(16))) float acc[1u << kBinTileLog2];
+  __shared__ __attribute__((aligned(16))) double acc[1u << kBinTileLog2];   // fp64: see halo_bin_accumulate_kernel
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
-  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0f;
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
   constexpr uint32_t kU = 4u, kMask = (1u << kBinTileLog2) - 1u;
@@ -113,17 +116,17 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & kMask], __uint_as_float(h[u].y));
+    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & kMask], static_cast<double>(__uint_as_float(h[u].y)));
   }
   for (; i < n; i += kBinBlock) {
     const uint2 h = src[i];
-    unsafeAtomicAdd(&acc[h.x & kMask], __uint_as_float(h.y));
+    unsafeAtomicAdd(&acc[h.x & kMask], static_cast<double>(__uint_as_float(h.y)));
   }
   __syncthreads();
   float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << kBinTileLog2));
-  const float4* a4 = reinterpret_cast<const float4*>(acc);
   for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2) / 4u; j += kBinBlock) {
-    const float4 v = a4[j];
+    const float4 v = make_float4(static_cast<float>(acc[4u * j]), static_cast<float>(acc[4u * j + 1u]), static_cast<float>(acc[4u * j + 2u]),
+                                 static_cast<float>(acc[4u * j + 3u]));
     if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
       float4 q = dst[j];
       q.x += v.x;
