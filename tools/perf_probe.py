@@ -46,7 +46,7 @@ if "stochd65" in which:
     sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
     rd_s = scenes.render(7, 2048, 1024, el=0, visible=2)
     import json
-    for opts in json.loads(os.environ.get("STOCH_OPTS", '[{}, {"bin": 0}, {"aggregate": 2}]')):
+    for opts in json.loads(os.environ.get("STOCH_OPTS", '[{}, {"lambda_planes": 1}, {"bin": 0}]')):
         hb = HipTraceBackend(device=0, seed=42, **opts)
         for n in (10_000_000, 50_000_000):
             best = 1e9
@@ -122,7 +122,7 @@ if "illum" in which:
         run_wl("D65 n=%dM lambda planes" % (n // 1_000_000), n, lambda_planes=1)
     run_wl("D65 n=10M mono=0 copies=1", 10_000_000, lambda_planes=0, mono_copies=1)
 if "bpc" in which:
-    for bpc in (8, 16, 20, 24, 32, 48):
+    for bpc in (4, 5, 8, 12, 24):
         run("config2 50M blocks_per_cu=%d" % bpc, sc, rd, n=50_000_000, reps=2, blocks_per_cu=bpc)
 if "hits" in which:
     for mh in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12):
