@@ -250,8 +250,11 @@ const char* halo_last_error(halo_handle_t h);
  * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
- * "bin" (binned accumulation through per-tile hit lists: -1 [default] = for full-sky renders of discrete-wavelength sessions
- * with launches >= 2 Mi rays, 0 = never, 1 = always when applicable),
+ * "bin" (binned accumulation through per-tile hit lists: -1 [default] = for full-sky renders with launches >= 2 Mi rays —
+ * one level of lists up to 512 tiles of 16 Ki accumulator slots, two levels (coarse lists, split pass) for the per-entry
+ * planes of illuminant sessions beyond that; 0 = never, 1 = always when applicable), "bin_l1" (coarse lists of the two-level
+ * route, default 128), "stoch_chunk" (rays per launch with device-generated crystal pools; default 64 Mi for prisms, 16 Mi
+ * otherwise),
  * "lambda_planes" (illuminant sessions: -1 [default] = one accumulation plane per wavelength-pool entry when the batch
  * has >= 8 Mi rays, else X/Y/Z planes; 0 = never; 1 = always),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
