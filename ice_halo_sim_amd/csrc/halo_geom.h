@@ -392,21 +392,79 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
 
   double verts[kPyrMaxVerts][3];
   int nv = 0;
+  // Of the C(20,3) = 1140 triples about a hundred meet in a point of the solid.  Running the exact test on all of them made the
+  // device generator scratch-bandwidth-bound: every thread streams its 20 fp64 planes through the feasibility scan, ~220 KB
+  // per crystal, 85 % of the kernel.  So (1) the planes are copied to a second array that is only ever indexed by fully
+  // unrolled loops (k of the pre-test, m of both scans) and therefore lives in registers; i and j stay dynamic and read
+  // theirs from `unit`; (2) a division-free test rejects first: with x = N / det, plane m is violated when
+  // sign(det) (n_m.N + d_m det) exceeds tol |det|.  It rejects only beyond TWICE the tolerance (its own rounding is ~1e-10 of
+  // that margin) and never for a det Concurrence would refuse, so every triple the exact test accepts still reaches it, in
+  // the same order; the exact scan evaluates the same expression on bit-identical copies.  Vertices, their order and the
+  // duplicate filter are unchanged.
+  double pre[20][4];
+  uint32_t act_mask = 0u;
+  for (int s = 0; s < 20; s++) {
+    pre[s][0] = unit[s].a;
+    pre[s][1] = unit[s].b;
+    pre[s][2] = unit[s].c;
+    pre[s][3] = unit[s].d;
+    if (active[s]) act_mask |= 1u << s;
+  }
+  const double lim = 2.0 * tol;
   for (int i = 0; i < 20; i++) {
     if (!active[i]) continue;
+    const double ia = unit[i].a, ib = unit[i].b, ic = unit[i].c, id = unit[i].d;
     for (int j = i + 1; j < 20; j++) {
       if (!active[j]) continue;
+      const double ja = unit[j].a, jb = unit[j].b, jc = unit[j].c, jd = unit[j].d;
+      const double cx = ib * jc - ic * jb, cy = ic * ja - ia * jc, cz = ia * jb - ib * ja;   // n_i x n_j
+      uint32_t surv = 0u;   // the k that are not provably outside
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int k = 0; k < 20; k++) {
+        if (k <= j || !((act_mask >> k) & 1u)) continue;
+        const double ka = pre[k][0], kb = pre[k][1], kc = pre[k][2], kd = pre[k][3];
+        const double det = cx * ka + cy * kb + cz * kc;
+        if (fabs(det) < 0.5e-9) continue;   // Concurrence refuses below 1e-9
+        // N = -(d_i (n_j x n_k) + d_j (n_k x n_i) + d_k (n_i x n_j))
+        const double ax = jb * kc - jc * kb, ay = jc * ka - ja * kc, az = ja * kb - jb * ka;
+        const double bx = kb * ic - kc * ib, by = kc * ia - ka * ic, bz = ka * ib - kb * ia;
+        const double nx = -(id * ax + jd * bx + kd * cx), ny = -(id * ay + jd * by + kd * cy), nz = -(id * az + jd * bz + kd * cz);
+        const double sgn = det > 0.0 ? 1.0 : -1.0;
+        const double bound = lim * fabs(det);
+        bool far = false;
+        // four groups (basal pair, prism, upper cone, lower cone) with a way out after each: crystals of one dispatch have
+        // the same topology, so a triple that is far outside for one lane is far outside for (nearly) all of them
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int m0 = 0; m0 < 20; m0 += (m0 == 0 ? 2 : 6)) {
+          const int m1 = (m0 == 0) ? 2 : m0 + 6;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+          for (int m = m0; m < m1; m++)
+            if ((act_mask >> m) & 1u) far = far || (sgn * (pre[m][0] * nx + pre[m][1] * ny + pre[m][2] * nz + pre[m][3] * det) > bound);
+          if (far) break;
+        }
+        if (!far) surv |= 1u << k;
+      }
       for (int k = j + 1; k < 20; k++) {
-        if (!active[k]) continue;
+        if (!((surv >> k) & 1u)) continue;
         double x[3];
         if (!Concurrence(unit[i], unit[j], unit[k], x)) continue;
         bool ok = true;
-        for (int m = 0; m < 20 && ok; m++)
-          if (active[m]) ok = EvalPlane(unit[m], x) <= tol;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol on the register copies (same expression, same values)
+          if ((act_mask >> m) & 1u) ok = ok && (pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3] <= tol);
         if (!ok) continue;
         bool dup = false;
         for (int v = 0; v < nv; v++) {
           const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
+          if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;   // farther than 2 tol for certain: no sqrt
           if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
             dup = true;
             break;

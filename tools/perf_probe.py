@@ -148,3 +148,21 @@ if "stoch" in which:
         print("stochastic prism 16M host_shapes=%d: wall %.1f ms (%.0f M rays/s), trace kernels %.2f ms" % (hs, dt * 1e3, 16 / dt, sum(s.kernel_ms for s in st)), flush=True)
         hb.close()
     run("stochastic prism 4M", scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8), scenes.render(7, 2048, 1024, el=0, visible=2), n=4_000_000)
+if "pyr" in which:
+    # stochastic pyramid (example crystal 5's Miller faces, gaussian face distances), full-sphere axis, rectangular full sky
+    import time
+    g = {"type": "gauss", "mean": 1.0, "std": 0.1}
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    pyr = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 5)
+    sc_p = scenes.scene([(0.0, [pyr])], max_hits=8)
+    rd_p = scenes.render(7, 2048, 1024, el=0, visible=2)
+    for opts in ({}, {"bin": 0}, {"aggregate": 2}):
+        hb = HipTraceBackend(device=0, seed=42, **opts)
+        for n in (4_000_000, 16_000_000):
+            best = 1e9
+            for r in range(3):
+                hb.sync(); t0 = time.perf_counter()
+                st = run_session(hb, sc_p, rd_p, scenes.wl_discrete(550.0), n)
+                hb.sync(); best = min(best, (time.perf_counter() - t0) * 1e3)
+            print("stochastic pyramid %s n=%dM: wall %.2f ms (%.0f M rays/s), kernels %.2f ms, exits/root %.2f" % (opts, n // 1_000_000, best, n / best / 1e3, sum(s.kernel_ms for s in st), st[0].exit_count / n), flush=True)
+        hb.close()
