@@ -19,7 +19,8 @@ constexpr int kGenBlock = 64;
 // written (an invalid draw leaves them 0 = empty crystal) and rows beyond the counts are never read, so the pool needs no
 // clearing.
 template <class S>
-__global__ void __launch_bounds__(kGenBlock) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
+// (two waves per SIMD for the general builder: the pyramid enumeration keeps its 20 fp64 planes in registers)
+__global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? 2 : 1)) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
                                                                    uint64_t first_index) {
   const uint32_t k = blockIdx.x * kGenBlock + threadIdx.x;
   if (k >= n) return;
