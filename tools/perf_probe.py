@@ -121,6 +121,8 @@ if "illum" in which:
         run_wl("D65 n=%dM xyz planes" % (n // 1_000_000), n, lambda_planes=0)
         run_wl("D65 n=%dM lambda planes" % (n // 1_000_000), n, lambda_planes=1)
     run_wl("D65 n=10M mono=0 copies=1", 10_000_000, lambda_planes=0, mono_copies=1)
+    run_wl("D65 n=50M lambda planes, binned (two-level)", 50_000_000, lambda_planes=1, bin=1)
+    run_wl("D65 n=10M lambda planes, binned (two-level)", 10_000_000, lambda_planes=1, bin=1)
 if "bpc" in which:
     for bpc in (4, 5, 8, 12, 24):
         run("config2 50M blocks_per_cu=%d" % bpc, sc, rd, n=50_000_000, reps=2, blocks_per_cu=bpc)
