@@ -110,6 +110,19 @@ def test_golden_normal_incidence_and_snell30():
         assert list(up["path"][:up["path_len"]]) == [1] and list(down["path"][:down["path_len"]]) == [1, 2]
 
 
+def test_golden_two_ms_continuation_normal_incidence():
+    """test/golden-analytic/backend/test_multi_ms_golden.cpp:381-469 on the HIP backend: the hop between two scattering layers
+    conserves the analytic sums  sum w(0,0,-1) = T^4 + R^2,  sum w(0,0,+1) = 2 R T^2."""
+    from tests.test_oracle_golden import _two_ms_normal_incidence
+    n_idx = float(np.float32(abi_refr(550.0)))
+    r = ((n_idx - 1.0) / (n_idx + 1.0)) ** 2
+    t = 1.0 - r
+    hb = hip_backend(seed=42, capture_exits=1)
+    down, up = _two_ms_normal_incidence(hb)
+    hb.close()
+    assert abs(down - (t ** 4 + r * r)) < 5e-4 and abs(up - 2.0 * r * t * t) < 5e-4
+
+
 def abi_refr(wl):
     from ice_halo_sim_amd.backend import load_library
     return load_library().halo_host_refractive_index(float(wl))

@@ -364,3 +364,35 @@ def test_oracle_filters_partition_the_exits():
     assert none == allx and len(allx) > 20000
     assert fin and fout and fin.isdisjoint(fout) and (fin | fout) == allx
     assert ee and cx >= fin and cx >= ee            # symmetry PB of the complex filter only widens each clause
+
+
+def _two_ms_normal_incidence(backend):
+    """The reference's multi-scatter known answer (test/golden-analytic/backend/test_multi_ms_golden.cpp:381-469): a ray at
+    normal incidence on a parallel slab (prism h=1, fixed axis), max_hits 2, layer 0 with prob 1.0 feeding an identical layer 1
+    through Recombine{shuffle=false}.  Layer 0 sends T^2 down and R up; layer 1 then gives
+    sum w(0,0,-1) = T^4 + R^2 and sum w(0,0,+1) = 2 R T^2, each within 5e-4 (the reference's tolerance)."""
+    slab = scenes.entry(scenes.prism_crystal(1.0), scenes.axis())
+    sc = scenes.scene([(1.0, [slab]), (0.0, [slab])], max_hits=2)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 64, 32, visible=abi.VISIBLE_FULL)
+    backend.BeginSession(sc, rd, scenes.wl_discrete(550.0), 1)
+    backend.TraceLayer(host_rays=([[0, 0, -1]], [[0, 0, 0.5]], [1.0], [0]))
+    assert backend.Recombine(False) >= 1
+    backend.TraceLayer(0)
+    ex = backend.DrainExits()
+    backend.EndSession()
+    ex = ex[ex["layer"] == 1]
+    assert len(ex) >= 2 and (ex["weight"] >= 0).all() and ex["weight"].astype(np.float64).sum() <= 1.0 + 1e-4
+    down = float(ex["weight"][ex["dir"] @ np.array([0, 0, -1], np.float32) >= 0.9999].sum())
+    up = float(ex["weight"][ex["dir"] @ np.array([0, 0, 1], np.float32) >= 0.9999].sum())
+    return down, up
+
+
+def test_two_ms_continuation_known_answer_on_the_oracle():
+    n_idx = float(np.float32(_libs.oracle().ho_ice_refractive_index(550.0)))
+    r = ((n_idx - 1.0) / (n_idx + 1.0)) ** 2
+    t = 1.0 - r
+    ob = OracleBackend(seed=42, capture_exits=1)
+    down, up = _two_ms_normal_incidence(ob)
+    ob.close()
+    assert abs(down - (t ** 4 + r * r)) < 5e-4 and abs(up - 2.0 * r * t * t) < 5e-4
+
