@@ -220,6 +220,29 @@ def test_stochastic_geometry_and_wl_pool_parity():
     assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
 
 
+@pytest.mark.parametrize("kind", ["prism", "pyramid"])
+def test_degenerate_random_geometry_parity(kind):
+    """The reference's crash reproducers (test/e2e/configs/repro_crash_face_distance.json, repro_crash_pyramid_face_distance.json;
+    sentinels test_face_distance_crash.py, test_pyramid_geometry_crash.py, test_cuda_degenerate_geometry_parity.py): six
+    gauss(1, 0.5) face distances make near-coincident corners, vanishing faces and, now and then, an empty crystal; thin 0.05
+    pyramid caps on top of that.  No crash, and per ray the same exits as the oracle — an empty or rejected sample traces
+    nothing on both sides."""
+    g = {"type": "gauss", "mean": 1.0, "std": 0.5}
+    ax = scenes.axis(zenith={"type": "gauss", "mean": 90.0, "std": 0.8}, azimuth={"type": "uniform", "mean": 0, "std": 360},
+                     roll={"type": "uniform", "mean": 0, "std": 360})
+    cr = scenes.prism_crystal(1.2, [g] * 6) if kind == "prism" else scenes.pyramid_crystal(0.05, 1.2, 0.05, upper_miller=(1, 1), lower_miller=(1, 1), face_distance=[g] * 6)
+    sc = scenes.scene([(0.0, [scenes.entry(cr, ax, 1.0, 1)])], max_hits=8)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    r = run_both(sc, rd, scenes.wl_discrete(550.0), 160_000, seed=13)
+    roots_h, roots_o = np.unique(r["eh"]["root"]), np.unique(r["eo"]["root"])
+    assert len(roots_o) > 0.8 * 160_000 * 0.9                          # most samples are solids ...
+    assert np.array_equal(roots_h, roots_o)                           # ... and both sides drop the same ones
+    frac, pix, path = match_exits(r["eh"], r["eo"])
+    assert frac >= 0.997 and pix >= 0.995 and path >= 0.998
+    assert abs(r["lh"] - r["lo"]) <= 2e-4 * r["lo"]
+    assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
+
+
 @pytest.mark.parametrize("planes", [0, 1])
 def test_illuminant_session_plane_modes(planes):
     """Illuminant (wavelength-pool) sessions accumulate either X/Y/Z planes (3 atomics per hit) or one scalar plane per pool
