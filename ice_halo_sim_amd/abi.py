@@ -37,7 +37,7 @@ class HaloEntry(C.Structure):
                 ("crystal_config_id", C.c_int32), ("filter_id", C.c_int32), ("color_id", C.c_int32)]
 
 
-FILTER_MAX_OR, FILTER_MAX_TERMS = 8, 16
+FILTER_MAX_OR, FILTER_MAX_TERMS = 64, 64
 FILTER_NONE, FILTER_RAYPATH, FILTER_ENTRY_EXIT, FILTER_DIRECTION, FILTER_CRYSTAL = range(5)
 SYM_P, SYM_B, SYM_D = 1, 2, 4
 

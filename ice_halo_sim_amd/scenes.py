@@ -84,8 +84,17 @@ def filter_term(kind="none", raypath=None, entry=None, exit=None, min_len=1, max
     return t
 
 
+
+def symmetry_bits(symmetry):
+    """FilterSymmetryFromString (config/filter_config.cpp:161-175): the letters P, B, D set their bit, every other character is
+    ignored — "none", "" and "PBD" are all legal spellings in the reference's configs."""
+    bits = 0
+    for c in symmetry or "":
+        bits |= {"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}.get(c, 0)
+    return bits
+
 def _sym(symmetry):
-    return sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+    return symmetry_bits(symmetry)
 
 
 def color_set(terms):
@@ -113,7 +122,7 @@ def color_class(bits, combine="any"):
 def simple_filter(term, symmetry="", action="filter_in"):
     f = abi.HaloFilter()
     f.action = 0 if action == "filter_in" else 1
-    f.symmetry = sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+    f.symmetry = symmetry_bits(symmetry)
     f.is_complex = 0
     f.terms[0] = term
     return f
@@ -123,7 +132,7 @@ def complex_filter(or_clauses, symmetry="", action="filter_in"):
     """or_clauses: list of AND-clauses, each a list of HaloFilterTerm (ComplexFilterParam, filter_config.hpp:44-46)."""
     f = abi.HaloFilter()
     f.action = 0 if action == "filter_in" else 1
-    f.symmetry = sum({"P": abi.SYM_P, "B": abi.SYM_B, "D": abi.SYM_D}[c] for c in symmetry)
+    f.symmetry = symmetry_bits(symmetry)
     f.is_complex = 1
     f.or_count = len(or_clauses)
     k = 0

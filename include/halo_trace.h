@@ -94,8 +94,12 @@ typedef struct HaloEntry {
 
 /* Emit-gate filters — FilterConfig (src/config/filter_config.hpp:20-86) as the device matcher consumes it
  * (DeviceFilterDesc, src/core/device_filter_desc.hpp:60-100).  Face ids are crystal face NUMBERS. */
-#define HALO_FILTER_MAX_OR 8      /* kDeviceFilterMaxOrClauses */
-#define HALO_FILTER_MAX_TERMS 16  /* total simple terms over all AND-clauses of one complex filter */
+/* The reference's physical complex filters keep their AND-term counts in a flat host-built buffer (any number of OR-clauses up
+ * to a 4096 sanity cap, device_filter_desc.hpp:56-79; its fixed 8 is the colour path's).  Here a complex filter is one
+ * fixed-size record staged in LDS: up to 64 OR-clauses and 64 simple terms in all — the reference's test configs use at
+ * most 12 (test/e2e/configs/parity_big_or_with_color.json). */
+#define HALO_FILTER_MAX_OR 64
+#define HALO_FILTER_MAX_TERMS 64  /* total simple terms over all AND-clauses of one complex filter */
 enum { HALO_FILTER_NONE = 0, HALO_FILTER_RAYPATH = 1, HALO_FILTER_ENTRY_EXIT = 2, HALO_FILTER_DIRECTION = 3,
        HALO_FILTER_CRYSTAL = 4 };
 enum { HALO_SYM_P = 1, HALO_SYM_B = 2, HALO_SYM_D = 4 }; /* FilterConfig::kSymP/B/D */

@@ -48,7 +48,8 @@ def oracle():
     if _oracle is not None:
         return _oracle
     src = os.path.join(ROOT, "oracle", "halo_oracle.c")
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    deps = [src, os.path.join(ROOT, "oracle", "halo_oracle.h"), os.path.join(ROOT, "include", "halo_trace.h")]
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
     L = C.CDLL(ORACLE_SO)
     sp = C.POINTER(HoStream)

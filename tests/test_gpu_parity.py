@@ -9,6 +9,8 @@ TIR or not, which pixel) can flip for rays sitting on a boundary.  Stated tolera
 (the north_star's "image L2 < 1e-3 at 50 M rays" is a Monte-Carlo bound between independent samples; with
 shared streams we hold a tighter, deterministic one at test sizes).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -932,3 +934,59 @@ def test_sharded_tracer_bound_accumulator_equals_plain_backend():
     assert landed1 != landed and landed1 == pytest.approx(landed, rel=5e-3)
     assert rel_l2(block_mean(img1, 16), block_mean(img, 16)) <= 0.15
     torch.cuda.synchronize()
+
+
+# --- the reference's own end-to-end config documents (tests/golden/e2e_configs: test/e2e/configs/*.json) ---------------------
+_E2E_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_configs")
+_E2E = sorted(f[:-5] for f in os.listdir(_E2E_DIR) if f.endswith(".json"))
+
+
+@pytest.mark.parametrize("name", _E2E)
+def test_reference_e2e_configs_parity(name):
+    """Each document goes through the JSON reader (ice_halo_sim_amd.config) and is traced with a reduced ray count on the HIP
+    backend and on the oracle: filters, symmetry spellings, multi-layer gates with prob < 1, pyramids, raypath colour, several
+    lenses, wide random geometry.  One scattering layer: the same exits per ray.  More layers: the continuation order differs,
+    so continuation counts, landed weight and the image agree statistically (the reference's own cross-backend battery)."""
+    from ice_halo_sim_amd import config
+    job = config.load_config(os.path.join(_E2E_DIR, name + ".json"))
+    rd = job.renders[sorted(job.renders)[0]]
+    wl = job.wavelengths[0]
+    layers = job.scene.layer_count
+    n = 120_000 if layers == 1 else 200_000
+    hb = hip_backend(seed=42, capture_exits=1)
+    ob = OracleBackend(seed=42, capture_exits=1, threads=8)
+    for b in (hb, ob):
+        if job.geom_clock:
+            b.set_option("geom_clock", job.geom_clock)
+        b.set_filters(job.filters)
+        if job.color_classes:
+            b.set_color(job.color_sets, job.color_classes)
+    sh = run_session(hb, job.scene, rd, wl, n)
+    so = run_session(ob, job.scene, rd, wl, n)
+    eh, eo = hb.DrainExits(), ob.DrainExits()
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    lanes = (hb.ReadbackClassLanes(), ob.ReadbackClassLanes()) if job.color_classes else None
+    hb.close()
+    ob.close()
+    assert len(eo) == 0 or len(eh) > 0
+    if layers == 1:
+        assert sh[0].exit_count == pytest.approx(so[0].exit_count, rel=1e-3, abs=20)
+        if len(eo):
+            frac, pix, path = match_exits(eh, eo)
+            assert frac >= 0.997 and pix >= 0.995 and path >= 0.998
+        assert abs(lh - lo) <= 3e-4 * max(lo, 1.0)
+        if io.sum() > 0:
+            assert rel_l2(block_mean(ih), block_mean(io)) <= 4e-3
+    else:
+        for l in range(layers - 1):
+            assert sh[l].continuation_count == pytest.approx(so[l].continuation_count, rel=2e-2, abs=50)
+        assert len(eh) == pytest.approx(len(eo), rel=3e-2, abs=100)
+        assert lh == pytest.approx(lo, rel=4e-2, abs=1.0)
+        if io.sum() > 0 and lo > 100.0:
+            a, b = block_mean(ih, 16)[..., 1].ravel(), block_mean(io, 16)[..., 1].ravel()
+            assert np.corrcoef(a, b)[0, 1] >= 0.9
+    if lanes is not None:
+        th, to = lanes[0].sum(axis=(1, 2)), lanes[1].sum(axis=(1, 2))
+        assert th == pytest.approx(to, rel=(2e-3 if layers == 1 else 6e-2), abs=1e-3 * max(float(to.max()), 1.0) + 0.5)
+
