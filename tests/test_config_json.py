@@ -2,6 +2,7 @@
 reference's published schema (keys `mean`/`std`, `zenith`, `upper_indices`, `scattering[].entries[]`, lens `f`)."""
 import copy
 import math
+import json
 import os
 
 import pytest
@@ -132,15 +133,16 @@ def test_reference_example_files_parse():
         assert job.ray_num == 450_000_000 and len(job.wavelengths) == 9 and sorted(job.renders) == [1, 2, 3, 4]
 
 
-E2E_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_configs")
-E2E_CONFIGS = sorted(f[:-5] for f in os.listdir(E2E_DIR) if f.endswith(".json"))
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_e2e_configs.json")) as _f:
+    E2E_DOCS = json.load(_f)       # tests/golden/make_e2e_config_bundle.py: the reference's test/e2e/configs/*.json
+E2E_CONFIGS = sorted(E2E_DOCS)
 
 
 @pytest.mark.parametrize("name", E2E_CONFIGS)
 def test_reference_e2e_config_documents_parse(name):
     """Every config document of the reference's end-to-end tests that is kept as a fixture maps onto the ABI structs: symmetry
     spellings ("none", "PBD"), 12-clause OR filters, raypath_color tables, several renderers, pyramid Miller indices ..."""
-    job = config.load_config(os.path.join(E2E_DIR, name + ".json"))
+    job = config.load_config(E2E_DOCS[name])
     assert job.scene.layer_count >= 1 and job.renders and job.wavelengths
     for l in range(job.scene.layer_count):
         for e in range(job.scene.layers[l].entry_count):

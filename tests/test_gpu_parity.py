@@ -936,9 +936,10 @@ def test_sharded_tracer_bound_accumulator_equals_plain_backend():
     torch.cuda.synchronize()
 
 
-# --- the reference's own end-to-end config documents (tests/golden/e2e_configs: test/e2e/configs/*.json) ---------------------
-_E2E_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_configs")
-_E2E = sorted(f[:-5] for f in os.listdir(_E2E_DIR) if f.endswith(".json"))
+# --- the reference's own end-to-end config documents (tests/golden/ref_e2e_configs.json: test/e2e/configs/*.json) -----------
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_e2e_configs.json")) as _f:
+    _E2E_DOCS = __import__("json").load(_f)
+_E2E = sorted(_E2E_DOCS)
 
 
 @pytest.mark.parametrize("name", _E2E)
@@ -948,7 +949,7 @@ def test_reference_e2e_configs_parity(name):
     lenses, wide random geometry.  One scattering layer: the same exits per ray.  More layers: the continuation order differs,
     so continuation counts, landed weight and the image agree statistically (the reference's own cross-backend battery)."""
     from ice_halo_sim_amd import config
-    job = config.load_config(os.path.join(_E2E_DIR, name + ".json"))
+    job = config.load_config(_E2E_DOCS[name])
     rd = job.renders[sorted(job.renders)[0]]
     wl = job.wavelengths[0]
     layers = job.scene.layer_count
