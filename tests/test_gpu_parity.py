@@ -563,6 +563,36 @@ def test_filter_and_color_state_does_not_leak_into_later_sessions():
     assert len(f2) == pytest.approx(len(f1), rel=2e-2) and st2[0].continuation_count == pytest.approx(st1[0].continuation_count, rel=2e-2)
 
 
+@pytest.mark.parametrize("case", ["single_prob1", "multi_prob1", "multi_prob0", "mid_layer_split"])
+def test_emit_gate_prob_semantics(case):
+    """The gate of CollectData as the reference's exit-record tests state it (test/unit-correctness/core/test_exit_records.cpp:255-343):
+    prob 1.0 on the final layer drops every exit ("continue" without a next layer); prob 1.0 on both layers of two leaves nothing;
+    prob 0.0 on the first layer emits everything there and feeds the second nothing; prob 0.6 then 0.0 splits the exits between
+    the layers in that proportion.  Same counts on the HIP backend and on the oracle."""
+    col = scenes.column_crystal_entry()
+    probs = {"single_prob1": [1.0], "multi_prob1": [1.0, 1.0], "multi_prob0": [0.0, 0.0], "mid_layer_split": [0.6, 0.0]}[case]
+    sc = scenes.scene([(p, [col]) for p in probs], max_hits=7)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 256, 128, visible=abi.VISIBLE_FULL)
+    n = 50_000
+    out = {}
+    for name, b in (("hip", hip_backend(seed=19, capture_exits=1)), ("oracle", OracleBackend(seed=19, capture_exits=1, threads=8))):
+        st = run_session(b, sc, rd, scenes.wl_discrete(550.0), n)
+        ex = b.DrainExits()
+        img, landed = b.ReadbackXyzAccum()
+        b.close()
+        out[name] = (np.bincount(ex["layer"], minlength=2)[:2], landed, float(img.sum()), [s.continuation_count for s in st])
+    for name, (by_layer, landed, total, cont) in out.items():
+        if case in ("single_prob1", "multi_prob1"):
+            assert by_layer.sum() == 0 and landed == 0.0 and total == 0.0
+        elif case == "multi_prob0":
+            assert by_layer[0] > 4 * n and by_layer[1] == 0 and cont[0] == 0 and landed > 0
+        else:
+            assert by_layer[0] > 0 and by_layer[1] > 0
+            assert cont[0] / (cont[0] + by_layer[0]) == pytest.approx(0.6, abs=0.01)     # u < prob continues
+    assert (out["hip"][0][0], out["hip"][3][0]) == (out["oracle"][0][0], out["oracle"][3][0])      # layer 0 is per-ray identical
+    assert out["hip"][0][1] == pytest.approx(out["oracle"][0][1], rel=2e-2, abs=5)
+
+
 def test_async_dispatch_equals_synchronous():
     """Option async=1 queues final-layer dispatches without a host sync; image, landed weight and the collected tallies must
     equal the synchronous run's bit for bit (same launches, same streams)."""
