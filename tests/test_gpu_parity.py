@@ -1021,3 +1021,57 @@ def test_reference_e2e_configs_parity(name):
         th, to = lanes[0].sum(axis=(1, 2)), lanes[1].sum(axis=(1, 2))
         assert th == pytest.approx(to, rel=(2e-3 if layers == 1 else 6e-2), abs=1e-3 * max(float(to.max()), 1.0) + 0.5)
 
+
+def test_raypath_4_6_and_7_3_render_the_same_halo():
+    """The reference's symmetry property (test/e2e-correctness/test_raypath_equivalence.py; configs raypath_symmetry_4_6 / _7_3): under
+    an isotropic orientation the raypaths [4, 6] and [7, 3] are images of each other, so the two filtered renders are the same
+    halo up to Monte Carlo noise — this exercises the latitude fold with its roll += pi coupling in the orientation sampler.
+    A GPU-sized property: 20 M rays each, compared on 8x8 block means."""
+    from ice_halo_sim_amd import config
+    imgs = []
+    for name in ("raypath_symmetry_4_6", "raypath_symmetry_7_3"):
+        job = config.load_config(_E2E_DOCS[name])
+        rd = job.renders[sorted(job.renders)[0]]
+        hb = hip_backend(seed=5)
+        hb.set_filters(job.filters)
+        run_session(hb, job.scene, rd, job.wavelengths[0], 20_000_000)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        assert landed > 0
+        imgs.append((block_mean(img, 8)[..., 1], landed))
+    (a, la), (b, lb) = imgs
+    assert la == pytest.approx(lb, rel=1e-2)
+    assert np.corrcoef(a.ravel(), b.ravel())[0, 1] >= 0.985
+    assert rel_l2(a[..., None], b[..., None]) <= 0.12
+
+
+def test_composition_encodings_of_one_predicate_trace_the_same_rays():
+    """test/e2e-correctness/test_composition_equivalence.py: the sum-of-products expansion a GUI export writes ([[1],[2],[3,4]] over
+    four simple filters, no dedup) and the hand-written form of the same predicate ([[1],[2],[1,3]] over three) differ only in
+    encoding.  The reference compares renders (PSNR >= 40 dB); with counter-based streams the two configs must agree ray for ray.
+    (The two documents carry prob 1.0 on their only layer, which — in the reference as here, see test_emit_gate_prob_semantics —
+    drops every exit and makes the reference's own render comparison one of black frames; the gate is opened here so that the
+    predicate is what is compared.)"""
+    import copy
+    from ice_halo_sim_amd import config
+    out = []
+    for name in ("composition_sop_gui_export", "composition_core_direct"):
+        doc = copy.deepcopy(_E2E_DOCS[name])
+        assert doc["scene"]["scattering"][0]["prob"] == 1.0 and len(doc["scene"]["scattering"]) == 1
+        doc["scene"]["scattering"][0]["prob"] = 0.0
+        job = config.load_config(doc)
+        rd = job.renders[sorted(job.renders)[0]]
+        hb = hip_backend(seed=11, capture_exits=1)
+        hb.set_filters(job.filters)
+        run_session(hb, job.scene, rd, job.wavelengths[0], 300_000)
+        ex = hb.DrainExits()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out.append((ex[np.lexsort((ex["seq"], ex["root"]))], img, landed))
+    (ea, ia, la), (eb, ib, lb) = out
+    assert len(ea) == len(eb) > 1000
+    for f in ("root", "seq", "pixel", "path_len"):
+        assert (ea[f] == eb[f]).all()
+    assert (ea["dir"] == eb["dir"]).all() and (ea["weight"] == eb["weight"]).all()
+    assert la == pytest.approx(lb, rel=1e-6) and rel_l2(ia, ib) <= 2e-6
+
