@@ -1075,3 +1075,44 @@ def test_composition_encodings_of_one_predicate_trace_the_same_rays():
     assert (ea["dir"] == eb["dir"]).all() and (ea["weight"] == eb["weight"]).all()
     assert la == pytest.approx(lb, rel=1e-6) and rel_l2(ia, ib) <= 2e-6
 
+
+def test_entry_face_frequencies_follow_face_areas_under_isotropic_orientation():
+    """Distribution gate for the projected-area entry pick together with the isotropic orientation sampler (the reference's AC1,
+    test/golden-analytic/core/test_incidence_sampling_polygon_oracle.cpp): per-face entry frequencies of an irregular prism (six
+    different face distances) under isotropic orientation, 600 k rays, against a numpy integration over directions.  The entry
+    face is the path of each root's reflection at entry (seq 0)."""
+    import ctypes as C
+    from ice_halo_sim_amd.backend import load_library
+    dist = np.array([1.0, 0.8, 1.2, 0.9, 1.1, 1.0], np.float32)
+    g = abi.HaloGeomTables()
+    assert load_library().halo_host_prism_geometry(1.3, dist.ctypes.data_as(C.POINTER(C.c_float)), C.byref(g)) == 0
+    # every orientation gets the same number of rays (no cross-section weighting in the reference's model), so the expectation is
+    # E_u[ proj_f(u) / proj_total(u) ] over incoming directions u uniform on the sphere, proj_f(u) = sum over the face's fan
+    # triangles of area * max(0, -u.n) — integrated here with plain numpy, independent of the sampler
+    rs = np.random.default_rng(1)
+    u = rs.normal(size=(1_000_000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    tn = np.array(g.tri_n[:3 * g.tri_cnt], np.float64).reshape(-1, 3)
+    ta = np.array(g.tri_area[:g.tri_cnt], np.float64)
+    tf = np.array([g.face_number[g.tri_face[t]] for t in range(g.tri_cnt)])
+    proj = np.maximum(-(u @ tn.T), 0.0) * ta                      # (samples, tris)
+    per_face = np.stack([proj[:, tf == f].sum(axis=1) for f in range(9)], axis=1)
+    expect = (per_face / per_face.sum(axis=1, keepdims=True)).mean(axis=0)
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    # isotropic: a latitude density that is flat before the sampler's cos(latitude) sphere weighting (a Gaussian so wide that it
+    # varies by 1e-6 over the sphere; `uniform` is uniform in the ANGLE and oversamples the poles)
+    iso = {"type": "gauss", "mean": 0.0, "std": 90000.0}
+    e = scenes.entry(scenes.prism_crystal(1.3, [float(x) for x in dist]), scenes.axis(zenith=iso, azimuth=full, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.0, [e])], max_hits=1)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 64, 32, visible=abi.VISIBLE_FULL)
+    n = 600_000
+    for make in (lambda: hip_backend(seed=29, capture_exits=1), lambda: OracleBackend(seed=29, capture_exits=1, threads=8)):
+        b = make()
+        run_session(b, sc, rd, scenes.wl_discrete(550.0), n)
+        ex = b.DrainExits()
+        b.close()
+        first = ex[ex["seq"] == 0]
+        assert n - 20 <= len(first) <= n and (first["path_len"] == 1).all()      # a few edge-on draws find no entry face
+        freq = np.bincount(first["path"][:, 0], minlength=9)[:9] / len(first)
+        assert freq[0] == 0 and np.abs(freq - expect).max() < 4.0 * np.sqrt(0.25 / n) + 4.0 * np.sqrt(0.25 / 1e6), (freq, expect)
+
