@@ -1116,3 +1116,36 @@ def test_entry_face_frequencies_follow_face_areas_under_isotropic_orientation():
         freq = np.bincount(first["path"][:, 0], minlength=9)[:9] / len(first)
         assert freq[0] == 0 and np.abs(freq - expect).max() < 4.0 * np.sqrt(0.25 / n) + 4.0 * np.sqrt(0.25 / 1e6), (freq, expect)
 
+
+def test_minimum_deviation_of_the_22_and_46_degree_halos():
+    """Physics anchor that involves neither the oracle nor the reference: light through two prism faces at 60 degrees (3-5, 4-6, ...)
+    is deviated by at least D22 = 2 asin(n sin 30) - 60 = 21.84 degrees at n(550 nm), through a basal and a prism face (90 degrees)
+    by at least D46 = 2 asin(n sin 45) - 90 = 45.7 degrees, with the exits piling up at the minimum (that is the halo); parallel
+    faces do not deviate.  Randomly oriented prisms, 400 k rays, angles measured from the mean direction of the undeviated exits."""
+    n_idx = float(np.float32(abi_refr(550.0)))
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    e = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.0, [e])], max_hits=4)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 256, 128, visible=abi.VISIBLE_FULL)
+    hb = hip_backend(seed=37, capture_exits=1)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 400_000)
+    ex = hb.DrainExits()
+    hb.close()
+    two = ex[ex["path_len"] == 2]
+    a, b = two["path"][:, 0].astype(int), two["path"][:, 1].astype(int)
+    side_a, side_b = a >= 3, b >= 3
+    parallel = ((a <= 2) & (b <= 2) & (a != b)) | (side_a & side_b & ((b - a) % 6 == 3))
+    wedge60 = side_a & side_b & (((b - a) % 6 == 2) | ((b - a) % 6 == 4))
+    wedge90 = (side_a & (b <= 2)) | ((a <= 2) & side_b)
+    d0 = two["dir"][parallel].astype(np.float64).mean(axis=0)
+    d0 /= np.linalg.norm(d0)
+    ang = np.degrees(np.arccos(np.clip(two["dir"].astype(np.float64) @ d0, -1.0, 1.0)))
+    assert parallel.sum() > 10_000 and ang[parallel].max() < 0.6                       # the sun disc is 0.5 degrees wide
+    for sel, apex in ((wedge60, 60.0), (wedge90, 90.0)):
+        dmin = 2.0 * np.degrees(np.arcsin(n_idx * np.sin(np.radians(apex / 2)))) - apex
+        t = ang[sel]
+        assert len(t) > 5_000
+        assert t.min() > dmin - 0.5                                                     # nothing inside the halo's inner edge
+        assert np.mean(t < dmin + 1.5) > 0.08 and np.mean(t < dmin + 1.5) > 4 * np.mean((t > dmin + 10) & (t < dmin + 11.5))
+    assert abs((2.0 * np.degrees(np.arcsin(n_idx * 0.5)) - 60.0) - 21.84) < 0.1
+
