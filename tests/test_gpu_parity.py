@@ -1149,3 +1149,39 @@ def test_minimum_deviation_of_the_22_and_46_degree_halos():
         assert np.mean(t < dmin + 1.5) > 0.08 and np.mean(t < dmin + 1.5) > 4 * np.mean((t > dmin + 10) & (t < dmin + 11.5))
     assert abs((2.0 * np.degrees(np.arcsin(n_idx * 0.5)) - 60.0) - 21.84) < 0.1
 
+
+def test_circumzenithal_and_parhelion_geometry():
+    """Two more closed forms, again without oracle or reference.  Horizontal plates (c-axis vertical, any roll), sun at altitude h:
+    * top face -> side face (the circumzenithal arc): the light leaves at the same angle from the vertical for EVERY roll,
+      |d_z| = sqrt(n^2 - cos^2 h)   (refraction at a horizontal then a vertical face) — a circle of constant altitude;
+    * side face -> side face at 60 degrees (the parhelia): the vertical component is untouched, |d_z| = sin h, and the deviation
+      projected on the horizontal plane is at least the skew-ray minimum 2 asin(n' sin 30) - 60 with n' = sqrt(n^2 - sin^2 h) / cos h.
+    Sun disc shrunk to a point so the identities are sharp."""
+    n_idx = float(np.float32(abi_refr(550.0)))
+    h = np.radians(25.0)
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    plate = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith=0.0, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.0, [plate])], max_hits=3, sun_altitude=25.0, sun_diameter=0.0)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 256, 128, visible=abi.VISIBLE_FULL)
+    hb = hip_backend(seed=53, capture_exits=1)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 300_000)
+    ex = hb.DrainExits()
+    hb.close()
+    two = ex[ex["path_len"] == 2]
+    a, b = two["path"][:, 0].astype(int), two["path"][:, 1].astype(int)
+    d = two["dir"].astype(np.float64)
+    undeviated = d[(a == 1) & (b == 2)]
+    assert len(undeviated) > 10_000 and abs(np.abs(undeviated[:, 2]).mean() - np.sin(h)) < 1e-4      # fixes the vertical axis and h
+    cza = d[(a == 1) & (b >= 3)]
+    assert len(cza) > 2_000
+    assert np.abs(np.abs(cza[:, 2]) - np.sqrt(n_idx ** 2 - np.cos(h) ** 2)).max() < 2e-4
+    par = d[(a >= 3) & (b >= 3) & (((b - a) % 6 == 2) | ((b - a) % 6 == 4))]
+    assert len(par) > 5_000
+    assert np.abs(np.abs(par[:, 2]) - np.sin(h)).max() < 2e-4
+    d0 = undeviated.mean(axis=0)
+    hor = lambda v: v[..., :2] / np.linalg.norm(v[..., :2], axis=-1, keepdims=True)
+    dev = np.degrees(np.arccos(np.clip(hor(par) @ hor(d0), -1.0, 1.0)))
+    n_skew = np.sqrt(n_idx ** 2 - np.sin(h) ** 2) / np.cos(h)
+    dmin = 2.0 * np.degrees(np.arcsin(n_skew * 0.5)) - 60.0
+    assert dev.min() > dmin - 0.05 and np.mean(dev < dmin + 1.0) > 0.1
+
