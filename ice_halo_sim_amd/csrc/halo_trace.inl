@@ -787,11 +787,22 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
 // ------------------------------------------------------------------------------------------------
 // the fused kernel.  MODE: 0 = production, 1 = + raypath recording and emit-gate filter, 2 = + exit capture (tests)
 // ------------------------------------------------------------------------------------------------
+// Per-face view of the fan-triangle table of a dispatch's ONE shape (deterministic crystals), built by the workgroup when it
+// stages the shape: the entry pick then walks the faces (8 for a prism) and only the triangles of the face it lands in,
+// instead of all fan triangles twice.  ok = 0 (shape pools, or a table whose triangles are not grouped face by face in face
+// order) selects the flat walk.
+struct FaceIndex {
+  float area[kMaxFaces];       // sum of the face's fan-triangle areas
+  uint8_t tri0[kMaxFaces];     // first fan triangle of the face
+  uint8_t tric[kMaxFaces];     // number of fan triangles
+  uint32_t ok;
+};
 template <bool MONO, bool SMALLC>
 struct LdsTables {
   float lut[3 * kLutNodes];
   PixCache<MONO, SMALLC> cache;
   uint32_t seg[kContShards + 4];
+  FaceIndex fidx;
 };
 constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
 template <bool ON>
@@ -996,6 +1007,64 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
   return static_cast<int>(sh->tri_face[tri]);
 }
 
+// The same categorical pick, face by face.  All fan triangles of a face share its plane, so their weights are
+// max(-d.n_f, 0) * area_t: one dot product per face decides how much of the target falls into it, and the triangle inside the
+// face is found on the areas alone.  Same uniform, same cumulative order (faces in table order, their triangles in table
+// order) as the flat walk; the two differ only by the rounding of the partial sums (and of n_f against the per-triangle
+// normals), i.e. in which of two adjacent triangles a ray within ~1e-7 of a boundary lands.
+template <typename ShapePtr>
+HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int face_cnt, int tri_cnt, const float* d, float* p) {
+  const float u_cat = uniform(s);
+  if (tri_cnt == 0) {
+    p[0] = p[1] = p[2] = 0.0f;
+    return -1;
+  }
+  float total = 0.0f;
+  for (int f = 0; f < face_cnt; ++f) {
+    const float4 pl = *reinterpret_cast<const float4*>(sh->face[f]);
+    total += fmaxf(-(d[0] * pl.x + d[1] * pl.y + d[2] * pl.z), 0.0f) * fi.area[f];
+  }
+  int tri = 0;
+  if (total > 0.0f) {
+    const float target = u_cat * total;
+    float cum = 0.0f;
+    tri = tri_cnt - 1;
+    for (int f = 0; f < face_cnt; ++f) {
+      const float4 pl = *reinterpret_cast<const float4*>(sh->face[f]);
+      const float c = fmaxf(-(d[0] * pl.x + d[1] * pl.y + d[2] * pl.z), 0.0f);
+      const float w = c * fi.area[f];
+      if (cum + w > target) {   // c > 0 here
+        const float r = (target - cum) * fast_rcp(c);
+        const int t0 = fi.tri0[f], tn = fi.tric[f];
+        float acc = 0.0f;
+        tri = t0 + tn - 1;
+        for (int k = 0; k < tn; ++k) {
+          acc += sh->tri_na[t0 + k][3];
+          if (acc > r) {
+            tri = t0 + k;
+            break;
+          }
+        }
+        break;
+      }
+      cum += w;
+    }
+  }
+  float u = uniform(s);
+  float v = uniform(s);
+  if (u + v > 1.0f) {
+    u = 1.0f - u;
+    v = 1.0f - v;
+  }
+  const float* vt = sh->tri_v[tri];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float a = vt[k], b = vt[3 + k], c = vt[6 + k];
+    p[k] = u * (b - a) + v * (c - a) + a;
+  }
+  return static_cast<int>(sh->tri_face[tri]);
+}
+
 template <int MODE, bool MONO, bool SMALLC, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
                   uint32_t tid, RaySums& sums) {
@@ -1032,7 +1101,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
     float dwz = P.s_lat * x + P.c_lat * z;
     apply_inverse(R, dwx, dwy, dwz, d);
-    face = sample_entry(s, sh, sh->tri_cnt, d, p);
+    face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     w = (P.wl_pool_size == 1u) ? P.wl_pool[0].spd_weight : P.wl_pool[wl_idx].spd_weight;
   } else if (P.source == kSrcTransit) {
     Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
@@ -1065,7 +1134,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
     build_crystal_rotation(lon, lat, roll, R);
     apply_inverse(R, dwx, dwy, dwz, d);
-    face = sample_entry(s, sh, sh->tri_cnt, d, p);
+    face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
   } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)
     R[0] = R[4] = R[8] = 1.0f;
     R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0f;
@@ -1280,10 +1349,40 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
     for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
   if (P.source == kSrcTransit)
     for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
+  if (threadIdx.x == 0) T.fidx.ok = 0u;
   if constexpr (!POOL) {
     const float4* src = reinterpret_cast<const float4*>(P.shapes);
     float4* dst = reinterpret_cast<float4*>(&s_shape.s[0]);
     for (uint32_t i = threadIdx.x; i < sizeof(ShapeDev) / 16u; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+    // per-face view of the fan table (FaceIndex): thread f sums face f's triangles; the grouping is verified, not assumed
+    const ShapeDev& S0 = s_shape.s[0];
+    const int fc = S0.face_cnt, tc = S0.tri_cnt;
+    if (static_cast<int>(threadIdx.x) < fc) {
+      const int f = static_cast<int>(threadIdx.x);
+      float a = 0.0f;
+      int first = tc, cnt = 0;
+      for (int t = 0; t < tc; ++t)
+        if (S0.tri_face[t] == f) {
+          a += S0.tri_na[t][3];
+          first = min(first, t);
+          cnt++;
+        }
+      T.fidx.area[f] = a;
+      T.fidx.tri0[f] = static_cast<uint8_t>(first);
+      T.fidx.tric[f] = static_cast<uint8_t>(cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bool ok = fc > 0 && fc <= kMaxFaces && tc > 0;
+      int next = 0;
+      for (int f = 0; f < fc && ok; ++f) {
+        ok = T.fidx.tric[f] > 0 && T.fidx.tri0[f] == next;
+        for (int k = 0; k < T.fidx.tric[f] && ok; ++k) ok = S0.tri_face[next + k] == f;
+        next += T.fidx.tric[f];
+      }
+      T.fidx.ok = (ok && next == tc) ? 1u : 0u;
+    }
   }
   __syncthreads();
 
