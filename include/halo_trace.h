@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 1
+#define HALO_ABI_VERSION 2   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16) */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), "libhalo_hip.so does not export " + sym
     assert declared == set(backend.EXPORTED_SYMBOLS), declared ^ set(backend.EXPORTED_SYMBOLS)
-    assert L.halo_abi_version() == 1
+    assert L.halo_abi_version() == 2
     for i, t in enumerate([abi.HaloScene, abi.HaloRender, abi.HaloWl, abi.HaloExitRecord, abi.HaloGeomTables,
                            abi.HaloLayerStats, abi.HaloEntry]):
         assert L.halo_abi_sizeof(i) == C.sizeof(t), t.__name__
