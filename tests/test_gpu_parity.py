@@ -1185,3 +1185,24 @@ def test_circumzenithal_and_parhelion_geometry():
     dmin = 2.0 * np.degrees(np.arcsin(n_skew * 0.5)) - 60.0
     assert dev.min() > dmin - 0.05 and np.mean(dev < dmin + 1.0) > 0.1
 
+
+@pytest.mark.parametrize("size", [(17, 13), (1, 1), (3, 1000), (4097, 3)])
+def test_edge_image_sizes(size):
+    """Image shapes that are no multiple of anything the accumulation planes use (1024-row slot map, 64x64 fold tiles, 16 Ki-slot
+    bin tiles): a discrete and an illuminant session into each, both lenses, same sums and image as the oracle."""
+    sc = scenes.config2_scene()
+    for lens in (abi.LENS_FISHEYE_EQUAL_AREA, abi.LENS_RECTANGULAR):
+        rd = scenes.render(lens, size[0], size[1], visible=abi.VISIBLE_FULL)
+        hb, ob = hip_backend(seed=3), OracleBackend(seed=3, threads=8)
+        for wl in (scenes.wl_discrete(550.0), scenes.wl_illuminant("D65", 16)):
+            run_session(hb, sc, rd, wl, 40_000)
+            run_session(ob, sc, rd, wl, 40_000)
+        ih, lh = hb.ReadbackXyzAccum()
+        io, lo = ob.ReadbackXyzAccum()
+        hb.close()
+        ob.close()
+        assert ih.shape == io.shape == (size[1], size[0], 3)
+        assert abs(lh - lo) <= 2e-4 * max(lo, 1.0)
+        if io.sum() > 0:
+            assert rel_l2(ih, io) <= 5e-3 and ih.sum() == pytest.approx(io.sum(), rel=1e-4)
+
