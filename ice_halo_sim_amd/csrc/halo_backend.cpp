@@ -750,7 +750,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       uint32_t fan_log2 = 0u;
       while (((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) > b->bin_l1) fan_log2++;
       const bool two_level = bin_tiles > 512u;
-      const bool bin_shape_ok = two_level ? (fan_log2 <= 7u && (bin_slots & 16383ull) == 0ull)
+      const bool bin_shape_ok = two_level ? (fan_log2 <= 8u && (bin_slots & 16383ull) == 0ull)
                                           : (bin_tiles >= 8u && (bin_tiles & (bin_tiles - 1u)) == 0u);
       const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_shape_ok && bin_slots <= (1ull << 31) &&
                            (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);

@@ -55,7 +55,7 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 // 2048 records at a time, ranks them per tile with LDS counters, reserves the `fan` segments with one returning atomic each
 // and places the records.  Everything moves as 8-byte records, coalesced on the read side and in runs per tile on the
 // write side; a tile list that overflows falls back to direct atomics on the plane.
-constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 128u;
+constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 256u;
 __global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                      const uint32_t* __restrict__ cnt1, uint2* __restrict__ list2, uint32_t cap2,
                                                                      uint32_t* __restrict__ cnt2, uint32_t fan_log2) {

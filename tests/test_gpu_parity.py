@@ -259,11 +259,12 @@ def test_illuminant_session_plane_modes(planes):
         assert r["ih"][..., ch].sum() == pytest.approx(r["io"][..., ch].sum(), rel=2e-4)
 
 
-@pytest.mark.parametrize("shape", [(512, 256, 64), (2048, 1024, 31), (2048, 1024, 64)])
+@pytest.mark.parametrize("shape", [(512, 256, 64), (2048, 1024, 31), (2048, 1024, 64), (4096, 2048, 64)])
 def test_illuminant_binned_over_entry_planes(shape):
     """Illuminant session, full-sky render, per-entry planes binned as one array.  512x256 x 64 entries fits 512 tiles (the
     reference's own GPU benchmark shape: D65, dual fisheye 512x256) and takes the one-level route; 2048x1024 x 31 / 64 entries
-    is 3968 / 8192 tiles (examples/bench_config_stoch.json's render) and takes the two-level route: coarse lists from the
+    is 3968 / 8192 tiles (examples/bench_config_stoch.json's render) and takes the two-level route, like the largest image the
+    accumulator accepts (4096x2048 x 64 entries: 32768 tiles, 128 coarse lists of 256): coarse lists from the
     trace kernel, halo_bin_split_kernel, halo_bin_accumulate_range_kernel.  Same image as the direct route and as the oracle."""
     full = {"type": "uniform", "mean": 0.0, "std": 360.0}
     sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.2), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)])], max_hits=7)
