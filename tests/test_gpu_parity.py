@@ -1207,3 +1207,40 @@ def test_edge_image_sizes(size):
         if io.sum() > 0:
             assert rel_l2(ih, io) <= 5e-3 and ih.sum() == pytest.approx(io.sum(), rel=1e-4)
 
+
+def test_halo_rings_land_at_their_radii_in_the_image():
+    """The same two minimum deviations, now through projection, pixel mapping, accumulation planes and fold: an equal-area fisheye
+    (fov 180, 1024x1024) aimed at the sun maps the angle t from its axis to r = 512 sin(t/2) / sin(45 deg) pixels.  The sun itself
+    (light through parallel faces, point source) must sit on the centre pixel, the inner edge of the 3-5 light at r(21.84 deg) =
+    137.2 px and that of the 1-3 light at r(45.7 deg) = 281.2 px.  20 M rays per render; no oracle involved."""
+    n_idx = float(np.float32(abi_refr(550.0)))
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    filters = [scenes.simple_filter(scenes.filter_term("raypath", raypath=[1, 2]), "PBD"),
+               scenes.simple_filter(scenes.filter_term("raypath", raypath=[3, 5]), "PBD"),
+               scenes.simple_filter(scenes.filter_term("raypath", raypath=[1, 3]), "PBD")]
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, 1024, 1024, fov=180.0, az=0.0, el=20.0, visible=abi.VISIBLE_FULL)
+    imgs = []
+    for fid in (1, 2, 3):
+        e = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+        e.filter_id = fid
+        hb = hip_backend(seed=7)
+        hb.set_filters(filters)
+        run_session(hb, scenes.scene([(0.0, [e])], max_hits=4, sun_altitude=20.0, sun_diameter=0.0), rd, scenes.wl_discrete(550.0), 20_000_000)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        assert landed > 0
+        imgs.append(img[..., 1].astype(np.float64))
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    sun = imgs[0]
+    cy, cx = (sun * yy).sum() / sun.sum(), (sun * xx).sum() / sun.sum()
+    assert abs(cx - 512.0) < 0.5 and abs(cy - 512.0) < 0.5 and sun[511:514, 511:514].sum() > 0.999 * sun.sum()
+    r = np.hypot(yy - cy, xx - cx).ravel()
+    order = np.argsort(r)
+    for im, apex in ((imgs[1], 60.0), (imgs[2], 90.0)):
+        dmin = 2.0 * np.degrees(np.arcsin(n_idx * np.sin(np.radians(apex / 2)))) - apex
+        expect = 512.0 * np.sin(np.radians(dmin / 2)) / np.sin(np.radians(45.0))
+        cw = np.cumsum(im.ravel()[order]) / im.sum()
+        edge = r[order][np.searchsorted(cw, 0.005)]            # radius inside which 0.5 % of the light falls
+        assert expect - 0.7 <= edge <= expect + 2.5, (apex, expect, edge)
+        assert cw[np.searchsorted(r[order], expect - 2.0)] < 1e-4     # dark inside the ring
+
