@@ -1244,3 +1244,26 @@ def test_halo_rings_land_at_their_radii_in_the_image():
         assert expect - 0.7 <= edge <= expect + 2.5, (apex, expect, edge)
         assert cw[np.searchsorted(r[order], expect - 2.0)] < 1e-4     # dark inside the ring
 
+
+def test_colour_anchors_monochromatic_ratio_and_d65_white_point():
+    """Colorimetry anchors from the CIE 1931 tables, not from the oracle: (1) a 550 nm session's image has X:Y:Z =
+    xbar:ybar:zbar(550) = 0.4334 : 0.9950 : 0.0087; (2) a D65 illuminant session over the full sky with nearly all energy
+    emitted (max_hits 16: what is still inside a crystal after 16 interactions is < 1e-3) is the colour of the illuminant,
+    chromaticity (0.3127, 0.3290) — scattering by clear ice is almost neutral, the pool's SPD weights and CMF carry the rest."""
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    e = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.0, [e])], max_hits=16)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    hb = hip_backend(seed=31)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 2_000_000)
+    img, landed = hb.ReadbackXyzAccum()
+    X, Y, Z = (float(img[..., c].astype(np.float64).sum()) for c in range(3))
+    assert X / Y == pytest.approx(0.4334 / 0.9950, rel=1e-2) and Z / Y == pytest.approx(0.0087 / 0.9950, rel=0.1)
+    for pool in (64, 255):
+        run_session(hb, sc, rd, scenes.wl_illuminant("D65", pool), 4_000_000)
+        img, landed = hb.ReadbackXyzAccum()
+        X, Y, Z = (float(img[..., c].astype(np.float64).sum()) for c in range(3))
+        x, y = X / (X + Y + Z), Y / (X + Y + Z)
+        assert abs(x - 0.3127) < 4e-3 and abs(y - 0.3290) < 4e-3, (pool, x, y)
+    hb.close()
+
