@@ -484,12 +484,33 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
   int on[20][HALO_MAX_FACE_VTX];
   int on_n[20];
   int present = 0;
+  // membership of every vertex in every plane, vertex-major: one load of the vertex, the 20 planes from their register copies
+  // (same expression as EvalPlane, same values; each face's list comes out in ascending vertex order as before)
+  int member_cnt[20];
+  {
+    int cnt_reg[20];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 20; s++) cnt_reg[s] = 0;
+    for (int v = 0; v < nv; v++) {
+      const double x0 = verts[v][0], x1 = verts[v][1], x2 = verts[v][2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int s = 0; s < 20; s++)
+        if (((act_mask >> s) & 1u) && fabs(pre[s][0] * x0 + pre[s][1] * x1 + pre[s][2] * x2 + pre[s][3]) <= 2.0 * tol && cnt_reg[s] < HALO_MAX_FACE_VTX)
+          on[s][cnt_reg[s]++] = v;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int s = 0; s < 20; s++) member_cnt[s] = cnt_reg[s];
+  }
   for (int s = 0; s < 20; s++) {
     on_n[s] = 0;
     if (!active[s]) continue;
-    int cnt = 0;
-    for (int v = 0; v < nv; v++)
-      if (fabs(EvalPlane(unit[s], verts[v])) <= 2.0 * tol && cnt < HALO_MAX_FACE_VTX) on[s][cnt++] = v;
+    const int cnt = member_cnt[s];
     if (cnt < 3) continue;
     double c[3] = {0, 0, 0};
     for (int q = 0; q < cnt; q++)
