@@ -17,4 +17,11 @@ for rep in range(3):
 sc_s = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
 for rep in range(3):
     run_session(hb, sc_s, scenes.render(7, 2048, 1024, el=0, visible=2), scenes.wl_discrete(550.0), 4_000_000)   # shapegen + pool trace
+for rep in range(3):                                                        # two-level binned route: split + range accumulate, 64-plane fold
+    run_session(hb, sc_s, scenes.render(7, 2048, 1024, el=0, visible=2), scenes.wl_illuminant("D65", 64), 20_000_000)
+g = {"type": "gauss", "mean": 1.0, "std": 0.1}
+full_ax = {"type": "uniform", "mean": 0.0, "std": 360.0}
+pyr = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6), scenes.axis(zenith=full_ax, azimuth=full_ax, roll=full_ax), 1.0, 5)
+for rep in range(3):                                                        # pyramid generator + ShapeDev pool trace
+    run_session(hb, scenes.scene([(0.0, [pyr])], max_hits=8), scenes.render(7, 2048, 1024, el=0, visible=2), scenes.wl_discrete(550.0), 4_000_000)
 hb.close()
