@@ -1288,3 +1288,31 @@ def test_energy_is_conserved_through_the_scattering_layers(probs):
     assert n * (1.0 - residual) <= landed <= n * (1.0 + 1e-5), landed / n
     assert float(img[..., 1].astype(np.float64).sum()) == pytest.approx(landed * 0.9950, rel=2e-3)     # ybar(550 nm)
 
+
+@pytest.mark.parametrize("kind", ["prism", "pyramid"])
+def test_pool_path_with_frozen_geometry_equals_the_one_shape_path(kind):
+    """A crystal whose face distances are gauss(1, 1e-7) is 'stochastic' to the dispatcher — device generator, shape pool, the pool
+    trace variants with their flat entry pick — but physically the fixed crystal, which takes the one-shape kernel with its by-face
+    entry pick.  Same ray streams, so the two routes must produce the same exits ray for ray (up to the 1e-7 wobble)."""
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    ax = scenes.axis(zenith=full, azimuth=full, roll=full)
+    g = {"type": "gauss", "mean": 1.0, "std": 1e-7}
+    if kind == "prism":
+        fixed, frozen = scenes.prism_crystal(1.3), scenes.prism_crystal(1.3, [g] * 6)
+    else:
+        fixed = scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3))
+        frozen = scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    out = []
+    for cr in (fixed, frozen):
+        hb = hip_backend(seed=47, capture_exits=1)
+        st = run_session(hb, scenes.scene([(0.0, [scenes.entry(cr, ax, 1.0, 1)])], max_hits=6), rd, scenes.wl_discrete(550.0), 150_000)
+        ex = hb.DrainExits()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out.append((ex, img, landed))
+    frac, pix, path = match_exits(out[1][0], out[0][0])
+    assert frac >= 0.995 and pix >= 0.99 and path >= 0.997
+    assert out[1][2] == pytest.approx(out[0][2], rel=2e-3)
+    assert rel_l2(block_mean(out[1][1]), block_mean(out[0][1])) <= 1e-2
+
