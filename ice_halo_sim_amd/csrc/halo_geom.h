@@ -4,8 +4,8 @@
 // halo_host_*_geometry exports) and inside halo_shapegen_kernel (stochastic crystals: one thread per sampled shape,
 // SURVEY §8 row f4).  Everything is fixed-size and uses only IEEE basic operations (+ - * / sqrt, fp64 solve, fp32
 // tables), so with contraction off both sides produce bit-identical tables from the same scalars.  The only libm
-// calls are in the scalar sampler (logf / cosf / sinf for Gauss / zigzag / Laplacian draws) and atan2 for the CCW
-// ordering of pyramid face loops, where an ulp moves nothing.
+// calls are in the scalar sampler (logf / cosf / sinf for Gauss / zigzag / Laplacian draws); the CCW ordering of pyramid
+// face loops sorts on a pseudo-angle built from basic operations (same order as atan2, no libm).
 //
 // Reference: ComputeClosedFormPrism geo3d_closedform.cpp:1318-1407, SolveHexCrossSection :124-302,
 // AdaptClosedFormPrismToCrystalGeom crystal.cpp:109-186, Crystal::PopulateFromCfGeom crystal.cpp:304-347,
@@ -524,8 +524,16 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     double ang[HALO_MAX_FACE_VTX];
     for (int q = 0; q < cnt; q++) {
       const double r[3] = {verts[on[s][q]][0] - c[0], verts[on[s][q]][1] - c[1], verts[on[s][q]][2] - c[2]};
-      double a = (q == 0) ? 0.0 : atan2(r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2]);
-      if (a < 0.0) a += 2.0 * kGeomPiD;
+      // sort key: a pseudo-angle that grows with atan2(y, x) mapped to [0, 2 pi) — t = |y| / (|x| + |y|) per quadrant, in
+      // [0, 4) — so the order is the CCW order an atan2 would give (the vertices of a face are at least 2 tol apart after the
+      // duplicate filter, far beyond any rounding of either key) at the price of one division
+      double a = 0.0;
+      if (q != 0) {
+        const double y = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], x = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
+        const double ax = fabs(x), ay = fabs(y);
+        const double t = (ax + ay > 0.0) ? ay / (ax + ay) : 0.0;
+        a = (y >= 0.0) ? (x >= 0.0 ? t : 2.0 - t) : (x < 0.0 ? 2.0 + t : 4.0 - t);
+      }
       ang[q] = a;
     }
     for (int q = 1; q < cnt; q++) {  // stable insertion sort by angle
