@@ -157,3 +157,10 @@ def test_pyramid_topology_matches_reference_goldens_and_oracle():
     # empty / degenerate inputs give the empty crystal on both sides
     e = abi.HaloGeomTables()
     assert L.halo_host_pyramid_geometry(28.0, 28.0, 0.0, 0.0, 0.0, fptr(np.ones(6, np.float32)), C.byref(e)) != 0 and e.face_cnt == 0
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() compiles (or finds up to date) every native piece, loads the C-ABI
+    library, resolves every exported symbol and checks the ABI version against include/halo_trace.h (no GPU needed)."""
+    import __graft_entry__ as g
+    g.build()
