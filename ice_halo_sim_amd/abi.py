@@ -104,6 +104,14 @@ class HaloExitRecord(C.Structure):
                 ("pixel", C.c_int32), ("crystal_id", C.c_uint16), ("wl_idx", C.c_uint16), ("color_mask", C.c_uint64)]
 
 
+class HaloRouteInfo(C.Structure):
+    _fields_ = [("launches", C.c_uint32), ("mode_mask", C.c_uint32), ("geom_mask", C.c_uint32), ("accum_mask", C.c_uint32),
+                ("source_mask", C.c_uint32), ("plane_cnt", C.c_uint32), ("plane_copies", C.c_uint32), ("shuffle_chunk", C.c_uint32)]
+
+
+ACCUM_XYZ, ACCUM_SCALAR, ACCUM_BIN1, ACCUM_BIN2 = 1, 2, 4, 8   # HaloRouteInfo.accum_mask bits
+
+
 class HaloGeomTables(C.Structure):
     _fields_ = [("face_cnt", C.c_int32), ("face_n", C.c_float * (MAX_FACES * 3)), ("face_d", C.c_float * MAX_FACES),
                 ("face_number", C.c_int32 * MAX_FACES), ("tri_cnt", C.c_int32), ("tri_v", C.c_float * (MAX_TRIS * 9)),
@@ -122,8 +130,11 @@ class ProjParams(C.Structure):
                 ("r_scale", C.c_float), ("max_abs_dz", C.c_float), ("rot", C.c_float * 9)]
 
 
-def dist(spec=None, default=0.0):
-    """HaloDist from a JSON-style value: number | {"type","mean","std"} (reference doc/configuration.md)."""
+def dist(spec=None, default=0.0, default_spread=0.0):
+    """HaloDist from a JSON-style value: number | {"type","mean","std"} (reference doc/configuration.md).
+    An object overwrites only the keys it carries: a missing "mean" / "std" keeps the DESTINATION slot's seeded value
+    (`default` / `default_spread`), exactly like from_json(Distribution&) (reference src/core/math.cpp:593-630) — e.g. axis
+    roll is seeded uniform / 0 / 360 (math.cpp:692-714), so {"type": "uniform"} there means a full turn, not spread 0."""
     d = HaloDist()
     if spec is None:
         d.type, d.center, d.spread = DIST_NONE, float(default), 0.0
@@ -135,6 +146,6 @@ def dist(spec=None, default=0.0):
         names = {"none": DIST_NONE, "uniform": DIST_UNIFORM, "gauss": DIST_GAUSS, "zigzag": DIST_ZIGZAG,
                  "laplacian": DIST_LAPLACIAN, "gauss_legacy": DIST_GAUSS_LEGACY}
         d.type = names[spec["type"]]
-        d.center = float(spec.get("mean", 0.0))
-        d.spread = float(spec.get("std", 0.0))
+        d.center = float(spec.get("mean", default))
+        d.spread = float(spec.get("std", default_spread))
     return d

@@ -56,6 +56,7 @@ def load_library():
         "halo_readback_xyz64": (C.c_int, [H, f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "halo_sync": (C.c_int, [H]),
         "halo_last_sample_counts": (C.c_int, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "halo_last_route": (C.c_int, [H, C.POINTER(abi.HaloRouteInfo)]),
         "halo_set_color": (C.c_int, [H, C.POINTER(abi.HaloColorSet), C.c_int, C.POINTER(abi.HaloColorClass), C.c_int]),
         "halo_readback_class_lanes": (C.c_int, [H, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]),
         "halo_generate_shapes": (C.c_int, [H, C.POINTER(abi.HaloCrystal), C.c_uint64, C.c_uint32, C.c_int, C.POINTER(abi.HaloGeomTables)]),
@@ -83,7 +84,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath",
 ]
@@ -171,6 +172,12 @@ class HipTraceBackend:
         self._check(self._L.halo_last_sample_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def last_route(self):
+        """HaloRouteInfo of the session traced last: which kernel instantiations and accumulation routes really ran."""
+        r = abi.HaloRouteInfo()
+        self._check(self._L.halo_last_route(self._h, C.byref(r)))
+        return r
+
     def collect_stats(self):
         """Summed tallies of every layer traced since the previous call (waits for the stream); the only source of
         exit / pixel-hit / kernel-time numbers for layers traced with option async=1."""
@@ -218,15 +225,17 @@ class HipTraceBackend:
         return n.value
 
     def DrainExits(self, max_records=None):
-        """Captured exit records since the last drain (only with option capture_exits=1); destructive."""
-        if max_records is None:
-            max_records = max(1, self._pending_roots * (self._scene.max_hits + 1))
-        buf = (abi.HaloExitRecord * int(max_records))()
+        """Captured exit records since the last drain (only with option capture_exits=1); destructive.  With max_records the
+        drain is piecewise: at most that many records now, the rest stays pending (halo_drain_exits)."""
         n = C.c_uint64()
-        self._check(self._L.halo_drain_exits(self._h, buf, int(max_records), C.byref(n)))
+        self._check(self._L.halo_drain_exits(self._h, None, 0, C.byref(n)))   # pending count, nothing consumed
+        take = n.value if max_records is None else min(n.value, int(max_records))
+        buf = (abi.HaloExitRecord * max(1, int(take)))()
+        if take:
+            self._check(self._L.halo_drain_exits(self._h, buf, int(take), C.byref(n)))
+            take = n.value
         self._pending_roots = 0
-        k = min(n.value, int(max_records))
-        return np.frombuffer(buf, dtype=EXIT_DTYPE, count=k).copy()
+        return np.frombuffer(buf, dtype=EXIT_DTYPE, count=int(take)).copy()
 
     def ReadbackXyzAccum(self, width=None, height=None):
         """Returns (xyz[H,W,3] float32, landed_weight float64) and zeroes the device accumulator."""

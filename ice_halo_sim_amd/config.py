@@ -35,7 +35,9 @@ class UnsupportedConfig(ConfigError):
     would answer `IsCompatible() == false` / BackendUnavailableError and fall back to its legacy CPU path."""
 
 
-def _dist(obj):
+def _dist(obj, default=0.0, default_spread=0.0):
+    """from_json(Distribution&) (math.cpp:593-630): `default` / `default_spread` are the destination slot's seeded values,
+    which an object keeps for the keys it does not carry."""
     if isinstance(obj, bool):
         raise ConfigError("distribution value is neither a number nor an object: %r" % (obj,))
     if isinstance(obj, (int, float)):
@@ -44,7 +46,7 @@ def _dist(obj):
         if "type" not in obj:
             raise ConfigError('distribution object is missing required key "type"')
         try:
-            return abi.dist(obj)
+            return abi.dist(obj, default, default_spread)
         except KeyError:
             raise ConfigError("unknown distribution type: %r" % (obj["type"],))
     raise ConfigError("distribution value is neither a number nor an object: %r" % (obj,))
@@ -77,14 +79,14 @@ def parse_crystal(j):
     fd = [abi.dist(1.0)] * 6
     if "face_distance" in shape:
         vals = list(shape["face_distance"])[:6]
-        fd = [_dist(v) for v in vals] + [abi.dist(1.0)] * (6 - len(vals))
+        fd = [_dist(v, 1.0) for v in vals] + [abi.dist(1.0)] * (6 - len(vals))  # slots seeded {none, 1.0} (crystal_config.cpp:310-313)
     sg = shape.get("sync_group", {})
     face_groups = list(sg.get("face_distance", [0] * 6))[:6]
     face_groups += [0] * (6 - len(face_groups))
     c = abi.HaloCrystal()
     if kind == "prism":
         c.kind = abi.CRYSTAL_PRISM
-        heights = [_dist(shape["height"]) if "height" in shape else abi.dist(1.0), abi.dist(0.0), abi.dist(0.0)]
+        heights = [_dist(shape["height"], 1.0) if "height" in shape else abi.dist(1.0), abi.dist(0.0), abi.dist(0.0)]  # h_ seeded {none, 1.0, 0} (crystal_config.hpp:63)
         groups = _canonical_sync_groups([int(sg.get("height", 0)), 0, 0] + [int(v) for v in face_groups],
                                         [True, False, False] + [True] * 6)
         c.wedge_upper_deg = c.wedge_lower_deg = 28.0

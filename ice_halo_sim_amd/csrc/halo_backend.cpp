@@ -82,6 +82,8 @@ struct HaloBackend {
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
+  uint32_t shuffle_chunk_log2 = 5;   // Recombine's shuffle moves chunks of 2^k pool entries (k = 0: per ray, like the reference)
+  HaloRouteInfo route{};       // kernels that served the current / last session (halo_last_route)
 
   // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
   uint64_t gen_count = 0, gate_count = 0, transit_count = 0, shape_count = 0;
@@ -99,7 +101,8 @@ struct HaloBackend {
   DevBuf<float> acc_own;       // W*H*3 + 4
   float* acc = nullptr;        // bound accumulator (own or external)
   uint64_t acc_floats = 0;
-  int acc_w = 0, acc_h = 0;
+  int acc_w = 0, acc_h = 0;    // image the bound accumulator (own or external) currently holds
+  int own_w = 0, own_h = 0;    // image the OWNED buffer was last sized and zeroed for
   std::vector<HaloFilter> filters;  // table referenced by HaloEntry::filter_id
   std::vector<HaloColorSet> color_sets;      // table referenced by HaloEntry::color_id
   std::vector<HaloColorClass> color_classes; // raypath-colour classes (Y lanes)
@@ -174,13 +177,17 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
     b->acc_h = h;
     return HALO_OK;
   }
-  if (!b->acc_own.ptr || b->acc_w != w || b->acc_h != h) {
+  // own_w/own_h describe the OWNED buffer's image (acc_w/acc_h are also written by the external-binding path above, so they
+  // cannot decide whether the owned buffer fits); capacity is checked on its own
+  if (!b->acc_own.ptr || b->acc_own.cap < need || b->own_w != w || b->own_h != h) {
     HIPCHK(b, b->acc_own.reserve(need));
     HIPCHK(b, hipMemsetAsync(b->acc_own.ptr, 0, need * sizeof(float), b->stream));
-    b->acc_w = w;
-    b->acc_h = h;
+    b->own_w = w;
+    b->own_h = h;
     b->landed_host = 0.0;
   }
+  b->acc_w = w;
+  b->acc_h = h;
   b->acc = b->acc_own.ptr;
   b->acc_floats = need;
   return HALO_OK;
@@ -260,7 +267,7 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
   }
   b->stream = b->own_stream;
   if (b->sums.reserve(kSumNum) != hipSuccess || b->counters.reserve(kCntNum) != hipSuccess) {
-    delete b;
+    halo_destroy(b);  // releases the stream, the ring, the pinned mirrors and the events as well
     return HALO_UNAVAILABLE;
   }
   (void)hipMemsetAsync(b->sums.ptr, 0, kSumNum * sizeof(double), b->stream);
@@ -314,8 +321,14 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   const std::string k(key);
   if (k == "capture_exits") b->capture = v ? 1 : 0;
   else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
-  else if (k == "chunk") b->chunk = static_cast<uint64_t>(v > 0 ? v : (1ll << 26));
-  else if (k == "bin_l1") b->bin_l1 = static_cast<uint32_t>(v >= 8 && v <= 512 ? v : 128);
+  else if (k == "chunk") {  // the kernels' grid-stride index is 32-bit: n_rays + one stride of workgroups must stay below 2^32
+    const uint64_t top = (1ull << 32) - (static_cast<uint64_t>(b->cu_count) * 64ull * kBlock) - kBlock;
+    b->chunk = std::min<uint64_t>(static_cast<uint64_t>(v > 0 ? v : (1ll << 26)), top);
+  }
+  else if (k == "bin_l1") {  // the kernels index the coarse lists with `& (lists - 1)`: a power of two in [8, 512]
+    if (v < 8 || v > 512 || (v & (v - 1)) != 0) return fail(b, HALO_FATAL, "bin_l1 must be a power of two in [8, 512]");
+    b->bin_l1 = static_cast<uint32_t>(v);
+  }
   else if (k == "stoch_chunk") b->stoch_chunk = static_cast<uint64_t>(v > 0 ? v : 0);
   else if (k == "aggregate") b->aggregate = static_cast<int>(v);
   else if (k == "mono") b->mono_enabled = v ? 1 : 0;
@@ -323,6 +336,11 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "lambda_planes") b->lambda_planes = static_cast<int>(v);
   else if (k == "bin") b->bin = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
+  else if (k == "shuffle_chunk") {
+    if (v < 1 || v > 64 || (v & (v - 1)) != 0) return fail(b, HALO_FATAL, "shuffle_chunk must be a power of two in [1, 64]");
+    b->shuffle_chunk_log2 = 0;
+    while ((1ll << b->shuffle_chunk_log2) < v) b->shuffle_chunk_log2++;
+  }
   else if (k == "mono_copies") {
     if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
     int c = 1;
@@ -445,6 +463,10 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     }
   }
   b->sess_crystal_samples = b->sess_orient_samples = 0;
+  b->route = HaloRouteInfo{};
+  b->route.plane_cnt = b->plane_cnt;
+  b->route.plane_copies = b->plane_copies;
+  b->route.shuffle_chunk = 1u << b->shuffle_chunk_log2;
   b->in_session = true;
   b->layer_idx = 0;
   b->cont_in_n = 0;
@@ -591,6 +613,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.transit_seed = b->seed ^ kNonceTransit;
     P.shuffle = static_cast<uint32_t>(b->cont_shuffle);
     P.shuffle_seed = (b->seed ^ kNonceShuffle) ^ static_cast<uint32_t>(layer);  // cuda_trace_backend.cu:4541
+    P.shuffle_chunk_log2 = b->shuffle_chunk_log2;
     // orientation wire params (BuildTransitGpParams cuda_trace_backend.cu:342-383)
     P.lat_path = host::SelectLatPath(E.axis);
     P.lat_mean_rad = E.axis.latitude.center * host::kDegToRad;
@@ -787,6 +810,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, geom, b->mono_session);
       b->mono_dirty = true;
+      b->route.launches++;
+      b->route.mode_mask |= 1u << (b->capture ? 2 : ((P.filter != nullptr || P.color != nullptr) ? 1 : 0));
+      b->route.geom_mask |= 1u << geom;
+      b->route.accum_mask |= use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u);
+      b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_bin) {
         hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
@@ -894,6 +922,12 @@ int halo_last_sample_counts(halo_handle_t b, uint64_t* crystal_samples, uint64_t
   return HALO_OK;
 }
 
+int halo_last_route(halo_handle_t b, HaloRouteInfo* out) {
+  if (!b || !out) return HALO_FATAL;
+  *out = b->route;
+  return HALO_OK;
+}
+
 int halo_collect_stats(halo_handle_t b, HaloLayerStats* out) {
   if (!b || !out) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
@@ -922,11 +956,28 @@ int halo_drain_exits(halo_handle_t b, HaloExitRecord* out, uint64_t cap, uint64_
   if (!b) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
   HIPCHK(b, hipStreamSynchronize(b->stream));
+  // Piecewise drain (trace_backend.hpp:430-448): a call takes at most `cap` records from the front and the rest stays
+  // pending; *count = records copied by THIS call.  out == NULL reports how many are pending without consuming any.
   const uint64_t n = b->exits_pending;
-  if (count) *count = n;
-  if (out && n) HIPCHK(b, hipMemcpy(out, b->exits.ptr, std::min(n, cap) * sizeof(HaloExitRecord), hipMemcpyDeviceToHost));
-  b->exits_pending = 0;
-  HIPCHK(b, hipMemsetAsync(b->counters.ptr + kCntExit, 0, sizeof(uint32_t), b->stream));
+  if (!out) {
+    if (count) *count = n;
+    return HALO_OK;
+  }
+  const uint64_t take = std::min(n, cap);
+  if (count) *count = take;
+  if (take) HIPCHK(b, hipMemcpy(out, b->exits.ptr, take * sizeof(HaloExitRecord), hipMemcpyDeviceToHost));
+  const uint64_t left = n - take;
+  if (left && take) {  // move the tail to the front (ranges may overlap: go through a scratch copy)
+    DevBuf<HaloExitRecord> tmp;
+    HIPCHK(b, tmp.reserve(left));
+    HIPCHK(b, hipMemcpy(tmp.ptr, b->exits.ptr + take, left * sizeof(HaloExitRecord), hipMemcpyDeviceToDevice));
+    HIPCHK(b, hipMemcpy(b->exits.ptr, tmp.ptr, left * sizeof(HaloExitRecord), hipMemcpyDeviceToDevice));
+    tmp.release();
+  }
+  b->exits_pending = left;
+  const uint32_t left32 = static_cast<uint32_t>(left);  // the device append counter continues behind the kept tail
+  HIPCHK(b, hipMemcpyAsync(b->counters.ptr + kCntExit, &left32, sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
   return HALO_OK;
 }
 
@@ -1090,6 +1141,7 @@ uint64_t halo_abi_sizeof(int which) {
     case 7: return sizeof(HaloColorSet);
     case 8: return sizeof(HaloColorClass);
     case 9: return sizeof(HaloFilter);
+    case 10: return sizeof(HaloRouteInfo);
     default: return 0;
   }
 }

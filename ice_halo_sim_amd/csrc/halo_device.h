@@ -151,6 +151,7 @@ struct DispatchParams {
   uint32_t gate_seed, gate_lo, gate_hi;
   uint32_t transit_seed, transit_lo, transit_hi;
   uint32_t shuffle, shuffle_seed;
+  uint32_t shuffle_chunk_log2;   // Recombine's shuffle permutes chunks of 2^k consecutive pool entries (option "shuffle_chunk")
   // --- orientation sampler (GenRootKernelParams, pcg_shared.h:150-189) ------------------------
   uint32_t lat_path;
   float lat_mean_rad, lat_std_rad;

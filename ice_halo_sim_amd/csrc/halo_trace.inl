@@ -123,7 +123,6 @@ HD float get_dist(Stream& s, uint32_t dtype, float mean, float spread) {  // pcg
   return mean - spread * sgn * logf(arg);
 }
 
-constexpr uint32_t kShuffleChunk = 32u;  // pool entries that move together through Recombine's shuffle (see trace_one)
 // 4-round balanced Feistel + cycle walk on [0, n)  (pcg_shared.h:550-603)
 HD uint32_t feistel_bijection(uint32_t i, uint32_t n, uint32_t seed) {
   if (n <= 1u) return i;
@@ -1108,15 +1107,16 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const uint32_t pos = P.ci_start + tid;
     // Recombine's shuffle, applied as a gather at read time.  The reference permutes single rays (shuffle_cont_kernel
     // cu:1633-1657, out[tid] = in[feistel(tid)]); a per-ray random gather costs five scattered 4-byte reads per ray (one
-    // 64 B sector each: 76 GB for 237 M rays).  Here the same Feistel bijection permutes CHUNKS of kShuffleChunk
-    // consecutive pool entries, so the five plane reads of a half-wave stay one 128 B line each.  A chunk holds rays of 32
-    // different roots (lanes of one ballot-compacted append), so nothing the shuffle is there to break up — position
-    // ranges assigned to crystal entries, the K-shape clock — sees correlated neighbours.  The tail past the last full
-    // chunk keeps its place.
+    // 64 B sector each: 76 GB for 237 M rays).  Here the same Feistel bijection permutes CHUNKS of 2^shuffle_chunk_log2
+    // (default 32) consecutive pool entries, so the five plane reads of a half-wave stay one 128 B line each.  A chunk holds
+    // rays of 32 different roots (lanes of one ballot-compacted append), so nothing the shuffle is there to break up —
+    // position ranges assigned to crystal entries, the K-shape clock — sees correlated neighbours.  The tail past the last
+    // full chunk keeps its place.  Option "shuffle_chunk" = 1 gives the reference's per-ray permutation (A/B in the tests).
     uint32_t logical = pos;
     if (P.shuffle) {
-      const uint32_t chunks = P.cont_in_n / kShuffleChunk;
-      if (pos < chunks * kShuffleChunk) logical = feistel_bijection(pos / kShuffleChunk, chunks, P.shuffle_seed) * kShuffleChunk + pos % kShuffleChunk;
+      const uint32_t cl = P.shuffle_chunk_log2;
+      const uint32_t chunks = P.cont_in_n >> cl;
+      if (pos < (chunks << cl)) logical = (feistel_bijection(pos >> cl, chunks, P.shuffle_seed) << cl) + (pos & ((1u << cl) - 1u));
     }
     uint32_t sh_i = 0u;  // largest shard with seg[shard] <= logical (empty shards repeat their neighbour's start)
 #pragma unroll

@@ -67,13 +67,16 @@ class HipTraceBackend {
     Check(halo_recombine(h_, shuffle ? 1 : 0, &n));
     return static_cast<size_t>(n);
   }
-  // Device-accumulating backend: DrainExits returns 0 records in production (trace_backend.hpp:430-448); with the
-  // "capture_exits" option (tests) it returns the captured records.
+  // TraceBackend::DrainExits (trace_backend.hpp:430-448): every record emitted since the previous drain, no clamp.  A
+  // device-accumulating backend has none in production; with the "capture_exits" option (tests) the captured records come
+  // back.  max_records > 0 drains in pieces: at most that many now, the rest stays pending for the next call.
   size_t DrainExits(std::vector<HaloExitRecord>& out, size_t max_records = 0) {
     uint64_t n = 0;
-    out.resize(max_records);
-    Check(halo_drain_exits(h_, max_records ? out.data() : nullptr, max_records, &n));
-    out.resize(static_cast<size_t>(n < max_records ? n : max_records));
+    Check(halo_drain_exits(h_, nullptr, 0, &n));  // pending count, nothing consumed
+    if (max_records && n > max_records) n = max_records;
+    out.resize(static_cast<size_t>(n));
+    if (n) Check(halo_drain_exits(h_, out.data(), n, &n));
+    out.resize(static_cast<size_t>(n));
     return out.size();
   }
   bool SupportsDeviceXyzAccum() const { return true; }

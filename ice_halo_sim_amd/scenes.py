@@ -49,11 +49,14 @@ def axis(zenith=None, azimuth=None, roll=None):
     default to uniform over 360; when absent everything is fixed with zenith 0."""
     a = abi.HaloAxis()
     present = not (zenith is None and azimuth is None and roll is None)
-    z = abi.dist(zenith, 0.0)
+    # seeded destination values an object with missing keys keeps (math.cpp:536-538, 692-714): zenith slot = the
+    # AxisDistribution default latitude {none, 90, 0} (so a zenith object without "mean" has zenith centre 90 BEFORE the
+    # 90 - x flip, i.e. latitude 0); azimuth / roll = {uniform, 0, 360}
+    z = abi.dist(zenith, 0.0) if not isinstance(zenith, dict) else abi.dist(zenith, 90.0, 0.0)
     a.latitude.type, a.latitude.center, a.latitude.spread = z.type, 90.0 - z.center, z.spread
     full = {"type": "uniform", "mean": 0.0, "std": 360.0}
-    a.azimuth = abi.dist(azimuth if azimuth is not None else (full if present else None), 0.0)
-    a.roll = abi.dist(roll if roll is not None else (full if present else None), 0.0)
+    a.azimuth = abi.dist(azimuth if azimuth is not None else (full if present else None), 0.0, 360.0)
+    a.roll = abi.dist(roll if roll is not None else (full if present else None), 0.0, 360.0)
     return a
 
 

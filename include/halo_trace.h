@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 2   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16) */
+#define HALO_ABI_VERSION 3   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
+                                halo_drain_exits, option "shuffle_chunk" */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 
@@ -263,7 +264,9 @@ const char* halo_last_error(halo_handle_t h);
  * has >= 8 Mi rays, else X/Y/Z planes; 0 = never; 1 = always),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
- * workgroup below that cap). */
+ * workgroup below that cap),
+ * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in
+ * [1, 64], default 32 = one 128-byte line per plane read; 1 = the reference's per-ray permutation, cu:1633-1657). */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
 int halo_set_stream(halo_handle_t h, void* hip_stream);
@@ -289,7 +292,9 @@ int halo_trace_layer(halo_handle_t h, uint64_t count, const HaloHostRays* rays, 
  * chunks of 32 consecutive pool entries (32 different parent rays), not single entries like the reference's CUDA
  * shuffle_cont_kernel (cu:1633-1657): same decorrelation of position ranges, coalesced reads. */
 int halo_recombine(halo_handle_t h, int shuffle, uint64_t* continuation_count);
-/* TraceBackend::DrainExits — trace_backend.hpp:430-448 (only with "capture_exits"). */
+/* TraceBackend::DrainExits — trace_backend.hpp:430-448 (only with "capture_exits").  Copies at most `cap` pending records
+ * (oldest first) into `out`, *count = records copied; the rest stays pending, so a caller may drain in pieces.
+ * out == NULL: *count = number of pending records, nothing is consumed. */
 int halo_drain_exits(halo_handle_t h, HaloExitRecord* out, uint64_t cap, uint64_t* count);
 /* TraceBackend::EndSession. The accumulator persists (SupportsThirdClockDrain, cu:4801-4808). */
 int halo_end(halo_handle_t h);
@@ -309,6 +314,19 @@ int halo_readback_class_lanes(halo_handle_t h, float* lanes, int width, int heig
  * crystal entry that is not IsDeterministic; 0 for fixed shapes) and rays whose orientation was drawn (every ray of an entry
  * whose axis has a non-fixed distribution).  Real counts of what the kernels did, not estimates. */
 int halo_last_sample_counts(halo_handle_t h, uint64_t* crystal_samples, uint64_t* orientation_samples);
+/* Which kernels served the session traced last (masks reset at halo_begin).  Diagnostics for the parity tests and the bench:
+ * a test that means to check the production binned shape-pool kernel asserts that it really ran. */
+typedef struct HaloRouteInfo {
+  uint32_t launches;     /* trace-kernel launches since halo_begin */
+  uint32_t mode_mask;    /* bit m: a launch ran the MODE m instantiation (0 production, 1 + path/filter/colour, 2 + exit capture) */
+  uint32_t geom_mask;    /* bit g: GEOM g (0 one shape per dispatch, 1 pool of 4.1 KB records, 2 pool of prism records) */
+  uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels */
+  uint32_t source_mask;  /* bit 0 generated roots, 1 continuation pool (layer >= 1), 2 host-injected rays */
+  uint32_t plane_cnt;    /* accumulation planes of the session (1 discrete, 3 X/Y/Z, M per-entry) */
+  uint32_t plane_copies; /* privatised copies of each plane */
+  uint32_t shuffle_chunk;/* pool entries that move together through Recombine's shuffle */
+} HaloRouteInfo;
+int halo_last_route(halo_handle_t h, HaloRouteInfo* out);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
  * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the

@@ -77,6 +77,30 @@ def test_absent_axis_and_sync_groups():
     assert c.face_dist[1].type == abi.DIST_GAUSS
 
 
+def test_partial_distribution_objects_keep_the_slot_defaults():
+    """An object overwrites only the keys it carries; the rest keep the destination's seeded value (from_json(Distribution&)
+    math.cpp:593-630 with the seeds of math.cpp:536-538 / :692-714 and crystal_config.hpp:63, crystal_config.cpp:310-313)."""
+    c, a = config.parse_crystal({"id": 1, "type": "prism", "shape": {"height": {"type": "gauss", "std": 0.1},
+                                                                      "face_distance": [{"type": "uniform", "std": 0.2}, 1.1]},
+                                 "axis": {"zenith": {"type": "gauss", "std": 5}, "roll": {"type": "uniform"},
+                                          "azimuth": {"type": "uniform", "mean": 10}}})
+    # zenith slot is seeded {none, 90, 0}: missing mean = zenith 90 -> latitude 0
+    assert (a.latitude.type, a.latitude.center, a.latitude.spread) == (abi.DIST_GAUSS, 0.0, 5.0)
+    # azimuth / roll are seeded {uniform, 0, 360}
+    assert (a.roll.type, a.roll.center, a.roll.spread) == (abi.DIST_UNIFORM, 0.0, 360.0)
+    assert (a.azimuth.type, a.azimuth.center, a.azimuth.spread) == (abi.DIST_UNIFORM, 10.0, 360.0)
+    # prism height is seeded {none, 1.0, 0}; face distances {none, 1.0, 0}
+    assert (c.height[0].type, c.height[0].center, c.height[0].spread) == (abi.DIST_GAUSS, 1.0, pytest.approx(0.1))
+    assert (c.face_dist[0].type, c.face_dist[0].center, c.face_dist[0].spread) == (abi.DIST_UNIFORM, 1.0, pytest.approx(0.2))
+    assert (c.face_dist[1].type, c.face_dist[1].center) == (abi.DIST_NONE, pytest.approx(1.1))
+    # pyramid heights are seeded {none, 0, 0} (crystal_config.hpp:69-71)
+    c2, _ = config.parse_crystal({"id": 2, "type": "pyramid", "shape": {"prism_h": {"type": "gauss", "std": 0.1}, "upper_h": 0.2}})
+    assert (c2.height[1].type, c2.height[1].center, c2.height[1].spread) == (abi.DIST_GAUSS, 0.0, pytest.approx(0.1))
+    # a full object is unchanged by the defaults
+    _, a3 = config.parse_crystal({"id": 3, "type": "prism", "shape": {}, "axis": {"zenith": {"type": "gauss", "mean": 20, "std": 5}}})
+    assert (a3.latitude.center, a3.latitude.spread, a3.roll.type, a3.roll.spread) == (70.0, 5.0, abi.DIST_UNIFORM, 360.0)
+
+
 def test_illuminant_and_rejections():
     doc = copy.deepcopy(DOC)
     doc["scene"]["light_source"]["spectrum"] = "D65"

@@ -1,0 +1,259 @@
+"""GPU parity of the PRODUCTION kernel instantiations (capture off) at launch sizes where the backend's own route selection
+fires: binned accumulation, per-wavelength planes, shape pools, transit-source launches.
+
+The per-ray tests in test_gpu_parity.py set capture_exits=1, which selects the MODE=2 instantiation of halo_trace_kernel and
+switches the binned route off.  Here nothing is captured: the kernels that serve BASELINE.json's configs[2] and configs[4]
+(`halo_trace_kernel<0, GEOM, MONO, BIN>`) are compared with the oracle through the image, the landed weight and the
+per-channel sums, and `halo_last_route` proves which instantiation / accumulation route really ran.
+
+Tolerances (stated): one scattering layer — both sides trace the SAME rays (shared counter-based streams), so landed weight
+rel 1e-4, 8x8 block-mean rel L2 <= 3e-3, per-channel sums rel 2e-4.  Two layers — the continuation order is nondeterministic
+on a GPU, so layer >= 1 is compared with the reference's statistical battery (4x4 block-mean Pearson >= 0.95, sum-Y within 5 %,
+test/e2e/_parity_metrics.py:27-66) tightened by the measured oracle-vs-oracle cross-seed floor: HIP-vs-oracle correlation must
+reach the oracle's own seed-A-vs-seed-B correlation minus 0.02 (the battery's G3 margin), and the sum-Y / landed deviations must
+stay inside 4x the cross-seed deviation (+ 2e-3).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, scenes
+from tests._oracle_backend import OracleBackend, run_session
+from tests.test_gpu_parity import block_mean, hip_backend, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+THREADS = max(8, min(os.cpu_count() or 8, 128))
+FULL = {"type": "uniform", "mean": 0.0, "std": 360.0}
+
+
+def _oracle_image(scene, render, wl, n, seed, **opts):
+    ob = OracleBackend(seed=seed, threads=THREADS, **opts)
+    st = run_session(ob, scene, render, wl, n)
+    img, landed = ob.ReadbackXyzAccum()
+    ob.close()
+    return img, landed, st
+
+
+def _stoch_pyramid_entry():
+    """examples/config_example.json crystal id 5 (pyramid, upper Miller (2,0,3)) with bench_config_stoch's gauss(1, 0.15) face
+    distances and its full-sphere axis: BASELINE configs[4]'s "stochastic-geometry pyramidal crystal"."""
+    g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+    return scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
+                        scenes.axis(zenith=FULL, azimuth=FULL, roll=FULL), 100.0, 5)
+
+
+def _check_single_layer(hip, ora):
+    ih, lh = hip
+    io, lo = ora
+    assert abs(lh - lo) <= 1e-4 * lo, (lh, lo)
+    err = rel_l2(block_mean(ih), block_mean(io))
+    assert err <= 3e-3, err
+    for ch in range(3):
+        assert ih[..., ch].sum(dtype=np.float64) == pytest.approx(io[..., ch].sum(dtype=np.float64), rel=2e-4)
+    return err
+
+
+@pytest.mark.parametrize("pool", [31, 64])
+def test_bench_config_stoch_shape_runs_the_binned_prism_pool_kernel(pool):
+    """examples/bench_config_stoch.json as the reference ships it — stochastic prism (six gauss(1, 0.15) face distances), D65
+    wavelength pool (31 entries: BASELINE configs[4]'s count; 64: the reference's default pool), rectangular 2048x1024 full sky,
+    max_hits 8 — at 9 Mi rays, where the backend's own selection takes per-entry planes (>= 8 Mi rays), device-generated prism
+    records (GEOM 2) and the two-level binned route (31 x 128 / 64 x 128 tiles > 512): halo_trace_kernel<0,2,true,true> +
+    halo_bin_split_kernel + halo_bin_accumulate_range_kernel.  Compared with the oracle on the same rays."""
+    sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
+    wl = scenes.wl_illuminant("D65", pool)
+    n = 9 << 20
+    hb = hip_backend(seed=23)
+    st = run_session(hb, sc, rd, wl, n)
+    route = hb.last_route()
+    crystals, orient = hb.last_sample_counts()
+    hip = hb.ReadbackXyzAccum()
+    hb.close()
+    assert (route.mode_mask, route.geom_mask, route.accum_mask, route.source_mask) == (1, 1 << 2, abi.ACCUM_BIN2, 1), \
+        (route.mode_mask, route.geom_mask, route.accum_mask)
+    assert route.plane_cnt == pool and route.launches == st[0].launches == 1
+    assert crystals == n // 32 and orient == n           # one sampled crystal per 32 rays (simulator.hpp:144-157)
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 23)
+    assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=1e-4)
+    assert st[0].pixel_hits == pytest.approx(st_o[0].exit_count, rel=1e-4)     # rectangular full sky: every exit lands once
+    err = _check_single_layer(hip, (img_o, landed_o))
+    print("bench_config_stoch pool %d: block-mean rel L2 %.2e, exits/root %.3f" % (pool, err, st[0].exit_count / n))
+
+
+@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_d65_planes"])
+def test_stochastic_pool_production_kernels_vs_oracle(case):
+    """The other production shape-pool instantiations at sizes where they are what the backend picks:
+      prism_discrete_binned  one wavelength, stochastic prism, full sky, 4.5 Mi rays  -> <0,2,true,true>, one-level binned (128 tiles)
+      pyramid_discrete       one wavelength, stochastic pyramid (4.1 KB records)      -> <0,1,true,false>, direct scalar plane
+      pyramid_d65_planes     D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,true,false>, one plane per entry"""
+    prism = case.startswith("prism")
+    sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry() if prism else _stoch_pyramid_entry()])], max_hits=8)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
+    d65 = case.endswith("planes")
+    wl = scenes.wl_illuminant("D65", 31) if d65 else scenes.wl_discrete(550.0)
+    n = (9 << 20) if d65 else (9 << 19)
+    hb = hip_backend(seed=29)
+    st = run_session(hb, sc, rd, wl, n)
+    route = hb.last_route()
+    hip = hb.ReadbackXyzAccum()
+    hb.close()
+    want_geom = (1 << 2) if prism else (1 << 1)
+    want_acc = abi.ACCUM_BIN1 if prism else abi.ACCUM_SCALAR
+    assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, want_geom, want_acc), (route.mode_mask, route.geom_mask, route.accum_mask)
+    assert route.plane_cnt == (31 if d65 else 1)
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 29)
+    assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=1e-4)
+    err = _check_single_layer(hip, (img_o, landed_o))
+    print("%s: block-mean rel L2 %.2e" % (case, err))
+
+
+def _pearson_blocks(a, b, k=4):
+    x, y = block_mean(a, k).ravel().astype(np.float64), block_mean(b, k).ravel().astype(np.float64)
+    return float(np.corrcoef(x, y)[0, 1])
+
+
+def test_config3_two_layer_multi_scatter_at_production_launch_sizes():
+    """BASELINE configs[2]: plate (prob 1.0) over a randomly oriented column, 9 wavelengths, fisheye 1920x1080 — with 600 k roots
+    per wavelength, so every second-layer launch reads >= 2.5 Mi continuation rays from the sharded pool through the Feistel
+    gather (`source_mask` bit 1) and the production kernels run (`mode_mask` == 1).  Layer 0 traces the same rays as the oracle
+    (continuation count equal to boundary flips); the second layer is compared statistically against the oracle AND against the
+    oracle's own cross-seed floor (module docstring)."""
+    sc = scenes.config3_scene()
+    rd = scenes.config2_render()
+    n = 600_000
+    wls = [scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9]
+    hb = hip_backend(seed=42)
+    cont_h, launches = [], 0
+    for wl in wls:
+        st = run_session(hb, sc, rd, wl, n)
+        route = hb.last_route()
+        assert route.mode_mask == 1 and route.source_mask == 0b011 and route.geom_mask == 1
+        assert st[1].root_count == st[0].continuation_count >= (5 << 19)
+        cont_h.append(st[0].continuation_count)
+        launches += st[1].launches
+    ih, lh = hb.ReadbackXyzAccum()
+    hb.close()
+
+    def oracle(seed):
+        ob = OracleBackend(seed=seed, threads=THREADS)
+        cont = []
+        for wl in wls:
+            cont.append(run_session(ob, sc, rd, wl, n)[0].continuation_count)
+        img, landed = ob.ReadbackXyzAccum()
+        ob.close()
+        return img, landed, cont
+    ia, la, cont_a = oracle(42)
+    ib, lb, _ = oracle(7)
+    for ch, co in zip(cont_h, cont_a):
+        assert ch == pytest.approx(co, rel=3e-4)                        # layer 0: same rays on both sides
+    # cross-seed floor of the oracle itself (the reference's G3 reading, test/e2e/_parity_metrics.py)
+    floor_corr = _pearson_blocks(ia, ib)
+    floor_y = abs(ia[..., 1].sum(dtype=np.float64) / ib[..., 1].sum(dtype=np.float64) - 1.0)
+    floor_l = abs(la / lb - 1.0)
+    corr = _pearson_blocks(ih, ia)
+    dy = abs(ih[..., 1].sum(dtype=np.float64) / ia[..., 1].sum(dtype=np.float64) - 1.0)
+    dl = abs(lh / la - 1.0)
+    print("configs[2] 9 x %d roots: corr %.5f (oracle cross-seed %.5f), sumY dev %.2e (floor %.2e), landed dev %.2e (floor %.2e), %d layer-1 launches"
+          % (n, corr, floor_corr, dy, floor_y, dl, floor_l, launches))
+    assert corr >= 0.95 and corr >= floor_corr - 0.02
+    assert dy <= 0.05 and dy <= 4.0 * floor_y + 2e-3
+    assert dl <= 4.0 * floor_l + 2e-3
+
+
+def test_chunked_shuffle_equals_the_per_ray_shuffle_in_mean_and_variance():
+    """Recombine's shuffle moves chunks of 32 continuation-pool entries (one 128-byte line per plane read) where the reference's
+    CUDA backend permutes single rays (cu:1633-1657); option "shuffle_chunk" = 1 restores the latter.  In a two-layer scene with
+    stochastic geometry in BOTH layers (rays of one chunk left the same sampled first-layer crystal and, moving together, meet the
+    same sampled second-layer crystal) the two must give the same image in the mean and the same block-to-block variance across
+    seeds: 8 seeds per mode, rectangular 512x256 full sky, 16x16 blocks."""
+    e = scenes.stochastic_prism_entry()
+    sc = scenes.scene([(1.0, [e]), (0.0, [e])], max_hits=6)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 512, 256, el=0.0, visible=abi.VISIBLE_FULL)
+    n = 1 << 20
+    seeds = (42, 7, 100, 200, 300, 999, 1234, 5678)          # the reference's stochastic-geometry seed set
+    stack = {}
+    for chunk in (32, 1):
+        imgs = []
+        for seed in seeds:
+            hb = hip_backend(seed=seed, shuffle_chunk=chunk)
+            st = run_session(hb, sc, rd, scenes.wl_discrete(550.0), n)
+            assert hb.last_route().shuffle_chunk == chunk and st[1].root_count > 4 * n
+            img, landed = hb.ReadbackXyzAccum()
+            hb.close()
+            imgs.append(block_mean(img, 16)[..., 1].astype(np.float64) * 256.0)     # block sums of Y
+        stack[chunk] = np.stack(imgs)
+    m32, m1 = stack[32].mean(0), stack[1].mean(0)
+    v32, v1 = stack[32].var(0, ddof=1), stack[1].var(0, ddof=1)
+    se = np.sqrt((v32 + v1) / len(seeds))
+    z = (m32 - m1) / np.maximum(se, 1e-12)
+    # mean image: block differences are noise (z-scores ~ N(0,1) over 512 blocks), totals agree to a few 1e-4
+    assert abs(m32.sum() / m1.sum() - 1.0) <= 2e-3
+    assert abs(z.mean()) <= 0.25 and 0.6 <= z.std() <= 1.5, (z.mean(), z.std())
+    # variance: ratio of the per-block variances, averaged over the image (each ratio is an F(7,7) draw: mean 7/5, wide;
+    # the log-ratio is symmetric around 0 when the variances are equal)
+    lr = np.log(v32 / v1)
+    print("chunk-32 vs per-ray shuffle: total ratio %.5f, z mean %.3f std %.3f, mean log variance ratio %.3f" %
+          (m32.sum() / m1.sum(), z.mean(), z.std(), lr.mean()))
+    assert abs(lr.mean()) <= 0.15, lr.mean()
+
+
+def test_exits_drain_in_pieces():
+    """halo_drain_exits copies at most `cap` records and keeps the rest pending (the reference's DrainExits hands back every
+    record, trace_backend.hpp:430-448; a bounded caller drains in pieces): three partial drains return, in order, exactly what
+    one full drain returns, and records captured by a later layer append behind a kept tail."""
+    sc, rd = scenes.config2_scene(), scenes.config2_render(480, 270)
+    n = 20_000
+    one = hip_backend(seed=5, capture_exits=1)
+    run_session(one, sc, rd, scenes.wl_discrete(550.0), n)
+    full = one.DrainExits()
+    assert len(one.DrainExits()) == 0
+    one.close()
+    hb = hip_backend(seed=5, capture_exits=1)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), n)
+    parts = [hb.DrainExits(max_records=1000), hb.DrainExits(max_records=len(full) // 2)]
+    assert len(parts[0]) == 1000 and len(parts[1]) == len(full) // 2
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 1000)         # more exits behind the kept tail
+    rest = hb.DrainExits()
+    hb.close()
+    got = np.concatenate(parts + [rest[: len(full) - 1000 - len(full) // 2]])
+    key = lambda e: np.lexsort((e["seq"], e["root"]))
+    a, b = full[key(full)], got[key(got)]
+    assert len(a) == len(b)
+    for f in ("root", "seq", "pixel"):
+        assert (a[f] == b[f]).all()
+    assert (a["dir"] == b["dir"]).all() and (a["weight"] == b["weight"]).all()
+    assert len(rest) > len(full) - 1000 - len(full) // 2                # the second session's records followed
+
+
+def test_owned_accumulator_is_resized_after_an_external_binding():
+    """own buffer at a small size, then a bound external accumulator at a larger size, then unbind and begin at the
+    larger size — the owned buffer must be reallocated (its capacity decides, not the last session's width/height)."""
+    import torch
+    sc = scenes.config2_scene()
+    small, big = scenes.config2_render(64, 32), scenes.config2_render(640, 360)
+    hb = hip_backend(seed=3)
+    run_session(hb, sc, small, scenes.wl_discrete(550.0), 10_000)
+    hb.ReadbackXyzAccum()
+    ext = torch.zeros(640 * 360 * 3 + 4, dtype=torch.float32, device="cuda")
+    hb.bind_accumulator(ext.data_ptr(), ext.numel())
+    run_session(hb, sc, big, scenes.wl_discrete(550.0), 50_000)
+    hb.sync()
+    torch.cuda.synchronize()
+    ref = ext[: 640 * 360 * 3].reshape(360, 640, 3).cpu().numpy().copy()
+    hb.take_landed()
+    hb.bind_accumulator(0, 0)
+    fresh = hip_backend(seed=3)
+    run_session(fresh, sc, small, scenes.wl_discrete(550.0), 10_000)      # same counter history as hb
+    fresh.ReadbackXyzAccum()
+    run_session(fresh, sc, big, scenes.wl_discrete(550.0), 50_000)        # skip the rays hb spent on the bound session
+    fresh.ReadbackXyzAccum()
+    run_session(fresh, sc, big, scenes.wl_discrete(550.0), 50_000)
+    want, _ = fresh.ReadbackXyzAccum()
+    fresh.close()
+    run_session(hb, sc, big, scenes.wl_discrete(550.0), 50_000)           # owned buffer, larger than it was ever allocated for
+    img, _ = hb.ReadbackXyzAccum(640, 360)
+    hb.close()
+    assert ref.sum() > 0 and rel_l2(img, want) <= 1e-5

@@ -25,9 +25,10 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(L, sym), "libhalo_hip.so does not export " + sym
     assert declared == set(backend.EXPORTED_SYMBOLS), declared ^ set(backend.EXPORTED_SYMBOLS)
-    assert L.halo_abi_version() == 2
+    want = int(re.search(r"#define\s+HALO_ABI_VERSION\s+(\d+)", header).group(1))
+    assert L.halo_abi_version() == want == 3
     for i, t in enumerate([abi.HaloScene, abi.HaloRender, abi.HaloWl, abi.HaloExitRecord, abi.HaloGeomTables,
-                           abi.HaloLayerStats, abi.HaloEntry]):
+                           abi.HaloLayerStats, abi.HaloEntry, abi.HaloColorSet, abi.HaloColorClass, abi.HaloFilter, abi.HaloRouteInfo]):
         assert L.halo_abi_sizeof(i) == C.sizeof(t), t.__name__
 
 
