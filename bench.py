@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — rays/s of the MI355X trace hot path on BASELINE.json's headline workload.
+"""bench.py — rays/s of the MI355X trace hot path on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4p] [--repeats R]
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch: configs[1] — single-scatter
-hex column (examples/config_example.json crystal 3), 9 wavelengths x 50 M root rays, fisheye_equal_area
-1920x1080 — i.e. 450 M root rays per GPU per step.  Rays shard by index range (disjoint RNG counter ranges per
-rank, no data-path collective); every step ends with ONE RCCL sum-reduce of the W*H*3(+4) fp32 accumulator to
-rank 0 (the reference's drain point, simulator.cpp:1409-1477).  Per-GPU work is fixed → "scaling": "weak".
+(one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch of the selected configuration:
 
-Rank 0 prints ONE JSON line.  `roofline` prices the fused kernel against HBM (no dense contraction → no MFMA):
-achieved = algorithmic accumulator bytes (in-frame pixel writes x 3 channels x 4 B x read+write)
-per launch / mean launch duration from HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
-(a port of the reference's algorithm; the reference itself cannot be built here) on the host cores on a bounded
-sample of the same workload — a reported baseline, not the target.
+  --config 1 (default, BASELINE `metric`)  configs[1]: single-scatter hex column (examples/config_example.json crystal 3),
+             9 wavelengths x 50 M root rays, fisheye_equal_area 1920x1080 -> 450 M root rays per GPU per step
+  --config 2  configs[2]: two-layer full multi-scattering (plate prob 1.0 over a randomly oriented column), 9 wavelengths x
+             50 M roots per GPU per step (each root becomes ~4.7 second-layer rays)
+  --config 4  configs[4] on the reference's file as shipped (examples/bench_config_stoch.json: stochastic PRISM, six
+             gauss(1, 0.15) face distances, D65, rectangular 2048x1024 full sky, max_hits 8), D65 pool of 31 wavelengths,
+             25 M rays per GPU per step (200 M over 8 GPUs)
+  --config 4p the pyramidal variant of the same (examples/config_example.json crystal 5 with the same face distances)
+
+Rays shard by index range (disjoint RNG counter ranges per rank, no data-path collective); every step ends with ONE RCCL
+sum-reduce of the W*H*3(+4) fp32 accumulator to rank 0 (the reference's drain point, simulator.cpp:1409-1477).  Per-GPU work
+is fixed -> "scaling": "weak".
+
+Timing follows the reference's protocol (doc/performance-testing.md:109-131: >= 5 repeats, median + CoV): after W warm-up
+steps the timed region — EXACTLY K steps between barrier + synchronize — is run R times (default 5); `value` and
+`ms_per_step` are the MEDIAN repeat, `repeats` carries every repeat and the coefficient of variation.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel of the configuration against HBM (no dense contraction
+-> no MFMA): achieved = ALGORITHMIC bytes per launch / mean launch duration from HIP events on the launch
+stream.  `cpu_baseline` times the CPU oracle (a port of the reference's algorithm; the reference's own CPU path cannot be
+built in this image without stand-ins for spdlog / nlohmann-json — DESIGN.md §5) on the host cores on a bounded sample of the
+same workload — a reported baseline, not the target.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,57 +44,99 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_ROUND = "r02"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
+
+# The reference's legacy CPU path measured by the survey in the build container (compiled with shims, 6 worker
+# threads, config_example-shaped scene): the only number that relates the oracle ("port") to the real reference.
+SURVEY_REFERENCE_CPU = {"rays_per_s": 1.71e6, "threads": 6, "where": "build container (8 vCPU), SURVEY.md §6"}
 
 
-def cpu_baseline(rays_per_wl_hint, budget_s=12.0):
+def workload(cfg):
+    """(scene, render, [wl sessions], rays per session, description, dominant kernel name) of a BASELINE configuration."""
+    from ice_halo_sim_amd import abi, scenes
+    if cfg == "1":
+        return dict(scene=scenes.config2_scene(), render=scenes.config2_render(),
+                    wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
+                    name="configs[1]: single-scatter hex column (prism h=1.3, zenith gauss(90,0.3)), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
+                    kernel="halo_trace_kernel<0,0,true,false>", metric="rays/sec (whole node) at 9 wavelengths, single-scatter hex column")
+    if cfg == "2":
+        return dict(scene=scenes.config3_scene(), render=scenes.config2_render(),
+                    wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
+                    name="configs[2]: two-layer full multi-scattering (plate h=0.3 zenith gauss(0,0.8) prob 1.0 over random column h=1.3), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
+                    kernel="halo_trace_kernel<0,0,true,false> (transit source: layer 1 reads the continuation pool)",
+                    metric="root rays/sec (whole node) at 9 wavelengths, two-layer full multi-scattering")
+    if cfg in ("4", "4p"):
+        full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+        g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+        if cfg == "4":
+            e = scenes.stochastic_prism_entry()
+            what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
+            kern = "halo_trace_kernel<0,2,true,true> + halo_bin_split_kernel + halo_bin_accumulate_range_kernel"
+        else:
+            e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
+                             scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)
+            what = "stochastic pyramid (config_example crystal 5, upper Miller (2,0,3), six gauss(1,0.15) face distances)"
+            kern = "halo_trace_kernel<0,1,true,false>"
+        return dict(scene=scenes.scene([(0.0, [e])], max_hits=8),
+                    render=scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL),
+                    wls=[scenes.wl_illuminant("D65", 31)], rays=25_000_000,
+                    name="configs[4]: " + what + ", full-sphere axis, D65 pool of 31 wavelengths, %d root rays per GPU per step (200 M over 8 GPUs), max_hits 8, rectangular 2048x1024 visible full",
+                    kernel=kern, metric="rays/sec (whole node), stochastic-geometry crystal, 31 wavelengths")
+    raise SystemExit("unknown --config %r" % cfg)
+
+
+def cpu_baseline(wk, budget_s=12.0):
     """CPU oracle ("port") on all host cores, bounded to ~budget_s of work on the same workload shape."""
-    from ice_halo_sim_amd import scenes
     from tests._oracle_backend import OracleBackend, run_session
     cores = os.cpu_count() or 1
     threads = min(cores, 128)
-    sc, rd = scenes.config2_scene(), scenes.config2_render()
+    sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
     ob = OracleBackend(seed=42, threads=threads)
     t0 = time.perf_counter()
-    run_session(ob, sc, rd, scenes.wl_discrete(550.0), 100_000)  # calibration (also warms the LUT/page cache)
+    run_session(ob, sc, rd, wls[0], 100_000)  # calibration (also warms the LUT/page cache)
     rate = 100_000 / max(time.perf_counter() - t0, 1e-6)
-    per_wl = int(max(20_000, min(rays_per_wl_hint, rate * budget_s / 9)))
+    per_wl = int(max(20_000, min(wk["rays"], rate * budget_s / len(wls))))
     t0 = time.perf_counter()
-    for wl in scenes.CONFIG_WAVELENGTHS_9:
-        run_session(ob, sc, rd, scenes.wl_discrete(wl), per_wl)
+    for wl in wls:
+        run_session(ob, sc, rd, wl, per_wl)
     dt = time.perf_counter() - t0
     ob.close()
-    return {"value": 9 * per_wl / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "configs[1] shape, 9 wavelengths x %d rays (%.1f s of CPU work), OpenMP over rays" % (per_wl, dt)}
+    return {"value": len(wls) * per_wl / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": "same workload shape, %d session(s) x %d root rays (%.1f s of CPU work), OpenMP over rays" % (len(wls), per_wl, dt),
+            "note": "kind=port: the reference's own CPU path (Simulator / CpuTraceBackend) needs spdlog + nlohmann-json >= 3.4, absent from this image, "
+                    "and may not be built against stand-ins; this is the repo's C restatement of it (oracle/halo_oracle.c). Calibration of the real "
+                    "reference: %.2f M rays/s on %d threads in the %s" % (SURVEY_REFERENCE_CPU["rays_per_s"] / 1e6, SURVEY_REFERENCE_CPU["threads"], SURVEY_REFERENCE_CPU["where"])}
 
 
-def _pmc_mean(name, key):
-    """mean-per-dispatch value of counter `key` for the trace kernel in a committed rocprofv3 PMC summary (tools/rocpd_summary.py)"""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+def _pmc_mean(name, key, kernel="halo_trace_kernel"):
+    """mean-per-dispatch value of counter `key` for `kernel` in a committed rocprofv3 PMC summary (tools/rocpd_summary.py)"""
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
     val = None
     for line in open(path):
-        if "halo_trace_kernel" in line and (" " + key + " ") in line:
+        if kernel in line and (" " + key + " ") in line:
             val = float(line.split(" " + key + " ")[1].split()[0])
     return val
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(cfg):
     """HBM-side bytes per trace-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_bench_pmc_{fetch,write}_size.txt; counters are collected in their own runs, never inside the timed one).
-    FETCH_SIZE / WRITE_SIZE are in KB; this kernel's traffic is scattered atomics, for which the guide calls the counters
-    uncalibrated — reported as measured, uncorrected."""
-    f, w = _pmc_mean("r01_bench_pmc_fetch_size.txt", "FETCH_SIZE"), _pmc_mean("r01_bench_pmc_write_size.txt", "WRITE_SIZE")
+    (profiles/<round>_bench<cfg>_pmc_{fetch,write}_size.txt; counters are collected in their own runs, never inside the timed
+    one).  FETCH_SIZE / WRITE_SIZE are in KB; this kernel's traffic is scattered atomics, for which the guide calls the
+    counters uncalibrated — reported as measured, uncorrected."""
+    tag = "%s_bench%s" % (PROFILE_ROUND, cfg)
+    f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE"), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE")
     return None if f is None or w is None else (f + w) * 1024.0
 
 
-def pmc_valu(rays_per_launch):
+def pmc_valu(cfg, rays_per_launch):
     """VALU issue utilisation and instructions per 64-ray wave pass of the trace kernel, from the committed PMC pass
-    (profiles/r01_bench_pmc_insts.txt: per-dispatch means are per counter instance = 32 SIMDs).  Issue fraction =
-    VALU wave-instructions per SIMD x 4 cycles (a wave64 VALU instruction occupies a SIMD for 4 cycles) / kernel duration
-    of that same pass at the nominal 2.4 GHz."""
-    insts = _pmc_mean("r01_bench_pmc_insts.txt", "SQ_INSTS_VALU")
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_pmc_insts.txt")
+    (per-dispatch means are per counter instance = 32 SIMDs).  Issue fraction = VALU wave-instructions per SIMD x 4 cycles
+    (a wave64 VALU instruction occupies a SIMD for 4 cycles) / kernel duration of that same pass at the nominal 2.4 GHz."""
+    name = "%s_bench%s_pmc_insts.txt" % (PROFILE_ROUND, cfg)
+    insts = _pmc_mean(name, "SQ_INSTS_VALU")
+    path = os.path.join(ROOT, "profiles", name)
     avg_us = None
     if os.path.exists(path):
         for line in open(path):
@@ -90,7 +146,7 @@ def pmc_valu(rays_per_launch):
     if not insts or not avg_us:
         return None
     return {"valu_issue_frac": (insts / 32.0) * 4.0 / (avg_us * 1e-6 * 2.4e9), "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
-            "assumes": "4 cycles per wave64 VALU instruction, 2.4 GHz", "source": "profiles/r01_bench_pmc_insts.txt"}
+            "assumes": "4 cycles per wave64 VALU instruction, 2.4 GHz", "source": "profiles/" + name}
 
 
 def main():
@@ -98,10 +154,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays-per-wl", type=int, default=50_000_000, help="root rays per wavelength per GPU per step")
+    ap.add_argument("--config", default="1", choices=["1", "2", "4", "4p"])
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (median reported)")
+    ap.add_argument("--rays-per-wl", type=int, default=0, help="root rays per session per GPU per step (0 = the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--aggregate", type=int, default=-1)
+    ap.add_argument("--opt", action="append", default=[], help="backend option key=value (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -127,18 +186,21 @@ def main():
         else:
             dist.init_process_group(backend=dist_backend)
 
-    from ice_halo_sim_amd import scenes
-    from ice_halo_sim_amd.backend import HipTraceBackend
     from ice_halo_sim_amd.dist import ShardedTracer
 
-    sc, rd = scenes.config2_scene(), scenes.config2_render()
+    wk = workload(args.config)
+    sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
+    n = args.rays_per_wl or wk["rays"]
     tracer = ShardedTracer(sc, rd, seed=42, device=local_rank, rank=rank, world=world, **{"async": 1})
     if args.blocks_per_cu > 0:
         tracer.backend.set_option("blocks_per_cu", args.blocks_per_cu)
     if args.aggregate >= 0:
         tracer.backend.set_option("aggregate", args.aggregate)
-    wls = [scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9]
-    n = args.rays_per_wl
+    for kv in args.opt:
+        k, v = kv.split("=")
+        tracer.backend.set_option(k, int(v))
+    layers = sc.layer_count
+    first_layer = {"ms": 0.0, "launches": 0, "hits": 0, "cont": 0}     # non-final layers return their tallies synchronously
 
     def barrier():
         if world > 1:
@@ -146,41 +208,67 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        stats = []
         for wl in wls:
-            stats.append(tracer.trace_session(wl, n))      # this rank's shard of the batch
+            sts = tracer.trace_session_layers(wl, n)        # this rank's shard of the batch
+            for st in sts[:-1]:
+                first_layer["ms"] += st.kernel_ms
+                first_layer["launches"] += st.launches
+                first_layer["hits"] += st.pixel_hits
+                first_layer["cont"] += st.continuation_count
         tracer.reduce_to_root()                              # one RCCL sum-reduce at the drain point
-        return stats
 
     for _ in range(args.warmup):
         step()
     tracer.zero()
     tracer.backend.collect_stats()                            # drop the warm-up tallies
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()                                               # dispatches are queued; nothing waits on the host per launch
-    barrier()
-    dt = time.perf_counter() - t0
-    st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of the timed region
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    for k in first_layer:
+        first_layer[k] = 0
+    times = []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()                                           # dispatches are queued; nothing waits on the host per launch
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t.item()))
+    st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
+    route = tracer.backend.last_route()
+    dt = statistics.median(times)
+    cov = (statistics.pstdev(times) / statistics.mean(times)) if len(times) > 1 else 0.0
 
-    rays_per_rank = args.steps * len(wls) * n
-    total_rays = rays_per_rank * world
+    reps = len(times)
+    rays_per_rank_step = len(wls) * n
+    rays_per_rank = reps * args.steps * rays_per_rank_step
     launches, kernel_ms, pixel_hits, exits = int(st.launches), float(st.kernel_ms), int(st.pixel_hits), int(st.exit_count)
-    assert int(st.root_count) == rays_per_rank
+    assert int(st.root_count) == rays_per_rank + first_layer["cont"], (int(st.root_count), rays_per_rank, first_layer["cont"])
 
     img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
     if rank == 0:
-        avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
-        alg_bytes_per_launch = pixel_hits * 24.0 / max(launches, 1)   # 3 ch x 4 B x (read + write) per in-frame pixel hit
-        achieved = alg_bytes_per_launch / max(avg_launch_s, 1e-12) / 1e9
+        # the dominant kernel: the last layer's launches (single-scatter: the only layer; multi-scatter: the transit-source layer)
+        dom_launches = launches - first_layer["launches"]
+        dom_ms = kernel_ms - first_layer["ms"]
+        dom_hits = pixel_hits - first_layer["hits"]
+        dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
+        avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+        # ALGORITHMIC bytes: 3 ch x 4 B x (read + write) per in-frame pixel hit; a transit-source launch also
+        # reads its 20-byte continuation records (and the layer before wrote them: 20 B out + 20 B in per continuation);
+        # a shape-pool launch reads one sampled-crystal record per 32 rays (and the generator wrote it)
+        alg = dom_hits * 24.0
+        if layers > 1:
+            alg += dom_rays * 40.0
+        shape_rec = {"4": 1360.0, "4p": 4112.0}.get(args.config)
+        if shape_rec:
+            alg += dom_rays / 32.0 * shape_rec * 2.0
+        alg_per_launch = alg / max(dom_launches, 1)
+        achieved = alg_per_launch / max(avg_launch_s, 1e-12) / 1e9
+        total_rays_step = rays_per_rank_step * world
         out = {
-            "metric": "rays/sec (whole node) at 9 wavelengths, single-scatter hex column",
-            "value": total_rays / dt,
+            "metric": wk["metric"],
+            "value": total_rays_step * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -191,21 +279,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: single-scatter hex column (prism h=1.3, zenith gauss(90,0.3)), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper" % n,
-                       "rays_per_step_per_gpu": len(wls) * n, "resolution": [rd.width, rd.height],
+            "config": {"workload": wk["name"] % n,
+                       "rays_per_step_per_gpu": rays_per_rank_step, "resolution": [rd.width, rd.height],
                        "sharding": "root-ray index ranges, 1 RCCL reduce of %d floats per step" % (rd.width * rd.height * 3 + 4),
-                       "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed},
+                       "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed,
+                       "route": {"mode_mask": route.mode_mask, "geom_mask": route.geom_mask, "accum_mask": route.accum_mask,
+                                 "source_mask": route.source_mask, "planes": route.plane_cnt, "plane_copies": route.plane_copies}},
+            "repeats": {"n": reps, "protocol": "reference doc/performance-testing.md:109-131 (>= 5 repeats, median + CoV); each repeat times exactly --steps steps",
+                        "median_ms_per_step": dt * 1e3 / args.steps, "cov": cov,
+                        "ms_per_step_all": [x * 1e3 / args.steps for x in times]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(),
-                         "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)",
-                         "kernel": "halo_trace_kernel<0,0,true,false>", "launches": launches,
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "kernel_rays_per_s": (rays_per_rank / max(kernel_ms * 1e-3, 1e-12)),
-                         "valu": pmc_valu(n),
-                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs, so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(args.config),
+                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)" % (PROFILE_ROUND, args.config),
+                         "kernel": wk["kernel"], "launches": dom_launches,
+                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
+                         "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
+                         "valu": pmc_valu(args.config, n),
+                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
         }
+        if layers > 1:
+            traced = rays_per_rank + first_layer["cont"]
+            out["multi_scatter"] = {"root_rays_per_s": out["value"], "traced_rays_per_s": traced / (reps * args.steps) * world / (dt / args.steps),
+                                    "continuations_per_root": first_layer["cont"] / max(rays_per_rank, 1),
+                                    "first_layer_kernel_ms_per_launch": first_layer["ms"] / max(first_layer["launches"], 1),
+                                    "last_layer_kernel_ms_per_launch": avg_launch_s * 1e3}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n)
+            out["cpu_baseline"] = cpu_baseline(wk)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -84,17 +84,23 @@ class ShardedTracer:
         self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
         self.landed = 0.0
 
-    def trace_session(self, wl, n_rays, shuffle=True):
-        """BeginSession → layers → EndSession for this rank's `n_rays` roots. Returns the last layer's stats."""
+    def trace_session_layers(self, wl, n_rays, shuffle=True):
+        """BeginSession → layers → EndSession for this rank's `n_rays` roots. Returns every layer's stats (with option async=1
+        the final layer's tallies are deferred to collect_stats; the layers before it are always synchronous — the host needs
+        their continuation counts)."""
         b = self.backend
         b.BeginSession(self.scene, self.render, wl, n_rays)
-        st = None
+        sts = []
         for li in range(self.scene.layer_count):
-            st = b.TraceLayer(n_rays if li == 0 else 0)
+            sts.append(b.TraceLayer(n_rays if li == 0 else 0))
             if li + 1 < self.scene.layer_count:
                 b.Recombine(shuffle)
         b.EndSession()
-        return st
+        return sts
+
+    def trace_session(self, wl, n_rays, shuffle=True):
+        """Same; returns the last layer's stats."""
+        return self.trace_session_layers(wl, n_rays, shuffle)[-1]
 
     def reduce_to_root(self):
         """The drain-point collective: ONE sum-reduce of the image accumulator, enqueued on the stream behind this rank's

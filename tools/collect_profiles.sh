@@ -1,25 +1,31 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats of the default bench, then PMC passes in their own runs.
-# Output: gpurun_out/prof_<tag>/  (rocpd sqlite) — summarise with tools/rocpd_summary.py into profiles/.
+# Runs on the GPU box (via gpurun): kernel-trace stats of `bench.py --config CFG`, then PMC passes in their own runs
+# (counters are never collected together with trace domains other than --kernel-trace).
+# Output: gpurun_out/prof_<tag>/<round>_bench<cfg>_*.txt — copy the summaries into profiles/.
+#   tools/collect_profiles.sh <round> <cfg> [rays-per-session]
 set -u
-TAG=${1:-r01b}
+ROUND=${1:-r02}
+CFG=${2:-1}
+RAYS=${3:-0}
+TAG=${ROUND}_bench${CFG}
 ROOT=$(pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="--config $CFG --no-cpu-baseline --repeats 1 --rays-per-wl $RAYS"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- $BENCH > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python $ROOT/bench.py --steps 2 --warmup 1 $ARGS > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 $ARGS > $OUT/pmc_$C.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_insts -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_insts.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM -d $OUT/pmc_cycles -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_cycles.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_insts -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 $ARGS > $OUT/pmc_insts.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM -d $OUT/pmc_cycles -o $TAG -- python $ROOT/bench.py --steps 1 --warmup 0 $ARGS > $OUT/pmc_cycles.log 2>&1
 cd $ROOT
+name() { case $1 in stats) echo kernel_stats;; pmc_FETCH_SIZE) echo pmc_fetch_size;; pmc_WRITE_SIZE) echo pmc_write_size;; *) echo $1;; esac; }
 for d in stats pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_insts pmc_cycles; do
   db=$(find $OUT/$d -name "*.db" | head -1)
-  [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/$d.txt 2>&1
-  find $OUT/$d -name "*.db" -size +30M -delete
+  [ -n "$db" ] && python tools/rocpd_summary.py $db > $OUT/${TAG}_$(name $d).txt 2>&1
+  rm -rf $OUT/$d
 done
-tail -2 $OUT/stats.log
+tail -2 $OUT/stats.log | cut -c1-400
 ls -la $OUT
