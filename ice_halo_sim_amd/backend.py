@@ -14,7 +14,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhalo_hip.so")
+# HALO_LIB selects another build of the same library (tools/phase_probe.py loads the -DHALO_PROBE build); default = the product
+LIB_PATH = os.environ.get("HALO_LIB") or os.path.join(_HERE, "libhalo_hip.so")
 _lib = None
 
 

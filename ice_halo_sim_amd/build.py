@@ -6,7 +6,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libhalo_hip.so")
+PROBE = bool(os.environ.get("HALO_PROBE"))   # phase-probe build (tools/phase_probe.py): its own file, never the shipped library
+# HALO_BUILD_TAG=x builds libhalo_hip_x.so in build_x/ (A/B experiments: load it with HALO_LIB=...); HALO_DEFS="-DA=1 -DB" adds macros
+TAG = "probe" if PROBE else os.environ.get("HALO_BUILD_TAG", "")
+LIB = os.path.join(HERE, "libhalo_hip_%s.so" % TAG if TAG else "libhalo_hip.so")
 SOURCES = ["halo_trace_m0.hip", "halo_trace_m1.hip", "halo_trace_m2.hip", "halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp",
            "halo_host.cpp"]
 NO_CONTRACT = {"halo_shapegen.hip"}   # geometry shared with the host: same rounding on both sides
@@ -31,7 +34,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cc = hipcc()
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build_" + TAG if TAG else "build")
     os.makedirs(bdir, exist_ok=True)
     common = ["-std=c++17", "-fPIC", "-I", os.path.join(HERE, "..", "include")]
 
@@ -39,6 +42,9 @@ def build(force=False, verbose=False):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
+            if PROBE:
+                cmd.append("-DHALO_PROBE=1")
+            cmd += os.environ.get("HALO_DEFS", "").split()
             for knob in ("HALO_MIN_WAVES", "HALO_MIN_WAVES_FILTER"):
                 if os.environ.get(knob):
                     cmd.append("-D%s=%s" % (knob, os.environ[knob]))

@@ -81,6 +81,7 @@ struct HaloBackend {
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
+  int entry_fast = 1;          // 1: full prisms of one-shape dispatches take the slab-wise entry pick (EntryFastDev)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
   uint32_t shuffle_chunk_log2 = 5;   // Recombine's shuffle moves chunks of 2^k pool entries (k = 0: per ray, like the reference)
   HaloRouteInfo route{};       // kernels that served the current / last session (halo_last_route)
@@ -336,6 +337,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "lambda_planes") b->lambda_planes = static_cast<int>(v);
   else if (k == "bin") b->bin = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
+  else if (k == "entry_fast") b->entry_fast = v ? 1 : 0;
   else if (k == "shuffle_chunk") {
     if (v < 1 || v > 64 || (v & (v - 1)) != 0) return fail(b, HALO_FATAL, "shuffle_chunk must be a power of two in [1, 64]");
     b->shuffle_chunk_log2 = 0;
@@ -720,7 +722,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         std::copy(lut.flip.begin(), lut.flip.end(), hs.lut + 2 * kLutNodes);
       }
       std::copy(b->wl_pool_host.begin(), b->wl_pool_host.end(), hs.wl);
-      if (deterministic) hs.shape = pool[0];
+      bool entry_fast = false;
+      if (deterministic) {
+        hs.shape = pool[0];
+        entry_fast = b->entry_fast && host::BuildEntryFast(pool[0], hs.efast);
+      }
       if (use_filter) hs.filter = fd;
       if (use_color) hs.color = cd;
       for (double& v : hs.sums) v = 0.0;
@@ -734,6 +740,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       P.lane_stride = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
       P.sums = ds->sums;
       P.cont_in_seg = ds->seg;
+      P.entry_fast = entry_fast ? &ds->efast : nullptr;
       if (deterministic) {
         P.shapes = &ds->shape;
       } else {

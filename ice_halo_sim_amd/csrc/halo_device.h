@@ -64,6 +64,20 @@ struct ShapePrism {
 };
 static_assert(sizeof(ShapePrism) % 16 == 0, "ShapePrism rows are read as float4");
 
+// Entry-pick view of a FULL hexagonal prism (8 faces present: slabs (0,1), (2,5), (3,6), (4,7), no single faces, at most 4
+// fan triangles per face, triangles grouped face by face), built on the host for one-shape dispatches.  The projected-area
+// pick then needs one dot product per SLAB (opposite faces see -d.n and +d.n, only one of them is lit), keeps the four
+// products in registers and walks the seven candidate weights branch-free in face order — same uniform, same cumulative
+// order, same partial sums as the walk over all faces (adding the unlit face's zero is exact).
+constexpr int kEntryFastFaces = 8, kEntryFastTris = 20;
+struct EntryFastDev {
+  float tri_area[kEntryFastFaces][4];   // areas of the face's fan triangles, zero-padded
+  uint32_t tri0n[kEntryFastFaces];      // first fan triangle | count << 8
+  float slab_area[4][2];                // total area of {plus face, minus face} of each slab
+  float tri_v[kEntryFastTris][12];      // fan-triangle corners in 48-byte rows (three 16-byte reads per pick)
+};
+static_assert(sizeof(EntryFastDev) % 16 == 0, "copied as float4");
+
 struct WlEntryDev {  // reference WlEntry, src/core/backend/wl_pool.hpp:29-35 (+pad to 32 B)
   float n_idx, spd_weight, cmf_x, cmf_y, cmf_z, pad0, pad1, pad2;
 };
@@ -133,6 +147,7 @@ struct DispatchSlot {
   alignas(16) double sums[4];
   alignas(16) uint32_t seg[kContShards + 4];
   alignas(16) ColorDev color;
+  alignas(16) EntryFastDev efast;
 };
 
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
@@ -169,6 +184,7 @@ struct DispatchParams {
   const float* lut;            // theta[257] | cdf[257] | flip[257]
   const WlEntryDev* wl_pool;
   const ShapeDev* shapes;
+  const EntryFastDev* entry_fast;   // one-shape dispatch of a full prism: the fast entry pick's tables (else nullptr)
   // --- continuation pools (SoA: dx | dy | dz | w | wl_idx, each cont_stride apart) ---------------
   const float* cont_in;
   uint32_t cont_in_n;

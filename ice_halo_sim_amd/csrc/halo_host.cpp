@@ -250,6 +250,41 @@ FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis) {
   return d;
 }
 
+bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out) {
+  std::memset(&out, 0, sizeof(out));
+  if (s.face_cnt != kEntryFastFaces || s.slab_cnt != 4 || s.single_cnt != 0 || s.tri_cnt < 8 || s.tri_cnt > kEntryFastTris) return false;
+  static const int want_plus[4] = {0, 2, 3, 4}, want_minus[4] = {1, 5, 6, 7};
+  for (int k = 0; k < 4; k++) {
+    int32_t ip, im;
+    std::memcpy(&ip, &s.slab[k][5], 4);
+    std::memcpy(&im, &s.slab[k][6], 4);
+    if (ip != want_plus[k] || im != want_minus[k]) return false;
+  }
+  int next = 0;
+  float face_area[kEntryFastFaces];
+  for (int f = 0; f < kEntryFastFaces; f++) {   // triangles grouped face by face, in face order, 1..4 per face
+    int cnt = 0;
+    while (next + cnt < s.tri_cnt && s.tri_face[next + cnt] == f) cnt++;
+    if (cnt < 1 || cnt > 4) return false;
+    float a = 0.0f;
+    for (int k = 0; k < cnt; k++) {
+      out.tri_area[f][k] = s.tri_na[next + k][3];
+      a += s.tri_na[next + k][3];   // the partial sums the device's per-face view (FaceIndex) forms, in the same order
+    }
+    face_area[f] = a;
+    out.tri0n[f] = static_cast<uint32_t>(next) | (static_cast<uint32_t>(cnt) << 8);
+    next += cnt;
+  }
+  if (next != s.tri_cnt) return false;
+  for (int k = 0; k < 4; k++) {
+    out.slab_area[k][0] = face_area[want_plus[k]];
+    out.slab_area[k][1] = face_area[want_minus[k]];
+  }
+  for (int t = 0; t < s.tri_cnt; t++)
+    for (int c = 0; c < 9; c++) out.tri_v[t][c] = s.tri_v[t][c];
+  return true;
+}
+
 bool IsDeterministic(const HaloCrystal& c) {
   const int nh = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
   for (int i = 0; i < nh; i++)

@@ -54,6 +54,9 @@ bool IsDeterministic(const HaloCrystal& c);                 // simulator.cpp:453
 bool MakeShape(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, HaloGeomTables& out);
 bool MakeShapeDev(uint32_t seed, const HaloCrystal& c, uint64_t shape_index, ShapeDev& out);   // same, device table layout
 
+// Tables of the fast entry pick (EntryFastDev); false = the shape is not a full prism in the expected layout.
+bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out);
+
 uint32_t PcgHash(uint32_t x);
 
 }  // namespace host

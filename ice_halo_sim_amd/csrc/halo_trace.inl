@@ -29,6 +29,36 @@ namespace halo {
 
 #define HD __device__ __forceinline__
 
+// Phase probe (tools/phase_probe.py; builds with -DHALO_PROBE only — never the shipped library): every wave stamps the shader
+// clock at phase boundaries and the kernel adds the per-wave cycle sums to g_halo_probe.  With several waves interleaving on
+// a SIMD a phase's elapsed time is its share of the SIMD's issue slots, which is what "where do the cycles go" asks.
+#ifdef HALO_PROBE
+__device__ unsigned long long g_halo_probe[16];
+struct Probe {
+  uint64_t t0;
+  uint32_t acc[12];
+};
+HD void probe_start(Probe& pr) {
+  __builtin_amdgcn_sched_barrier(0);
+  pr.t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int K>
+HD void probe_mark(Probe& pr) {
+  __builtin_amdgcn_sched_barrier(0);
+  const uint64_t t = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+  pr.acc[K] += static_cast<uint32_t>(t - pr.t0);
+  pr.t0 = t;
+}
+#define PROBE_MARK(pr, K) probe_mark<K>(pr)
+#else
+struct Probe {};
+#define PROBE_MARK(pr, K) ((void)0)
+#endif
+enum { kPhStream = 0, kPhOrient = 1, kPhRotation = 2, kPhSun = 3, kPhEntry = 4, kPhFresnel = 5, kPhEmitGate = 6, kPhProject = 7,
+       kPhAccum = 8, kPhSlab = 9, kPhKernelFixed = 10, kPhTotal = 11 };
+
 constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
 constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
 constexpr float kSlabEps = 1e-5f;                 // traversal_shared.h:46
@@ -802,6 +832,7 @@ struct LdsTables {
   PixCache<MONO, SMALLC> cache;
   uint32_t seg[kContShards + 4];
   FaceIndex fidx;
+  __attribute__((aligned(16))) EntryFastDev efast;   // staged only when P.entry_fast != nullptr (full prism, one shape per dispatch)
 };
 constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
 template <bool ON>
@@ -880,7 +911,7 @@ HD void stage_shape(SlotT* slot, const SlotT* g, uint32_t l32) {
 template <int MODE, bool MONO, bool SMALLC>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
                   float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const PathView& pv, RaySums& sums) {
+                  const PathView& pv, RaySums& sums, Probe& pr) {
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
   float wx = R[0] * lx + R[1] * ly + R[2] * lz;
   float wy = R[3] * lx + R[4] * ly + R[5] * lz;
@@ -921,24 +952,28 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     }
     return;
   }
-  Hits h = project_exit(P.proj, wx, wy, wz);
+  PROBE_MARK(pr, kPhEmitGate);
+  const ProjDev& pj = P.proj;
+  Hits h = project_exit(pj, wx, wy, wz);
+  PROBE_MARK(pr, kPhProject);
   int primary = -1;
-  if (h.count >= 1 && h.px0 >= 0 && h.px0 < P.proj.img_w && h.py0 >= 0 && h.py0 < P.proj.img_h) {
-    uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px0);
+  if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
+    uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px0);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
     primary = static_cast<int>(pix);
   }
-  if (h.count == 2 && h.px1 >= 0 && h.px1 < P.proj.img_w && h.py1 >= 0 && h.py1 < P.proj.img_h) {
-    uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(P.proj.img_w) + static_cast<uint32_t>(h.px1);
+  if (h.count == 2 && h.px1 >= 0 && h.px1 < pj.img_w && h.py1 >= 0 && h.py1 < pj.img_h) {
+    uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px1);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.pix_n++;
   }
   sums.exit_w += w;
   sums.exit_n++;
+  PROBE_MARK(pr, kPhAccum);
   if (MODE == kModeCapture) {
     uint32_t slot = atomicAdd(&P.counters[kCntExit], 1u);
     if (slot < P.exit_cap) {
@@ -1064,9 +1099,88 @@ HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int fac
   return static_cast<int>(sh->tri_face[tri]);
 }
 
+// The same pick for a FULL prism (EntryFastDev, halo_device.h): one dot product per slab, the four products stay in registers,
+// and the seven candidate weights (face 0 or 1, then sides 2, 3, 4, then their opposites 5, 6, 7 — face order) are walked without
+// a branch.  Weights, partial sums and the uniform are those of sample_entry_by_face: the unlit face of a slab contributes an
+// exact zero there.
+template <typename ShapePtr>
+HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tri_cnt, const float* d, float* p) {
+  const float u_cat = uniform(s);
+  float dn[4], ap[4], am[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float4 g = *reinterpret_cast<const float4*>(sh->slab[k]);
+    dn[k] = d[0] * g.x + d[1] * g.y + d[2] * g.z;
+    const float2v a = *reinterpret_cast<const float2v*>(ef.slab_area[k]);
+    ap[k] = a.x;
+    am[k] = a.y;
+  }
+  // candidate k: 0 = basal slab (face 0 or 1), 1..3 = sides 2..4 (lit when d.n < 0), 4..6 = their opposites 5..7
+  float wgt[7], cs[7];
+  cs[0] = fabsf(dn[0]);
+  wgt[0] = cs[0] * (dn[0] < 0.0f ? ap[0] : am[0]);
+#pragma unroll
+  for (int k = 1; k < 4; k++) {
+    cs[k] = fmaxf(-dn[k], 0.0f);
+    wgt[k] = cs[k] * ap[k];
+    cs[3 + k] = fmaxf(dn[k], 0.0f);
+    wgt[3 + k] = cs[3 + k] * am[k];
+  }
+  float total = wgt[0];
+#pragma unroll
+  for (int k = 1; k < 7; k++) total += wgt[k];
+  const float target = u_cat * total;
+  int face = 7;
+  float rem = 0.0f, c = 1.0f, cum = 0.0f;
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const float nc = cum + wgt[k];
+    const bool hit = !found && (nc > target);
+    const int f = (k == 0) ? (dn[0] < 0.0f ? 0 : 1) : (k + 1);
+    face = hit ? f : face;
+    rem = hit ? (target - cum) : rem;
+    c = hit ? cs[k] : c;
+    found = found || hit;
+    cum = nc;
+  }
+  int tri;
+  if (!(total > 0.0f)) {   // no lit face: the flat walk's tri = 0
+    tri = 0;
+    face = 0;
+  } else {
+    const uint32_t t0n = ef.tri0n[face];
+    const int t0 = static_cast<int>(t0n & 0xFFu), tn = static_cast<int>(t0n >> 8);
+    tri = t0 + tn - 1;
+    if (found) {
+      const float r = rem * fast_rcp(c);
+      const float4 ar = *reinterpret_cast<const float4*>(ef.tri_area[face]);
+      const float a0 = ar.x, a1 = a0 + ar.y, a2 = a1 + ar.z;   // zero-padded past tn: the partial sum stops growing
+      tri = (a2 > r) ? t0 + 2 : tri;
+      tri = (a1 > r) ? t0 + 1 : tri;
+      tri = (a0 > r) ? t0 : tri;
+      tri = min(tri, t0 + tn - 1);
+    } else {
+      tri = tri_cnt - 1;   // the walk ran off the end (cannot happen for finite weights): last triangle, like the flat walk
+    }
+  }
+  float u = uniform(s);
+  float v = uniform(s);
+  if (u + v > 1.0f) {
+    u = 1.0f - u;
+    v = 1.0f - v;
+  }
+  const float4* vt = reinterpret_cast<const float4*>(ef.tri_v[tri]);
+  const float4 q0 = vt[0], q1 = vt[1], q2 = vt[2];   // a = q0.xyz, b = (q0.w, q1.x, q1.y), c = (q1.z, q1.w, q2.x)
+  p[0] = u * (q0.w - q0.x) + v * (q1.z - q0.x) + q0.x;
+  p[1] = u * (q1.x - q0.y) + v * (q1.w - q0.y) + q0.y;
+  p[2] = u * (q1.y - q0.z) + v * (q2.x - q0.z) + q0.z;
+  return face;
+}
+
 template <int MODE, bool MONO, bool SMALLC, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  uint32_t tid, RaySums& sums) {
+                  uint32_t tid, RaySums& sums, Probe& pr) {
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
   int face;
@@ -1084,8 +1198,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
     }
     float lon, lat, roll;
+    PROBE_MARK(pr, kPhStream);
     sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    PROBE_MARK(pr, kPhOrient);
     build_crystal_rotation(lon, lat, roll, R);
+    PROBE_MARK(pr, kPhRotation);
     // sun cone (sample_sph_cap pcg_shared.h:514-529; trig of the fixed sun angles is host-evaluated)
     float u = uniform(s);
     float x = add_rn(u, mul_rn(1.0f - u, P.c_cap));  // separately rounded: see the note on r below
@@ -1100,8 +1217,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
     float dwz = P.s_lat * x + P.c_lat * z;
     apply_inverse(R, dwx, dwy, dwz, d);
-    face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
+    PROBE_MARK(pr, kPhSun);
+    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
+    else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     w = (P.wl_pool_size == 1u) ? P.wl_pool[0].spd_weight : P.wl_pool[wl_idx].spd_weight;
+    PROBE_MARK(pr, kPhEntry);
   } else if (P.source == kSrcTransit) {
     Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
     const uint32_t pos = P.ci_start + tid;
@@ -1131,10 +1251,16 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[5u * st + src]) |
                 (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[6u * st + src]) << 32);
     float lon, lat, roll;
+    PROBE_MARK(pr, kPhStream);
     sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    PROBE_MARK(pr, kPhOrient);
     build_crystal_rotation(lon, lat, roll, R);
+    PROBE_MARK(pr, kPhRotation);
     apply_inverse(R, dwx, dwy, dwz, d);
-    face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
+    PROBE_MARK(pr, kPhSun);
+    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
+    else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
+    PROBE_MARK(pr, kPhEntry);
   } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)
     R[0] = R[4] = R[8] = 1.0f;
     R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0f;
@@ -1164,6 +1290,8 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     pv.len = 1u;
   }
 
+  bool stray = false;
+  uint32_t stray_seq = 0u;
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
@@ -1186,10 +1314,12 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     // one otherwise; the other child leaves through `face` and is the outgoing candidate.
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
+    PROBE_MARK(pr, kPhFresnel);
     if (has_exit) {
       emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
-                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), pv, sums);
+                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), pv, sums, pr);
     }
+    PROBE_MARK(pr, kPhEmitGate);
     if (i + 1u == P.max_hits) break;
     const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
     d[0] = entering ? rfx : rlx;
@@ -1213,7 +1343,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       const float den = fabsf(r.x);
       const float num = pos ? -(r.y + g.w) : (r.y - e.x);
       const int fi = pos ? __float_as_int(e.y) : __float_as_int(e.z);
-      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
+      // the face the ray stands on is never ahead: the child that stays inside has n.d < 0 there (it was built from the
+      // face normal a few lines up), so the `den > eps` gate already excludes it — no index compare needed
+      const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
       num_b = better ? num : num_b;
       den_b = better ? den : den_b;
       hit = better ? fi : hit;
@@ -1224,15 +1356,17 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       const float2v r = X * g.x + Y * g.y + Z * g.z;
       const float den = r.x;
       const float num = -(r.y + g.w);
-      const bool better = (fi != face) && (den > kSlabEps) && (num * den_b < num_b * den);
+      const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
       num_b = better ? num : num_b;
       den_b = better ? den : den_b;
       hit = better ? fi : hit;
     }
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
-      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678)
-      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, pv, sums);
+      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678).  Emitted behind
+      // the loop, so that the loop body holds ONE copy of the emit code.
+      stray = true;
+      stray_seq = inward_seq;
       break;
     }
     p[0] += t_best * d[0];
@@ -1249,7 +1383,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       }
       pv.len++;
     }
+    PROBE_MARK(pr, kPhSlab);
   }
+  if (stray) emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, stray_seq, pv, sums, pr);
 }
 
 // Bin the staged hits by image tile and append them to the tiles' lists (all kBlock threads call this together).
@@ -1310,6 +1446,12 @@ HD float wave_sum(float v) {
 template <int MODE, int GEOM, bool MONO, bool BIN>
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
+  Probe pr;
+#ifdef HALO_PROBE
+  for (int k = 0; k < 12; k++) pr.acc[k] = 0u;
+  probe_start(pr);
+  const uint64_t t_begin = pr.t0;
+#endif
   constexpr bool SMALLC = BIN && GEOM != kGeomOne;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
@@ -1350,6 +1492,11 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   if (P.source == kSrcTransit)
     for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
   if (threadIdx.x == 0) T.fidx.ok = 0u;
+  if (!POOL && P.entry_fast != nullptr) {
+    const float4* src = reinterpret_cast<const float4*>(P.entry_fast);
+    float4* dst = reinterpret_cast<float4*>(&T.efast);
+    for (uint32_t i = threadIdx.x; i < sizeof(EntryFastDev) / 16u; i += kBlock) dst[i] = src[i];
+  }
   if constexpr (!POOL) {
     const float4* src = reinterpret_cast<const float4*>(P.shapes);
     float4* dst = reinterpret_cast<float4*>(&s_shape.s[0]);
@@ -1387,6 +1534,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   __syncthreads();
 
   RaySums sums = {0.0f, 0.0f, 0u, 0u};
+  PROBE_MARK(pr, kPhKernelFixed);
   const uint32_t stride = gridDim.x * kBlock;
   uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
   bool staged = false;
@@ -1406,7 +1554,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolSlot*>(P.shapes) + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums);
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums, pr);
       __builtin_amdgcn_wave_barrier();
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
@@ -1420,10 +1568,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
           const PoolSlot* sh = reinterpret_cast<const PoolSlot*>(P.shapes) + (tid / P.geom_clock);
-          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums);
+          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums, pr);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums);
+          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums, pr);
         }
       }
       if constexpr (BIN) {
@@ -1436,6 +1584,9 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
     bin_flush(P, s_hits.b);
   }
   // ---- flush the workgroup's pixel cache: one global atomic per claimed slot and channel ----
+#ifdef HALO_PROBE
+  probe_start(pr);
+#endif
   if (P.aggregate == 1u || P.aggregate == 3u) {
     __syncthreads();
     for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) {
@@ -1463,6 +1614,12 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
     if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
     if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
   }
+#ifdef HALO_PROBE
+  PROBE_MARK(pr, kPhKernelFixed);
+  pr.acc[kPhTotal] = static_cast<uint32_t>(pr.t0 - t_begin);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 12; k++) atomicAdd(&g_halo_probe[k], static_cast<unsigned long long>(pr.acc[k]));
+#endif
 }
 
 // host-callable launcher pieces: each halo_trace_m<MODE>.hip translation unit instantiates the kernels of one MODE
