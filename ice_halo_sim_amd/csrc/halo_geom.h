@@ -339,7 +339,7 @@ HALO_GEOM_HD bool ConeApexZ(const Plane3* cone, double tol, int sign, double& z)
   return found;
 }
 
-constexpr int kPyrMaxVerts = 96;
+constexpr int kPyrMaxVerts = 48;   // a hexagonal prism capped by two truncated hexagonal pyramids has 24 corners; the reference's pools peak at 30
 
 // cot_u / cot_l = sqrt3/4 / tan(wedge) for a legal wedge, negative = that cone absent (the caller evaluates tan once)
 HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float h2, float h3, const float dist[6], ShapeDev& out) {
@@ -392,15 +392,20 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
 
   double verts[kPyrMaxVerts][3];
   int nv = 0;
-  // Of the C(20,3) = 1140 triples about a hundred meet in a point of the solid.  Running the exact test on all of them made the
-  // device generator scratch-bandwidth-bound: every thread streams its 20 fp64 planes through the feasibility scan, ~220 KB
-  // per crystal, 85 % of the kernel.  So (1) the planes are copied to a second array that is only ever indexed by fully
-  // unrolled loops (k of the pre-test, m of both scans) and therefore lives in registers; i and j stay dynamic and read
-  // theirs from `unit`; (2) a division-free test rejects first: with x = N / det, plane m is violated when
-  // sign(det) (n_m.N + d_m det) exceeds tol |det|.  It rejects only beyond TWICE the tolerance (its own rounding is ~1e-10 of
-  // that margin) and never for a det Concurrence would refuse, so every triple the exact test accepts still reaches it, in
-  // the same order; the exact scan evaluates the same expression on bit-identical copies.  Vertices, their order and the
-  // duplicate filter are unchanged.
+  // Vertices = feasible concurrences of three planes.  Of the C(20,3) = 1140 triples only ~100 can meet in a point OF THE
+  // SOLID, and which ones follows from the plane set alone (cone slope a > 0):
+  //   * above the shoulder (z > h2/2) upper-cone plane i is tighter than prism plane i (its bound on cos x + sin y shrinks with
+  //     z) and the lower cone is looser still, so only upper-cone planes and the top basal plane can be tight there; mirrored
+  //     below -h2/2; strictly between the shoulders only the vertical prism planes are tight, and three vertical planes
+  //     never meet in a point;
+  //   * AT a shoulder, cone plane i and prism plane i share the horizontal line of side i, so a corner of the cross-section
+  //     there is the concurrence of prism i, prism j and the cone planes i, j.
+  // Hence every vertex is found by one of: three planes of the same cone (2 x 20 triples); a basal plane with two planes of
+  // its cone, or with two prism planes when that cone is absent (2 x 15); two prism planes i < j with cone plane i (2 x 15).
+  // The triples are visited in lexicographic order and each list above contains the lexicographically FIRST triple of every
+  // vertex, so the kept vertices, their order and their coordinates are those of the exhaustive enumeration this replaces
+  // (which spent 1140 solves and feasibility scans per crystal to find them; the duplicate filter stays for the coincident
+  // triples that remain).
   double pre[20][4];
   uint32_t act_mask = 0u;
   for (int s = 0; s < 20; s++) {
@@ -410,74 +415,44 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     pre[s][3] = unit[s].d;
     if (active[s]) act_mask |= 1u << s;
   }
-  const double lim = 2.0 * tol;
-  for (int i = 0; i < 20; i++) {
-    if (!active[i]) continue;
-    const double ia = unit[i].a, ib = unit[i].b, ic = unit[i].c, id = unit[i].d;
-    for (int j = i + 1; j < 20; j++) {
-      if (!active[j]) continue;
-      const double ja = unit[j].a, jb = unit[j].b, jc = unit[j].c, jd = unit[j].d;
-      const double cx = ib * jc - ic * jb, cy = ic * ja - ia * jc, cz = ia * jb - ib * ja;   // n_i x n_j
-      uint32_t surv = 0u;   // the k that are not provably outside
+  auto try_triple = [&](int i, int j, int k) {
+    double x[3];
+    if (!Concurrence(unit[i], unit[j], unit[k], x)) return;
+    bool ok = true;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int k = 0; k < 20; k++) {
-        if (k <= j || !((act_mask >> k) & 1u)) continue;
-        const double ka = pre[k][0], kb = pre[k][1], kc = pre[k][2], kd = pre[k][3];
-        const double det = cx * ka + cy * kb + cz * kc;
-        if (fabs(det) < 0.5e-9) continue;   // Concurrence refuses below 1e-9
-        // N = -(d_i (n_j x n_k) + d_j (n_k x n_i) + d_k (n_i x n_j))
-        const double ax = jb * kc - jc * kb, ay = jc * ka - ja * kc, az = ja * kb - jb * ka;
-        const double bx = kb * ic - kc * ib, by = kc * ia - ka * ic, bz = ka * ib - kb * ia;
-        const double nx = -(id * ax + jd * bx + kd * cx), ny = -(id * ay + jd * by + kd * cy), nz = -(id * az + jd * bz + kd * cz);
-        const double sgn = det > 0.0 ? 1.0 : -1.0;
-        const double bound = lim * fabs(det);
-        bool far = false;
-        // four groups (basal pair, prism, upper cone, lower cone) with a way out after each: crystals of one dispatch have
-        // the same topology, so a triple that is far outside for one lane is far outside for (nearly) all of them
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int m0 = 0; m0 < 20; m0 += (m0 == 0 ? 2 : 6)) {
-          const int m1 = (m0 == 0) ? 2 : m0 + 6;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-          for (int m = m0; m < m1; m++)
-            if ((act_mask >> m) & 1u) far = far || (sgn * (pre[m][0] * nx + pre[m][1] * ny + pre[m][2] * nz + pre[m][3] * det) > bound);
-          if (far) break;
-        }
-        if (!far) surv |= 1u << k;
-      }
-      for (int k = j + 1; k < 20; k++) {
-        if (!((surv >> k) & 1u)) continue;
-        double x[3];
-        if (!Concurrence(unit[i], unit[j], unit[k], x)) continue;
-        bool ok = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol on the register copies (same expression, same values)
-          if ((act_mask >> m) & 1u) ok = ok && (pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3] <= tol);
-        if (!ok) continue;
-        bool dup = false;
-        for (int v = 0; v < nv; v++) {
-          const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
-          if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;   // farther than 2 tol for certain: no sqrt
-          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
-            dup = true;
-            break;
-          }
-        }
-        if (!dup && nv < kPyrMaxVerts) {
-          verts[nv][0] = x[0];
-          verts[nv][1] = x[1];
-          verts[nv][2] = x[2];
-          nv++;
-        }
-      }
+    for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol
+      if ((act_mask >> m) & 1u) ok = ok && (pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3] <= tol);
+    if (!ok) return;
+    for (int v = 0; v < nv; v++) {
+      const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
+      if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;   // farther than 2 tol for certain: no sqrt
+      if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) return;   // duplicate
     }
+    if (nv < kPyrMaxVerts) {
+      verts[nv][0] = x[0];
+      verts[nv][1] = x[1];
+      verts[nv][2] = x[2];
+      nv++;
+    }
+  };
+  for (int b = 0; b < 2; b++) {   // i = 0, 1: a basal plane with two planes of its cone (or two prism planes without one)
+    const int lo = (b == 0) ? (upper ? 8 : 2) : (lower ? 14 : 2);
+    for (int j = lo; j < lo + 6; j++)
+      for (int k = j + 1; k < lo + 6; k++) try_triple(b, j, k);
+  }
+  for (int i = 2; i < 8; i++)     // i = prism plane: with a later prism plane and cone plane i of either cone
+    for (int j = i + 1; j < 8; j++) {
+      if (upper) try_triple(i, j, 8 + (i - 2));
+      if (lower) try_triple(i, j, 14 + (i - 2));
+    }
+  for (int c = 0; c < 2; c++) {   // i in a cone: three planes of the same cone
+    if (!(c == 0 ? upper : lower)) continue;
+    const int lo = (c == 0) ? 8 : 14;
+    for (int i = lo; i < lo + 6; i++)
+      for (int j = i + 1; j < lo + 6; j++)
+        for (int k = j + 1; k < lo + 6; k++) try_triple(i, j, k);
   }
   // a face is present with >= 3 vertices on its plane; the crystal needs >= 4 present faces
   // (IsValidClosedFormPyramid crystal.cpp:93-101), so the loops are ordered in a first pass and emitted in a second
@@ -512,9 +487,12 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     if (!active[s]) continue;
     const int cnt = member_cnt[s];
     if (cnt < 3) continue;
+    // centroid of the face's vertices: only the angular ORDER around it is used below (the loop starts at the face's first
+    // vertex whatever its value), so it is summed first and divided once — three fp64 divisions per face, not per vertex
     double c[3] = {0, 0, 0};
     for (int q = 0; q < cnt; q++)
-      for (int a = 0; a < 3; a++) c[a] += verts[on[s][q]][a] / static_cast<double>(cnt);
+      for (int a = 0; a < 3; a++) c[a] += verts[on[s][q]][a];
+    for (int a = 0; a < 3; a++) c[a] /= static_cast<double>(cnt);
     const double n[3] = {unit[s].a, unit[s].b, unit[s].c};
     double e1[3] = {verts[on[s][0]][0] - c[0], verts[on[s][0]][1] - c[1], verts[on[s][0]][2] - c[2]};
     const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);

@@ -18,9 +18,13 @@ constexpr int kGenBlock = 64;
 // S = ShapeDev (any crystal; 4.1 KB records) or ShapePrism (prism pools; 1.4 KB records).  Every record gets its counts
 // written (an invalid draw leaves them 0 = empty crystal) and rows beyond the counts are never read, so the pool needs no
 // clearing.
+#ifndef HALO_GEN_WAVES
+#define HALO_GEN_WAVES 2
+#endif
 template <class S>
-// (two waves per SIMD for the general builder: the pyramid enumeration keeps its 20 fp64 planes in registers)
-__global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? 2 : 1)) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
+// (waves per SIMD the general builder is compiled for: measured below; the pyramid feasibility scans keep the 20 fp64 planes
+// in registers)
+__global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? HALO_GEN_WAVES : 1)) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
                                                                    uint64_t first_index) {
   const uint32_t k = blockIdx.x * kGenBlock + threadIdx.x;
   if (k >= n) return;
