@@ -1134,6 +1134,20 @@ int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int
   return HALO_OK;
 }
 double halo_host_refractive_index(double wl) { return host::IceRefractiveIndex(wl); }
+float halo_host_illuminant_spd(int illuminant, float wl) { return host::IlluminantSpd(illuminant, wl); }
+int halo_host_wl_pool(const HaloWl* wl, float* entries5, int cap) {
+  if (!wl || !entries5 || cap < 0) return 0;
+  const std::vector<WlEntryDev> pool = host::BuildWlPool(*wl);
+  for (size_t m = 0; m < pool.size() && static_cast<int>(m) < cap; m++) {
+    float* e = entries5 + 5 * m;
+    e[0] = pool[m].n_idx;
+    e[1] = pool[m].spd_weight;
+    e[2] = pool[m].cmf_x;
+    e[3] = pool[m].cmf_y;
+    e[4] = pool[m].cmf_z;
+  }
+  return static_cast<int>(pool.size());
+}
 
 // sizes of the boundary structs, for the Python layout check
 uint64_t halo_abi_sizeof(int which) {

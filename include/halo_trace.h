@@ -391,6 +391,12 @@ int halo_host_partition(const float* proportions, int n, uint64_t ray_num, doubl
 int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int32_t sigma_a, int32_t d_applicable, uint8_t* out);
 /* IceRefractiveIndex::Get — optics.cpp:180-197. */
 double halo_host_refractive_index(double wavelength_nm);
+/* GetIlluminantSpd(type, wavelength) — util/illuminant.cpp:113-134 (HALO_ILLUM_*; 0 outside the tabulated range). */
+float halo_host_illuminant_spd(int illuminant, float wavelength_nm);
+/* ComputeWlPool — core/backend/wl_pool.hpp:67-91: the session's wavelength entries as the kernels read them, 5 floats each
+ * {refractive index, SPD weight, cmf_x, cmf_y, cmf_z}; a discrete HaloWl gives one entry.  Returns the entry count (<= cap
+ * entries are written), 0 on error. */
+int halo_host_wl_pool(const HaloWl* wl, float* entries5, int cap);
 int halo_abi_version(void);
 /* sizeof() of boundary structs as compiled (0 scene, 1 render, 2 wl, 3 exit record, 4 geom tables, 5 layer stats, 6 entry). */
 uint64_t halo_abi_sizeof(int which);
@@ -398,4 +404,34 @@ uint64_t halo_abi_sizeof(int which);
 #ifdef __cplusplus
 }
 #endif
+
+/* Layout pins of every struct that crosses the boundary (LP64, natural alignment).  A field added, removed or re-typed on
+ * either side of the ABI — here, in a binding (ice_halo_sim_amd/abi.py checks the same numbers through halo_abi_sizeof), or
+ * in the reference-side glue (integration/hip_backend_glue.hpp) — fails to compile instead of shifting what the kernels read. */
+#if defined(__cplusplus)
+#define HALO_STATIC_ASSERT(c, m) static_assert(c, m)
+#elif defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+#define HALO_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#else
+#define HALO_STATIC_ASSERT(c, m)
+#endif
+HALO_STATIC_ASSERT(sizeof(HaloDist) == 12, "HaloDist");
+HALO_STATIC_ASSERT(sizeof(HaloAxis) == 36, "HaloAxis");
+HALO_STATIC_ASSERT(sizeof(HaloCrystal) == 4 + 9 * 12 + 9 * 4 + 8, "HaloCrystal");
+HALO_STATIC_ASSERT(sizeof(HaloEntry) == sizeof(HaloCrystal) + sizeof(HaloAxis) + 16, "HaloEntry");
+HALO_STATIC_ASSERT(sizeof(HaloFilterTerm) == 8 + HALO_MAX_HITS + 16 + 8 + 12 + 4, "HaloFilterTerm");
+HALO_STATIC_ASSERT(sizeof(HaloFilter) == 16 + 4 * HALO_FILTER_MAX_OR + HALO_FILTER_MAX_TERMS * sizeof(HaloFilterTerm), "HaloFilter");
+HALO_STATIC_ASSERT(sizeof(HaloColorTerm) == sizeof(HaloFilterTerm) + 8, "HaloColorTerm");
+HALO_STATIC_ASSERT(sizeof(HaloColorSet) == 8 + HALO_COLOR_MAX_TERMS * sizeof(HaloColorTerm), "HaloColorSet");
+HALO_STATIC_ASSERT(sizeof(HaloColorClass) == 16, "HaloColorClass");
+HALO_STATIC_ASSERT(sizeof(HaloLayer) == 8 + HALO_MAX_ENTRIES * sizeof(HaloEntry), "HaloLayer");
+HALO_STATIC_ASSERT(sizeof(HaloScene) == 20 + HALO_MAX_LAYERS * sizeof(HaloLayer), "HaloScene");
+HALO_STATIC_ASSERT(sizeof(HaloRender) == 44, "HaloRender");
+HALO_STATIC_ASSERT(sizeof(HaloWl) == 16, "HaloWl");
+HALO_STATIC_ASSERT(sizeof(HaloHostRays) == 4 * sizeof(void*), "HaloHostRays");
+HALO_STATIC_ASSERT(sizeof(HaloLayerStats) == 56, "HaloLayerStats");
+HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 56, "HaloExitRecord");
+HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 32, "HaloRouteInfo");
+HALO_STATIC_ASSERT(sizeof(HaloDisplay) == 28, "HaloDisplay");
+HALO_STATIC_ASSERT(sizeof(HaloGeomTables) == 4 + HALO_MAX_FACES * 20 + 4 + HALO_MAX_TRIS * (36 + 12 + 4 + 4), "HaloGeomTables");
 #endif /* HALO_TRACE_H_ */

@@ -1011,13 +1011,33 @@ def test_reference_e2e_configs_parity(name):
         if io.sum() > 0:
             assert rel_l2(block_mean(ih), block_mean(io)) <= 4e-3
     else:
+        # More than one layer: the continuation order is nondeterministic on a GPU, so layers >= 1 pair rays with different
+        # draws on the two sides and parity is statistical.  The yardstick is the oracle's OWN seed-to-seed scatter on this very
+        # document (the reference battery's reading, test/e2e/_parity_metrics.py; tests/golden/NOISE_FLOOR.md): a second oracle
+        # render with the battery's second seed gives the floor, and HIP must sit within 4 floors (+ a small absolute term
+        # for floors that happen to come out tiny) of the first — instead of the fixed 2 % / 4 % / 0.9 this test used to allow.
+        ob2 = OracleBackend(seed=7, capture_exits=1, threads=8)
+        if job.geom_clock:
+            ob2.set_option("geom_clock", job.geom_clock)
+        ob2.set_filters(job.filters)
+        if job.color_classes:
+            ob2.set_color(job.color_sets, job.color_classes)
+        so2 = run_session(ob2, job.scene, rd, wl, n)
+        eo2 = ob2.DrainExits()
+        io2, lo2 = ob2.ReadbackXyzAccum()
+        ob2.close()
+
+        def within(h, a, b, abs_floor):
+            return abs(h - a) <= 4.0 * abs(a - b) + abs_floor
         for l in range(layers - 1):
-            assert sh[l].continuation_count == pytest.approx(so[l].continuation_count, rel=2e-2, abs=50)
-        assert len(eh) == pytest.approx(len(eo), rel=3e-2, abs=100)
-        assert lh == pytest.approx(lo, rel=4e-2, abs=1.0)
+            a, b = so[l].continuation_count, so2[l].continuation_count
+            assert within(sh[l].continuation_count, a, b, 5e-3 * a + 50), (l, sh[l].continuation_count, a, b)
+        assert within(len(eh), len(eo), len(eo2), 1e-2 * len(eo) + 100), (len(eh), len(eo), len(eo2))
+        assert within(lh, lo, lo2, 1e-2 * lo + 1.0), (lh, lo, lo2)
         if io.sum() > 0 and lo > 100.0:
-            a, b = block_mean(ih, 16)[..., 1].ravel(), block_mean(io, 16)[..., 1].ravel()
-            assert np.corrcoef(a, b)[0, 1] >= 0.9
+            pear = lambda x, y: float(np.corrcoef(block_mean(x, 16)[..., 1].ravel(), block_mean(y, 16)[..., 1].ravel())[0, 1])
+            floor_corr = pear(io, io2)
+            assert pear(ih, io) >= min(0.9, floor_corr) - 0.02 and pear(ih, io) >= floor_corr - 0.02, (pear(ih, io), floor_corr)
     if lanes is not None:
         th, to = lanes[0].sum(axis=(1, 2)), lanes[1].sum(axis=(1, 2))
         assert th == pytest.approx(to, rel=(2e-3 if layers == 1 else 6e-2), abs=1e-3 * max(float(to.max()), 1.0) + 0.5)
