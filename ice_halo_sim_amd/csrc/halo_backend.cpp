@@ -23,7 +23,7 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
-                           hipStream_t stream);
+                           hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
                        hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
@@ -81,6 +81,7 @@ struct HaloBackend {
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
+  int gen_serial = 0;          // 1: pyramids are generated one thread per crystal (the serial builder) instead of one team of 32 lanes
   int entry_fast = 1;          // 1: full prisms of one-shape dispatches take the slab-wise entry pick (EntryFastDev)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
   uint32_t shuffle_chunk_log2 = 5;   // Recombine's shuffle moves chunks of 2^k pool entries (k = 0: per ray, like the reference)
@@ -338,6 +339,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "bin") b->bin = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "entry_fast") b->entry_fast = v ? 1 : 0;
+  else if (k == "gen_serial") b->gen_serial = v ? 1 : 0;
   else if (k == "shuffle_chunk") {
     if (v < 1 || v > 64 || (v & (v - 1)) != 0) return fail(b, HALO_FATAL, "shuffle_chunk must be a power of two in [1, 64]");
     b->shuffle_chunk_log2 = 0;
@@ -748,7 +750,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         if (host_pool) {
           HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
         } else {  // device generator: one thread per sampled crystal, same stream → ordered before the trace kernel
-          hipError_t ge = launch_shapegen(b->shapes.ptr, geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream);
+          hipError_t ge = launch_shapegen(b->shapes.ptr, geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream, b->gen_serial != 0);
           if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
         }
         P.shapes = b->shapes.ptr;
@@ -884,7 +886,7 @@ int halo_generate_shapes(halo_handle_t b, const HaloCrystal* crystal, uint64_t f
     HIPCHK(b, hipSetDevice(b->device));
     DevBuf<ShapeDev> dev;
     HIPCHK(b, dev.reserve(n));
-    hipError_t ge = launch_shapegen(dev.ptr, false, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream);
+    hipError_t ge = launch_shapegen(dev.ptr, false, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream, b->gen_serial != 0);
     if (ge == hipSuccess) ge = hipMemcpyAsync(pool.data(), dev.ptr, static_cast<size_t>(n) * sizeof(ShapeDev), hipMemcpyDeviceToHost, b->stream);
     if (ge == hipSuccess) ge = hipStreamSynchronize(b->stream);
     dev.release();

@@ -339,12 +339,77 @@ HALO_GEOM_HD bool ConeApexZ(const Plane3* cone, double tol, int sign, double& z)
   return found;
 }
 
-constexpr int kPyrMaxVerts = 48;   // a hexagonal prism capped by two truncated hexagonal pyramids has 24 corners; the reference's pools peak at 30
+constexpr int kPyrMaxVerts = 40;   // a hexagonal prism capped by two truncated hexagonal pyramids has 24 corners; the reference's pools peak at 24
+
+// Plane of slot s (2..7 prism sides, 8..13 upper cone, 14..19 lower cone) as FillHexCrystalCoef states it (geo3d.cpp:346-512);
+// a1 / a2 = cone slopes, half = h2 / 2, k8 = sqrt3 / 8.  One definition for the serial builder and the team builder.
+HALO_GEOM_HD Plane3 PyrRawPlane(int s, double a1, double a2, double half, double k8, const float dist[6]) {
+  if (s < 8) {
+    const int i = s - 2;
+    return Plane3{0.5 * Cos6(i), 0.5 * Sin6(i), 0.0, -k8 * static_cast<double>(dist[i])};
+  }
+  if (s < 14) {
+    const int i = s - 8;
+    return Plane3{0.5 * a1 * Cos6(i), 0.5 * a1 * Sin6(i), k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
+  }
+  const int i = s - 14;
+  return Plane3{0.5 * a2 * Cos6(i), 0.5 * a2 * Sin6(i), -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
+}
+HALO_GEOM_HD Plane3 PyrUnitPlane(const Plane3& raw) {
+  const double len = sqrt(raw.a * raw.a + raw.b * raw.b + raw.c * raw.c);
+  return Plane3{raw.a / len, raw.b / len, raw.c / len, raw.d / len};
+}
+constexpr int kPyrFaceNumber[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
+
+// The vertices of one face, given as indices `on[0..cnt)` into verts, put into CCW order seen from outside (in place; the
+// loop starts at the face's first vertex).  Returns cnt, or 0 when the face degenerates to a point.  `ang` is caller-provided
+// scratch of cnt doubles.  One definition for the serial builder and the team builder.
+template <class IndexT>
+HALO_GEOM_HD int PyrOrderFace(const double (*verts)[3], IndexT* on, int cnt, const Plane3& unit, double tol, double* ang) {
+  // centroid of the face's vertices: only the angular ORDER around it is used below (the loop starts at the face's first
+  // vertex whatever its value), so it is summed first and divided once — three fp64 divisions per face, not per vertex
+  double c[3] = {0, 0, 0};
+  for (int q = 0; q < cnt; q++)
+    for (int a = 0; a < 3; a++) c[a] += verts[on[q]][a];
+  for (int a = 0; a < 3; a++) c[a] /= static_cast<double>(cnt);
+  const double n[3] = {unit.a, unit.b, unit.c};
+  double e1[3] = {verts[on[0]][0] - c[0], verts[on[0]][1] - c[1], verts[on[0]][2] - c[2]};
+  const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+  if (l1 <= tol) return 0;
+  for (int a = 0; a < 3; a++) e1[a] /= l1;
+  const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+  for (int q = 0; q < cnt; q++) {
+    const double r[3] = {verts[on[q]][0] - c[0], verts[on[q]][1] - c[1], verts[on[q]][2] - c[2]};
+    // sort key: a pseudo-angle that grows with atan2(y, x) mapped to [0, 2 pi) — t = |y| / (|x| + |y|) per quadrant, in
+    // [0, 4) — so the order is the CCW order an atan2 would give (the vertices of a face are at least 2 tol apart after the
+    // duplicate filter, far beyond any rounding of either key) at the price of one division
+    double a = 0.0;
+    if (q != 0) {
+      const double y = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], x = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
+      const double ax = fabs(x), ay = fabs(y);
+      const double t = (ax + ay > 0.0) ? ay / (ax + ay) : 0.0;
+      a = (y >= 0.0) ? (x >= 0.0 ? t : 2.0 - t) : (x < 0.0 ? 2.0 + t : 4.0 - t);
+    }
+    ang[q] = a;
+  }
+  for (int q = 1; q < cnt; q++) {  // stable insertion sort by angle
+    const double ka = ang[q];
+    const IndexT kv = on[q];
+    int p = q - 1;
+    while (p >= 0 && ang[p] > ka) {
+      ang[p + 1] = ang[p];
+      on[p + 1] = on[p];
+      p--;
+    }
+    ang[p + 1] = ka;
+    on[p + 1] = kv;
+  }
+  return cnt;
+}
 
 // cot_u / cot_l = sqrt3/4 / tan(wedge) for a legal wedge, negative = that cone absent (the caller evaluates tan once)
 HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float h2, float h3, const float dist[6], ShapeDev& out) {
   ClearShape(out);
-  const int number[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
   const bool upper = h1 > kGeomFloatEps && cot_u >= 0.0;
   const bool lower = h3 > kGeomFloatEps && cot_l >= 0.0;
   if (!upper && !lower && h2 < kGeomFloatEps) return false;
@@ -357,23 +422,14 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     active[s] = false;
     raw[s] = unit[s] = Plane3{0.0, 0.0, 0.0, 0.0};
   }
-  for (int i = 0; i < 6; i++) {
-    raw[2 + i] = Plane3{0.5 * Cos6(i), 0.5 * Sin6(i), 0.0, -k8 * static_cast<double>(dist[i])};
-    active[2 + i] = true;
-    if (upper) {
-      raw[8 + i] = Plane3{0.5 * a1 * Cos6(i), 0.5 * a1 * Sin6(i), k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
-      active[8 + i] = true;
-    }
-    if (lower) {
-      raw[14 + i] = Plane3{0.5 * a2 * Cos6(i), 0.5 * a2 * Sin6(i), -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
-      active[14 + i] = true;
-    }
+  for (int s = 2; s < 20; s++) {
+    active[s] = (s < 8) || (s < 14 ? upper : lower);
+    if (active[s]) raw[s] = PyrRawPlane(s, a1, a2, half, k8, dist);
   }
   double scale = fabs(half);
   for (int s = 2; s < 20; s++) {
     if (!active[s]) continue;
-    const double len = sqrt(raw[s].a * raw[s].a + raw[s].b * raw[s].b + raw[s].c * raw[s].c);
-    unit[s] = Plane3{raw[s].a / len, raw[s].b / len, raw[s].c / len, raw[s].d / len};
+    unit[s] = PyrUnitPlane(raw[s]);
     scale = fmax(scale, fabs(unit[s].d));
   }
   const double tol = 5.0 * static_cast<double>(kGeomFloatEps) * fmax(scale, 1e-3);
@@ -487,45 +543,8 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     if (!active[s]) continue;
     const int cnt = member_cnt[s];
     if (cnt < 3) continue;
-    // centroid of the face's vertices: only the angular ORDER around it is used below (the loop starts at the face's first
-    // vertex whatever its value), so it is summed first and divided once — three fp64 divisions per face, not per vertex
-    double c[3] = {0, 0, 0};
-    for (int q = 0; q < cnt; q++)
-      for (int a = 0; a < 3; a++) c[a] += verts[on[s][q]][a];
-    for (int a = 0; a < 3; a++) c[a] /= static_cast<double>(cnt);
-    const double n[3] = {unit[s].a, unit[s].b, unit[s].c};
-    double e1[3] = {verts[on[s][0]][0] - c[0], verts[on[s][0]][1] - c[1], verts[on[s][0]][2] - c[2]};
-    const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-    if (l1 <= tol) continue;
-    for (int a = 0; a < 3; a++) e1[a] /= l1;
-    const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
     double ang[HALO_MAX_FACE_VTX];
-    for (int q = 0; q < cnt; q++) {
-      const double r[3] = {verts[on[s][q]][0] - c[0], verts[on[s][q]][1] - c[1], verts[on[s][q]][2] - c[2]};
-      // sort key: a pseudo-angle that grows with atan2(y, x) mapped to [0, 2 pi) — t = |y| / (|x| + |y|) per quadrant, in
-      // [0, 4) — so the order is the CCW order an atan2 would give (the vertices of a face are at least 2 tol apart after the
-      // duplicate filter, far beyond any rounding of either key) at the price of one division
-      double a = 0.0;
-      if (q != 0) {
-        const double y = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], x = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
-        const double ax = fabs(x), ay = fabs(y);
-        const double t = (ax + ay > 0.0) ? ay / (ax + ay) : 0.0;
-        a = (y >= 0.0) ? (x >= 0.0 ? t : 2.0 - t) : (x < 0.0 ? 2.0 + t : 4.0 - t);
-      }
-      ang[q] = a;
-    }
-    for (int q = 1; q < cnt; q++) {  // stable insertion sort by angle
-      const double ka = ang[q];
-      const int kv = on[s][q];
-      int p = q - 1;
-      while (p >= 0 && ang[p] > ka) {
-        ang[p + 1] = ang[p];
-        on[s][p + 1] = on[s][p];
-        p--;
-      }
-      ang[p + 1] = ka;
-      on[s][p + 1] = kv;
-    }
+    if (PyrOrderFace(verts, on[s], cnt, unit[s], tol, ang) == 0) continue;
     on_n[s] = cnt;
     present++;
   }
@@ -538,7 +557,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     const float nrm[3] = {static_cast<float>(unit[s].a), static_cast<float>(unit[s].b), static_cast<float>(unit[s].c)};
     for (int q = 0; q < on_n[s]; q++)
       for (int a = 0; a < 3; a++) loop[q][a] = static_cast<float>(verts[on[s][q]][a]);
-    EmitFace(out, cur, plane, nrm, number[s], loop, on_n[s]);
+    EmitFace(out, cur, plane, nrm, kPyrFaceNumber[s], loop, on_n[s]);
   }
   FinalizeSlabs(out, cur);
   return out.face_cnt > 0;
@@ -560,9 +579,9 @@ HALO_GEOM_HD bool BuildPyramidDispatch(const CrystalRecipe&, const float*, const
   return false;
 }
 
-// S = ShapeDev (any crystal) or ShapePrism (prisms only: a pyramid recipe yields the empty shape)
-template <class S>
-HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, S& out) {
+// The shape scalars of crystal instance `shape_index`, slot order [h0, h1, h2, d0..d5] (prism: h0 only), raw draws (heights
+// are folded with fabs by the callers).  Members of a sync group share the draw of the group's first member.
+HALO_GEOM_HD void DrawShapeScalars(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, float sc[9]) {
   const HaloCrystal& c = rc.c;
   const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
   const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
@@ -571,7 +590,7 @@ HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t 
   int grp[9];
   float val[9];
   int cached = 0;
-  float sc[9];
+  for (int i = 0; i < 9; i++) sc[i] = 0.0f;
   const int n_h = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
   for (int i = 0; i < n_h + 6; i++) {
     const int slot = (i < n_h) ? i : 3 + (i - n_h);
@@ -596,6 +615,61 @@ HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t 
     }
     sc[slot] = v;
   }
+}
+
+// RNG slots one draw of `d` consumes (Uniform: 1, Box-Muller Gaussian: 2; see Draw)
+HALO_GEOM_HD uint32_t DrawSlots(const HaloDist& d) {
+  switch (d.type) {
+    case HALO_DIST_UNIFORM:
+    case HALO_DIST_ZIGZAG:
+    case HALO_DIST_LAPLACIAN: return 1u;
+    case HALO_DIST_GAUSS:
+    case HALO_DIST_GAUSS_LEGACY: return 2u;
+    default: return 0u;
+  }
+}
+// ONE of the nine scalars of DrawShapeScalars (slot `want` of [h0, h1, h2, d0..d5]; 0 for a slot the crystal kind does not
+// have): walks the same draw sequence, stepping the stream over the draws that are not asked for instead of evaluating them
+// (a Gaussian draw is a logf and a cosf).  Lets nine lanes draw the nine scalars side by side.
+HALO_GEOM_HD float DrawShapeScalarOne(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, int want) {
+  const HaloCrystal& c = rc.c;
+  const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
+  const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
+  ScalarStream rng{(hi == 0u) ? (seed ^ kNonceShape) : ((seed ^ kNonceShape) ^ PcgHash32(hi)), lo * 1000003u, 0u};
+  const int n_h = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
+  // the slot whose draw `want` takes: itself, or the first member (in draw order) of its sync group
+  int target = -1;
+  const int want_group = (want >= 0 && want < 9) ? c.sync_group[want] : 0;
+  bool want_exists = false;
+  for (int i = 0; i < n_h + 6; i++) {
+    const int slot = (i < n_h) ? i : 3 + (i - n_h);
+    if (slot == want) want_exists = true;
+    if (target < 0 && (slot == want || (want_group != 0 && c.sync_group[slot] == want_group))) target = slot;
+  }
+  if (!want_exists || target < 0) return 0.0f;
+  int seen_groups[9];
+  int n_seen = 0;
+  for (int i = 0; i < n_h + 6; i++) {
+    const int slot = (i < n_h) ? i : 3 + (i - n_h);
+    const HaloDist& d = (i < n_h) ? c.height[i] : c.face_dist[i - n_h];
+    const int group = c.sync_group[slot];
+    bool have = false;
+    if (group != 0)
+      for (int q = 0; q < n_seen; q++) have = have || (seen_groups[q] == group);
+    if (have) continue;                 // a later member of a group: reuses, draws nothing
+    if (slot == target) return Draw(rng, d);
+    rng.slot += DrawSlots(d);
+    if (group != 0) seen_groups[n_seen++] = group;
+  }
+  return 0.0f;
+}
+
+// S = ShapeDev (any crystal) or ShapePrism (prisms only: a pyramid recipe yields the empty shape)
+template <class S>
+HALO_GEOM_HD bool MakeShapeDev(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, S& out) {
+  const HaloCrystal& c = rc.c;
+  float sc[9];
+  DrawShapeScalars(seed, rc, shape_index, sc);
   float dist[6];
   for (int i = 0; i < 6; i++) dist[i] = sc[3 + i];
   if (c.kind == HALO_CRYSTAL_PRISM) return BuildPrismShape(fabsf(sc[0]), dist, out);  // heights fold, distances stay signed

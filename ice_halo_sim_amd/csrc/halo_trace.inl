@@ -36,7 +36,7 @@ namespace halo {
 __device__ unsigned long long g_halo_probe[16];
 struct Probe {
   uint64_t t0;
-  uint32_t acc[12];
+  uint32_t acc[14];
 };
 HD void probe_start(Probe& pr) {
   __builtin_amdgcn_sched_barrier(0);
@@ -57,7 +57,7 @@ struct Probe {};
 #define PROBE_MARK(pr, K) ((void)0)
 #endif
 enum { kPhStream = 0, kPhOrient = 1, kPhRotation = 2, kPhSun = 3, kPhEntry = 4, kPhFresnel = 5, kPhEmitGate = 6, kPhProject = 7,
-       kPhAccum = 8, kPhSlab = 9, kPhKernelFixed = 10, kPhTotal = 11 };
+       kPhAccum = 8, kPhSlab = 9, kPhKernelFixed = 10, kPhTotal = 11, kPhStage = 12, kPhFlush = 13 };
 
 constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
 constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
@@ -1448,7 +1448,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
-  for (int k = 0; k < 12; k++) pr.acc[k] = 0u;
+  for (int k = 0; k < 14; k++) pr.acc[k] = 0u;
   probe_start(pr);
   const uint64_t t_begin = pr.t0;
 #endif
@@ -1551,14 +1551,18 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
     for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
       const uint32_t tid = base + threadIdx.x;
       const uint32_t first = base + (threadIdx.x & ~31u);
+      PROBE_MARK(pr, kPhSlab);   // (loop bookkeeping since the last ray goes with the previous phase)
       if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolSlot*>(P.shapes) + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
+      PROBE_MARK(pr, kPhStage);
       if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums, pr);
       __builtin_amdgcn_wave_barrier();
+      PROBE_MARK(pr, kPhSlab);
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
       }
+      PROBE_MARK(pr, kPhFlush);
     }
    }
   }
@@ -1618,7 +1622,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   PROBE_MARK(pr, kPhKernelFixed);
   pr.acc[kPhTotal] = static_cast<uint32_t>(pr.t0 - t_begin);
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 12; k++) atomicAdd(&g_halo_probe[k], static_cast<unsigned long long>(pr.acc[k]));
+    for (int k = 0; k < 14; k++) atomicAdd(&g_halo_probe[k], static_cast<unsigned long long>(pr.acc[k]));
 #endif
 }
 

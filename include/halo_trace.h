@@ -265,6 +265,8 @@ const char* halo_last_error(halo_handle_t h);
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
  * workgroup below that cap),
+ * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
+ * same builder the host runs; records are bit-identical either way, A/B knob),
  * "entry_fast" (1 [default]: one-shape dispatches of a full 8-face prism pick the entry face slab by slab, in registers;
  * 0: the generic walk over faces — same uniform, same cumulative order, A/B knob),
  * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in

@@ -14,7 +14,7 @@ from ice_halo_sim_amd.backend import HipTraceBackend, load_library  # noqa: E402
 from tests._oracle_backend import run_session  # noqa: E402
 
 NAMES = ["streams+wavelength", "orientation sample", "rotation matrix", "sun cone + R^T", "entry pick", "fresnel", "emit: rotate/filter/gate",
-         "emit: project", "emit: accumulate", "slab search + advance", "kernel prologue/epilogue", "TOTAL (wave resident)"]
+         "emit: project", "emit: accumulate", "slab search + advance", "kernel prologue/epilogue", "TOTAL (wave resident)", "pool: stage shape record", "binned: flush hit buffer"]
 
 
 def dump(reset=True):
@@ -35,9 +35,9 @@ def run(label, sc, rd, wl, n):
     hb.close()
     tot = max(v[11], 1)
     print("%s: %d rays, kernels %.3f ms" % (label, n, sum(s.kernel_ms for s in st)))
-    for k in range(11):
+    for k in list(range(11)) + [12, 13]:
         print("   %-28s %6.2f %%" % (NAMES[k], 100.0 * v[k] / tot))
-    print("   %-28s %6.2f %%   (loop overhead, stamps, divergence waits)" % ("unattributed", 100.0 * (tot - sum(v[:11])) / tot))
+    print("   %-28s %6.2f %%   (loop overhead, stamps, divergence waits)" % ("unattributed", 100.0 * (tot - sum(v[:11]) - v[12] - v[13]) / tot))
 
 
 which = sys.argv[1:] or ["cfg1"]
