@@ -122,31 +122,28 @@ def _pmc_mean(name, key, kernel="halo_trace_kernel"):
 
 def pmc_traffic_per_launch(cfg):
     """HBM-side bytes per trace-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>_bench<cfg>_pmc_{fetch,write}_size.txt; counters are collected in their own runs, never inside the timed
-    one).  FETCH_SIZE / WRITE_SIZE are in KB; this kernel's traffic is scattered atomics, for which the guide calls the
-    counters uncalibrated — reported as measured, uncorrected."""
+    (profiles/<round>_bench<cfg>_pmc_{fetch,write}_size.txt; FETCH_SIZE and WRITE_SIZE are collected in their own passes —
+    they do not fit one — and never inside the timed run).  Units and corrections per MI355X_MICROARCH.md §HBM: both counters
+    are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (64 B tallied per 128-B
+    request), so it is doubled; WRITE_SIZE (here: atomic read-modify-writes and 4/8-byte stores) is uncalibrated and taken
+    as reported."""
     tag = "%s_bench%s" % (PROFILE_ROUND, cfg)
     f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE"), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE")
-    return None if f is None or w is None else (f + w) * 1024.0
+    return None if f is None or w is None else (2.0 * f + w) * 1024.0
 
 
 def pmc_valu(cfg, rays_per_launch):
-    """VALU issue utilisation and instructions per 64-ray wave pass of the trace kernel, from the committed PMC pass
-    (per-dispatch means are per counter instance = 32 SIMDs).  Issue fraction = VALU wave-instructions per SIMD x 4 cycles
-    (a wave64 VALU instruction occupies a SIMD for 4 cycles) / kernel duration of that same pass at the nominal 2.4 GHz."""
-    name = "%s_bench%s_pmc_insts.txt" % (PROFILE_ROUND, cfg)
-    insts = _pmc_mean(name, "SQ_INSTS_VALU")
-    path = os.path.join(ROOT, "profiles", name)
-    avg_us = None
-    if os.path.exists(path):
-        for line in open(path):
-            if "halo_trace_kernel" in line and "SQ_" not in line:
-                avg_us = float(line.split()[-4])          # calls total_us avg_us min_us max_us pct
-                break
-    if not insts or not avg_us:
+    """VALU occupancy of the trace kernel from the committed PMC passes (per-dispatch means are per counter instance = one
+    shader engine = 32 SIMDs): instructions per 64-ray wave pass from SQ_INSTS_VALU; VALU-active fraction =
+    SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 32 SIMDs / SQ_BUSY_CYCLES of the same pass — measured cycles, no clock assumed."""
+    insts = _pmc_mean("%s_bench%s_pmc_insts.txt" % (PROFILE_ROUND, cfg), "SQ_INSTS_VALU")
+    cyc = "%s_bench%s_pmc_cycles.txt" % (PROFILE_ROUND, cfg)
+    active, busy, wave = _pmc_mean(cyc, "SQ_ACTIVE_INST_VALU"), _pmc_mean(cyc, "SQ_BUSY_CYCLES"), _pmc_mean(cyc, "SQ_WAVE_CYCLES")
+    if not insts or not active or not busy:
         return None
-    return {"valu_issue_frac": (insts / 32.0) * 4.0 / (avg_us * 1e-6 * 2.4e9), "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
-            "assumes": "4 cycles per wave64 VALU instruction, 2.4 GHz", "source": "profiles/" + name}
+    return {"valu_active_frac": active * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
+            "waves_per_simd": (wave * 4.0 / busy / 32.0) if wave else None,
+            "source": "profiles/%s_bench%s_pmc_{insts,cycles}.txt (counter means over every launch of the kernel in that pass)" % (PROFILE_ROUND, cfg)}
 
 
 def main():
@@ -290,11 +287,11 @@ def main():
                         "ms_per_step_all": [x * 1e3 / args.steps for x in times]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(args.config),
-                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command, bytes per launch, uncorrected)" % (PROFILE_ROUND, args.config),
+                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated; mean over every launch of the trace kernel in the pass)" % (PROFILE_ROUND, args.config),
                          "kernel": wk["kernel"], "launches": dom_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
                          "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
-                         "valu": pmc_valu(args.config, n),
+                         "valu": pmc_valu(args.config, (rays_per_rank + first_layer["cont"]) / max(launches, 1)),
                          "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
         }
         if layers > 1:

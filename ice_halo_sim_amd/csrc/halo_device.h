@@ -78,6 +78,23 @@ struct EntryFastDev {
 };
 static_assert(sizeof(EntryFastDev) % 16 == 0, "copied as float4");
 
+// LDS slot of a general pool shape (the HBM record stays a ShapeDev).  A convex solid with V corners has 2 (V - 2) fan
+// triangles whatever its faces look like (Euler), and the pyramid family has at most 24 corners (two hexagonal rings per
+// cap) — 44 triangles; 48 rows instead of ShapeDev's 64 make the slot 3.2 KB, and a workgroup's eight slots plus its tables
+// then fit three times into a CU's LDS instead of twice.  stage_shape clamps to the slot's capacity like it always did.
+struct ShapeSlot48 {
+  int32_t face_cnt, tri_cnt, slab_cnt, single_cnt;
+  float face[kMaxFaces][4];
+  float slab[kMaxSlabs][8];
+  float tri_v[48][9];
+  float tri_na[48][4];
+  uint8_t tri_face[48];
+  uint8_t face_number[kMaxFaces];
+  uint8_t single[kMaxFaces];
+  uint8_t pad[8];
+};
+static_assert(sizeof(ShapeSlot48) % 16 == 0, "rows are read as float4");
+
 struct WlEntryDev {  // reference WlEntry, src/core/backend/wl_pool.hpp:29-35 (+pad to 32 B)
   float n_idx, spd_weight, cmf_x, cmf_y, cmf_z, pad0, pad1, pad2;
 };

@@ -861,13 +861,18 @@ static_assert(offsetof(ShapeDev, tri_v) % 16 == 0 && offsetof(ShapeDev, tri_na) 
 
 constexpr int kGeomOne = 0, kGeomPool = 1, kGeomPoolPrism = 2;   // GEOM: one shape per dispatch | pool of ShapeDev | pool of ShapePrism (HBM records and LDS slots)
 template <int GEOM>
-struct PoolSlotType {
-  typedef ShapeDev type;
+struct PoolSlotType {   // type = the LDS slot of a half-wave, rec = the record in the HBM pool
+  typedef ShapeSlot48 type;
+  typedef ShapeDev rec;
 };
 template <>
 struct PoolSlotType<kGeomPoolPrism> {
   typedef ShapePrism type;
+  typedef ShapePrism rec;
 };
+static_assert(offsetof(ShapeSlot48, tri_v) % 16 == 0 && offsetof(ShapeSlot48, tri_na) % 16 == 0 && offsetof(ShapeSlot48, slab) % 16 == 0 &&
+              offsetof(ShapeSlot48, tri_face) % 4 == 0 && offsetof(ShapeSlot48, face_number) % 4 == 0 && offsetof(ShapeSlot48, single) % 4 == 0,
+              "rows are copied as float4 / dwords");
 template <bool ON, typename SlotT, int N = kBlock / 32>
 struct PoolSlots {
   SlotT s[N];
@@ -878,8 +883,8 @@ struct PoolSlots<false, SlotT, N> {
 };
 
 // 32 lanes copy the rows one pool shape uses into their half-wave's LDS slot (coalesced 16-byte loads)
-template <typename SlotT>
-HD void stage_shape(SlotT* slot, const SlotT* g, uint32_t l32) {
+template <typename SlotT, typename RecT>
+HD void stage_shape(SlotT* slot, const RecT* g, uint32_t l32) {
   constexpr uint32_t kF = sizeof(slot->face) / 16u, kS = sizeof(slot->slab) / 32u, kT = sizeof(slot->tri_na) / 16u, kN = sizeof(slot->single);
   const uint32_t fc = min(static_cast<uint32_t>(g->face_cnt), kF), tc = min(static_cast<uint32_t>(g->tri_cnt), kT);
   const uint32_t sc = min(static_cast<uint32_t>(g->slab_cnt), kS), n1 = min(static_cast<uint32_t>(g->single_cnt), kN);
@@ -1465,6 +1470,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
   constexpr bool POOL = GEOM != kGeomOne;
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
+  typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, ShapeDev, 1> s_shape;  // deterministic: the dispatch's one shape
   __shared__ __attribute__((aligned(16))) ColorSlot<MODE != kModePlain> s_color;
@@ -1552,7 +1558,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       const uint32_t tid = base + threadIdx.x;
       const uint32_t first = base + (threadIdx.x & ~31u);
       PROBE_MARK(pr, kPhSlab);   // (loop bookkeeping since the last ray goes with the previous phase)
-      if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolSlot*>(P.shapes) + first / P.geom_clock, l32);
+      if (first < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolRec*>(P.shapes) + first / P.geom_clock, l32);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhStage);
@@ -1571,7 +1577,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       const uint32_t tid = base + threadIdx.x;
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
-          const PoolSlot* sh = reinterpret_cast<const PoolSlot*>(P.shapes) + (tid / P.geom_clock);
+          const PoolRec* sh = reinterpret_cast<const PoolRec*>(P.shapes) + (tid / P.geom_clock);
           trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums, pr);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
