@@ -21,10 +21,13 @@ constexpr int kGenBlock = 64;
 #ifndef HALO_GEN_WAVES
 #define HALO_GEN_WAVES 2
 #endif
+#ifndef HALO_GEN_WAVES_PRISM
+#define HALO_GEN_WAVES_PRISM 1
+#endif
 template <class S>
 // (waves per SIMD the general builder is compiled for: measured below; the pyramid feasibility scans keep the 20 fp64 planes
 // in registers)
-__global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? HALO_GEN_WAVES : 1)) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
+__global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? HALO_GEN_WAVES : HALO_GEN_WAVES_PRISM)) halo_shapegen_kernel(S* __restrict__ pool, uint32_t n, uint32_t seed, const geom::CrystalRecipe rc,
                                                                    uint64_t first_index) {
   const uint32_t k = blockIdx.x * kGenBlock + threadIdx.x;
   if (k >= n) return;
