@@ -45,6 +45,7 @@ def build(force=False, verbose=False):
             if PROBE:
                 cmd.append("-DHALO_PROBE=1")
             cmd += os.environ.get("HALO_DEFS", "").split()
+            cmd += os.environ.get("HALO_HIPFLAGS", "").split()   # experiment knob: extra compiler flags for the kernel TUs
             for knob in ("HALO_MIN_WAVES", "HALO_MIN_WAVES_FILTER"):
                 if os.environ.get(knob):
                     cmd.append("-D%s=%s" % (knob, os.environ[knob]))

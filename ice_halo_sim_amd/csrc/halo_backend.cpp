@@ -5,6 +5,7 @@
 //   halo_begin → (halo_trace_layer → halo_recombine)* → halo_trace_layer → halo_end ; halo_readback_xyz any time.
 // There is no CPU fallback in this library: every entry point that computes needs a gfx950 device and fails
 // with HALO_UNAVAILABLE otherwise.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -934,6 +935,29 @@ int halo_last_sample_counts(halo_handle_t b, uint64_t* crystal_samples, uint64_t
 int halo_last_route(halo_handle_t b, HaloRouteInfo* out) {
   if (!b || !out) return HALO_FATAL;
   *out = b->route;
+  return HALO_OK;
+}
+
+int halo_reduce_accumulator(halo_handle_t b, void* nccl_comm, int root, int this_rank) {
+  if (!b || !nccl_comm) return HALO_FATAL;
+  if (!b->acc || b->acc_w <= 0) return fail(b, HALO_FATAL, "reduce_accumulator before any session");
+  // ncclReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, root, comm, stream) — rccl.h:550
+  typedef int (*nccl_reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
+  static nccl_reduce_fn reduce = nullptr;
+  if (!reduce) {
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib) reduce = reinterpret_cast<nccl_reduce_fn>(dlsym(lib, "ncclReduce"));
+    if (!reduce) return fail(b, HALO_UNAVAILABLE, "RCCL (librccl.so: ncclReduce) cannot be loaded");
+  }
+  HIPCHK(b, hipSetDevice(b->device));
+  int rc = fold_if_dirty(b);   // an unfinished session still owes its planes to the accumulator
+  if (rc != HALO_OK) return rc;
+  const size_t n = static_cast<size_t>(b->acc_w) * static_cast<size_t>(b->acc_h) * 3 + 4;
+  const int nr = reduce(b->acc, b->acc, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, root, nccl_comm, b->stream);
+  if (nr != 0) return fail(b, HALO_FATAL, "ncclReduce failed with code " + std::to_string(nr));
+  if (this_rank != root) HIPCHK(b, hipMemsetAsync(b->acc, 0, n * sizeof(float), b->stream));   // drained, in stream order
   return HALO_OK;
 }
 

@@ -105,6 +105,13 @@ class HipTraceBackend {
     lane_data.assign(class_count_ * static_cast<size_t>(width_) * static_cast<size_t>(height_), 0.0f);
     if (class_count_) Check(halo_readback_class_lanes(h_, lane_data.data(), width_, height_, static_cast<int>(class_count_)));
   }
+  // multi-GPU drain from a C++ host: one ncclReduce of the accumulator onto `root`, the other ranks drained (halo_reduce_accumulator)
+  void ReduceAccumulator(void* nccl_comm, int root, int this_rank) { Check(halo_reduce_accumulator(h_, nccl_comm, root, this_rank)); }
+  double TakeLanded() {
+    double l = 0.0;
+    Check(halo_take_landed(h_, &l));
+    return l;
+  }
   // option "async" = 1: final-layer TraceLayer only queues; the summed LayerStats of everything traced since the last call
   HaloLayerStats CollectStats() {
     HaloLayerStats st{};

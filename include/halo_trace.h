@@ -341,6 +341,15 @@ int halo_collect_stats(halo_handle_t h, HaloLayerStats* out);
  * bound external accumulator that is reduced across ranks in place. */
 int halo_take_landed(halo_handle_t h, double* landed_weight);
 
+/* Multi-GPU drain for a C/C++ host (one process — or one thread — per GPU, one backend per GPU): sum-reduce this rank's XYZ
+ * accumulator (width*height*3+4 floats, owned or bound) onto rank `root` with ONE ncclReduce over RCCL/xGMI, queued on the
+ * backend's stream behind its trace kernels; every other rank's accumulator is then zeroed (drained) in stream order.
+ * `nccl_comm` is the caller's ncclComm_t (rccl.h); `root` its root rank.  The landed-weight scalars stay on their devices: read
+ * them with halo_take_landed and add on the host.  RCCL is loaded lazily (dlopen "librccl.so"): the library has no link-time
+ * dependency on it, and a host that never calls this never loads it.  HALO_UNAVAILABLE when RCCL cannot be loaded.
+ * Reference: the drain point is Simulator::DrainDeviceXyz (simulator.cpp:1409-1477); Lumice itself has no multi-GPU code. */
+int halo_reduce_accumulator(halo_handle_t h, void* nccl_comm, int root, int this_rank);
+
 /* --- consumer on device (RenderConsumer::ConsumeDeviceFused / PrepareSnapshot / PostSnapshot, server/render.cpp) -- */
 /* HaloDisplay: the RenderConfig fields PostSnapshot reads (render_config.hpp:84-92). ray_color[0] < 0 = real colour. */
 typedef struct HaloDisplay {

@@ -1,5 +1,7 @@
 // Exercises ice_halo_sim_amd/csrc/hip_trace_backend.hpp the way Simulator::SimulateOneWavelengthWithBackend drives a
 // backend (reference simulator.cpp:1498-1632).  Exit codes: 0 ok, 3 BackendUnavailableError (no gfx950), 1 failure.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -101,6 +103,39 @@ int main() {
     for (uint8_t v : rgb) mx = v > mx ? v : mx;
     std::printf("consumer: total intensity %.3f max rgb %u\n", total, mx);
     ok = ok && total > 0.0 && mx > 0;
+
+    // multi-GPU drain from C++: a one-rank RCCL communicator — the reduce is the identity, the call path
+    // (lazy dlopen of librccl, ncclReduce on the backend's stream) is what is exercised here
+    {
+      void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      typedef int (*init_all_fn)(void**, int, const int*);
+      typedef int (*destroy_fn)(void*);
+      init_all_fn init_all = lib ? reinterpret_cast<init_all_fn>(dlsym(lib, "ncclCommInitAll")) : nullptr;
+      destroy_fn destroy = lib ? reinterpret_cast<destroy_fn>(dlsym(lib, "ncclCommDestroy")) : nullptr;
+      void* comm = nullptr;
+      const int dev0 = 0;
+      if (init_all && destroy && init_all(&comm, 1, &dev0) == 0) {
+        be.SetOption("async", 0);
+        be.SetFilters({});
+        be.SetColor({}, {});
+        sc.layers[0].entries[0].filter_id = 0;
+        sc.layers[0].entries[0].color_id = 0;
+        be.BeginSession(sc, rd, wl, n);
+        be.TraceLayer(n);
+        be.EndSession();
+        be.ReduceAccumulator(comm, 0, 0);
+        float landed3 = 0.0f;
+        be.ReadbackXyzAccum(xyz, landed3);
+        double y3 = 0.0;
+        for (size_t i = 1; i < img.size(); i += 3) y3 += img[i];
+        std::printf("rccl one-rank reduce: landed %.3f sumY %.3f\n", landed3, y3);
+        ok = ok && landed3 > 0.4f * n && std::fabs(y3 / (0.995 * landed3) - 1.0) < 0.02;
+        destroy(comm);
+      } else {
+        std::printf("rccl not loadable here: reduce path skipped\n");
+      }
+    }
     return ok ? 0 : 1;
   } catch (const halo::BackendUnavailableError& e) {
     std::printf("BackendUnavailableError: %s\n", e.what());

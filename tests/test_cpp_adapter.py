@@ -15,7 +15,7 @@ def _build():
     backend.load_library()
     libdir = os.path.join(ROOT, "ice_halo_sim_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", EXE, os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp"),
-                           "-L" + libdir, "-lhalo_hip", "-Wl,-rpath," + libdir])
+                           "-L" + libdir, "-lhalo_hip", "-ldl", "-Wl,-rpath," + libdir])
 
 
 def test_adapter_compiles_and_reports_unavailable_without_gpu():
