@@ -8,7 +8,7 @@ import ctypes as C
 HALO_OK, HALO_UNAVAILABLE, HALO_FATAL = 0, 1, 2
 MAX_LAYERS, MAX_ENTRIES, MAX_HITS, MAX_FACES, MAX_FACE_VTX, MAX_TRIS = 4, 16, 64, 20, 12, 64
 HALO_MAX_LAYERS, HALO_MAX_ENTRIES, HALO_MAX_HITS = MAX_LAYERS, MAX_ENTRIES, MAX_HITS
-LUT_NODES, WL_POOL_MAX, PATH_CAP = 257, 255, 16
+LUT_NODES, WL_POOL_MAX, PATH_CAP = 257, 255, 64
 
 DIST_NONE, DIST_UNIFORM, DIST_GAUSS, DIST_ZIGZAG, DIST_LAPLACIAN, DIST_GAUSS_LEGACY = range(6)
 CRYSTAL_PRISM, CRYSTAL_PYRAMID = 0, 1

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define HALO_ABI_VERSION 3   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
-                                halo_drain_exits, option "shuffle_chunk" */
+                                halo_drain_exits, option "shuffle_chunk", exit records carry full 64-face paths */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 
@@ -39,7 +39,7 @@ enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 #define HALO_MAX_TRIS 64         /* lm_pcg::kMaxTriPerKernel, src/core/shared/pcg_shared.h:71 */
 #define HALO_LUT_NODES 257       /* LatLut::kNodes, src/core/lat_lut.hpp:31 */
 #define HALO_WL_POOL_MAX 255     /* kWlPoolSizeMax, src/core/backend/wl_pool.hpp:41 */
-#define HALO_PATH_CAP 16         /* face numbers kept per exit record (reference ExitFaceSeq::kCap is 64) */
+#define HALO_PATH_CAP 64         /* face numbers kept per exit record = the reference's ExitFaceSeq::kCap (exit_seam.hpp:22) */
 
 /* DistributionType — src/core/math.hpp:123-130 (values are wire values, pcg_shared.h:64-69). */
 enum {
@@ -441,7 +441,7 @@ HALO_STATIC_ASSERT(sizeof(HaloRender) == 44, "HaloRender");
 HALO_STATIC_ASSERT(sizeof(HaloWl) == 16, "HaloWl");
 HALO_STATIC_ASSERT(sizeof(HaloHostRays) == 4 * sizeof(void*), "HaloHostRays");
 HALO_STATIC_ASSERT(sizeof(HaloLayerStats) == 56, "HaloLayerStats");
-HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 56, "HaloExitRecord");
+HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 40 + HALO_PATH_CAP, "HaloExitRecord");
 HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 32, "HaloRouteInfo");
 HALO_STATIC_ASSERT(sizeof(HaloDisplay) == 28, "HaloDisplay");
 HALO_STATIC_ASSERT(sizeof(HaloGeomTables) == 4 + HALO_MAX_FACES * 20 + 4 + HALO_MAX_TRIS * (36 + 12 + 4 + 4), "HaloGeomTables");

@@ -756,8 +756,8 @@ def test_edge_zero_proportion_and_empty_crystal():
 
 @pytest.mark.parametrize("max_hits", [1, 2, 16, 64])
 def test_edge_max_hits_limits(max_hits):
-    """max_hits = 1 (entry reflection only) up to HALO_MAX_HITS = 64; recorded paths saturate at HALO_PATH_CAP = 16 face
-    numbers while path_len keeps counting (ExitFaceSeq semantics)."""
+    """max_hits = 1 (entry reflection only) up to HALO_MAX_HITS = 64; exit records carry the full path (HALO_PATH_CAP = 64 face
+    numbers = the reference's ExitFaceSeq::kCap, exit_seam.hpp:22), compared face by face with the oracle's."""
     sc = scenes.scene([(0.0, [scenes.column_crystal_entry()])], max_hits=max_hits)
     r = run_both(sc, scenes.config2_render(320, 180), scenes.wl_discrete(550.0), 20_000 if max_hits < 64 else 4_000, seed=17)
     assert r["sh"][0].exit_count == pytest.approx(r["so"][0].exit_count, rel=2e-3)
@@ -766,6 +766,7 @@ def test_edge_max_hits_limits(max_hits):
     if max_hits == 1:
         assert (r["eh"]["seq"] == 0).all() and (r["eh"]["path_len"] == 1).all()      # only the external reflection leaves
     assert int(r["eh"]["seq"].max()) <= 2 * max_hits - 1
+    assert int(r["eh"]["path_len"].max()) == max_hits == int(r["eo"]["path_len"].max())        # the longest path is recorded whole
     # energy: what has not left after max_hits interactions is dropped; exits never exceed the injected weight
     assert r["sh"][0].exit_w_sum <= r["sh"][0].root_count * (1 + 1e-5)
 
