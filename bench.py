@@ -71,7 +71,7 @@ def workload(cfg):
         if cfg == "4":
             e = scenes.stochastic_prism_entry()
             what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,2,true,true> + halo_bin_split_kernel + halo_bin_accumulate_range_kernel"
+            kern = "halo_trace_kernel<0,2,true,true> + halo_split_kernel + halo_bin_accumulate_range_kernel"
         else:
             e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
                              scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)

@@ -23,6 +23,8 @@ hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream,
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
+hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
+                            uint32_t tiles, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -83,6 +85,9 @@ struct HaloBackend {
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int gen_serial = 0;          // 1: pyramids are generated one thread per crystal (the serial builder) instead of one team of 32 lanes
+  int hit_log = -1;            // hit-log accumulation of cache misses: -1 auto (one-plane sessions, launches >= 2 Mi rays), 0 off, 1 on
+  uint32_t hit_log_cap = 0;    // test knob: records per log region (0 = sized from the launch); the tile lists then get half their even share
+  int hex_fast = 1;            // 1: regular hexagonal prisms of one-shape dispatches run the literal-normal next-face search
   int entry_fast = 1;          // 1: full prisms of one-shape dispatches take the slab-wise entry pick (EntryFastDev)
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
   uint32_t shuffle_chunk_log2 = 5;   // Recombine's shuffle moves chunks of 2^k pool entries (k = 0: per ray, like the reference)
@@ -340,6 +345,9 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "bin") b->bin = static_cast<int>(v);
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "entry_fast") b->entry_fast = v ? 1 : 0;
+  else if (k == "hex_fast") b->hex_fast = v ? 1 : 0;
+  else if (k == "hit_log") b->hit_log = static_cast<int>(v);
+  else if (k == "hit_log_cap") b->hit_log_cap = static_cast<uint32_t>(std::max<int64_t>(v, 0));
   else if (k == "gen_serial") b->gen_serial = v ? 1 : 0;
   else if (k == "shuffle_chunk") {
     if (v < 1 || v > 64 || (v & (v - 1)) != 0) return fail(b, HALO_FATAL, "shuffle_chunk must be a power of two in [1, 64]");
@@ -655,6 +663,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.bin_list = nullptr;
+    P.bin_log = 0u;
     P.bin_shift = 0u;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
@@ -789,6 +798,37 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
                            (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       const uint32_t lists1 = two_level ? ((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) : bin_tiles;
       uint32_t cap2 = 0u;
+      // Hit log (halo_trace.inl log_hit): where the binned route is not taken, a production-mode one-plane launch still runs into
+      // the 21 G/s of memory-side fp32 atomics once its trace is fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).
+      // Its cache misses go to one log region per workgroup instead and are summed per tile afterwards.
+      const bool use_log = !use_bin && b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
+                           bin_tiles >= 1u && bin_tiles <= 256u && (bin_slots & 16383ull) == 0ull && (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
+      if (use_log) {
+        // a region takes 4 hits per ray of its workgroup (configs[1]: 1.4 logged per ray; a full-sky render under the binned
+        // route's threshold ~5) and a tile list twice its even share; what runs over falls back to direct atomics
+        const uint64_t per_wg = (m + static_cast<uint64_t>(blocks) - 1u) / static_cast<uint64_t>(blocks);
+        uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
+        cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
+        uint64_t c2 = std::max<uint64_t>(2ull * 4ull * m / bin_tiles, 1ull << 14);
+        c2 = std::min<uint64_t>(c2, (6ull << 30) / (8ull * bin_tiles));
+        if (b->hit_log_cap) {   // tests: run both overflow fallbacks
+          cap = b->hit_log_cap;
+          c2 = std::max<uint64_t>(cap * static_cast<uint64_t>(blocks) / (2ull * bin_tiles), 64ull);
+        }
+        cap2 = static_cast<uint32_t>(c2);
+        HIPCHK(b, b->bin_cnt.reserve(std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u)));
+        HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(512) * 16u));
+        HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+        HIPCHK(b, b->bin_list.reserve(cap * static_cast<uint64_t>(blocks)));
+        HIPCHK(b, b->bin_list2.reserve(c2 * bin_tiles));
+        P.bin_list = b->bin_list.ptr;
+        P.bin_cap = static_cast<uint32_t>(cap);
+        P.bin_tiles = bin_tiles;
+        P.bin_shift = 0u;
+        P.bin_cnt = b->bin_cnt.ptr;   // one fill count per region, written by the trace kernel
+        P.bin_log = 1u;
+        P.mono_copy_mask = 0u;   // logged slots and their fallbacks address copy 0
+      } else
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
         // (the coarse and tile lists of the two-level route are slot ranges interleaved over the image — rows p % 1024 — and
@@ -804,6 +844,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.bin_tiles = two_level ? b->bin_l1 : bin_tiles;
         P.bin_shift = two_level ? 14u + fan_log2 : 0u;
         P.bin_cnt = b->bin_cnt.ptr;
+        P.bin_log = 0u;
         P.mono_copy_mask = 0u;   // staged hits and their fallbacks address copy 0
         if (two_level) {
           uint64_t c2 = std::max<uint64_t>(slack * 6ull * m / bin_tiles, 1ull << 12);
@@ -815,17 +856,25 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         }
       } else {
         P.bin_list = nullptr;
+        P.bin_log = 0u;
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
-      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, geom, b->mono_session);
+      // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
+      const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hs.efast.hex_regular) ? 3 : geom;
+      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, launch_geom, b->mono_session);
       b->mono_dirty = true;
       b->route.launches++;
       b->route.mode_mask |= 1u << (b->capture ? 2 : ((P.filter != nullptr || P.color != nullptr) ? 1 : 0));
-      b->route.geom_mask |= 1u << geom;
-      b->route.accum_mask |= use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u);
+      b->route.geom_mask |= 1u << launch_geom;
+      b->route.accum_mask |= use_log ? 16u : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
+      if (use_log) {
+        hipError_t be = launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, bin_tiles,
+                                         b->stream);
+        if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
+      }
       if (use_bin) {
         hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
                                                          bin_tiles, fan_log2, b->stream)

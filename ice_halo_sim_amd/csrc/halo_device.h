@@ -75,6 +75,11 @@ struct EntryFastDev {
   uint32_t tri0n[kEntryFastFaces];      // first fan triangle | count << 8
   float slab_area[4][2];                // total area of {plus face, minus face} of each slab
   float tri_v[kEntryFastTris][12];      // fan-triangle corners in 48-byte rows (three 16-byte reads per pick)
+  // REGULAR hexagonal prism (all eight faces, unit normals exactly (0, 0, +-1) and (cos, sin)(i x 60 deg) from the builder's
+  // tables, equal side distances): the next-face search then needs no table at all — normals are literals in the instruction
+  // stream, the two plane constants below are all that varies.  hex_regular = 0: not such a prism.
+  uint32_t hex_regular;
+  float hex_d_basal, hex_d_side, hex_pad;
 };
 static_assert(sizeof(EntryFastDev) % 16 == 0, "copied as float4");
 
@@ -229,6 +234,9 @@ struct DispatchParams {
   uint32_t bin_tiles;
   uint32_t bin_shift;          // list of a hit = (slot >> bin_shift) & (bin_tiles - 1): 0 = interleaved tiles, > 0 = contiguous slot ranges (two-level binning)
   uint32_t* bin_cnt;           // list fill counts, kBinCntStride apart
+  uint32_t bin_log;            // 1 (production mode, one plane): hit log — bin_list holds one region of bin_cap records per WORKGROUP, a hit
+                               // that misses the pixel cache is appended there instead of going out as a global atomic, and the
+                               // kernel leaves each region's fill count in bin_cnt[blockIdx.x]
   uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)

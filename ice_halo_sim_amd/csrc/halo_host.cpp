@@ -282,6 +282,18 @@ bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out) {
   }
   for (int t = 0; t < s.tri_cnt; t++)
     for (int c = 0; c < 9; c++) out.tri_v[t][c] = s.tri_v[t][c];
+  // regular hexagonal prism?  slab normals = the builder's exact table values, one plane constant for both basal faces, one
+  // for all six sides (the kernel's literals: halo_trace.inl kHexC / kHexS)
+  {
+    const float c60 = 0.5f, s60 = static_cast<float>(geom::Sin6(1));
+    const float want[4][3] = {{0.0f, 0.0f, 1.0f}, {1.0f, 0.0f, 0.0f}, {c60, s60, 0.0f}, {-c60, s60, 0.0f}};
+    bool reg = true;
+    for (int k = 0; k < 4 && reg; k++) reg = s.slab[k][0] == want[k][0] && s.slab[k][1] == want[k][1] && s.slab[k][2] == want[k][2] && s.slab[k][3] == s.slab[k][4];
+    for (int k = 2; k < 4 && reg; k++) reg = s.slab[k][3] == s.slab[1][3];
+    out.hex_regular = reg ? 1u : 0u;
+    out.hex_d_basal = s.slab[0][3];
+    out.hex_d_side = s.slab[1][3];
+  }
   return true;
 }
 

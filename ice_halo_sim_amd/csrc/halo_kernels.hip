@@ -48,26 +48,37 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
   return hipGetLastError();
 }
 
-// ---- two-level binning: accumulators of more than 512 tiles (per-wavelength planes: 64 planes x 2 Mi slots = 8192 tiles) ----
-// The trace kernel can feed at most 512 lists from its 1536-record LDS buffer (fewer than ~3 records per list and flush and
-// the appends stop coalescing).  For larger accumulators its lists are COARSE — list l1 holds the hits of `fan` consecutive
-// tiles (bin_shift = 14 + fan_log2) — and this kernel deals each coarse list out to its `fan` tile lists: a workgroup takes
-// 2048 records at a time, ranks them per tile with LDS counters, reserves the `fan` segments with one returning atomic each
-// and places the records.  Everything moves as 8-byte records, coalesced on the read side and in runs per tile on the
-// write side; a tile list that overflows falls back to direct atomics on the plane.
-constexpr uint32_t kSplitBlock = 256u, kSplitPer = 8u, kSplitParts = 8u, kSplitFanMax = 256u;
-__global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
-                                                                     const uint32_t* __restrict__ cnt1, uint2* __restrict__ list2, uint32_t cap2,
-                                                                     uint32_t* __restrict__ cnt2, uint32_t fan_log2) {
-  __shared__ uint32_t s_cnt[kSplitFanMax], s_base[kSplitFanMax];
-  const uint32_t l1 = blockIdx.x / kSplitParts, part = blockIdx.x % kSplitParts;
-  const uint32_t n = min(cnt1[l1 * kBinCntStride], cap1);
-  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kSplitParts);
-  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kSplitParts);
-  const uint32_t fan = 1u << fan_log2, fmask = fan - 1u;
+// ---- the split pass: hit records of a source list dealt out to per-tile lists ----
+// Two callers.  (1) Two-level binning, accumulators of more than 512 tiles (per-wavelength planes: 64 planes x 2 Mi slots = 8192
+// tiles): the trace kernel can feed at most 512 lists from its 1536-record LDS buffer (fewer than ~3 records per list and flush
+// and the appends stop coalescing), so its lists are COARSE — list l1 holds the hits of `fan` consecutive tiles (bin_shift = 14 +
+// fan_log2) — and this kernel deals each coarse list out to its `fan` tile lists, kSplitParts workgroups per list.  (2) The hit
+// log (halo_trace.inl log_hit): one UNSORTED region per trace workgroup, every region may hold every tile of an accumulator of
+// at most kSplitFanMax tiles; one workgroup per region.
+// A workgroup takes 4096 records per step.  Scattered 8-byte stores run at ~90 G/s on this part whatever their locality
+// (tools/atomic_rate_bench.hip), so the records of a step are first SORTED by tile in LDS — rank from an LDS counter per tile,
+// run offsets from a scan of the counters — and then written by consecutive lanes: a wave's store covers a few runs of
+// consecutive addresses instead of 64 lists (the log split went from 0.67 to 0.37 ms per 68 M records with that).  One returning
+// global atomic per tile and step reserves the run's place in the tile list; a tile list that overflows falls back to direct
+// atomics on the plane.
+constexpr uint32_t kSplitBlock = 256u, kSplitPer = 16u, kSplitParts = 8u, kSplitFanMax = 256u;
+static_assert(kSplitBlock == kSplitFanMax, "halo_split_kernel: one thread per tile counter");
+__global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
+                                                                 const uint32_t* __restrict__ cnt1, uint32_t cnt1_stride, uint32_t parts,
+                                                                 uint2* __restrict__ list2, uint32_t cap2, uint32_t* __restrict__ cnt2, uint32_t fan_log2,
+                                                                 uint32_t coarse) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSplitFanMax], s_off[kSplitFanMax];
+  __shared__ uint32_t s_base[kSplitFanMax];
+  __shared__ uint2 s_rec[kSplitBlock * kSplitPer];
+  const uint32_t l1 = blockIdx.x / parts, part = blockIdx.x % parts;
+  const uint32_t n = min(cnt1[static_cast<size_t>(l1) * cnt1_stride], cap1);
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / parts);
+  const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / parts);
+  const uint32_t fmask = (1u << fan_log2) - 1u;
+  const uint32_t tile0 = coarse ? (l1 << fan_log2) : 0u;   // the first destination tile of this source list
   const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
   for (uint32_t b0 = lo; b0 < hi; b0 += kSplitBlock * kSplitPer) {   // workgroup-uniform trip count
-    if (threadIdx.x < fan) s_cnt[threadIdx.x] = 0u;
+    s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     uint2 h[kSplitPer];
     uint32_t rank[kSplitPer];
@@ -80,18 +91,37 @@ __global__ void __launch_bounds__(kSplitBlock) halo_bin_split_kernel(float* __re
     for (uint32_t u = 0; u < kSplitPer; ++u)
       rank[u] = h[u].x != 0xFFFFFFFFu ? atomicAdd(&s_cnt[(h[u].x >> kBinTileLog2) & fmask], 1u) : 0u;
     __syncthreads();
-    if (threadIdx.x < fan) {
+    if (threadIdx.x < 64u) {   // exclusive scan of the 256 counters: 4 per lane, then across the wave
+      const uint4 c = *reinterpret_cast<const uint4*>(&s_cnt[threadIdx.x * 4u]);
+      const uint32_t own = c.x + c.y + c.z + c.w;
+      uint32_t incl = own;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (static_cast<int>(threadIdx.x) >= d) incl += up;
+      }
+      const uint32_t ex = incl - own;
+      *reinterpret_cast<uint4*>(&s_off[threadIdx.x * 4u]) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+    }
+    {
       const uint32_t c = s_cnt[threadIdx.x];
-      s_base[threadIdx.x] = c ? atomicAdd(&cnt2[static_cast<size_t>((l1 << fan_log2) + threadIdx.x) * kBinCntStride], c) : 0u;
+      s_base[threadIdx.x] = c ? atomicAdd(&cnt2[static_cast<size_t>(tile0 + threadIdx.x) * kBinCntStride], c) : 0u;
     }
     __syncthreads();
 #pragma unroll
+    for (uint32_t u = 0; u < kSplitPer; ++u)
+      if (h[u].x != 0xFFFFFFFFu) s_rec[s_off[(h[u].x >> kBinTileLog2) & fmask] + rank[u]] = h[u];
+    __syncthreads();
+    const uint32_t n_step = min(kSplitBlock * kSplitPer, hi - b0);
+#pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u) {
-      if (h[u].x == 0xFFFFFFFFu) continue;
-      const uint32_t tile = h[u].x >> kBinTileLog2;
-      const uint32_t pos = s_base[tile & fmask] + rank[u];
-      if (pos < cap2) list2[static_cast<size_t>(tile) * cap2 + pos] = h[u];
-      else atomic_add_f32(plane + h[u].x, __uint_as_float(h[u].y));
+      const uint32_t i = u * kSplitBlock + threadIdx.x;
+      if (i >= n_step) continue;
+      const uint2 r = s_rec[i];
+      const uint32_t t = (r.x >> kBinTileLog2) & fmask;
+      const uint32_t pos = s_base[t] + (i - s_off[t]);
+      if (pos < cap2) list2[static_cast<size_t>(tile0 + t) * cap2 + pos] = r;
+      else atomic_add_f32(plane + r.x, __uint_as_float(r.y));
     }
     __syncthreads();
   }
@@ -138,10 +168,22 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
   }
 }
 
+hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
+                            uint32_t tiles, hipStream_t stream) {
+  // hit-log route: regions -> the tile lists of one plane array of at most kSplitFanMax tiles (fan 256 covers any of them)
+  (void)tiles;
+  hipLaunchKernelGGL(halo_split_kernel, dim3(regions), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+                     reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
+  return hipGetLastError();
+}
+
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
-  hipLaunchKernelGGL(halo_bin_split_kernel, dim3(lists1 * kSplitParts), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
-                     cnt1, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2);
+  hipLaunchKernelGGL(halo_split_kernel, dim3(lists1 * kSplitParts), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
+                     cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);

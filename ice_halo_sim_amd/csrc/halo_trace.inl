@@ -453,6 +453,7 @@ struct PixCache {
 // flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
 // sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
+constexpr int kAccDirect = 0, kAccBin = 1, kAccLog = 2;   // halo_trace_kernel ACC
 constexpr int kHitBuf = 1536;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
 constexpr int kBinMaxTiles = 512;
@@ -474,6 +475,7 @@ template <bool MONO, bool SMALLC>
 struct AccCtx {
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
+  uint32_t* log_n;   // hit-log kernels: the workgroup's log cursor (LDS); nullptr otherwise
 };
 
 // Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
@@ -495,6 +497,23 @@ HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
   if (pos >= static_cast<uint32_t>(kHitBuf)) return false;
   hb->h[pos] = make_uint2(key, __float_as_uint(w));
   return true;
+}
+
+// Hit log.  Global fp32 atomics execute memory-side on this part, 21 G/s whatever the footprint or the lanes per instruction
+// (tools/atomic_rate_bench.hip) — a floor of 2.8 ms under configs[1]'s 58 M cache misses, next to a 2.4 ms trace — while a wave
+// appending 8-byte records to a private run of HBM sustains > 200 G records/s.  So a logging kernel ADDS nothing: a hit that
+// misses the pixel cache goes to the workgroup's own log region (cursor in LDS, one ds_add_rtn per wave and call), and
+// halo_split_kernel / halo_bin_accumulate_range_kernel sum the logs per 16 Ki-slot tile in LDS afterwards.  A full region
+// falls back to the direct atomic.  Call with any subset of a wave's lanes active.
+HD void log_hit(const DispatchParams& P, uint32_t* log_n, uint32_t slot, float w) {
+  const uint64_t mask = __ballot(1);
+  // position among the active lanes; the first of them reserves the wave's run
+  const uint32_t before = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+  uint32_t base = 0u;
+  if (before == 0u) base = atomicAdd(log_n, static_cast<uint32_t>(__popcll(mask)));
+  const uint32_t idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base))) + before;
+  if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(blockIdx.x) * P.bin_cap + idx] = make_uint2(slot, __float_as_uint(w));
+  else atomic_add_f32(P.mono + slot, w);   // copy 0
 }
 
 // MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
@@ -526,6 +545,10 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
       return;
     }
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
+  }
+  if (MONO && ctx.log_n != nullptr) {
+    log_hit(P, ctx.log_n, (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2), w);
+    return;
   }
   if (MONO) {
     // binned: {slot, w}; the planes of a per-entry-plane session lie back to back, so `slot` addresses them as one array
@@ -860,6 +883,7 @@ static_assert(offsetof(ShapeDev, tri_v) % 16 == 0 && offsetof(ShapeDev, tri_na) 
               "rows are copied as float4 / dwords");
 
 constexpr int kGeomOne = 0, kGeomPool = 1, kGeomPoolPrism = 2;   // GEOM: one shape per dispatch | pool of ShapeDev | pool of ShapePrism (HBM records and LDS slots)
+constexpr int kGeomOneHex = 3;   // one shape per dispatch AND it is a regular hexagonal prism (EntryFastDev::hex_regular): literal normals
 template <int GEOM>
 struct PoolSlotType {   // type = the LDS slot of a half-wave, rec = the record in the HBM pool
   typedef ShapeSlot48 type;
@@ -1183,7 +1207,7 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
   return face;
 }
 
-template <int MODE, bool MONO, bool SMALLC, typename ShapePtr>
+template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
                   uint32_t tid, RaySums& sums, Probe& pr) {
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
@@ -1297,6 +1321,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 
   bool stray = false;
   uint32_t stray_seq = 0u;
+  float hex_d_basal = 0.0f, hex_d_side = 0.0f;
+  if constexpr (HEX) {
+    hex_d_basal = T.efast.hex_d_basal;
+    hex_d_side = T.efast.hex_d_side;
+  }
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
@@ -1338,6 +1367,27 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     int hit = -1;
     // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain
     const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
+    if constexpr (HEX) {
+      // Regular hexagonal prism: slab k has normal (0,0,1), (1,0,0), (1/2, s60, 0), (-1/2, s60, 0) — the builder's exact table
+      // values, here literals — and face ids (0,1), (2,5), (3,6), (4,7); both faces of a slab have the same plane constant.  The
+      // generic search below with its table reads gone and the zero / unit components folded (x * 1 + 0 == x exactly): same
+      // candidates, same order, same comparisons.
+      constexpr float kS60 = 0.86602540378443864676f;
+      const float db = hex_d_basal, ds = hex_d_side;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? (X * 0.5f + Y * kS60) : (X * -0.5f + Y * kS60);
+        const float dk = (k == 0) ? db : ds;
+        const bool pos = r.x > 0.0f;
+        const float den = fabsf(r.x);
+        const float num = pos ? -(r.y + dk) : (r.y - dk);
+        const int fi = (k == 0) ? (pos ? 0 : 1) : (pos ? 1 + k : 4 + k);
+        const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
+        num_b = better ? num : num_b;
+        den_b = better ? den : den_b;
+        hit = better ? fi : hit;
+      }
+    } else {
     const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
     for (int k = 0; k < slab_cnt; ++k) {
       // opposite faces +n / -n: den(-n) = -den(+n) and n.p flips sign, so only the face the ray travels towards can be ahead
@@ -1365,6 +1415,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       num_b = better ? num : num_b;
       den_b = better ? den : den_b;
       hit = better ? fi : hit;
+    }
     }
     const float t_best = num_b * fast_rcp(den_b);
     if (hit < 0 || t_best <= -kSlabEps) {
@@ -1448,8 +1499,10 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES_FILTER
 #define HALO_MIN_WAVES_FILTER 3
 #endif
-template <int MODE, int GEOM, bool MONO, bool BIN>
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (ACC != kAccDirect ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+  constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog;
+  static_assert(!LOG || (MONO && MODE == kModePlain), "the hit log is a production-mode, one-plane route");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
@@ -1457,18 +1510,24 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
   probe_start(pr);
   const uint64_t t_begin = pr.t0;
 #endif
-  constexpr bool SMALLC = BIN && GEOM != kGeomOne;
+  constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
   AccCtx<MONO, SMALLC> acc;
   acc.cache = &T.cache;
   acc.hits = nullptr;
+  acc.log_n = nullptr;
+  __shared__ uint32_t s_log_n;
+  if constexpr (LOG) {
+    acc.log_n = &s_log_n;
+    if (threadIdx.x == 0) s_log_n = 0u;
+  }
   if constexpr (BIN) {
     acc.hits = &s_hits.b;
     if (threadIdx.x == 0) s_hits.b.n = 0u;
   }
   __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
-  constexpr bool POOL = GEOM != kGeomOne;
+  constexpr bool POOL = GEOM != kGeomOne && GEOM != kGeomOneHex;
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
@@ -1562,7 +1621,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhStage);
-      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums, pr);
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums, pr);
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhSlab);
       if constexpr (BIN) {
@@ -1578,10 +1637,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
           const PoolRec* sh = reinterpret_cast<const PoolRec*>(P.shapes) + (tid / P.geom_clock);
-          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums, pr);
+          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, tid, sums, pr);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO, SMALLC>(P, T, acc, filter, color, sh, tid, sums, pr);
+          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, tid, sums, pr);
         }
       }
       if constexpr (BIN) {
@@ -1605,13 +1664,19 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
       const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;
       if (MONO) {
         const float v = T.cache.val[i];
-        if (v != 0.0f) atomic_add_f32(mono_slot(P, pl, pix), v);
+        if (v == 0.0f) continue;
+        if (LOG) log_hit(P, &s_log_n, (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2), v);
+        else atomic_add_f32(mono_slot(P, pl, pix), v);
       } else {
         atomic_add_f32(mono_slot(P, 0u, pix), T.cache.val[i * 3 + 0]);
         atomic_add_f32(mono_slot(P, 1u, pix), T.cache.val[i * 3 + 1]);
         atomic_add_f32(mono_slot(P, 2u, pix), T.cache.val[i * 3 + 2]);
       }
     }
+  }
+  if constexpr (LOG) {   // the region's fill count, for the split pass
+    __syncthreads();
+    if (threadIdx.x == 0) P.bin_cnt[blockIdx.x] = min(s_log_n, P.bin_cap);
   }
   // ---- per-wave reduction of the scalar tallies: one fp64 atomic per wave, not per exit ----
   float landed = wave_sum(sums.landed);
@@ -1636,14 +1701,31 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (BIN ? 4 : HALO_MIN_WAVES
 // (the 18 instantiations compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
 template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, true>), grid, block, 0, stream, P);
-  else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, false>), grid, block, 0, stream, P);
-  else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, false>), grid, block, 0, stream, P);
+  if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode
+    if (mono && P.bin_log != 0u) {
+      hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
+      return;
+    }
+  }
+  if constexpr (GEOM == kGeomOneHex) {   // ... and the regular-prism instantiation for the production mode's scalar-plane routes
+    hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccDirect>), grid, block, 0, stream, P);
+  } else {
+    if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccBin>), grid, block, 0, stream, P);
+    else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccDirect>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccDirect>), grid, block, 0, stream, P);
+  }
 }
 
 template <int MODE>
 static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
   dim3 grid(blocks), block(kBlock);
+  if constexpr (MODE == kModePlain) {
+    if (geom == kGeomOneHex && mono && (P.bin_list == nullptr || P.bin_log != 0u)) {
+      launch_mono<MODE, kGeomOneHex>(P, grid, block, stream, mono);
+      return hipGetLastError();
+    }
+  }
+  if (geom == kGeomOneHex) geom = kGeomOne;
   if (geom == kGeomPoolPrism) launch_mono<MODE, kGeomPoolPrism>(P, grid, block, stream, mono);
   else if (geom == kGeomPool) launch_mono<MODE, kGeomPool>(P, grid, block, stream, mono);
   else launch_mono<MODE, kGeomOne>(P, grid, block, stream, mono);

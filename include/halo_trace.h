@@ -267,6 +267,12 @@ const char* halo_last_error(halo_handle_t h);
  * workgroup below that cap),
  * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
  * same builder the host runs; records are bit-identical either way, A/B knob),
+ * "hit_log" (-1 [default]: production-mode one-plane launches >= 2 Mi rays that do not take the binned route append the hits that
+ * miss the pixel cache to a log region per workgroup — plain stores instead of memory-side fp32 atomics — which a split pass
+ * and a per-tile LDS pass then add to the plane; 0 = never (direct atomics), 1 = whenever applicable), "hit_log_cap" (test
+ * knob: records per log region, 0 [default] = sized from the launch; what runs over a region or a tile list is added directly),
+ * "hex_fast" (1 [default]: one-shape dispatches of a REGULAR hexagonal prism run the instantiation whose next-face search has the
+ * normals as literals; 0: the table-driven search — same candidates, order and comparisons, A/B knob),
  * "entry_fast" (1 [default]: one-shape dispatches of a full 8-face prism pick the entry face slab by slab, in registers;
  * 0: the generic walk over faces — same uniform, same cumulative order, A/B knob),
  * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in
@@ -323,8 +329,8 @@ int halo_last_sample_counts(halo_handle_t h, uint64_t* crystal_samples, uint64_t
 typedef struct HaloRouteInfo {
   uint32_t launches;     /* trace-kernel launches since halo_begin */
   uint32_t mode_mask;    /* bit m: a launch ran the MODE m instantiation (0 production, 1 + path/filter/colour, 2 + exit capture) */
-  uint32_t geom_mask;    /* bit g: GEOM g (0 one shape per dispatch, 1 pool of 4.1 KB records, 2 pool of prism records) */
-  uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels */
+  uint32_t geom_mask;    /* bit g: GEOM g (0 one shape per dispatch, 1 pool of 4.1 KB records, 2 pool of prism records, 3 one shape = regular hexagonal prism) */
+  uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels, 4 hit log */
   uint32_t source_mask;  /* bit 0 generated roots, 1 continuation pool (layer >= 1), 2 host-injected rays */
   uint32_t plane_cnt;    /* accumulation planes of the session (1 discrete, 3 X/Y/Z, M per-entry) */
   uint32_t plane_copies; /* privatised copies of each plane */

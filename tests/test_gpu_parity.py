@@ -265,7 +265,7 @@ def test_illuminant_binned_over_entry_planes(shape):
     reference's own GPU benchmark shape: D65, dual fisheye 512x256) and takes the one-level route; 2048x1024 x 31 / 64 entries
     is 3968 / 8192 tiles (examples/bench_config_stoch.json's render) and takes the two-level route, like the largest image the
     accumulator accepts (4096x2048 x 64 entries: 32768 tiles, 128 coarse lists of 256): coarse lists from the
-    trace kernel, halo_bin_split_kernel, halo_bin_accumulate_range_kernel.  Same image as the direct route and as the oracle."""
+    trace kernel, halo_split_kernel, halo_bin_accumulate_range_kernel.  Same image as the direct route and as the oracle."""
     full = {"type": "uniform", "mean": 0.0, "std": 360.0}
     sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.2), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)])], max_hits=7)
     rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, shape[0], shape[1], visible=abi.VISIBLE_FULL)
@@ -1034,7 +1034,10 @@ def test_reference_e2e_configs_parity(name):
             a, b = so[l].continuation_count, so2[l].continuation_count
             assert within(sh[l].continuation_count, a, b, 5e-3 * a + 50), (l, sh[l].continuation_count, a, b)
         assert within(len(eh), len(eo), len(eo2), 1e-2 * len(eo) + 100), (len(eh), len(eo), len(eo2))
-        assert within(lh, lo, lo2, 1e-2 * lo + 1.0), (lh, lo, lo2)
+        # the landed weight of a filtered three-layer document scatters by 0.7 % r.m.s. between renders — on either side, the
+        # oracle's threads reorder its continuations too (tools/diag_ms.py ms3_direction_filter) — and ONE pair of oracle renders
+        # now and then lands within 1e-4 of each other, so the absolute term carries 3.5 sigma by itself
+        assert within(lh, lo, lo2, 2.5e-2 * lo + 1.0), (lh, lo, lo2)
         if io.sum() > 0 and lo > 100.0:
             pear = lambda x, y: float(np.corrcoef(block_mean(x, 16)[..., 1].ravel(), block_mean(y, 16)[..., 1].ravel())[0, 1])
             floor_corr = pear(io, io2)

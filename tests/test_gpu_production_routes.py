@@ -61,7 +61,7 @@ def test_bench_config_stoch_shape_runs_the_binned_prism_pool_kernel(pool):
     wavelength pool (31 entries: BASELINE configs[4]'s count; 64: the reference's default pool), rectangular 2048x1024 full sky,
     max_hits 8 — at 9 Mi rays, where the backend's own selection takes per-entry planes (>= 8 Mi rays), device-generated prism
     records (GEOM 2) and the two-level binned route (31 x 128 / 64 x 128 tiles > 512): halo_trace_kernel<0,2,true,true> +
-    halo_bin_split_kernel + halo_bin_accumulate_range_kernel.  Compared with the oracle on the same rays."""
+    halo_split_kernel + halo_bin_accumulate_range_kernel.  Compared with the oracle on the same rays."""
     sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
     rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
     wl = scenes.wl_illuminant("D65", pool)
@@ -83,25 +83,26 @@ def test_bench_config_stoch_shape_runs_the_binned_prism_pool_kernel(pool):
     print("bench_config_stoch pool %d: block-mean rel L2 %.2e, exits/root %.3f" % (pool, err, st[0].exit_count / n))
 
 
-@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_d65_planes"])
+@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65_planes"])
 def test_stochastic_pool_production_kernels_vs_oracle(case):
     """The other production shape-pool instantiations at sizes where they are what the backend picks:
       prism_discrete_binned  one wavelength, stochastic prism, full sky, 4.5 Mi rays  -> <0,2,true,true>, one-level binned (128 tiles)
-      pyramid_discrete       one wavelength, stochastic pyramid (4.1 KB records)      -> <0,1,true,false>, direct scalar plane
-      pyramid_d65_planes     D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,true,false>, one plane per entry"""
+      pyramid_discrete       one wavelength, stochastic pyramid (4.1 KB records)      -> <0,1,true,kAccLog>, hit log + split + per-tile sums
+      pyramid_discrete_direct  the same with option hit_log = 0                       -> <0,1,true,kAccDirect>, direct scalar plane
+      pyramid_d65_planes     D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,true,kAccDirect>, one plane per entry"""
     prism = case.startswith("prism")
     sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry() if prism else _stoch_pyramid_entry()])], max_hits=8)
     rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
     d65 = case.endswith("planes")
     wl = scenes.wl_illuminant("D65", 31) if d65 else scenes.wl_discrete(550.0)
     n = (9 << 20) if d65 else (9 << 19)
-    hb = hip_backend(seed=29)
+    hb = hip_backend(seed=29, **({"hit_log": 0} if case.endswith("direct") else {}))
     st = run_session(hb, sc, rd, wl, n)
     route = hb.last_route()
     hip = hb.ReadbackXyzAccum()
     hb.close()
     want_geom = (1 << 2) if prism else (1 << 1)
-    want_acc = abi.ACCUM_BIN1 if prism else abi.ACCUM_SCALAR
+    want_acc = abi.ACCUM_BIN1 if prism else (abi.ACCUM_LOG if case == "pyramid_discrete" else abi.ACCUM_SCALAR)
     assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, want_geom, want_acc), (route.mode_mask, route.geom_mask, route.accum_mask)
     assert route.plane_cnt == (31 if d65 else 1)
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 29)
@@ -130,7 +131,8 @@ def test_config3_two_layer_multi_scatter_at_production_launch_sizes():
     for wl in wls:
         st = run_session(hb, sc, rd, wl, n)
         route = hb.last_route()
-        assert route.mode_mask == 1 and route.source_mask == 0b011 and route.geom_mask == 1
+        assert route.mode_mask == 1 and route.source_mask == 0b011 and route.geom_mask == 1 << 3   # regular prisms: the literal-normal instantiation
+        assert route.accum_mask == abi.ACCUM_SCALAR | abi.ACCUM_LOG   # 600 k roots: direct atomics; >= 2.5 Mi continuations: the hit log
         assert st[1].root_count == st[0].continuation_count >= (5 << 19)
         cont_h.append(st[0].continuation_count)
         launches += st[1].launches
@@ -280,3 +282,43 @@ def test_prism_entry_pick_by_slab_equals_the_walk_over_faces():
         same = (a["root"] == b["root"]) & (a["seq"] == b["seq"]) & (np.abs(a["dir"] - b["dir"]).max(axis=1) <= 1e-6) & \
                (np.abs(a["weight"] - b["weight"]) <= 1e-6) & (a["path"] == b["path"]).all(axis=1)
         assert same.mean() >= 0.9995, same.mean()
+
+
+def test_hit_log_route_equals_the_direct_route():
+    """Option hit_log: configs[1]'s scene at 3 Mi rays — above the 2 Mi threshold, so the backend's own choice is the hit log
+    (halo_trace_kernel<0,3,true,kAccLog> + halo_split_kernel + halo_bin_accumulate_range_kernel) — against the same
+    session with direct atomics, and with log regions / tile lists too small for the launch, where most hits take the two
+    overflow fallbacks.  The three trace the SAME rays to the SAME pixels; only the order of the float sums differs."""
+    sc, rd, wl = scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0)
+    n = 3 << 20
+    out = {}
+    for name, opts, acc in (("auto", {}, abi.ACCUM_LOG), ("direct", {"hit_log": 0}, abi.ACCUM_SCALAR), ("overflow", {"hit_log_cap": 2048}, abi.ACCUM_LOG)):
+        hb = hip_backend(seed=61, **opts)
+        st = run_session(hb, sc, rd, wl, n)
+        route = hb.last_route()
+        assert (route.mode_mask, route.accum_mask, route.geom_mask) == (1, acc, 1 << 3), (name, route.mode_mask, route.accum_mask, route.geom_mask)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (img, landed, st[0].pixel_hits, st[0].exit_count)
+    ref = out["direct"]
+    assert ref[0].sum() > 0
+    for name in ("auto", "overflow"):
+        img, landed, hits, exits = out[name]
+        assert (hits, exits) == (ref[2], ref[3])
+        assert landed == pytest.approx(ref[1], rel=1e-6)
+        # float32 sums in three different orders (8 privatised copies of atomics / fp64 tile sums / one copy of atomics): the
+        # pixels of the sun's image take ~10^4 hits each and carry most of the norm — measured 1e-6 (auto) and 4e-6 (overflow)
+        assert rel_l2(img, ref[0]) <= 2e-5, (name, rel_l2(img, ref[0]))
+        assert np.abs(img - ref[0]).max() <= 1e-4 * ref[0].max()
+    # a small launch (below the threshold) takes the log only when told to
+    hb = hip_backend(seed=61, hit_log=1)
+    run_session(hb, sc, rd, wl, 100_000)
+    assert hb.last_route().accum_mask == abi.ACCUM_LOG
+    small, _ = hb.ReadbackXyzAccum()
+    hb.close()
+    hb = hip_backend(seed=61)
+    run_session(hb, sc, rd, wl, 100_000)
+    assert hb.last_route().accum_mask == abi.ACCUM_SCALAR
+    want, _ = hb.ReadbackXyzAccum()
+    hb.close()
+    assert rel_l2(small, want) <= 2e-5
