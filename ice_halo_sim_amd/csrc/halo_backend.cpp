@@ -815,7 +815,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
           cap = b->hit_log_cap;
           c2 = std::max<uint64_t>(cap * static_cast<uint64_t>(blocks) / (2ull * bin_tiles), 64ull);
         }
-        cap2 = static_cast<uint32_t>(c2);
+        cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
         HIPCHK(b, b->bin_cnt.reserve(std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u)));
         HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(512) * 16u));
         HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
@@ -849,7 +849,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         if (two_level) {
           uint64_t c2 = std::max<uint64_t>(slack * 6ull * m / bin_tiles, 1ull << 12);
           c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * bin_tiles));
-          cap2 = static_cast<uint32_t>(c2);
+          cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
           HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(bin_tiles) * 16u));
           HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
           HIPCHK(b, b->bin_list2.reserve(c2 * bin_tiles));

@@ -61,8 +61,12 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 // consecutive addresses instead of 64 lists (the log split went from 0.67 to 0.37 ms per 68 M records with that).  One returning
 // global atomic per tile and step reserves the run's place in the tile list; a tile list that overflows falls back to direct
 // atomics on the plane.
-constexpr uint32_t kSplitBlock = 256u, kSplitPer = 16u, kSplitParts = 8u, kSplitFanMax = 256u;
-static_assert(kSplitBlock == kSplitFanMax, "halo_split_kernel: one thread per tile counter");
+constexpr uint32_t kSplitParts = 8u, kSplitFanMax = 256u;
+// Step sizes (threads x records per thread).  The hit log has 128..256 destinations per step, and its stores only coalesce
+// when a step is large: 16384 records (a region is read in one or two steps; 128 KB of LDS, one workgroup per CU) runs
+// at 0.23 ms per 58 M records where 4096 takes 0.36 and 1024 takes 1.1.  The coarse lists of the two-level route have <= 32
+// destinations per step, whose runs are long anyway, and ~1000 long chains that want many workgroups resident: 256 x 16.
+template <uint32_t kSplitBlock, uint32_t kSplitPer>
 __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                  const uint32_t* __restrict__ cnt1, uint32_t cnt1_stride, uint32_t parts,
                                                                  uint2* __restrict__ list2, uint32_t cap2, uint32_t* __restrict__ cnt2, uint32_t fan_log2,
@@ -70,6 +74,7 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSplitFanMax], s_off[kSplitFanMax];
   __shared__ uint32_t s_base[kSplitFanMax];
   __shared__ uint2 s_rec[kSplitBlock * kSplitPer];
+  static_assert(kSplitBlock >= kSplitFanMax, "one thread per tile counter");
   const uint32_t l1 = blockIdx.x / parts, part = blockIdx.x % parts;
   const uint32_t n = min(cnt1[static_cast<size_t>(l1) * cnt1_stride], cap1);
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / parts);
@@ -77,16 +82,18 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   const uint32_t fmask = (1u << fan_log2) - 1u;
   const uint32_t tile0 = coarse ? (l1 << fan_log2) : 0u;   // the first destination tile of this source list
   const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
-  for (uint32_t b0 = lo; b0 < hi; b0 += kSplitBlock * kSplitPer) {   // workgroup-uniform trip count
-    s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    uint2 h[kSplitPer];
-    uint32_t rank[kSplitPer];
+  // The steps of a workgroup are a chain of dependent latencies (loads, LDS ranks, the reserving atomic, stores), so the next
+  // step's records are loaded while this step's are written out, and the reserving atomic flies during the LDS scatter.
+  uint2 h[kSplitPer];
+  uint32_t rank[kSplitPer];
 #pragma unroll
-    for (uint32_t u = 0; u < kSplitPer; ++u) {
-      const uint32_t i = b0 + u * kSplitBlock + threadIdx.x;
-      h[u] = i < hi ? src[i] : make_uint2(0xFFFFFFFFu, 0u);
-    }
+  for (uint32_t u = 0; u < kSplitPer; ++u) {
+    const uint32_t i = lo + u * kSplitBlock + threadIdx.x;
+    h[u] = i < hi ? src[i] : make_uint2(0xFFFFFFFFu, 0u);
+  }
+  if (threadIdx.x < kSplitFanMax) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t b0 = lo; b0 < hi; b0 += kSplitBlock * kSplitPer) {   // workgroup-uniform trip count
 #pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u)
       rank[u] = h[u].x != 0xFFFFFFFFu ? atomicAdd(&s_cnt[(h[u].x >> kBinTileLog2) & fmask], 1u) : 0u;
@@ -103,14 +110,20 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
       const uint32_t ex = incl - own;
       *reinterpret_cast<uint4*>(&s_off[threadIdx.x * 4u]) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
     }
-    {
-      const uint32_t c = s_cnt[threadIdx.x];
-      s_base[threadIdx.x] = c ? atomicAdd(&cnt2[static_cast<size_t>(tile0 + threadIdx.x) * kBinCntStride], c) : 0u;
-    }
+    const uint32_t c_own = threadIdx.x < kSplitFanMax ? s_cnt[threadIdx.x] : 0u;
+    const uint32_t base = c_own ? atomicAdd(&cnt2[static_cast<size_t>(tile0 + threadIdx.x) * kBinCntStride], c_own) : 0u;
     __syncthreads();
+    if (threadIdx.x < kSplitFanMax) s_cnt[threadIdx.x] = 0u;   // for the next step (ranked after the barrier that ends this one)
 #pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u)
       if (h[u].x != 0xFFFFFFFFu) s_rec[s_off[(h[u].x >> kBinTileLog2) & fmask] + rank[u]] = h[u];
+    const uint32_t nb = b0 + kSplitBlock * kSplitPer;
+#pragma unroll
+    for (uint32_t u = 0; u < kSplitPer; ++u) {
+      const uint32_t i = nb + u * kSplitBlock + threadIdx.x;
+      h[u] = i < hi ? src[i] : make_uint2(0xFFFFFFFFu, 0u);
+    }
+    if (threadIdx.x < kSplitFanMax) s_base[threadIdx.x] = base;
     __syncthreads();
     const uint32_t n_step = min(kSplitBlock * kSplitPer, hi - b0);
 #pragma unroll
@@ -172,7 +185,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
                             uint32_t tiles, hipStream_t stream) {
   // hit-log route: regions -> the tile lists of one plane array of at most kSplitFanMax tiles (fan 256 covers any of them)
   (void)tiles;
-  hipLaunchKernelGGL(halo_split_kernel, dim3(regions), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -182,7 +195,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
 
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
-  hipLaunchKernelGGL(halo_split_kernel, dim3(lists1 * kSplitParts), dim3(kSplitBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
+  hipLaunchKernelGGL((halo_split_kernel<256u, 16u>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
