@@ -471,8 +471,31 @@ template <>
 struct HitSlot<false> {
   uint32_t unused;
 };
+// Exit queue (production one-shape kernels).  An interaction hands the image at most one exit per lane, and most of them go
+// nowhere: configs[1] emits 4.7 exits per ray of which 1.6 are in frame (`visible: upper` and the camera's half space cull the
+// rest), TIR lanes emit none — yet projection, pixel cache and miss path ran once per interaction with a third of their lanes
+// on.  So an interaction only PUSHES its exits that pass the cheap culls {world direction, weight, wavelength index} onto the
+// wave's queue in LDS (ballot-compacted), and the wave pops 64 of them at a time: the expensive half of the emit runs ~2.5
+// times per ray pass instead of 7, with full lanes.  The count lives in a register — every lane still in the interaction
+// loop takes part in every push, so theirs agree — and is parked in LDS between passes (lanes that left a pass early hold a
+// stale copy).
+constexpr uint32_t kExitQ = 128u;   // < 64 left after a drain + <= 64 pushed by one interaction
+struct ExitQueue {
+  float x[kExitQ], y[kExitQ], z[kExitQ], w[kExitQ];
+  uint32_t wl[kExitQ];
+  uint32_t n;
+};
+template <bool ON>
+struct ExitQueues {
+  ExitQueue q[kBlock / 64];
+};
+template <>
+struct ExitQueues<false> {
+  uint32_t unused;
+};
 template <bool MONO, bool SMALLC>
 struct AccCtx {
+  ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
   uint32_t* log_n;   // hit-log kernels: the workgroup's log cursor (LDS); nullptr otherwise
@@ -566,6 +589,7 @@ struct RaySums {
   float exit_w;
   uint32_t exit_n;
   uint32_t pix_n;
+  uint32_t qn;   // exit queue fill (see ExitQueue)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -937,51 +961,10 @@ HD void stage_shape(SlotT* slot, const RecT* g, uint32_t l32) {
   if (l32 < (n1 + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->single)[l32] = reinterpret_cast<const uint32_t*>(g->single)[l32];
 }
 
+// One exit that goes to the image: project, accumulate, tally (the tail of CollectData, simulator.cpp:719-760).
 template <int MODE, bool MONO, bool SMALLC>
-HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, float lx, float ly, float lz, float w,
-                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const PathView& pv, RaySums& sums, Probe& pr) {
-  // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
-  float wx = R[0] * lx + R[1] * ly + R[2] * lz;
-  float wy = R[3] * lx + R[4] * ly + R[5] * lz;
-  float wz = R[6] * lx + R[7] * ly + R[8] * lz;
-  // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
-  if (MODE != kModePlain && filter != nullptr) {
-    if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
-  }
-  uint64_t cmask = carried;
-  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
-  // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
-  // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
-  bool pass = false;
-  if (P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
-  if (pass) {
-    if (P.final_layer) return;  // "continue" with no next layer is dropped (simulator.cpp:719-722)
-    // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
-    const uint64_t mask = __ballot(1);
-    const uint32_t lane = __lane_id();
-    const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
-    uint32_t base = 0u;
-    const uint32_t shard = blockIdx.x & (kContShards - 1);
-    if (lane == leader) base = atomicAdd(&P.cont_cnt[shard * kContCntStride], static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, static_cast<int>(leader));
-    const uint32_t off = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-    if (off < P.cont_out_cap) {
-      const uint32_t slot = shard * P.cont_out_cap + off;
-      const uint32_t st = P.cont_out_stride;
-      P.cont_out[slot] = wx;
-      P.cont_out[st + slot] = wy;
-      P.cont_out[2u * st + slot] = wz;
-      P.cont_out[3u * st + slot] = w;
-      reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
-      if (MODE != kModePlain && color != nullptr) {  // the mask rides with the continuation (cu:922,1129)
-        reinterpret_cast<uint32_t*>(P.cont_out)[5u * st + slot] = static_cast<uint32_t>(cmask);
-        reinterpret_cast<uint32_t*>(P.cont_out)[6u * st + slot] = static_cast<uint32_t>(cmask >> 32);
-      }
-    }
-    return;
-  }
-  PROBE_MARK(pr, kPhEmitGate);
+HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
+                 float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
   const ProjDev& pj = P.proj;
   Hits h = project_exit(pj, wx, wy, wz);
   PROBE_MARK(pr, kPhProject);
@@ -1000,9 +983,116 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
     sums.pix_n++;
   }
+  PROBE_MARK(pr, kPhAccum);
+  return primary;
+}
+
+// The culls of project_exit that need no projection: false = this exit cannot land (conservative at cz ~ 0, where the
+// projection itself decides).
+HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz) {
+  const int t = p.proj_type;
+  if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT || t == HALO_LENS_FISHEYE_STEREOGRAPHIC ||
+      t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
+    if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
+    return p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz) > -1e-6f;
+  }
+  return true;
+}
+
+// Pop exits off the wave's queue, one per active lane and round, until fewer than 64 are left (`all`: until it is empty).
+// Called where every lane that took part in the pushes is active (their counts agree).
+template <bool MONO, bool SMALLC>
+HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, RaySums& sums, bool all, Probe& pr) {
+  ExitQueue& Q = *cache.q;
+  const uint64_t m = __ballot(1);
+  const uint32_t k = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+  const uint32_t na = static_cast<uint32_t>(__popcll(m));
+  uint32_t qn = sums.qn;
+  while (all ? qn > 0u : qn >= 64u) {
+    if (k < qn) {
+      const uint32_t i = qn - 1u - k;
+      land_exit<kModePlain, MONO, SMALLC>(P, cache, nullptr, 0ull, Q.x[i], Q.y[i], Q.z[i], Q.w[i], 0.0f, 0.0f, 0.0f, Q.wl[i], sums, pr);
+    }
+    qn -= min(na, qn);
+  }
+  sums.qn = qn;
+}
+
+
+
+template <int MODE, bool MONO, bool SMALLC>
+HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, bool live,
+                  float lx, float ly, float lz, float w, float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
+                  const PathView& pv, RaySums& sums, Probe& pr) {
+  // `live`: this lane has an outgoing candidate.  Kernels with an exit queue call this with every lane of the interaction loop
+  // (the push is a wave-wide step); the others branch around it here.
+  const bool queued = MODE == kModePlain && cache.q != nullptr;
+  if (!queued && !live) return;
+  // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
+  float wx = R[0] * lx + R[1] * ly + R[2] * lz;
+  float wy = R[3] * lx + R[4] * ly + R[5] * lz;
+  float wz = R[6] * lx + R[7] * ly + R[8] * lz;
+  // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
+  if (MODE != kModePlain && filter != nullptr) {
+    if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
+  }
+  uint64_t cmask = carried;
+  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
+  // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
+  // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
+  bool pass = false;
+  if (live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
+  if (pass) {
+    if (!P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
+      // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
+      const uint64_t mask = __ballot(1);
+      const uint32_t lane = __lane_id();
+      const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(mask))) - 1u;
+      uint32_t base = 0u;
+      const uint32_t shard = blockIdx.x & (kContShards - 1);
+      if (lane == leader) base = atomicAdd(&P.cont_cnt[shard * kContCntStride], static_cast<uint32_t>(__popcll(mask)));
+      base = __shfl(base, static_cast<int>(leader));
+      const uint32_t off = base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+      if (off < P.cont_out_cap) {
+        const uint32_t slot = shard * P.cont_out_cap + off;
+        const uint32_t st = P.cont_out_stride;
+        P.cont_out[slot] = wx;
+        P.cont_out[st + slot] = wy;
+        P.cont_out[2u * st + slot] = wz;
+        P.cont_out[3u * st + slot] = w;
+        reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
+        if (MODE != kModePlain && color != nullptr) {  // the mask rides with the continuation (cu:922,1129)
+          reinterpret_cast<uint32_t*>(P.cont_out)[5u * st + slot] = static_cast<uint32_t>(cmask);
+          reinterpret_cast<uint32_t*>(P.cont_out)[6u * st + slot] = static_cast<uint32_t>(cmask >> 32);
+        }
+      }
+    }
+    if (!queued) return;
+  }
+  PROBE_MARK(pr, kPhEmitGate);
+  if (queued) {
+    if (P.prob >= 1.0f) return;   // dispatch-uniform: every candidate of this layer continues, nothing goes to the image
+    const bool out = live && !pass;
+    sums.exit_w += out ? w : 0.0f;
+    sums.exit_n += out ? 1u : 0u;
+    const bool want = out && exit_may_land(P.proj, wx, wy, wz);
+    const uint64_t m = __ballot(want);
+    ExitQueue& Q = *cache.q;
+    if (want) {
+      const uint32_t i = sums.qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      Q.x[i] = wx;
+      Q.y[i] = wy;
+      Q.z[i] = wz;
+      Q.w[i] = w;
+      Q.wl[i] = wl_idx;
+    }
+    sums.qn += static_cast<uint32_t>(__popcll(m));
+    if (sums.qn >= 64u) drain_exits<MONO, SMALLC>(P, cache, sums, false, pr);
+    return;
+  }
+  const int primary = land_exit<MODE, MONO, SMALLC>(P, cache, color, cmask, wx, wy, wz, w, cmf_x, cmf_y, cmf_z, wl_idx, sums, pr);
   sums.exit_w += w;
   sums.exit_n++;
-  PROBE_MARK(pr, kPhAccum);
   if (MODE == kModeCapture) {
     uint32_t slot = atomicAdd(&P.counters[kCntExit], 1u);
     if (slot < P.exit_cap) {
@@ -1319,13 +1409,15 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     pv.len = 1u;
   }
 
-  bool stray = false;
+  bool stray = false, done = false;
   uint32_t stray_seq = 0u;
   float hex_d_basal = 0.0f, hex_d_side = 0.0f;
   if constexpr (HEX) {
     hex_d_basal = T.efast.hex_d_basal;
     hex_d_side = T.efast.hex_d_side;
   }
+  const bool queued = MODE == kModePlain && acc.q != nullptr;
+  if (queued) sums.qn = acc.q->n;   // parked there between passes (ExitQueue)
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
@@ -1349,12 +1441,17 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const bool entering = cos_t < 0.0f;
     const bool has_exit = entering || !tir;
     PROBE_MARK(pr, kPhFresnel);
-    if (has_exit) {
-      emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, entering ? rlx : rfx, entering ? rly : rfy, entering ? rlz : rfz,
-                         entering ? w_refl : w_refr, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, 2u * i + (entering ? 0u : 1u), pv, sums, pr);
-    }
+    // A ray that found no face ahead in the previous interaction (`stray`, below) has its turn at the emit site now, as it is,
+    // and then idles to the end of the loop: the loop body holds ONE copy of the emit code, and every lane that entered the
+    // loop is still there at every emit (the exit queue's push is a wave-wide step).
+    const bool live = !done && (stray || has_exit);
+    emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, live, stray ? d[0] : (entering ? rlx : rfx), stray ? d[1] : (entering ? rly : rfy),
+                                  stray ? d[2] : (entering ? rlz : rfz), stray ? w : (entering ? w_refl : w_refr), cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid,
+                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, sums, pr);
     PROBE_MARK(pr, kPhEmitGate);
+    done = done || stray;
     if (i + 1u == P.max_hits) break;
+    if (!queued && done) break;
     const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
     d[0] = entering ? rfx : rlx;
     d[1] = entering ? rfy : rly;
@@ -1418,30 +1515,34 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     }
     }
     const float t_best = num_b * fast_rcp(den_b);
-    if (hit < 0 || t_best <= -kSlabEps) {
-      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678).  Emitted behind
-      // the loop, so that the loop body holds ONE copy of the emit code.
+    if (!done && (hit < 0 || t_best <= -kSlabEps)) {
+      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678) — emitted by the
+      // next turn of the loop
       stray = true;
       stray_seq = inward_seq;
-      break;
     }
-    p[0] += t_best * d[0];
-    p[1] += t_best * d[1];
-    p[2] += t_best * d[2];
-    face = hit;
-    if (MODE != kModePlain) {
-      const uint8_t fn = sh->face_number[face];
-      if (pv.len < 16u) {
-        pv.reg = pk_shl8(pv.reg);
-        pv.reg.lo |= fn;
-      } else if (pv.len < kFilterPathCap) {
-        path[pv.len] = fn;
+    if (!stray) {
+      p[0] += t_best * d[0];
+      p[1] += t_best * d[1];
+      p[2] += t_best * d[2];
+      face = hit;
+      if (MODE != kModePlain) {
+        const uint8_t fn = sh->face_number[face];
+        if (pv.len < 16u) {
+          pv.reg = pk_shl8(pv.reg);
+          pv.reg.lo |= fn;
+        } else if (pv.len < kFilterPathCap) {
+          path[pv.len] = fn;
+        }
+        pv.len++;
       }
-      pv.len++;
     }
     PROBE_MARK(pr, kPhSlab);
   }
-  if (stray) emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, stray_seq, pv, sums, pr);
+  if (queued) {   // park the count: the lanes here agree on it, the first of them writes
+    const uint64_t m = __ballot(1);
+    if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) == 0u) acc.q->n = sums.qn;
+  }
 }
 
 // Bin the staged hits by image tile and append them to the tiles' lists (all kBlock threads call this together).
@@ -1500,7 +1601,7 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES_FILTER 3
 #endif
 template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (ACC != kAccDirect ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (MONO && (GEOM == kGeomOne || GEOM == kGeomOneHex))) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog;
   static_assert(!LOG || (MONO && MODE == kModePlain), "the hit log is a production-mode, one-plane route");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
@@ -1513,7 +1614,14 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (ACC != kAccDirect ? 4 : 
   constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
+  constexpr bool QUEUE = MODE == kModePlain && MONO && ACC != kAccBin && (GEOM == kGeomOne || GEOM == kGeomOneHex);
+  __shared__ __attribute__((aligned(16))) ExitQueues<QUEUE> s_queue;
   AccCtx<MONO, SMALLC> acc;
+  acc.q = nullptr;
+  if constexpr (QUEUE) {
+    acc.q = &s_queue.q[threadIdx.x >> 6];
+    if ((threadIdx.x & 63u) == 0u) acc.q->n = 0u;
+  }
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
@@ -1598,7 +1706,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (ACC != kAccDirect ? 4 : 
   }
   __syncthreads();
 
-  RaySums sums = {0.0f, 0.0f, 0u, 0u};
+  RaySums sums = {0.0f, 0.0f, 0u, 0u, 0u};
   PROBE_MARK(pr, kPhKernelFixed);
   const uint32_t stride = gridDim.x * kBlock;
   uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
@@ -1647,6 +1755,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (ACC != kAccDirect ? 4 : 
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
       }
     }
+  }
+  if constexpr (QUEUE) {   // what the last passes left on the wave's exit queue
+    sums.qn = acc.q->n;
+    drain_exits<MONO, SMALLC>(P, acc, sums, true, pr);
   }
   if constexpr (BIN) {
     __syncthreads();
