@@ -802,6 +802,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // the 21 G/s of memory-side fp32 atomics once its trace is fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).
       // Its cache misses go to one log region per workgroup instead and are summed per tile afterwards.
       const bool use_log = !use_bin && b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
+                           (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
+
                            bin_tiles >= 1u && bin_tiles <= 256u && (bin_slots & 16383ull) == 0ull && (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
       if (use_log) {
         // a region takes 4 hits per ray of its workgroup (configs[1]: 1.4 logged per ray; a full-sky render under the binned
