@@ -58,12 +58,13 @@ def workload(cfg):
         return dict(scene=scenes.config2_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[1]: single-scatter hex column (prism h=1.3, zenith gauss(90,0.3)), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,0,true,false>", metric="rays/sec (whole node) at 9 wavelengths, single-scatter hex column")
+                    kernel="halo_trace_kernel<0,3,true,kAccLog> (regular-prism instantiation, exit queue, hit log) + halo_split_kernel<1024,16> + halo_bin_accumulate_range_kernel",
+                    metric="rays/sec (whole node) at 9 wavelengths, single-scatter hex column")
     if cfg == "2":
         return dict(scene=scenes.config3_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[2]: two-layer full multi-scattering (plate h=0.3 zenith gauss(0,0.8) prob 1.0 over random column h=1.3), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,0,true,false> (transit source: layer 1 reads the continuation pool)",
+                    kernel="halo_trace_kernel<0,3,true,kAccLog> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16> + halo_bin_accumulate_range_kernel",
                     metric="root rays/sec (whole node) at 9 wavelengths, two-layer full multi-scattering")
     if cfg in ("4", "4p"):
         full = {"type": "uniform", "mean": 0.0, "std": 360.0}
@@ -71,12 +72,12 @@ def workload(cfg):
         if cfg == "4":
             e = scenes.stochastic_prism_entry()
             what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,2,true,true> + halo_split_kernel + halo_bin_accumulate_range_kernel"
+            kern = "halo_trace_kernel<0,2,true,kAccBin> + halo_split_kernel<256,16> + halo_bin_accumulate_range_kernel"
         else:
             e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
                              scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)
             what = "stochastic pyramid (config_example crystal 5, upper Miller (2,0,3), six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,1,true,false>"
+            kern = "halo_trace_kernel<0,1,true,kAccDirect>"
         return dict(scene=scenes.scene([(0.0, [e])], max_hits=8),
                     render=scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL),
                     wls=[scenes.wl_illuminant("D65", 31)], rays=25_000_000,
@@ -120,16 +121,25 @@ def _pmc_mean(name, key, kernel="halo_trace_kernel"):
     return val
 
 
+GROUP_KERNELS = ("halo_trace_kernel", "halo_split_kernel", "halo_bin_accumulate_range_kernel", "halo_bin_accumulate_kernel")
+
+
 def pmc_traffic_per_launch(cfg):
-    """HBM-side bytes per trace-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>_bench<cfg>_pmc_{fetch,write}_size.txt; FETCH_SIZE and WRITE_SIZE are collected in their own passes —
-    they do not fit one — and never inside the timed run).  Units and corrections per MI355X_MICROARCH.md §HBM: both counters
-    are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (64 B tallied per 128-B
-    request), so it is doubled; WRITE_SIZE (here: atomic read-modify-writes and 4/8-byte stores) is uncalibrated and taken
-    as reported."""
+    """HBM-side bytes per launch GROUP — the trace kernel plus the accumulation passes that follow it on the stream (split,
+    per-tile sums), which is also what the HIP events around a launch time — from the committed rocprofv3 PMC passes of this
+    same command (profiles/<round>_bench<cfg>_pmc_{fetch,write}_size.txt; FETCH_SIZE and WRITE_SIZE are collected in their own
+    passes — they do not fit one — and never inside the timed run).  Units and corrections per MI355X_MICROARCH.md §HBM: both
+    counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (64 B tallied per 128-B
+    request), so it is doubled; WRITE_SIZE is uncalibrated and taken as reported.  Sum of the per-dispatch means of the
+    group's kernels."""
     tag = "%s_bench%s" % (PROFILE_ROUND, cfg)
-    f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE"), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE")
-    return None if f is None or w is None else (2.0 * f + w) * 1024.0
+    tot, seen = 0.0, False
+    for k in GROUP_KERNELS:
+        f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE", k), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE", k)
+        if f is not None and w is not None:
+            tot += (2.0 * f + w) * 1024.0
+            seen = seen or k == "halo_trace_kernel"
+    return tot if seen else None
 
 
 def pmc_valu(cfg, rays_per_launch):
@@ -287,12 +297,12 @@ def main():
                         "ms_per_step_all": [x * 1e3 / args.steps for x in times]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(args.config),
-                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated; mean over every launch of the trace kernel in the pass)" % (PROFILE_ROUND, args.config),
+                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % (PROFILE_ROUND, args.config),
                          "kernel": wk["kernel"], "launches": dom_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
                          "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
                          "valu": pmc_valu(args.config, (rays_per_rank + first_layer["cont"]) / max(launches, 1)),
-                         "note": "fused kernel keeps rays in registers: HBM sees only accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+                         "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
         }
         if layers > 1:
             traced = rays_per_rank + first_layer["cont"]

@@ -1297,9 +1297,14 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
   return face;
 }
 
+struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kernel
+  WlEntryDev e;
+  float inv_n;
+};
+
 template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  uint32_t tid, RaySums& sums, Probe& pr) {
+                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr) {
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
   int face;
@@ -1339,7 +1344,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     PROBE_MARK(pr, kPhSun);
     if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
-    w = (P.wl_pool_size == 1u) ? P.wl_pool[0].spd_weight : P.wl_pool[wl_idx].spd_weight;
+    w = (P.wl_pool_size == 1u) ? wl0.e.spd_weight : P.wl_pool[wl_idx].spd_weight;
     PROBE_MARK(pr, kPhEntry);
   } else if (P.source == kSrcTransit) {
     Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
@@ -1393,13 +1398,16 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   }
   if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
 
-  // the wavelength pool (<= 8 KB) is read where it lies: one entry for a discrete session (a scalar load), a couple of
-  // L1-resident reads per ray otherwise — staging it cost every workgroup 8 KB of LDS
-  WlEntryDev wle;
-  if (P.wl_pool_size == 1u) wle = P.wl_pool[0];   // uniform address: one scalar load per ray pass
-  else wle = P.wl_pool[wl_idx];
+  // the wavelength pool (<= 8 KB) is read where it lies: a couple of L1-resident reads per ray — staging it cost every workgroup
+  // 8 KB of LDS.  The one entry of a discrete session comes in registers (Wl0): a load here would also make the wave wait for
+  // every store it has in flight (hit-log records, continuation rays) once per pass
+  WlEntryDev wle = wl0.e;   // a one-entry pool (discrete wavelength): read once per kernel, not per pass
+  float inv_n = wl0.inv_n;
+  if (P.wl_pool_size != 1u) {
+    wle = P.wl_pool[wl_idx];
+    inv_n = 1.0f / wle.n_idx;  // once per ray, IEEE like the reference
+  }
   const float n_idx = wle.n_idx;
-  const float inv_n = 1.0f / n_idx;  // once per ray, IEEE like the reference
   const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
 
   uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
@@ -1707,6 +1715,9 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
   __syncthreads();
 
   RaySums sums = {0.0f, 0.0f, 0u, 0u, 0u};
+  Wl0 wl0;
+  wl0.e = P.wl_pool[0];
+  wl0.inv_n = 1.0f / wl0.e.n_idx;
   PROBE_MARK(pr, kPhKernelFixed);
   const uint32_t stride = gridDim.x * kBlock;
   uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
@@ -1729,7 +1740,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhStage);
-      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), tid, sums, pr);
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr);
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhSlab);
       if constexpr (BIN) {
@@ -1745,10 +1756,10 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
       if (tid < P.n_rays) {
         if constexpr (POOL) {  // shape clock not a multiple of 32: lanes of a half-wave may differ, read the pool through L1/L2
           const PoolRec* sh = reinterpret_cast<const PoolRec*>(P.shapes) + (tid / P.geom_clock);
-          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, tid, sums, pr);
+          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, wl0, tid, sums, pr);
         } else {
           const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
-          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, tid, sums, pr);
+          trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, wl0, tid, sums, pr);
         }
       }
       if constexpr (BIN) {
