@@ -91,6 +91,11 @@ HALO_GEOM_HD float Draw(ScalarStream& s, const HaloDist& d) {
 // ---------------------------------------------------------------------------------------------------
 struct ShapeCursor {
   int fid = 0, tri = 0;
+  // The builder's own copy of the emitted face rows (unit normal, plane constant), for FinalizeSlabs: on the device the record
+  // lies in HBM, 1.4-4 KB from the next lane's, and every value read back from it is a dependent, uncoalesced load (the prism
+  // generator sat idle 90 % of its time on those: 10.8 % VALU-active, 1.3 GB fetched by a kernel that has no input).
+  float (*fn)[4] = nullptr;
+  float d_last = 0.0f;   // plane constant of the face emitted last
 };
 
 // Host: zero the record.  Device: the generator's caller clears the whole pool with one memset instead of 3.7 KB of
@@ -110,20 +115,29 @@ template <class S>
 HALO_GEOM_HD void EmitFace(S& s, ShapeCursor& cur, const float plane[4], const float normal[3], int number,
                            const float (*loop)[3], int nv) {
   const int fid = cur.fid;
+  const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
+  const float dn = (len > kGeomFloatEps) ? plane[3] / len : 0.0f;
   s.face[fid][0] = normal[0];
   s.face[fid][1] = normal[1];
   s.face[fid][2] = normal[2];
-  const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
-  s.face[fid][3] = (len > kGeomFloatEps) ? plane[3] / len : 0.0f;
+  s.face[fid][3] = dn;
+  cur.d_last = dn;
+  if (cur.fn != nullptr) {
+    cur.fn[fid][0] = normal[0];
+    cur.fn[fid][1] = normal[1];
+    cur.fn[fid][2] = normal[2];
+    cur.fn[fid][3] = dn;
+  }
   s.face_number[fid] = static_cast<uint8_t>(number);
   for (int k = 1; k + 1 < nv && nv >= 3 && cur.tri < static_cast<int>(sizeof(s.tri_na) / 16u); k++) {
     const int t = cur.tri;
-    float* v = s.tri_v[t];
+    float v[9];   // computed on the values, stored once: nothing is read back from the record
     for (int a = 0; a < 3; a++) {
       v[a] = loop[0][a];
       v[3 + a] = loop[k][a];
       v[6 + a] = loop[k + 1][a];
     }
+    for (int a = 0; a < 9; a++) s.tri_v[t][a] = v[a];
     const float a[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
     const float b[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
     float nrm[3] = {-b[1] * a[2] + a[1] * b[2], b[0] * a[2] - a[0] * b[2], -b[0] * a[1] + a[0] * b[1]};  // Cross3 math.cpp:36
@@ -141,6 +155,7 @@ template <class S>
 HALO_GEOM_HD void FinalizeSlabs(S& s, const ShapeCursor& cur) {
   s.face_cnt = cur.fid;
   s.tri_cnt = cur.tri;
+  const float (*fn)[4] = cur.fn != nullptr ? cur.fn : s.face;   // the builder's copy where there is one (ShapeCursor)
   bool used[kMaxFaces];
   for (int i = 0; i < kMaxFaces; i++) used[i] = false;
   int ns = 0, n1 = 0;
@@ -148,18 +163,18 @@ HALO_GEOM_HD void FinalizeSlabs(S& s, const ShapeCursor& cur) {
     if (used[i]) continue;
     int mate = -1;
     for (int j = i + 1; j < cur.fid && mate < 0; j++)
-      if (!used[j] && s.face[i][0] == -s.face[j][0] && s.face[i][1] == -s.face[j][1] && s.face[i][2] == -s.face[j][2]) mate = j;
+      if (!used[j] && fn[i][0] == -fn[j][0] && fn[i][1] == -fn[j][1] && fn[i][2] == -fn[j][2]) mate = j;
     if (mate < 0) {
       s.single[n1++] = static_cast<uint8_t>(i);
       continue;
     }
     used[mate] = true;
     float* r = s.slab[ns++];
-    r[0] = s.face[i][0];
-    r[1] = s.face[i][1];
-    r[2] = s.face[i][2];
-    r[3] = s.face[i][3];
-    r[4] = s.face[mate][3];
+    r[0] = fn[i][0];
+    r[1] = fn[i][1];
+    r[2] = fn[i][2];
+    r[3] = fn[i][3];
+    r[4] = fn[mate][3];
     int32_t ip = i, im = mate;
     uint32_t bp, bm;
     bp = static_cast<uint32_t>(ip);
@@ -264,6 +279,8 @@ HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], S& out) {
   }
   const float zt = 0.5f * h, zb = -0.5f * h;
   ShapeCursor cur;
+  float fn_rows[kMaxFaces][4];
+  cur.fn = fn_rows;
   float loop[HALO_MAX_FACE_VTX][3];
   if (hs.bounded) {  // basal faces (numbers 1, 2)
     const float plane_t[4] = {0.0f, 0.0f, 1.0f, -zt}, nrm_t[3] = {0.0f, 0.0f, 1.0f};
@@ -550,6 +567,8 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
   }
   if (present < 4) return false;
   ShapeCursor cur;
+  float fn_rows[kMaxFaces][4];
+  cur.fn = fn_rows;
   float loop[HALO_MAX_FACE_VTX][3];
   for (int s = 0; s < 20; s++) {
     if (on_n[s] == 0) continue;

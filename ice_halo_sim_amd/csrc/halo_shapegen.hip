@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     T.fn[fid][0] = nrm[0];
     T.fn[fid][1] = nrm[1];
     T.fn[fid][2] = nrm[2];
-    T.fn[fid][3] = out.face[fid][3];
+    T.fn[fid][3] = cur.d_last;
   }
   // opposite-face slabs (geom::FinalizeSlabs): face i pairs with the first later face whose unit normal is its exact negative
   const int face_cnt = __popc(present);
