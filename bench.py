@@ -301,7 +301,7 @@ def main():
                          "kernel": wk["kernel"], "launches": dom_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
                          "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
-                         "valu": pmc_valu(args.config, (rays_per_rank + first_layer["cont"]) / max(launches, 1)),
+                         "valu": pmc_valu(args.config, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
                          "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
         }
         if layers > 1:
