@@ -322,3 +322,36 @@ def test_hit_log_route_equals_the_direct_route():
     want, _ = hb.ReadbackXyzAccum()
     hb.close()
     assert rel_l2(small, want) <= 2e-5
+
+
+@pytest.mark.parametrize("lens", list(range(11)))
+@pytest.mark.parametrize("visible", [abi.VISIBLE_UPPER, abi.VISIBLE_LOWER, abi.VISIBLE_FULL])
+def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible):
+    """The exit queue of the one-shape production kernels (MODE 0: an interaction pushes only the exits that pass the cheap
+    culls of `exit_may_land`, projection and accumulation run on popped batches) against the kernels that project at the emit
+    site — the capture instantiation (MODE 2, same rays, same streams) — and against the oracle, for every lens and visibility
+    range: a cull that is not conservative for some lens would lose hits here.  Same pixel-hit and exit counts, same landed
+    weight, same image up to the order of float sums."""
+    sc = scenes.config2_scene()
+    overlap = 0.0872 if lens in (4, 5, 6) else 0.0
+    rd = scenes.render(lens, 512, 256, fov=120.0 if lens not in (4, 5, 6, 7, 9) else 180.0, el=30.0 if lens != 7 else 0.0, visible=visible, overlap=overlap)
+    wl, n = scenes.wl_discrete(530.0), 300_000
+    out = {}
+    for name, kw in (("queue", {}), ("emit_site", {"capture_exits": 1})):
+        hb = hip_backend(seed=19, **kw)
+        st = run_session(hb, sc, rd, wl, n)
+        route = hb.last_route()
+        assert route.mode_mask == (1 if name == "queue" else 4)
+        if kw:
+            hb.DrainExits()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (img, landed, st[0].pixel_hits, st[0].exit_count)
+    q, e = out["queue"], out["emit_site"]
+    assert (q[2], q[3]) == (e[2], e[3])
+    assert q[1] == pytest.approx(e[1], rel=1e-6, abs=1e-3)
+    if e[0].sum() > 0:   # (the sun's pixels take ~10^5 float adds each, in a different order on the two sides: 4.5e-5 seen)
+        assert rel_l2(q[0], e[0]) <= 2e-4
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 19)
+    assert q[1] == pytest.approx(landed_o, rel=2e-4, abs=1.0)
+    assert q[3] == pytest.approx(st_o[0].exit_count, rel=2e-4, abs=20)
