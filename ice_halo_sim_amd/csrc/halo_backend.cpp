@@ -25,6 +25,8 @@ hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
                             uint32_t tiles, hipStream_t stream);
+hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
+                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -120,6 +122,7 @@ struct HaloBackend {
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
+  bool xyz_log = false;        // illuminant session on X, Y, Z planes whose big production launches go through the hit log
   bool mono_dirty = false;
   uint32_t plane_cnt = 1, plane_copies = 8;
   std::vector<std::array<float, 3>> plane_coef;  // fold coefficients of the pending planes
@@ -447,7 +450,10 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   const size_t npix = static_cast<size_t>(render->width) * render->height;
   if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
   const bool discrete = wl->illuminant < 0;
-  b->mono_by_wl = b->mono_enabled && !discrete && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
+  //  * illuminant, batch >= 8 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
+  //    the per-tile pass applies the CMF (halo_log_accumulate_xyz_kernel): no plane per entry, no two-level split, a 3-plane fold
+  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (8ull << 20);
+  b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
   b->plane_copies = b->mono_by_wl ? 1u : static_cast<uint32_t>(b->mono_copies);  // hits already spread over the pool's planes
@@ -664,6 +670,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.bin_list = nullptr;
     P.bin_log = 0u;
+    P.log_xyz = 0u;
+    P.log_plane_stride = 0u;
     P.bin_shift = 0u;
     P.landed = b->sums.ptr + kSumLanded;
     P.exits = b->exits.ptr;
@@ -801,35 +809,43 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Hit log (halo_trace.inl log_hit): where the binned route is not taken, a production-mode one-plane launch still runs into
       // the 21 G/s of memory-side fp32 atomics once its trace is fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).
       // Its cache misses go to one log region per workgroup instead and are summed per tile afterwards.
-      const bool use_log = !use_bin && b->mono_session && !b->mono_by_wl && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
+      // X/Y/Z hit log: tiles are 4 Ki slots of ONE plane (three fp64 tiles in LDS), at most 512 of them
+      const uint64_t plane_slots = static_cast<uint64_t>(kMonoRows) << b->mono_s_log2;
+      const uint32_t log_tiles = b->xyz_log ? static_cast<uint32_t>(plane_slots >> 12) : bin_tiles;
+      const bool log_layout_ok = b->xyz_log ? (log_tiles >= 1u && log_tiles <= 512u && (plane_slots & 4095ull) == 0ull && plane_slots <= (1ull << kLogWlShift))
+                                            : (b->mono_session && !b->mono_by_wl && bin_tiles >= 1u && bin_tiles <= 256u && (bin_slots & 16383ull) == 0ull);
+      const bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
                            (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
-
-                           bin_tiles >= 1u && bin_tiles <= 256u && (bin_slots & 16383ull) == 0ull && (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
+                           (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
+      const bool use_log_xyz = use_log && b->xyz_log;
       if (use_log) {
         // a region takes 4 hits per ray of its workgroup (configs[1]: 1.4 logged per ray; a full-sky render under the binned
         // route's threshold ~5) and a tile list twice its even share; what runs over falls back to direct atomics
         const uint64_t per_wg = (m + static_cast<uint64_t>(blocks) - 1u) / static_cast<uint64_t>(blocks);
         uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
         cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
-        uint64_t c2 = std::max<uint64_t>(2ull * 4ull * m / bin_tiles, 1ull << 14);
-        c2 = std::min<uint64_t>(c2, (6ull << 30) / (8ull * bin_tiles));
+        if (use_log_xyz) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));   // full-sky renders: 5-6 hits per ray
+        uint64_t c2 = std::max<uint64_t>(2ull * (use_log_xyz ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
+        c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * log_tiles));
         if (b->hit_log_cap) {   // tests: run both overflow fallbacks
           cap = b->hit_log_cap;
-          c2 = std::max<uint64_t>(cap * static_cast<uint64_t>(blocks) / (2ull * bin_tiles), 64ull);
+          c2 = std::max<uint64_t>(cap * static_cast<uint64_t>(blocks) / (2ull * log_tiles), 64ull);
         }
         cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
         HIPCHK(b, b->bin_cnt.reserve(std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u)));
         HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(512) * 16u));
-        HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+        HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), b->stream));
         HIPCHK(b, b->bin_list.reserve(cap * static_cast<uint64_t>(blocks)));
-        HIPCHK(b, b->bin_list2.reserve(c2 * bin_tiles));
+        HIPCHK(b, b->bin_list2.reserve(c2 * log_tiles));
         P.bin_list = b->bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
-        P.bin_tiles = bin_tiles;
+        P.bin_tiles = log_tiles;
         P.bin_shift = 0u;
         P.bin_cnt = b->bin_cnt.ptr;   // one fill count per region, written by the trace kernel
         P.bin_log = 1u;
         P.mono_copy_mask = 0u;   // logged slots and their fallbacks address copy 0
+        P.log_xyz = use_log_xyz ? 1u : 0u;
+        P.log_plane_stride = static_cast<uint32_t>(plane_slots * b->plane_copies);
       } else
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
@@ -847,6 +863,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.bin_shift = two_level ? 14u + fan_log2 : 0u;
         P.bin_cnt = b->bin_cnt.ptr;
         P.bin_log = 0u;
+        P.log_xyz = 0u;
+        P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
         P.mono_copy_mask = 0u;   // staged hits and their fallbacks address copy 0
         if (two_level) {
           uint64_t c2 = std::max<uint64_t>(slack * 6ull * m / bin_tiles, 1ull << 12);
@@ -859,6 +877,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       } else {
         P.bin_list = nullptr;
         P.bin_log = 0u;
+        P.log_xyz = 0u;
+        P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
@@ -869,12 +889,14 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->route.launches++;
       b->route.mode_mask |= 1u << (b->capture ? 2 : ((P.filter != nullptr || P.color != nullptr) ? 1 : 0));
       b->route.geom_mask |= 1u << launch_geom;
-      b->route.accum_mask |= use_log ? 16u : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
+      b->route.accum_mask |= use_log ? (use_log_xyz ? 32u : 16u) : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_log) {
-        hipError_t be = launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, bin_tiles,
-                                         b->stream);
+        hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
+                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, b->stream)
+                                    : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
+                                                       b->bin_cnt2.ptr, bin_tiles, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {

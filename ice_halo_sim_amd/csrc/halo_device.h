@@ -153,6 +153,7 @@ struct ColorDev {
 // through that region's own counter (64 B apart: same-line atomics serialise), and the next layer reads logical index j
 // through the prefix table of the fill counts.  Dense logical order, no holes, no compaction pass.
 constexpr int kContShards = 256;
+constexpr uint32_t kLogWlShift = 23u;   // DispatchParams::log_xyz records: slot in bits 0..22, CMF code above: a wavelength-pool entry, or pool size + c for a weight that is already channel c of X, Y, Z
 constexpr int kContCntStride = 16;
 
 struct HitRec {  // one staged pixel hit of the binned accumulation: slot inside plane 0 and the weight's bits
@@ -238,6 +239,9 @@ struct DispatchParams {
                                // that misses the pixel cache is appended there instead of going out as a global atomic, and the
                                // kernel leaves each region's fill count in bin_cnt[blockIdx.x]
   uint32_t mono_by_wl;         // 1: plane index = the ray's wavelength-pool entry (illuminant session, one plane per entry)
+  uint32_t log_xyz;            // hit log of an illuminant session on X, Y, Z planes (with bin_log, X/Y/Z kernels): a record is the hit's slot
+                               // in ONE plane | CMF code << kLogWlShift, and the per-tile pass applies the code's CMF row
+  uint32_t log_plane_stride;   // ... floats between the X, Y and Z planes (fallback atomics of a full log)
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)
   HaloExitRecord* exits;

@@ -61,25 +61,39 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 // consecutive addresses instead of 64 lists (the log split went from 0.67 to 0.37 ms per 68 M records with that).  One returning
 // global atomic per tile and step reserves the run's place in the tile list; a tile list that overflows falls back to direct
 // atomics on the plane.
-constexpr uint32_t kSplitParts = 8u, kSplitFanMax = 256u;
+constexpr uint32_t kSplitParts = 8u;
 // Step sizes (threads x records per thread).  The hit log has 128..256 destinations per step, and its stores only coalesce
 // when a step is large: 16384 records (a region is read in one or two steps; 128 KB of LDS, one workgroup per CU) runs
 // at 0.23 ms per 58 M records where 4096 takes 0.36 and 1024 takes 1.1.  The coarse lists of the two-level route have <= 32
 // destinations per step, whose runs are long anyway, and ~1000 long chains that want many workgroups resident: 256 x 16.
-template <uint32_t kSplitBlock, uint32_t kSplitPer>
+// Tile of a record: ((slot & slot_mask) >> tile_log2) & (fan - 1) — contiguous 16 Ki-slot tiles of the plane array (tile_log2 14),
+// or, X/Y/Z hit log, interleaved tiles of one plane (tile_log2 0, mix_log2 = log2 of the plane's columns; the wavelength-pool
+// entry above the slot is cut off by slot_mask).  kSplitFanMax = destination tiles per source list.
+struct SplitXyz {              // X/Y/Z hit log only: what a record that finds its tile list full is added to
+  const WlEntryDev* pool;      // nullptr = scalar planes: plane[slot] += w
+  uint32_t pool_size;          // CMF codes: pool entries, then pool_size + c = "the weight is channel c already"
+  uint32_t plane_stride;
+};
+template <uint32_t kSplitBlock, uint32_t kSplitPer, uint32_t kSplitFanMax>
 __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                  const uint32_t* __restrict__ cnt1, uint32_t cnt1_stride, uint32_t parts,
                                                                  uint2* __restrict__ list2, uint32_t cap2, uint32_t* __restrict__ cnt2, uint32_t fan_log2,
-                                                                 uint32_t coarse) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSplitFanMax], s_off[kSplitFanMax];
+                                                                 uint32_t coarse, uint32_t slot_mask, uint32_t tile_log2, uint32_t mix_log2, SplitXyz xyz) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSplitFanMax];
+  __shared__ __attribute__((aligned(16))) uint32_t s_off[kSplitFanMax];
   __shared__ uint32_t s_base[kSplitFanMax];
   __shared__ uint2 s_rec[kSplitBlock * kSplitPer];
-  static_assert(kSplitBlock >= kSplitFanMax, "one thread per tile counter");
+  static_assert(kSplitBlock >= kSplitFanMax && kSplitFanMax % 256u == 0u, "one thread per tile counter; the scan takes 4 per lane and round");
   const uint32_t l1 = blockIdx.x / parts, part = blockIdx.x % parts;
   const uint32_t n = min(cnt1[static_cast<size_t>(l1) * cnt1_stride], cap1);
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / parts);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / parts);
   const uint32_t fmask = (1u << fan_log2) - 1u;
+  // mix_log2 != 0 (with tile_log2 0): tile = (column + row) mod fan, slot = row << mix_log2 | column — see halo_log_accumulate_xyz_kernel
+  auto tile_of = [&](uint32_t x) {
+    const uint32_t sl = x & slot_mask;
+    return ((mix_log2 != 0u ? sl + (sl >> mix_log2) : sl >> tile_log2)) & fmask;
+  };
   const uint32_t tile0 = coarse ? (l1 << fan_log2) : 0u;   // the first destination tile of this source list
   const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
   // The steps of a workgroup are a chain of dependent latencies (loads, LDS ranks, the reserving atomic, stores), so the next
@@ -96,19 +110,24 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   for (uint32_t b0 = lo; b0 < hi; b0 += kSplitBlock * kSplitPer) {   // workgroup-uniform trip count
 #pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u)
-      rank[u] = h[u].x != 0xFFFFFFFFu ? atomicAdd(&s_cnt[(h[u].x >> kBinTileLog2) & fmask], 1u) : 0u;
+      rank[u] = h[u].x != 0xFFFFFFFFu ? atomicAdd(&s_cnt[tile_of(h[u].x)], 1u) : 0u;
     __syncthreads();
-    if (threadIdx.x < 64u) {   // exclusive scan of the 256 counters: 4 per lane, then across the wave
-      const uint4 c = *reinterpret_cast<const uint4*>(&s_cnt[threadIdx.x * 4u]);
-      const uint32_t own = c.x + c.y + c.z + c.w;
-      uint32_t incl = own;
+    if (threadIdx.x < 64u) {   // exclusive scan of the counters by one wave: 4 per lane and round
+      uint32_t carry = 0u;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (static_cast<int>(threadIdx.x) >= d) incl += up;
+      for (uint32_t g = 0; g < kSplitFanMax; g += 256u) {
+        const uint4 c = *reinterpret_cast<const uint4*>(&s_cnt[g + threadIdx.x * 4u]);
+        const uint32_t own = c.x + c.y + c.z + c.w;
+        uint32_t incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = __shfl_up(incl, d);
+          if (static_cast<int>(threadIdx.x) >= d) incl += up;
+        }
+        const uint32_t ex = carry + incl - own;
+        *reinterpret_cast<uint4*>(&s_off[g + threadIdx.x * 4u]) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+        carry += __shfl(incl, 63);
       }
-      const uint32_t ex = incl - own;
-      *reinterpret_cast<uint4*>(&s_off[threadIdx.x * 4u]) = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
     }
     const uint32_t c_own = threadIdx.x < kSplitFanMax ? s_cnt[threadIdx.x] : 0u;
     const uint32_t base = c_own ? atomicAdd(&cnt2[static_cast<size_t>(tile0 + threadIdx.x) * kBinCntStride], c_own) : 0u;
@@ -116,7 +135,7 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
     if (threadIdx.x < kSplitFanMax) s_cnt[threadIdx.x] = 0u;   // for the next step (ranked after the barrier that ends this one)
 #pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u)
-      if (h[u].x != 0xFFFFFFFFu) s_rec[s_off[(h[u].x >> kBinTileLog2) & fmask] + rank[u]] = h[u];
+      if (h[u].x != 0xFFFFFFFFu) s_rec[s_off[tile_of(h[u].x)] + rank[u]] = h[u];
     const uint32_t nb = b0 + kSplitBlock * kSplitPer;
 #pragma unroll
     for (uint32_t u = 0; u < kSplitPer; ++u) {
@@ -131,10 +150,25 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
       const uint32_t i = u * kSplitBlock + threadIdx.x;
       if (i >= n_step) continue;
       const uint2 r = s_rec[i];
-      const uint32_t t = (r.x >> kBinTileLog2) & fmask;
+      const uint32_t t = tile_of(r.x);
       const uint32_t pos = s_base[t] + (i - s_off[t]);
-      if (pos < cap2) list2[static_cast<size_t>(tile0 + t) * cap2 + pos] = r;
-      else atomic_add_f32(plane + r.x, __uint_as_float(r.y));
+      if (pos < cap2) {
+        list2[static_cast<size_t>(tile0 + t) * cap2 + pos] = r;
+      } else if (xyz.pool != nullptr) {
+        const uint32_t code = r.x >> kLogWlShift;
+        float c[3];
+        if (code < xyz.pool_size) {
+          const WlEntryDev e = xyz.pool[code];
+          c[0] = e.cmf_x, c[1] = e.cmf_y, c[2] = e.cmf_z;
+        } else {
+          for (uint32_t k = 0; k < 3u; ++k) c[k] = code == xyz.pool_size + k ? 1.0f : 0.0f;
+        }
+        float* at = plane + (r.x & slot_mask);
+        for (uint32_t k = 0; k < 3u; ++k)
+          if (c[k] != 0.0f) atomic_add_f32(at + k * xyz.plane_stride, c[k] * __uint_as_float(r.y));
+      } else {
+        atomic_add_f32(plane + r.x, __uint_as_float(r.y));
+      }
     }
     __syncthreads();
   }
@@ -181,22 +215,95 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
   }
 }
 
+// X/Y/Z hit log (illuminant sessions): one workgroup per tile of 4 Ki slots of ONE plane sums its list into X, Y and Z tiles —
+// the record's wavelength-pool entry picks the CMF row (pool staged in LDS), three fp64 LDS adds per record — and adds them to
+// the three planes.  This is where an illuminant session's colour is made: no plane per pool entry (31 x 128 tiles at
+// configs[4], a two-level split) and a fold over 3 planes instead of 31.
+// Tiles are INTERLEAVED over the plane: a slot is row << s_log2 | column (MonoSlot: row = pixel mod 1024, column = a hash of
+// pixel / 1024), and its tile is (column + row) mod tiles.  Contiguous slot ranges are image columns x mod 1024 and run 6x
+// uneven on a full-sky render (the light is around the sun's azimuth) — with them the hot tiles' lists overflowed into 3
+// contended atomics per record and the split took 10.9 ms; the column alone is a hash of the image ROW, just as uneven over
+// 512 tiles.  A tile holds tiles' worth of scattered slots, so its write-out is 3 x 4 Ki plain 4-byte read-modify-writes (the
+// workgroup is the only writer of its slots while this kernel runs).
+constexpr uint32_t kXyzTileLog2 = 12u;
+__global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_xyz_kernel(float* __restrict__ planes, uint32_t plane_stride, const uint2* __restrict__ list, uint32_t cap,
+                                                                            const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
+                                                                            uint32_t tiles_log2, uint32_t s_log2) {
+  __shared__ __attribute__((aligned(16))) double acc[3][1u << kXyzTileLog2];   // fp64: see halo_bin_accumulate_kernel
+  __shared__ float s_cmf[HALO_WL_POOL_MAX + 3][3];   // CMF codes: pool entries, then the three unit rows (a cached pixel's X, Y, Z records)
+  const uint32_t tile = blockIdx.x;
+  const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
+  if (n == 0u) return;
+  for (uint32_t j = threadIdx.x; j < 3u << kXyzTileLog2; j += kBinBlock) (&acc[0][0])[j] = 0.0;
+  for (uint32_t j = threadIdx.x; j < pool_size + 3u; j += kBinBlock) {
+    const bool unit = j >= pool_size;
+    s_cmf[j][0] = unit ? (j == pool_size ? 1.0f : 0.0f) : pool[j].cmf_x;
+    s_cmf[j][1] = unit ? (j == pool_size + 1u ? 1.0f : 0.0f) : pool[j].cmf_y;
+    s_cmf[j][2] = unit ? (j == pool_size + 2u ? 1.0f : 0.0f) : pool[j].cmf_z;
+  }
+  __syncthreads();
+  const uint2* src = list + static_cast<size_t>(tile) * cap;
+  constexpr uint32_t kU = 4u, kSlotMask = (1u << kLogWlShift) - 1u;
+  auto add = [&](uint2 h) {
+    const uint32_t sl = h.x & kSlotMask, wl = h.x >> kLogWlShift;
+    const uint32_t s = ((sl >> s_log2) << (s_log2 - tiles_log2)) | ((sl & ((1u << s_log2) - 1u)) >> tiles_log2);   // row, high bits of the column
+    const double w = static_cast<double>(__uint_as_float(h.y));
+    const float cx = s_cmf[wl][0], cy = s_cmf[wl][1], cz = s_cmf[wl][2];
+    if (cx != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(cx) * w);
+    if (cy != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(cy) * w);
+    if (cz != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(cz) * w);
+  };
+  uint32_t i = threadIdx.x;
+  for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
+    uint2 h[kU];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) add(h[u]);
+  }
+  for (; i < n; i += kBinBlock) add(src[i]);
+  __syncthreads();
+  for (uint32_t c = 0; c < 3u; ++c) {
+    float* dst = planes + static_cast<size_t>(c) * plane_stride;
+    for (uint32_t j = threadIdx.x; j < (1u << kXyzTileLog2); j += kBinBlock) {
+      const float v = static_cast<float>(acc[c][j]);
+      if (v == 0.0f) continue;
+      const uint32_t row = j >> (s_log2 - tiles_log2), hi = j & ((1u << (s_log2 - tiles_log2)) - 1u);
+      const uint32_t col = (hi << tiles_log2) | ((tile - row) & ((1u << tiles_log2) - 1u));
+      dst[(static_cast<size_t>(row) << s_log2) | col] += v;
+    }
+  }
+}
+
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
                             uint32_t tiles, hipStream_t stream) {
-  // hit-log route: regions -> the tile lists of one plane array of at most kSplitFanMax tiles (fan 256 covers any of them)
-  (void)tiles;
-  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
-                     reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u);
+  // hit-log route: regions -> the tile lists of one plane array of at most 256 tiles
+  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+                     reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u, 0xFFFFFFFFu, static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
   return hipGetLastError();
 }
 
+// the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of 4 Ki slots of one plane
+hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
+                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream) {
+  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));   // tiles = 1024 << s_log2 >> 12: tiles_log2 = s_log2 - 2
+  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+                     reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride});
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(halo_log_accumulate_xyz_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
+                     pool, pool_size, tiles_log2, s_log2);
+  return hipGetLastError();
+}
+
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
-  hipLaunchKernelGGL((halo_split_kernel<256u, 16u>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
-                     cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u);
+  hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
+                     cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
+                     static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);

@@ -535,9 +535,30 @@ HD void log_hit(const DispatchParams& P, uint32_t* log_n, uint32_t slot, float w
   uint32_t base = 0u;
   if (before == 0u) base = atomicAdd(log_n, static_cast<uint32_t>(__popcll(mask)));
   const uint32_t idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base))) + before;
-  if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(blockIdx.x) * P.bin_cap + idx] = make_uint2(slot, __float_as_uint(w));
-  else atomic_add_f32(P.mono + slot, w);   // copy 0
+  if (idx < P.bin_cap) {
+    reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(blockIdx.x) * P.bin_cap + idx] = make_uint2(slot, __float_as_uint(w));
+  } else if (P.log_xyz != 0u) {   // full region: X, Y, Z directly (copy 0)
+    const uint32_t code = slot >> kLogWlShift;
+    float cx, cy, cz;
+    if (code < P.wl_pool_size) {
+      const WlEntryDev e = P.wl_pool[code];
+      cx = e.cmf_x, cy = e.cmf_y, cz = e.cmf_z;
+    } else {
+      cx = code == P.wl_pool_size ? 1.0f : 0.0f, cy = code == P.wl_pool_size + 1u ? 1.0f : 0.0f, cz = code == P.wl_pool_size + 2u ? 1.0f : 0.0f;
+    }
+    float* at = P.mono + (slot & ((1u << kLogWlShift) - 1u));
+    if (cx != 0.0f) atomic_add_f32(at, cx * w);
+    if (cy != 0.0f) atomic_add_f32(at + P.log_plane_stride, cy * w);
+    if (cz != 0.0f) atomic_add_f32(at + 2u * P.log_plane_stride, cz * w);
+  } else {
+    atomic_add_f32(P.mono + slot, w);   // copy 0
+  }
 }
+
+// What a hit of scalar plane `pl` (0, or the ray's wavelength-pool entry) on pixel `pix` is called in the log: its slot in the array of planes.
+HD uint32_t log_slot(const DispatchParams& P, uint32_t pl, uint32_t pix) { return (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2); }
+// X/Y/Z kernels under the hit log: the slot in ONE plane with the CMF code above it (the per-tile pass makes X, Y, Z)
+HD uint32_t log_slot_xyz(const DispatchParams& P, uint32_t code, uint32_t pix) { return MonoSlot(pix, P.mono_s_log2) | (code << kLogWlShift); }
 
 // MONO: one scalar per hit into plane 0 (discrete wavelength) or plane wl_idx (illuminant session with one plane per
 // pool entry); the CMF is applied by halo_fold_kernel.  !MONO: X, Y, Z into planes 0..2.
@@ -569,8 +590,8 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
     }
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
-  if (MONO && ctx.log_n != nullptr) {
-    log_hit(P, ctx.log_n, (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2), w);
+  if (ctx.log_n != nullptr) {   // hit-log kernels: a scalar record; for X/Y/Z planes it names the ray's pool entry instead of three products
+    log_hit(P, ctx.log_n, MONO ? log_slot(P, pl, pix) : log_slot_xyz(P, wl_idx, pix), w);
     return;
   }
   if (MONO) {
@@ -1611,7 +1632,7 @@ HD float wave_sum(float v) {
 template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (MONO && (GEOM == kGeomOne || GEOM == kGeomOneHex))) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog;
-  static_assert(!LOG || (MONO && MODE == kModePlain), "the hit log is a production-mode, one-plane route");
+  static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
@@ -1788,8 +1809,13 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
       if (MONO) {
         const float v = T.cache.val[i];
         if (v == 0.0f) continue;
-        if (LOG) log_hit(P, &s_log_n, (pl << (P.mono_s_log2 + 10u)) + MonoSlot(pix, P.mono_s_log2), v);
+        if (LOG) log_hit(P, &s_log_n, log_slot(P, pl, pix), v);
         else atomic_add_f32(mono_slot(P, pl, pix), v);
+      } else if (LOG) {   // a cached pixel leaves as three records whose weights ARE X, Y, Z (codes pool size + channel)
+        for (uint32_t c = 0; c < 3u; ++c) {
+          const float v = T.cache.val[i * 3 + c];
+          if (v != 0.0f) log_hit(P, &s_log_n, log_slot_xyz(P, P.wl_pool_size + c, pix), v);
+        }
       } else {
         atomic_add_f32(mono_slot(P, 0u, pix), T.cache.val[i * 3 + 0]);
         atomic_add_f32(mono_slot(P, 1u, pix), T.cache.val[i * 3 + 1]);
@@ -1821,12 +1847,13 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
 }
 
 // host-callable launcher pieces: each halo_trace_m<MODE>.hip translation unit instantiates the kernels of one MODE
-// (the 18 instantiations compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
+// (the instantiations of the three MODEs compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
 template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode
-    if (mono && P.bin_log != 0u) {
-      hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
+  if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode: scalar planes, or X/Y/Z planes of an illuminant session
+    if (P.bin_log != 0u) {
+      if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
+      else if constexpr (GEOM != kGeomOneHex) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
     }
   }

@@ -55,56 +55,63 @@ def _check_single_layer(hip, ora):
     return err
 
 
+@pytest.mark.parametrize("route", ["log_xyz", "log_xyz_overflow", "bin2"])
 @pytest.mark.parametrize("pool", [31, 64])
-def test_bench_config_stoch_shape_runs_the_binned_prism_pool_kernel(pool):
+def test_bench_config_stoch_shape_runs_the_prism_pool_production_kernels(pool, route):
     """examples/bench_config_stoch.json as the reference ships it — stochastic prism (six gauss(1, 0.15) face distances), D65
     wavelength pool (31 entries: BASELINE configs[4]'s count; 64: the reference's default pool), rectangular 2048x1024 full sky,
-    max_hits 8 — at 9 Mi rays, where the backend's own selection takes per-entry planes (>= 8 Mi rays), device-generated prism
-    records (GEOM 2) and the two-level binned route (31 x 128 / 64 x 128 tiles > 512): halo_trace_kernel<0,2,true,true> +
-    halo_split_kernel + halo_bin_accumulate_range_kernel.  Compared with the oracle on the same rays."""
+    max_hits 8 — at 9 Mi rays, with device-generated prism records (GEOM 2), on the two routes such a session can take:
+      log_xyz  the backend's own selection (>= 8 Mi rays): X, Y, Z planes, halo_trace_kernel<0,2,false,kAccLog> logging
+               {slot, CMF code, w} + halo_split_kernel<1024,16,512> + halo_log_accumulate_xyz_kernel (CMF in the per-tile pass)
+      log_xyz_overflow  the same with log regions and tile lists far too small (option hit_log_cap): most records take the two
+               overflow fallbacks (three direct atomics with the code's CMF row)
+      bin2     option lambda_planes = 1: one plane per pool entry, the two-level binned route (31 x 128 / 64 x 128 tiles > 512):
+               halo_trace_kernel<0,2,true,kAccBin> + halo_split_kernel<256,16,256> + halo_bin_accumulate_range_kernel
+    Compared with the oracle on the same rays."""
     sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
     rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
     wl = scenes.wl_illuminant("D65", pool)
     n = 9 << 20
-    hb = hip_backend(seed=23)
+    hb = hip_backend(seed=23, **({"lambda_planes": 1} if route == "bin2" else {"hit_log_cap": 4096} if route.endswith("overflow") else {}))
     st = run_session(hb, sc, rd, wl, n)
-    route = hb.last_route()
+    r = hb.last_route()
     crystals, orient = hb.last_sample_counts()
     hip = hb.ReadbackXyzAccum()
     hb.close()
-    assert (route.mode_mask, route.geom_mask, route.accum_mask, route.source_mask) == (1, 1 << 2, abi.ACCUM_BIN2, 1), \
-        (route.mode_mask, route.geom_mask, route.accum_mask)
-    assert route.plane_cnt == pool and route.launches == st[0].launches == 1
+    want = (1, 1 << 2, abi.ACCUM_LOG_XYZ, 1, 3) if route.startswith("log_xyz") else (1, 1 << 2, abi.ACCUM_BIN2, 1, pool)
+    assert (r.mode_mask, r.geom_mask, r.accum_mask, r.source_mask, r.plane_cnt) == want, (r.mode_mask, r.geom_mask, r.accum_mask, r.source_mask, r.plane_cnt)
+    assert r.launches == st[0].launches == 1
     assert crystals == n // 32 and orient == n           # one sampled crystal per 32 rays (simulator.hpp:144-157)
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 23)
     assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=1e-4)
     assert st[0].pixel_hits == pytest.approx(st_o[0].exit_count, rel=1e-4)     # rectangular full sky: every exit lands once
     err = _check_single_layer(hip, (img_o, landed_o))
-    print("bench_config_stoch pool %d: block-mean rel L2 %.2e, exits/root %.3f" % (pool, err, st[0].exit_count / n))
+    print("bench_config_stoch pool %d %s: block-mean rel L2 %.2e, exits/root %.3f" % (pool, route, err, st[0].exit_count / n))
 
 
-@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65_planes"])
+@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65", "pyramid_d65_planes"])
 def test_stochastic_pool_production_kernels_vs_oracle(case):
     """The other production shape-pool instantiations at sizes where they are what the backend picks:
       prism_discrete_binned  one wavelength, stochastic prism, full sky, 4.5 Mi rays  -> <0,2,true,true>, one-level binned (128 tiles)
       pyramid_discrete       one wavelength, stochastic pyramid (4.1 KB records)      -> <0,1,true,kAccLog>, hit log + split + per-tile sums
       pyramid_discrete_direct  the same with option hit_log = 0                       -> <0,1,true,kAccDirect>, direct scalar plane
-      pyramid_d65_planes     D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,true,kAccDirect>, one plane per entry"""
+      pyramid_d65            D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,false,kAccLog>, X/Y/Z hit log (3 planes)
+      pyramid_d65_planes     the same with option lambda_planes = 1                   -> <0,1,true,kAccDirect>, one plane per entry"""
     prism = case.startswith("prism")
     sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry() if prism else _stoch_pyramid_entry()])], max_hits=8)
     rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
-    d65 = case.endswith("planes")
+    d65 = "d65" in case
     wl = scenes.wl_illuminant("D65", 31) if d65 else scenes.wl_discrete(550.0)
     n = (9 << 20) if d65 else (9 << 19)
-    hb = hip_backend(seed=29, **({"hit_log": 0} if case.endswith("direct") else {}))
+    hb = hip_backend(seed=29, **({"hit_log": 0} if case.endswith("direct") else {"lambda_planes": 1} if case.endswith("planes") else {}))
     st = run_session(hb, sc, rd, wl, n)
     route = hb.last_route()
     hip = hb.ReadbackXyzAccum()
     hb.close()
     want_geom = (1 << 2) if prism else (1 << 1)
-    want_acc = abi.ACCUM_BIN1 if prism else (abi.ACCUM_LOG if case == "pyramid_discrete" else abi.ACCUM_SCALAR)
+    want_acc = abi.ACCUM_BIN1 if prism else {"pyramid_discrete": abi.ACCUM_LOG, "pyramid_d65": abi.ACCUM_LOG_XYZ}.get(case, abi.ACCUM_SCALAR)
     assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, want_geom, want_acc), (route.mode_mask, route.geom_mask, route.accum_mask)
-    assert route.plane_cnt == (31 if d65 else 1)
+    assert route.plane_cnt == (3 if case == "pyramid_d65" else 31 if d65 else 1)
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 29)
     assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=1e-4)
     err = _check_single_layer(hip, (img_o, landed_o))
