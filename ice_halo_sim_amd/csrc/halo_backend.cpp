@@ -24,7 +24,7 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, hipStream_t stream);
+                            uint32_t tiles, uint32_t s_log2, bool interleaved, hipStream_t stream);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
@@ -451,7 +451,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
   const bool discrete = wl->illuminant < 0;
   //  * illuminant, batch >= 8 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
-  //    the per-tile pass applies the CMF (halo_log_accumulate_xyz_kernel): no plane per entry, no two-level split, a 3-plane fold
+  //    the per-tile pass applies the CMF (halo_log_accumulate_kernel<3>): no plane per entry, no two-level split, a 3-plane fold
   b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (8ull << 20);
   b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
@@ -824,8 +824,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         const uint64_t per_wg = (m + static_cast<uint64_t>(blocks) - 1u) / static_cast<uint64_t>(blocks);
         uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
         cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
-        if (use_log_xyz) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));   // full-sky renders: 5-6 hits per ray
-        uint64_t c2 = std::max<uint64_t>(2ull * (use_log_xyz ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
+        if (use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));   // full-sky renders: 5-6 hits per ray
+        uint64_t c2 = std::max<uint64_t>(2ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);   // full-sky renders: 5-6 records per ray
         c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * log_tiles));
         if (b->hit_log_cap) {   // tests: run both overflow fallbacks
           cap = b->hit_log_cap;
@@ -896,7 +896,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
                                                            b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
-                                                       b->bin_cnt2.ptr, bin_tiles, b->stream);
+                                                       b->bin_cnt2.ptr, bin_tiles, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {

@@ -74,7 +74,7 @@ struct SplitXyz {              // X/Y/Z hit log only: what a record that finds i
   uint32_t pool_size;          // CMF codes: pool entries, then pool_size + c = "the weight is channel c already"
   uint32_t plane_stride;
 };
-template <uint32_t kSplitBlock, uint32_t kSplitPer, uint32_t kSplitFanMax>
+template <uint32_t kSplitBlock, uint32_t kSplitPer, uint32_t kSplitFanMax, bool kXyz, bool kMix>
 __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                  const uint32_t* __restrict__ cnt1, uint32_t cnt1_stride, uint32_t parts,
                                                                  uint2* __restrict__ list2, uint32_t cap2, uint32_t* __restrict__ cnt2, uint32_t fan_log2,
@@ -89,10 +89,10 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / parts);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / parts);
   const uint32_t fmask = (1u << fan_log2) - 1u;
-  // mix_log2 != 0 (with tile_log2 0): tile = (column + row) mod fan, slot = row << mix_log2 | column — see halo_log_accumulate_xyz_kernel
+  // kMix: tile = (column + row) mod fan, slot = row << mix_log2 | column — see halo_log_accumulate_kernel
   auto tile_of = [&](uint32_t x) {
     const uint32_t sl = x & slot_mask;
-    return ((mix_log2 != 0u ? sl + (sl >> mix_log2) : sl >> tile_log2)) & fmask;
+    return (kMix ? sl + (sl >> mix_log2) : sl >> tile_log2) & fmask;
   };
   const uint32_t tile0 = coarse ? (l1 << fan_log2) : 0u;   // the first destination tile of this source list
   const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
       const uint32_t pos = s_base[t] + (i - s_off[t]);
       if (pos < cap2) {
         list2[static_cast<size_t>(tile0 + t) * cap2 + pos] = r;
-      } else if (xyz.pool != nullptr) {
+      } else if (kXyz) {
         const uint32_t code = r.x >> kLogWlShift;
         float c[3];
         if (code < xyz.pool_size) {
@@ -215,43 +215,52 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
   }
 }
 
-// X/Y/Z hit log (illuminant sessions): one workgroup per tile of 4 Ki slots of ONE plane sums its list into X, Y and Z tiles —
-// the record's wavelength-pool entry picks the CMF row (pool staged in LDS), three fp64 LDS adds per record — and adds them to
-// the three planes.  This is where an illuminant session's colour is made: no plane per pool entry (31 x 128 tiles at
-// configs[4], a two-level split) and a fold over 3 planes instead of 31.
+// The hit log's per-tile pass.  CH = 1: one scalar plane (discrete wavelength), records {slot, w}, tiles of 16 Ki slots.
+// CH = 3: an illuminant session on X, Y, Z planes, records {slot in ONE plane | CMF code << kLogWlShift, w}, tiles of 4 Ki slots:
+// the code picks the CMF row (pool entries, then three unit rows for a cached pixel's X, Y, Z records; staged in LDS) and the
+// record goes into X, Y and Z tiles with three fp64 LDS adds.  This is where an illuminant session's colour is made: no plane
+// per pool entry (31 x 128 tiles at configs[4], a two-level split) and a fold over 3 planes instead of 31.
 // Tiles are INTERLEAVED over the plane: a slot is row << s_log2 | column (MonoSlot: row = pixel mod 1024, column = a hash of
 // pixel / 1024), and its tile is (column + row) mod tiles.  Contiguous slot ranges are image columns x mod 1024 and run 6x
-// uneven on a full-sky render (the light is around the sun's azimuth) — with them the hot tiles' lists overflowed into 3
-// contended atomics per record and the split took 10.9 ms; the column alone is a hash of the image ROW, just as uneven over
-// 512 tiles.  A tile holds tiles' worth of scattered slots, so its write-out is 3 x 4 Ki plain 4-byte read-modify-writes (the
-// workgroup is the only writer of its slots while this kernel runs).
-constexpr uint32_t kXyzTileLog2 = 12u;
-__global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_xyz_kernel(float* __restrict__ planes, uint32_t plane_stride, const uint2* __restrict__ list, uint32_t cap,
-                                                                            const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
-                                                                            uint32_t tiles_log2, uint32_t s_log2) {
-  __shared__ __attribute__((aligned(16))) double acc[3][1u << kXyzTileLog2];   // fp64: see halo_bin_accumulate_kernel
-  __shared__ float s_cmf[HALO_WL_POOL_MAX + 3][3];   // CMF codes: pool entries, then the three unit rows (a cached pixel's X, Y, Z records)
+// uneven on a full-sky render (the light is around the sun's azimuth) — with them the hot tiles' lists overflowed into
+// contended atomics and configs[4]'s split took 10.9 ms; the column alone is a hash of the image ROW, just as uneven over 512
+// tiles.  A tile's slots are scattered, so its write-out is plain 4-byte read-modify-writes (the workgroup is the only writer
+// of its slots while this kernel runs).
+template <uint32_t CH>
+__global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* __restrict__ planes, uint32_t plane_stride, const uint2* __restrict__ list, uint32_t cap,
+                                                                        const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
+                                                                        uint32_t tiles_log2, uint32_t s_log2) {
+  constexpr uint32_t kTileLog2 = CH == 3u ? 12u : 14u;
+  __shared__ __attribute__((aligned(16))) double acc[CH][1u << kTileLog2];   // fp64: see halo_bin_accumulate_kernel
+  __shared__ float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][3];
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
-  for (uint32_t j = threadIdx.x; j < 3u << kXyzTileLog2; j += kBinBlock) (&acc[0][0])[j] = 0.0;
-  for (uint32_t j = threadIdx.x; j < pool_size + 3u; j += kBinBlock) {
-    const bool unit = j >= pool_size;
-    s_cmf[j][0] = unit ? (j == pool_size ? 1.0f : 0.0f) : pool[j].cmf_x;
-    s_cmf[j][1] = unit ? (j == pool_size + 1u ? 1.0f : 0.0f) : pool[j].cmf_y;
-    s_cmf[j][2] = unit ? (j == pool_size + 2u ? 1.0f : 0.0f) : pool[j].cmf_z;
+  for (uint32_t j = threadIdx.x; j < CH << kTileLog2; j += kBinBlock) (&acc[0][0])[j] = 0.0;
+  if constexpr (CH == 3u) {
+    for (uint32_t j = threadIdx.x; j < pool_size + 3u; j += kBinBlock) {
+      const bool unit = j >= pool_size;
+      s_cmf[j][0] = unit ? (j == pool_size ? 1.0f : 0.0f) : pool[j].cmf_x;
+      s_cmf[j][1] = unit ? (j == pool_size + 1u ? 1.0f : 0.0f) : pool[j].cmf_y;
+      s_cmf[j][2] = unit ? (j == pool_size + 2u ? 1.0f : 0.0f) : pool[j].cmf_z;
+    }
   }
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
-  constexpr uint32_t kU = 4u, kSlotMask = (1u << kLogWlShift) - 1u;
+  constexpr uint32_t kU = 4u, kSlotMask = CH == 3u ? (1u << kLogWlShift) - 1u : 0xFFFFFFFFu;
   auto add = [&](uint2 h) {
-    const uint32_t sl = h.x & kSlotMask, wl = h.x >> kLogWlShift;
+    const uint32_t sl = h.x & kSlotMask;
     const uint32_t s = ((sl >> s_log2) << (s_log2 - tiles_log2)) | ((sl & ((1u << s_log2) - 1u)) >> tiles_log2);   // row, high bits of the column
     const double w = static_cast<double>(__uint_as_float(h.y));
-    const float cx = s_cmf[wl][0], cy = s_cmf[wl][1], cz = s_cmf[wl][2];
-    if (cx != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(cx) * w);
-    if (cy != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(cy) * w);
-    if (cz != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(cz) * w);
+    if constexpr (CH == 3u) {
+      const uint32_t code = h.x >> kLogWlShift;
+      const float cx = s_cmf[code][0], cy = s_cmf[code][1], cz = s_cmf[code][2];
+      if (cx != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(cx) * w);
+      if (cy != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(cy) * w);
+      if (cz != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(cz) * w);
+    } else {
+      unsafeAtomicAdd(&acc[0][s], w);
+    }
   };
   uint32_t i = threadIdx.x;
   for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
@@ -263,9 +272,9 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_xyz_kernel(floa
   }
   for (; i < n; i += kBinBlock) add(src[i]);
   __syncthreads();
-  for (uint32_t c = 0; c < 3u; ++c) {
+  for (uint32_t c = 0; c < CH; ++c) {
     float* dst = planes + static_cast<size_t>(c) * plane_stride;
-    for (uint32_t j = threadIdx.x; j < (1u << kXyzTileLog2); j += kBinBlock) {
+    for (uint32_t j = threadIdx.x; j < (1u << kTileLog2); j += kBinBlock) {
       const float v = static_cast<float>(acc[c][j]);
       if (v == 0.0f) continue;
       const uint32_t row = j >> (s_log2 - tiles_log2), hi = j & ((1u << (s_log2 - tiles_log2)) - 1u);
@@ -275,14 +284,24 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_xyz_kernel(floa
   }
 }
 
+// hit-log route, one scalar plane: regions -> `tiles` (a power of two <= 256) tiles of 16 Ki slots -> the plane.  Contiguous tiles
+// (plain float4 write-out, 3-5 % faster at configs[1] / [2]) where the lists have room for an uneven image — renders that cull
+// most exits, ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, hipStream_t stream) {
-  // hit-log route: regions -> the tile lists of one plane array of at most 256 tiles
-  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
-                     reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u, 0xFFFFFFFFu, static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
+                            uint32_t tiles, uint32_t s_log2, bool interleaved, hipStream_t stream) {
+  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));   // tiles = 1024 << s_log2 >> 14: tiles_log2 = s_log2 - 4
+  if (interleaved)
+    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
+  else
+    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, false>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u, 0xFFFFFFFFu, static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
+  if (interleaved)
+    hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
+                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2);
+  else hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
   return hipGetLastError();
 }
 
@@ -290,18 +309,18 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));   // tiles = 1024 << s_log2 >> 12: tiles_log2 = s_log2 - 2
-  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, true, true>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(halo_log_accumulate_xyz_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
+  hipLaunchKernelGGL((halo_log_accumulate_kernel<3u>), dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                      pool, pool_size, tiles_log2, s_log2);
   return hipGetLastError();
 }
 
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
-  hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
+  hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u, false, false>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
                      static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();

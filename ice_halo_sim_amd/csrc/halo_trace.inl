@@ -528,6 +528,7 @@ HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
 // misses the pixel cache goes to the workgroup's own log region (cursor in LDS, one ds_add_rtn per wave and call), and
 // halo_split_kernel / halo_bin_accumulate_range_kernel sum the logs per 16 Ki-slot tile in LDS afterwards.  A full region
 // falls back to the direct atomic.  Call with any subset of a wave's lanes active.
+template <bool XYZ>   // XYZ: record of an X/Y/Z kernel (slot in one plane | CMF code); else a scalar plane's
 HD void log_hit(const DispatchParams& P, uint32_t* log_n, uint32_t slot, float w) {
   const uint64_t mask = __ballot(1);
   // position among the active lanes; the first of them reserves the wave's run
@@ -537,7 +538,7 @@ HD void log_hit(const DispatchParams& P, uint32_t* log_n, uint32_t slot, float w
   const uint32_t idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base))) + before;
   if (idx < P.bin_cap) {
     reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(blockIdx.x) * P.bin_cap + idx] = make_uint2(slot, __float_as_uint(w));
-  } else if (P.log_xyz != 0u) {   // full region: X, Y, Z directly (copy 0)
+  } else if (XYZ) {   // full region: X, Y, Z directly (copy 0)
     const uint32_t code = slot >> kLogWlShift;
     float cx, cy, cz;
     if (code < P.wl_pool_size) {
@@ -591,7 +592,7 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
   if (ctx.log_n != nullptr) {   // hit-log kernels: a scalar record; for X/Y/Z planes it names the ray's pool entry instead of three products
-    log_hit(P, ctx.log_n, MONO ? log_slot(P, pl, pix) : log_slot_xyz(P, wl_idx, pix), w);
+    log_hit<!MONO>(P, ctx.log_n, MONO ? log_slot(P, pl, pix) : log_slot_xyz(P, wl_idx, pix), w);
     return;
   }
   if (MONO) {
@@ -1809,12 +1810,12 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
       if (MONO) {
         const float v = T.cache.val[i];
         if (v == 0.0f) continue;
-        if (LOG) log_hit(P, &s_log_n, log_slot(P, pl, pix), v);
+        if (LOG) log_hit<false>(P, &s_log_n, log_slot(P, pl, pix), v);
         else atomic_add_f32(mono_slot(P, pl, pix), v);
       } else if (LOG) {   // a cached pixel leaves as three records whose weights ARE X, Y, Z (codes pool size + channel)
         for (uint32_t c = 0; c < 3u; ++c) {
           const float v = T.cache.val[i * 3 + c];
-          if (v != 0.0f) log_hit(P, &s_log_n, log_slot_xyz(P, P.wl_pool_size + c, pix), v);
+          if (v != 0.0f) log_hit<true>(P, &s_log_n, log_slot_xyz(P, P.wl_pool_size + c, pix), v);
         }
       } else {
         atomic_add_f32(mono_slot(P, 0u, pix), T.cache.val[i * 3 + 0]);

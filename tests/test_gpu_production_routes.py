@@ -62,7 +62,7 @@ def test_bench_config_stoch_shape_runs_the_prism_pool_production_kernels(pool, r
     wavelength pool (31 entries: BASELINE configs[4]'s count; 64: the reference's default pool), rectangular 2048x1024 full sky,
     max_hits 8 — at 9 Mi rays, with device-generated prism records (GEOM 2), on the two routes such a session can take:
       log_xyz  the backend's own selection (>= 8 Mi rays): X, Y, Z planes, halo_trace_kernel<0,2,false,kAccLog> logging
-               {slot, CMF code, w} + halo_split_kernel<1024,16,512> + halo_log_accumulate_xyz_kernel (CMF in the per-tile pass)
+               {slot, CMF code, w} + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3> (CMF in the per-tile pass)
       log_xyz_overflow  the same with log regions and tile lists far too small (option hit_log_cap): most records take the two
                overflow fallbacks (three direct atomics with the code's CMF row)
       bin2     option lambda_planes = 1: one plane per pool entry, the two-level binned route (31 x 128 / 64 x 128 tiles > 512):
