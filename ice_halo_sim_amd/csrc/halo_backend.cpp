@@ -803,7 +803,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const bool bin_shape_ok = two_level ? (fan_log2 <= 8u && (bin_slots & 16383ull) == 0ull)
                                           : (bin_tiles >= 8u && (bin_tiles & (bin_tiles - 1u)) == 0u);
       const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_shape_ok && bin_slots <= (1ull << 31) &&
-                           (b->bin < 0 ? (bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
+                           // own choice: only where the hit log cannot go (one plane per pool entry) — the log beats the binned route on every
+                           // one-plane full-sky launch measured (tools/bin_vs_log_probe.py: dual fisheye 50 M rays 5.13 -> 4.42 ms)
+                           (b->bin < 0 ? (b->mono_by_wl && bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       const uint32_t lists1 = two_level ? ((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) : bin_tiles;
       uint32_t cap2 = 0u;
       // Hit log (halo_trace.inl log_hit): where the binned route is not taken, a production-mode one-plane launch still runs into

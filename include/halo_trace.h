@@ -255,22 +255,24 @@ const char* halo_last_error(halo_handle_t h);
  * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
- * "bin" (binned accumulation through per-tile hit lists: -1 [default] = for full-sky renders with launches >= 2 Mi rays —
- * one level of lists up to 512 tiles of 16 Ki accumulator slots, two levels (coarse lists, split pass) for the per-entry
- * planes of illuminant sessions beyond that; 0 = never, 1 = always when applicable), "bin_l1" (coarse lists of the two-level
- * route, default 128), "stoch_chunk" (rays per launch with device-generated crystal pools; default 64 Mi for prisms, 16 Mi
- * otherwise),
- * "lambda_planes" (illuminant sessions: -1 [default] = one accumulation plane per wavelength-pool entry when the batch
- * has >= 8 Mi rays, else X/Y/Z planes; 0 = never; 1 = always),
+ * "bin" (binned accumulation: hits staged in LDS and flushed to per-tile hit lists by the trace kernel — one level of lists up to
+ * 512 tiles of 16 Ki accumulator slots, two levels (coarse lists, split pass) beyond; -1 [default] = only for the full-sky
+ * launches >= 2 Mi rays of sessions with one plane per pool entry ("lambda_planes" = 1), where the hit log cannot go; 0 = never;
+ * 1 = always when applicable), "bin_l1" (coarse lists of the two-level route, default 128), "stoch_chunk" (rays per launch with
+ * device-generated crystal pools; default 64 Mi for prisms, 16 Mi otherwise),
+ * "lambda_planes" (illuminant sessions: -1 [default] = X/Y/Z planes; with batches >= 8 Mi rays and the hit log on, the launches
+ * log {slot, pool entry, weight} and the log's per-tile pass makes X, Y, Z; 0 = X/Y/Z planes by direct atomics only; 1 = one
+ * scalar plane per wavelength-pool entry, CMF applied by the closing fold),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
  * workgroup below that cap),
  * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
  * same builder the host runs; records are bit-identical either way, A/B knob),
- * "hit_log" (-1 [default]: production-mode one-plane launches >= 2 Mi rays that do not take the binned route append the hits that
- * miss the pixel cache to a log region per workgroup — plain stores instead of memory-side fp32 atomics — which a split pass
- * and a per-tile LDS pass then add to the plane; 0 = never (direct atomics), 1 = whenever applicable), "hit_log_cap" (test
- * knob: records per log region, 0 [default] = sized from the launch; what runs over a region or a tile list is added directly),
+ * "hit_log" (-1 [default]: production-mode launches >= 2 Mi rays on one scalar plane, or on the X/Y/Z planes of an illuminant
+ * session of >= 8 Mi rays, append the hits that miss the pixel cache to a log region per workgroup — plain stores instead of
+ * memory-side fp32 atomics — which a split pass and a per-tile LDS pass then add to the plane(s); 0 = never (direct atomics),
+ * 1 = whenever applicable), "hit_log_cap" (test knob: records per log region, 0 [default] = sized from the launch; what runs
+ * over a region or a tile list is added directly),
  * "hex_fast" (1 [default]: one-shape dispatches of a REGULAR hexagonal prism run the instantiation whose next-face search has the
  * normals as literals; 0: the table-driven search — same candidates, order and comparisons, A/B knob),
  * "entry_fast" (1 [default]: one-shape dispatches of a full 8-face prism pick the entry face slab by slab, in registers;

@@ -89,10 +89,11 @@ def test_bench_config_stoch_shape_runs_the_prism_pool_production_kernels(pool, r
     print("bench_config_stoch pool %d %s: block-mean rel L2 %.2e, exits/root %.3f" % (pool, route, err, st[0].exit_count / n))
 
 
-@pytest.mark.parametrize("case", ["prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65", "pyramid_d65_planes"])
+@pytest.mark.parametrize("case", ["prism_discrete", "prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65", "pyramid_d65_planes"])
 def test_stochastic_pool_production_kernels_vs_oracle(case):
     """The other production shape-pool instantiations at sizes where they are what the backend picks:
-      prism_discrete_binned  one wavelength, stochastic prism, full sky, 4.5 Mi rays  -> <0,2,true,true>, one-level binned (128 tiles)
+      prism_discrete         one wavelength, stochastic prism, full sky, 4.5 Mi rays  -> <0,2,true,kAccLog>, hit log over interleaved tiles
+      prism_discrete_binned  the same with option bin = 1                             -> <0,2,true,kAccBin>, one-level binned (128 tiles)
       pyramid_discrete       one wavelength, stochastic pyramid (4.1 KB records)      -> <0,1,true,kAccLog>, hit log + split + per-tile sums
       pyramid_discrete_direct  the same with option hit_log = 0                       -> <0,1,true,kAccDirect>, direct scalar plane
       pyramid_d65            D65 pool of 31, stochastic pyramid, 9 Mi rays            -> <0,1,false,kAccLog>, X/Y/Z hit log (3 planes)
@@ -103,13 +104,13 @@ def test_stochastic_pool_production_kernels_vs_oracle(case):
     d65 = "d65" in case
     wl = scenes.wl_illuminant("D65", 31) if d65 else scenes.wl_discrete(550.0)
     n = (9 << 20) if d65 else (9 << 19)
-    hb = hip_backend(seed=29, **({"hit_log": 0} if case.endswith("direct") else {"lambda_planes": 1} if case.endswith("planes") else {}))
+    hb = hip_backend(seed=29, **({"hit_log": 0} if case.endswith("direct") else {"lambda_planes": 1} if case.endswith("planes") else {"bin": 1} if case.endswith("binned") else {}))
     st = run_session(hb, sc, rd, wl, n)
     route = hb.last_route()
     hip = hb.ReadbackXyzAccum()
     hb.close()
     want_geom = (1 << 2) if prism else (1 << 1)
-    want_acc = abi.ACCUM_BIN1 if prism else {"pyramid_discrete": abi.ACCUM_LOG, "pyramid_d65": abi.ACCUM_LOG_XYZ}.get(case, abi.ACCUM_SCALAR)
+    want_acc = {"prism_discrete": abi.ACCUM_LOG, "prism_discrete_binned": abi.ACCUM_BIN1, "pyramid_discrete": abi.ACCUM_LOG, "pyramid_d65": abi.ACCUM_LOG_XYZ}.get(case, abi.ACCUM_SCALAR)
     assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, want_geom, want_acc), (route.mode_mask, route.geom_mask, route.accum_mask)
     assert route.plane_cnt == (3 if case == "pyramid_d65" else 31 if d65 else 1)
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 29)

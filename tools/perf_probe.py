@@ -18,7 +18,7 @@ def run(label, sc, rd, n=10_000_000, reps=3, wl=550.0, **opts):
 
 sc = scenes.config2_scene()
 rd = scenes.config2_render()
-which = sys.argv[1:] or ["base"]
+which = (sys.argv[1:] or ["base"]) if __name__ == "__main__" else []
 if "base" in which:
     run("config2 1920x1080 upper (default)", sc, rd)
     run("  no accumulation (aggregate=2)", sc, rd, aggregate=2)
