@@ -450,9 +450,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   const size_t npix = static_cast<size_t>(render->width) * render->height;
   if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
   const bool discrete = wl->illuminant < 0;
-  //  * illuminant, batch >= 8 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
+  //  * illuminant, batch >= 2 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
   //    the per-tile pass applies the CMF (halo_log_accumulate_kernel<3>): no plane per entry, no two-level split, a 3-plane fold
-  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (8ull << 20);
+  //    (images above 512 Ki pixels: on small ones most hits land in the pixel cache, and the X/Y/Z cache pays three fp32 LDS adds — the
+  //    slow kind on gfx950 — per hit where a scalar plane pays one: the reference's 512x256 D65 scene runs 2.8 vs 8.0 G rays/s)
+  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > (1u << 19);
   b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
@@ -811,11 +813,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Hit log (halo_trace.inl log_hit): where the binned route is not taken, a production-mode one-plane launch still runs into
       // the 21 G/s of memory-side fp32 atomics once its trace is fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).
       // Its cache misses go to one log region per workgroup instead and are summed per tile afterwards.
-      // X/Y/Z hit log: tiles are 4 Ki slots of ONE plane (three fp64 tiles in LDS), at most 512 of them
-      const uint64_t plane_slots = static_cast<uint64_t>(kMonoRows) << b->mono_s_log2;
-      const uint32_t log_tiles = b->xyz_log ? static_cast<uint32_t>(plane_slots >> 12) : bin_tiles;
-      const bool log_layout_ok = b->xyz_log ? (log_tiles >= 1u && log_tiles <= 512u && (plane_slots & 4095ull) == 0ull && plane_slots <= (1ull << kLogWlShift))
-                                            : (b->mono_session && !b->mono_by_wl && bin_tiles >= 1u && bin_tiles <= 256u && (bin_slots & 16383ull) == 0ull);
+      // Hit-log tiles: as many as the split pass feeds (256 on a scalar plane, 512 on the X/Y/Z planes of an illuminant session),
+      // of at least 256 and at most 16 Ki (X/Y/Z: 4 Ki) slots of ONE plane — whatever the image size, because the per-tile pass
+      // has one workgroup per tile
+      const uint32_t log_t_log2 = std::min<uint32_t>(b->xyz_log ? 9u : 8u, b->mono_s_log2 + 2u);
+      const uint32_t log_tiles = 1u << log_t_log2;
+      const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && !b->mono_by_wl && b->mono_s_log2 <= 12u);
       const bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
                            (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
                            (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
@@ -847,7 +850,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.bin_log = 1u;
         P.mono_copy_mask = 0u;   // logged slots and their fallbacks address copy 0
         P.log_xyz = use_log_xyz ? 1u : 0u;
-        P.log_plane_stride = static_cast<uint32_t>(plane_slots * b->plane_copies);
+        P.log_plane_stride = static_cast<uint32_t>((static_cast<uint64_t>(kMonoRows) << b->mono_s_log2) * b->plane_copies);
       } else
       if (use_bin) {
         // lists sized for ~6 hits per ray spread 4x unevenly; an overflowing list falls back to direct atomics
@@ -898,7 +901,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
                                                            b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
-                                                       b->bin_cnt2.ptr, bin_tiles, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
+                                                       b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {

@@ -48,6 +48,35 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
   return hipGetLastError();
 }
 
+// Interleaved tiles of one accumulation plane (the hit log's full-sky and X/Y/Z routes).  A slot is row << s | column (MonoSlot:
+// row = pixel mod 1024 — for the usual image widths the image column mod 1024 — and column = a hash of pixel / 1024, i.e. of the
+// image row).  Contiguous slot ranges are bands of image columns and run 6x uneven on a full-sky render, whose light sits
+// around the sun's azimuth; the column alone is just as uneven (the sun's elevation).  So a tile takes both: with T = 2^t tiles
+// and S = 2^s columns, tile = (column + row) mod T for T <= S, else (row mod T/S) * S + (column + row / (T/S)) mod S; `local` is
+// what is left of the slot.  1024 * S / T slots per tile, a bijection (slot_of inverts it).
+struct TileMap {
+  uint32_t s, t;
+  __device__ __forceinline__ void split(uint32_t slot, uint32_t& tile, uint32_t& local) const {
+    const uint32_t row = slot >> s, col = slot & ((1u << s) - 1u);
+    if (t <= s) {
+      tile = (col + row) & ((1u << t) - 1u);
+      local = (row << (s - t)) | (col >> t);
+    } else {
+      const uint32_t d = t - s;
+      tile = ((row & ((1u << d) - 1u)) << s) | ((col + (row >> d)) & ((1u << s) - 1u));
+      local = row >> d;
+    }
+  }
+  __device__ __forceinline__ uint32_t slot_of(uint32_t tile, uint32_t local) const {
+    if (t <= s) {
+      const uint32_t row = local >> (s - t), chi = local & ((1u << (s - t)) - 1u);
+      return (row << s) | (chi << t) | ((tile - row) & ((1u << t) - 1u));
+    }
+    const uint32_t d = t - s, r_hi = local;
+    return ((((r_hi << d) | (tile >> s))) << s) | (((tile & ((1u << s) - 1u)) - r_hi) & ((1u << s) - 1u));
+  }
+};
+
 // ---- the split pass: hit records of a source list dealt out to per-tile lists ----
 // Two callers.  (1) Two-level binning, accumulators of more than 512 tiles (per-wavelength planes: 64 planes x 2 Mi slots = 8192
 // tiles): the trace kernel can feed at most 512 lists from its 1536-record LDS buffer (fewer than ~3 records per list and flush
@@ -89,10 +118,15 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / parts);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / parts);
   const uint32_t fmask = (1u << fan_log2) - 1u;
-  // kMix: tile = (column + row) mod fan, slot = row << mix_log2 | column — see halo_log_accumulate_kernel
+  // kMix: interleaved tiles (TileMap, s = mix_log2, t = fan_log2); else contiguous ranges of 2^tile_log2 slots
   auto tile_of = [&](uint32_t x) {
     const uint32_t sl = x & slot_mask;
-    return (kMix ? sl + (sl >> mix_log2) : sl >> tile_log2) & fmask;
+    if (kMix) {
+      uint32_t tile, local;
+      TileMap{mix_log2, fan_log2}.split(sl, tile, local);
+      return tile;
+    }
+    return (sl >> tile_log2) & fmask;
   };
   const uint32_t tile0 = coarse ? (l1 << fan_log2) : 0u;   // the first destination tile of this source list
   const uint2* src = list1 + static_cast<size_t>(l1) * cap1;
@@ -178,30 +212,31 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
 // coalesced float4 read-modify-writes — the workgroup is the only writer of those slots while this kernel runs (direct
 // atomics of the trace / split kernels are ordered before it on the stream).
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
-                                                                               const uint32_t* __restrict__ cnt) {
-  __shared__ __attribute__((aligned(16))) double acc[1u << kBinTileLog2];   // fp64: see halo_bin_accumulate_kernel
+                                                                               const uint32_t* __restrict__ cnt, uint32_t tile_log2) {
+  __shared__ __attribute__((aligned(16))) double acc[1u << kBinTileLog2];   // fp64: see halo_bin_accumulate_kernel; tile_log2 <= kBinTileLog2
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
-  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0;
+  const uint32_t slots = 1u << tile_log2, mask = slots - 1u;
+  for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[j] = 0.0;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
-  constexpr uint32_t kU = 4u, kMask = (1u << kBinTileLog2) - 1u;
+  constexpr uint32_t kU = 4u;
   uint32_t i = threadIdx.x;
   for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
     uint2 h[kU];
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & kMask], static_cast<double>(__uint_as_float(h[u].y)));
+    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & mask], static_cast<double>(__uint_as_float(h[u].y)));
   }
   for (; i < n; i += kBinBlock) {
     const uint2 h = src[i];
-    unsafeAtomicAdd(&acc[h.x & kMask], static_cast<double>(__uint_as_float(h.y)));
+    unsafeAtomicAdd(&acc[h.x & mask], static_cast<double>(__uint_as_float(h.y)));
   }
   __syncthreads();
-  float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << kBinTileLog2));
-  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2) / 4u; j += kBinBlock) {
+  float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << tile_log2));
+  for (uint32_t j = threadIdx.x; j < slots / 4u; j += kBinBlock) {
     const float4 v = make_float4(static_cast<float>(acc[4u * j]), static_cast<float>(acc[4u * j + 1u]), static_cast<float>(acc[4u * j + 2u]),
                                  static_cast<float>(acc[4u * j + 3u]));
     if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
@@ -220,12 +255,10 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 // the code picks the CMF row (pool entries, then three unit rows for a cached pixel's X, Y, Z records; staged in LDS) and the
 // record goes into X, Y and Z tiles with three fp64 LDS adds.  This is where an illuminant session's colour is made: no plane
 // per pool entry (31 x 128 tiles at configs[4], a two-level split) and a fold over 3 planes instead of 31.
-// Tiles are INTERLEAVED over the plane: a slot is row << s_log2 | column (MonoSlot: row = pixel mod 1024, column = a hash of
-// pixel / 1024), and its tile is (column + row) mod tiles.  Contiguous slot ranges are image columns x mod 1024 and run 6x
-// uneven on a full-sky render (the light is around the sun's azimuth) — with them the hot tiles' lists overflowed into
-// contended atomics and configs[4]'s split took 10.9 ms; the column alone is a hash of the image ROW, just as uneven over 512
-// tiles.  A tile's slots are scattered, so its write-out is plain 4-byte read-modify-writes (the workgroup is the only writer
-// of its slots while this kernel runs).
+// Tiles are interleaved over the plane (TileMap) and as many as the split pass can feed (256 / 512), whatever the image size:
+// the pass has one workgroup per tile, and a 512 x 256 image cut into 16 Ki-slot tiles would leave it 8 workgroups.  A tile's
+// slots are scattered, so its write-out is plain 4-byte read-modify-writes (the workgroup is the only writer of its slots
+// while this kernel runs).
 template <uint32_t CH>
 __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* __restrict__ planes, uint32_t plane_stride, const uint2* __restrict__ list, uint32_t cap,
                                                                         const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
@@ -236,7 +269,10 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
-  for (uint32_t j = threadIdx.x; j < CH << kTileLog2; j += kBinBlock) (&acc[0][0])[j] = 0.0;
+  const TileMap map{s_log2, tiles_log2};
+  const uint32_t slots = 1u << (s_log2 + 10u - tiles_log2);   // <= 1 << kTileLog2
+  for (uint32_t c = 0; c < CH; ++c)
+    for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[c][j] = 0.0;
   if constexpr (CH == 3u) {
     for (uint32_t j = threadIdx.x; j < pool_size + 3u; j += kBinBlock) {
       const bool unit = j >= pool_size;
@@ -249,8 +285,8 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   const uint2* src = list + static_cast<size_t>(tile) * cap;
   constexpr uint32_t kU = 4u, kSlotMask = CH == 3u ? (1u << kLogWlShift) - 1u : 0xFFFFFFFFu;
   auto add = [&](uint2 h) {
-    const uint32_t sl = h.x & kSlotMask;
-    const uint32_t s = ((sl >> s_log2) << (s_log2 - tiles_log2)) | ((sl & ((1u << s_log2) - 1u)) >> tiles_log2);   // row, high bits of the column
+    uint32_t t_unused, s;
+    map.split(h.x & kSlotMask, t_unused, s);
     const double w = static_cast<double>(__uint_as_float(h.y));
     if constexpr (CH == 3u) {
       const uint32_t code = h.x >> kLogWlShift;
@@ -274,41 +310,38 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   __syncthreads();
   for (uint32_t c = 0; c < CH; ++c) {
     float* dst = planes + static_cast<size_t>(c) * plane_stride;
-    for (uint32_t j = threadIdx.x; j < (1u << kTileLog2); j += kBinBlock) {
+    for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) {
       const float v = static_cast<float>(acc[c][j]);
-      if (v == 0.0f) continue;
-      const uint32_t row = j >> (s_log2 - tiles_log2), hi = j & ((1u << (s_log2 - tiles_log2)) - 1u);
-      const uint32_t col = (hi << tiles_log2) | ((tile - row) & ((1u << tiles_log2) - 1u));
-      dst[(static_cast<size_t>(row) << s_log2) | col] += v;
+      if (v != 0.0f) dst[map.slot_of(tile, j)] += v;
     }
   }
 }
 
-// hit-log route, one scalar plane: regions -> `tiles` (a power of two <= 256) tiles of 16 Ki slots -> the plane.  Contiguous tiles
-// (plain float4 write-out, 3-5 % faster at configs[1] / [2]) where the lists have room for an uneven image — renders that cull
-// most exits, ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
+// hit-log route, one scalar plane: regions -> `tiles` (a power of two <= 256) tiles -> the plane.  Contiguous tiles (plain float4
+// write-out, 3-5 % faster at configs[1] / [2]) where the lists have room for an uneven image — renders that cull most exits,
+// ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
                             uint32_t tiles, uint32_t s_log2, bool interleaved, hipStream_t stream) {
-  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));   // tiles = 1024 << s_log2 >> 14: tiles_log2 = s_log2 - 4
+  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
   if (interleaved)
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
   else
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, false>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, 8u, 0u, 0xFFFFFFFFu, static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (interleaved)
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                        static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2);
-  else hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
+  else hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2, tile_log2);
   return hipGetLastError();
 }
 
-// the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of 4 Ki slots of one plane
+// the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of <= 4 Ki slots of one plane
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream) {
-  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));   // tiles = 1024 << s_log2 >> 12: tiles_log2 = s_log2 - 2
+  const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
   hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, true, true>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride});
   hipError_t e = hipGetLastError();
@@ -325,7 +358,8 @@ hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1
                      static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2);
+  hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
+                     static_cast<uint32_t>(kBinTileLog2));
   return hipGetLastError();
 }
 

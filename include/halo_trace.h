@@ -260,16 +260,17 @@ const char* halo_last_error(halo_handle_t h);
  * launches >= 2 Mi rays of sessions with one plane per pool entry ("lambda_planes" = 1), where the hit log cannot go; 0 = never;
  * 1 = always when applicable), "bin_l1" (coarse lists of the two-level route, default 128), "stoch_chunk" (rays per launch with
  * device-generated crystal pools; default 64 Mi for prisms, 16 Mi otherwise),
- * "lambda_planes" (illuminant sessions: -1 [default] = X/Y/Z planes; with batches >= 8 Mi rays and the hit log on, the launches
- * log {slot, pool entry, weight} and the log's per-tile pass makes X, Y, Z; 0 = X/Y/Z planes by direct atomics only; 1 = one
- * scalar plane per wavelength-pool entry, CMF applied by the closing fold),
+ * "lambda_planes" (illuminant sessions: -1 [default] = batches >= 2 Mi rays on images above 512 Ki pixels keep X/Y/Z planes and
+ * their launches log {slot, pool entry, weight}, the log's per-tile pass makes X, Y, Z; other batches >= 8 Mi rays keep one
+ * scalar plane per wavelength-pool entry, CMF applied by the closing fold; the rest X/Y/Z planes by direct atomics; 0 = never
+ * per-entry planes nor the X/Y/Z log; 1 = always per-entry planes),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
  * workgroup below that cap),
  * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
  * same builder the host runs; records are bit-identical either way, A/B knob),
  * "hit_log" (-1 [default]: production-mode launches >= 2 Mi rays on one scalar plane, or on the X/Y/Z planes of an illuminant
- * session of >= 8 Mi rays, append the hits that miss the pixel cache to a log region per workgroup — plain stores instead of
+ * session (>= 2 Mi rays, image above 512 Ki pixels), append the hits that miss the pixel cache to a log region per workgroup — plain stores instead of
  * memory-side fp32 atomics — which a split pass and a per-tile LDS pass then add to the plane(s); 0 = never (direct atomics),
  * 1 = whenever applicable), "hit_log_cap" (test knob: records per log region, 0 [default] = sized from the launch; what runs
  * over a region or a tile list is added directly),
