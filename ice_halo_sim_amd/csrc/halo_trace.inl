@@ -1033,7 +1033,13 @@ HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, 
   while (all ? qn > 0u : qn >= 64u) {
     if (k < qn) {
       const uint32_t i = qn - 1u - k;
-      land_exit<kModePlain, MONO, SMALLC>(P, cache, nullptr, 0ull, Q.x[i], Q.y[i], Q.z[i], Q.w[i], 0.0f, 0.0f, 0.0f, Q.wl[i], sums, pr);
+      const uint32_t wl = Q.wl[i];
+      float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+      if (!MONO) {   // X/Y/Z planes: the popping lane is not the ray's, so the CMF row comes from the pool (<= 8 KB, cache-resident)
+        const WlEntryDev e = P.wl_pool[wl];
+        cx = e.cmf_x, cy = e.cmf_y, cz = e.cmf_z;
+      }
+      land_exit<kModePlain, MONO, SMALLC>(P, cache, nullptr, 0ull, Q.x[i], Q.y[i], Q.z[i], Q.w[i], cx, cy, cz, wl, sums, pr);
     }
     qn -= min(na, qn);
   }
@@ -1631,7 +1637,7 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES_FILTER 3
 #endif
 template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (MONO && (GEOM == kGeomOne || GEOM == kGeomOneHex))) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GEOM == kGeomOne || GEOM == kGeomOneHex) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog;
   static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
@@ -1644,7 +1650,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || (M
   constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
-  constexpr bool QUEUE = MODE == kModePlain && MONO && ACC != kAccBin && (GEOM == kGeomOne || GEOM == kGeomOneHex);
+  constexpr bool QUEUE = MODE == kModePlain && ACC != kAccBin && (GEOM == kGeomOne || GEOM == kGeomOneHex);
   __shared__ __attribute__((aligned(16))) ExitQueues<QUEUE> s_queue;
   AccCtx<MONO, SMALLC> acc;
   acc.q = nullptr;
@@ -1854,12 +1860,13 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
   if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode: scalar planes, or X/Y/Z planes of an illuminant session
     if (P.bin_log != 0u) {
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
-      else if constexpr (GEOM != kGeomOneHex) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
     }
   }
-  if constexpr (GEOM == kGeomOneHex) {   // ... and the regular-prism instantiation for the production mode's scalar-plane routes
-    hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccDirect>), grid, block, 0, stream, P);
+  if constexpr (GEOM == kGeomOneHex) {   // ... and the regular-prism instantiation for the production mode's direct and logged routes
+    if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccDirect>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccDirect>), grid, block, 0, stream, P);
   } else {
     if (mono && P.bin_list != nullptr) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccBin>), grid, block, 0, stream, P);
     else if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccDirect>), grid, block, 0, stream, P);
@@ -1871,7 +1878,7 @@ template <int MODE>
 static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
   dim3 grid(blocks), block(kBlock);
   if constexpr (MODE == kModePlain) {
-    if (geom == kGeomOneHex && mono && (P.bin_list == nullptr || P.bin_log != 0u)) {
+    if (geom == kGeomOneHex && (P.bin_list == nullptr || P.bin_log != 0u)) {
       launch_mono<MODE, kGeomOneHex>(P, grid, block, stream, mono);
       return hipGetLastError();
     }
