@@ -334,16 +334,17 @@ def test_hit_log_route_equals_the_direct_route():
 
 @pytest.mark.parametrize("lens", list(range(11)))
 @pytest.mark.parametrize("visible", [abi.VISIBLE_UPPER, abi.VISIBLE_LOWER, abi.VISIBLE_FULL])
-def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible):
+@pytest.mark.parametrize("spectrum", ["discrete", "d65"])
+def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible, spectrum):
     """The exit queue of the one-shape production kernels (MODE 0: an interaction pushes only the exits that pass the cheap
-    culls of `exit_may_land`, projection and accumulation run on popped batches) against the kernels that project at the emit
-    site — the capture instantiation (MODE 2, same rays, same streams) — and against the oracle, for every lens and visibility
+    culls of `exit_may_land`, projection and accumulation run on popped batches; scalar-plane kernels for a discrete wavelength,
+    X/Y/Z kernels — the popping lane fetches the CMF row — for D65) against the kernels that project at the emit site — the capture instantiation (MODE 2, same rays, same streams) — and against the oracle, for every lens and visibility
     range: a cull that is not conservative for some lens would lose hits here.  Same pixel-hit and exit counts, same landed
     weight, same image up to the order of float sums."""
     sc = scenes.config2_scene()
     overlap = 0.0872 if lens in (4, 5, 6) else 0.0
     rd = scenes.render(lens, 512, 256, fov=120.0 if lens not in (4, 5, 6, 7, 9) else 180.0, el=30.0 if lens != 7 else 0.0, visible=visible, overlap=overlap)
-    wl, n = scenes.wl_discrete(530.0), 300_000
+    wl, n = (scenes.wl_discrete(530.0) if spectrum == "discrete" else scenes.wl_illuminant("D65", 31)), 300_000
     out = {}
     for name, kw in (("queue", {}), ("emit_site", {"capture_exits": 1})):
         hb = hip_backend(seed=19, **kw)
