@@ -816,7 +816,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Hit-log tiles: as many as the split pass feeds (256 on a scalar plane, 512 on the X/Y/Z planes of an illuminant session),
       // of at least 256 and at most 16 Ki (X/Y/Z: 4 Ki) slots of ONE plane — whatever the image size, because the per-tile pass
       // has one workgroup per tile
-      const uint32_t log_t_log2 = std::min<uint32_t>(b->xyz_log ? 9u : 8u, b->mono_s_log2 + 2u);
+      // (scalar plane: 128 tiles where that keeps them <= 16 Ki slots — longer runs in the split pass, 0.23 vs 0.25 ms at configs[1])
+      const uint32_t log_t_log2 = b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
       const uint32_t log_tiles = 1u << log_t_log2;
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && !b->mono_by_wl && b->mono_s_log2 <= 12u);
       const bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
