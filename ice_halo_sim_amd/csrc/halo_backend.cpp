@@ -418,6 +418,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   if (scene->layer_count < 1 || scene->layer_count > HALO_MAX_LAYERS) return fail(b, HALO_FATAL, "layer_count out of range");
   if (scene->max_hits < 1 || scene->max_hits > HALO_MAX_HITS) return fail(b, HALO_FATAL, "max_hits out of range");
   if (render->width <= 0 || render->height <= 0) return fail(b, HALO_FATAL, "bad resolution");
+  bool plain_scene = !b->capture;   // no filter, raypath colour or capture anywhere: every launch runs the production kernels
   for (int l = 0; l < scene->layer_count; l++) {
     if (scene->layers[l].entry_count < 1 || scene->layers[l].entry_count > HALO_MAX_ENTRIES)
       return fail(b, HALO_FATAL, "entry_count out of range");
@@ -426,6 +427,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       if (fid < 0 || fid > static_cast<int>(b->filters.size())) return fail(b, HALO_FATAL, "entry refers to a filter_id outside the table");
       const int cid = scene->layers[l].entries[e].color_id;
       if (cid < 0 || cid > static_cast<int>(b->color_sets.size())) return fail(b, HALO_FATAL, "entry refers to a color_id outside the table");
+      if (fid > 0 || cid > 0) plain_scene = false;
       const int kind = scene->layers[l].entries[e].crystal.kind;
       if (kind != HALO_CRYSTAL_PRISM && kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
     }
@@ -458,7 +460,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
-  b->plane_copies = b->mono_by_wl ? 1u : static_cast<uint32_t>(b->mono_copies);  // hits already spread over the pool's planes
+  // privatised copies spread the direct atomics of hot pixels; per-entry planes spread them already, and a session whose
+  // launches all go through the hit log (copy 0 only) would just make the closing fold read seven empty copies
+  const bool all_logged = plain_scene && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (2ull << 20) && (discrete || b->xyz_log) &&
+                          (b->mono_session || b->xyz_log);
+  b->plane_copies = (b->mono_by_wl || all_logged) ? 1u : static_cast<uint32_t>(b->mono_copies);
   b->plane_coef.clear();
   for (uint32_t m = 0; m < b->plane_cnt; m++) {
     if (b->mono_session) b->plane_coef.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
