@@ -364,3 +364,21 @@ def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible, 
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 19)
     assert q[1] == pytest.approx(landed_o, rel=2e-4, abs=1.0)
     assert q[3] == pytest.approx(st_o[0].exit_count, rel=2e-4, abs=20)
+
+
+@pytest.mark.parametrize("size", [(256, 128), (512, 256), (1024, 512)])
+@pytest.mark.parametrize("visible", [abi.VISIBLE_UPPER, abi.VISIBLE_FULL])
+def test_hit_log_tiles_on_small_images(size, visible):
+    """The hit log keeps 128 tiles whatever the image size — on a 256x128 image that is more tiles than the plane has columns
+    (TileMap's second form) — contiguous for `visible: upper`, interleaved for a full-sky render: same image as direct atomics."""
+    sc, wl = scenes.config2_scene(), scenes.wl_discrete(550.0)
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, size[0], size[1], fov=180.0, el=30.0, visible=visible)
+    img = {}
+    for name, opts, acc in (("log", {"hit_log": 1}, abi.ACCUM_LOG), ("direct", {"hit_log": 0}, abi.ACCUM_SCALAR)):
+        hb = hip_backend(seed=67, **opts)
+        st = run_session(hb, sc, rd, wl, 400_000)
+        assert hb.last_route().accum_mask == acc
+        img[name], landed = hb.ReadbackXyzAccum()
+        hb.close()
+    assert img["direct"].sum() > 0 and rel_l2(img["log"], img["direct"]) <= 2e-5
+    assert np.abs(img["log"] - img["direct"]).max() <= 1e-4 * img["direct"].max()
