@@ -382,3 +382,29 @@ def test_hit_log_tiles_on_small_images(size, visible):
         hb.close()
     assert img["direct"].sum() > 0 and rel_l2(img["log"], img["direct"]) <= 2e-5
     assert np.abs(img["log"] - img["direct"]).max() <= 1e-4 * img["direct"].max()
+
+
+def test_xyz_hit_log_on_a_deterministic_crystal_equals_direct_xyz_atomics():
+    """D65 (pool of 31) on configs[1]'s scene at 3 Mi rays: the X/Y/Z ONE-shape kernel under the hit log
+    (halo_trace_kernel<0,3,false,kAccLog>: exit queue with the CMF row fetched by the popping lane, regular-prism search,
+    {slot, CMF code, w} records, halo_log_accumulate_kernel<3>) against the same session on direct X/Y/Z atomics and against the
+    oracle."""
+    sc, rd, wl = scenes.config2_scene(), scenes.config2_render(), scenes.wl_illuminant("D65", 31)
+    n = 3 << 20
+    out = {}
+    for name, opts, acc in (("log", {}, abi.ACCUM_LOG_XYZ), ("direct", {"hit_log": 0}, abi.ACCUM_XYZ), ("overflow", {"hit_log_cap": 2048}, abi.ACCUM_LOG_XYZ)):
+        hb = hip_backend(seed=71, **opts)
+        st = run_session(hb, sc, rd, wl, n)
+        r = hb.last_route()
+        assert (r.mode_mask, r.accum_mask, r.geom_mask, r.plane_cnt) == (1, acc, 1 << 3, 3), (name, r.mode_mask, r.accum_mask, r.geom_mask, r.plane_cnt)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (img, landed, st[0].pixel_hits, st[0].exit_count)
+    ref = out["direct"]
+    for name in ("log", "overflow"):
+        img, landed, hits, exits = out[name]
+        assert (hits, exits) == (ref[2], ref[3])
+        assert landed == pytest.approx(ref[1], rel=1e-6)
+        assert rel_l2(img, ref[0]) <= 2e-5, (name, rel_l2(img, ref[0]))
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 71)
+    _check_single_layer((out["log"][0], out["log"][1]), (img_o, landed_o))
