@@ -1,5 +1,5 @@
-// halo_kernels.hip — the kernels around the trace kernel (binned-accumulation pass, plane fold, device consumer) and
-// the launch dispatcher.  The trace kernel itself is a template in halo_trace.inl, instantiated per MODE in
+// halo_kernels.hip — the kernels around the trace kernel (the hit log's split and per-tile passes, binned-accumulation passes,
+// plane fold, device consumer) and the launch dispatcher.  The trace kernel itself is a template in halo_trace.inl, instantiated per MODE in
 // halo_trace_m{0,1,2}.hip.
 #include "halo_trace.inl"
 

@@ -5,8 +5,9 @@
 //     →  emit gate  →  lens projection  →  CIE-XYZ accumulation  |  continuation append
 // Ray state lives in VGPRs for its whole life; the crystal plane/slab/fan tables and the latitude LUT are
 // staged once per workgroup (or, for sampled crystals, once per half-wave pass) into LDS and read back as
-// wave-wide broadcasts (ds_read_b128, conflict-free); HBM sees only the accumulation traffic (atomics on
-// line-decorrelated planes, or binned hit lists) and — for multi-scatter layers — the 20-byte SoA
+// wave-wide broadcasts (ds_read_b128, conflict-free); the one-shape production kernels queue their exits per wave and run
+// projection + accumulation on full batches; HBM sees only the accumulation traffic (the hit log's 8-byte records for big
+// launches, else atomics on line-decorrelated planes or binned hit lists) and — for multi-scatter layers — the 20-byte SoA
 // continuation record, appended with wave64 ballot compaction into sharded regions and gathered by the next
 // layer through the Feistel permutation, so neither the reference's 80 B/ray root buffers nor its separate
 // gen / transit / shuffle kernels exist here.
