@@ -252,7 +252,7 @@ int halo_destroy(halo_handle_t h);
 const char* halo_last_error(halo_handle_t h);
 /* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
  * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams),
- * "chunk" (max rays per kernel launch), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
+ * "chunk" (max rays per kernel launch, default 256 Mi), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
  * "bin" (binned accumulation: hits staged in LDS and flushed to per-tile hit lists by the trace kernel — one level of lists up to
