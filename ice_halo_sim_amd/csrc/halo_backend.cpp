@@ -816,13 +816,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
                            (b->bin < 0 ? (b->mono_by_wl && bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       const uint32_t lists1 = two_level ? ((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) : bin_tiles;
       uint32_t cap2 = 0u;
-      // Hit log (halo_trace.inl log_hit): where the binned route is not taken, a production-mode one-plane launch still runs into
-      // the 21 G/s of memory-side fp32 atomics once its trace is fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).
-      // Its cache misses go to one log region per workgroup instead and are summed per tile afterwards.
-      // Hit-log tiles: as many as the split pass feeds (256 on a scalar plane, 512 on the X/Y/Z planes of an illuminant session),
-      // of at least 256 and at most 16 Ki (X/Y/Z: 4 Ki) slots of ONE plane — whatever the image size, because the per-tile pass
-      // has one workgroup per tile
-      // (scalar plane: 128 tiles where that keeps them <= 16 Ki slots — longer runs in the split pass, 0.23 vs 0.25 ms at configs[1])
+      // Hit log (halo_trace.inl log_hit): global fp32 atomics retire memory-side at 21 G/s on this part, which bounded every big
+      // launch once its trace was fast enough (configs[1]: 2.4 ms of trace, 2.8 ms of atomics).  A production-mode launch on one
+      // scalar plane, or on the X/Y/Z planes of an illuminant session, appends its cache misses to one log region per workgroup
+      // instead; a split pass and a per-tile pass add them to the plane(s) afterwards.
+      // Tiles: as many as the split pass feeds whatever the image size — the per-tile pass has one workgroup per tile — of at least
+      // 256 and at most 16 Ki slots (X/Y/Z: 4 Ki) of ONE plane: 512 for X/Y/Z; for a scalar plane 128 where that keeps them within
+      // 16 Ki slots (longer runs in the split pass: 0.23 vs 0.25 ms at configs[1]).
       const uint32_t log_t_log2 = b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
       const uint32_t log_tiles = 1u << log_t_log2;
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && !b->mono_by_wl && b->mono_s_log2 <= 12u);
@@ -831,13 +831,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
                            (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
       const bool use_log_xyz = use_log && b->xyz_log;
       if (use_log) {
-        // a region takes 4 hits per ray of its workgroup (configs[1]: 1.4 logged per ray; a full-sky render under the binned
-        // route's threshold ~5) and a tile list twice its even share; what runs over falls back to direct atomics
+        // a region takes 4 records per ray of its workgroup (configs[1]: 1.2 logged per ray), 8 for full-sky renders (5-6 per ray),
+        // and a tile list twice its even share of that; what runs over falls back to direct atomics
         const uint64_t per_wg = (m + static_cast<uint64_t>(blocks) - 1u) / static_cast<uint64_t>(blocks);
         uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
         cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
-        if (use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));   // full-sky renders: 5-6 hits per ray
-        uint64_t c2 = std::max<uint64_t>(2ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);   // full-sky renders: 5-6 records per ray
+        if (use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
+        uint64_t c2 = std::max<uint64_t>(2ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
         c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * log_tiles));
         if (b->hit_log_cap) {   // tests: run both overflow fallbacks
           cap = b->hit_log_cap;
