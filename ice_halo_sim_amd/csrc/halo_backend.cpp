@@ -552,7 +552,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // 64 Mi rays), other device-generated shapes 4.1 KB (2 GB per 16 Mi rays); host-built pools (pageable staging + H2D)
     // stay at 4 Mi rays
     if (!host::IsDeterministic(crystal)) {
-      const uint64_t dev = b->stoch_chunk ? b->stoch_chunk : (crystal.kind == HALO_CRYSTAL_PRISM ? (1ull << 26) : (1ull << 24));
+      const uint64_t dev = b->stoch_chunk ? b->stoch_chunk : (1ull << 26);   // records: 2.9 GB (prism) / 8.6 GB (general) per 64 Mi rays
       m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : dev);
     }
     return m;

@@ -259,7 +259,7 @@ const char* halo_last_error(halo_handle_t h);
  * 512 tiles of 16 Ki accumulator slots, two levels (coarse lists, split pass) beyond; -1 [default] = only for the full-sky
  * launches >= 2 Mi rays of sessions with one plane per pool entry ("lambda_planes" = 1), where the hit log cannot go; 0 = never;
  * 1 = always when applicable), "bin_l1" (coarse lists of the two-level route, default 128), "stoch_chunk" (rays per launch with
- * device-generated crystal pools; default 64 Mi for prisms, 16 Mi otherwise),
+ * device-generated crystal pools; default 64 Mi),
  * "lambda_planes" (illuminant sessions: -1 [default] = batches >= 2 Mi rays on images above 512 Ki pixels keep X/Y/Z planes and
  * their launches log {slot, pool entry, weight}, the log's per-tile pass makes X, Y, Z; other batches >= 8 Mi rays keep one
  * scalar plane per wavelength-pool entry, CMF applied by the closing fold; the rest X/Y/Z planes by direct atomics; 0 = never
