@@ -109,7 +109,7 @@ class HaloRouteInfo(C.Structure):
                 ("source_mask", C.c_uint32), ("plane_cnt", C.c_uint32), ("plane_copies", C.c_uint32), ("shuffle_chunk", C.c_uint32)]
 
 
-ACCUM_XYZ, ACCUM_SCALAR, ACCUM_BIN1, ACCUM_BIN2, ACCUM_LOG, ACCUM_LOG_XYZ = 1, 2, 4, 8, 16, 32   # HaloRouteInfo.accum_mask bits
+ACCUM_XYZ, ACCUM_SCALAR, ACCUM_BIN1, ACCUM_BIN2, ACCUM_LOG, ACCUM_LOG_XYZ, ACCUM_NONE = 1, 2, 4, 8, 16, 32, 64   # HaloRouteInfo.accum_mask bits
 
 
 class HaloGeomTables(C.Structure):

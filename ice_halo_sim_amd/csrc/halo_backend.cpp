@@ -893,6 +893,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
         P.mono_copy_mask = b->plane_copies - 1u;
       }
+      P.no_land = (P.prob >= 1.0f && !P.final_layer && !b->capture && P.filter == nullptr && P.color == nullptr && b->aggregate == 1) ? 1u : 0u;
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hs.efast.hex_regular) ? 3 : geom;
@@ -901,7 +902,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->route.launches++;
       b->route.mode_mask |= 1u << (b->capture ? 2 : ((P.filter != nullptr || P.color != nullptr) ? 1 : 0));
       b->route.geom_mask |= 1u << launch_geom;
-      b->route.accum_mask |= use_log ? (use_log_xyz ? 32u : 16u) : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
+      b->route.accum_mask |= P.no_land ? 64u : use_log ? (use_log_xyz ? 32u : 16u) : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_log) {

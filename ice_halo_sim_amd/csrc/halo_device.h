@@ -242,6 +242,7 @@ struct DispatchParams {
   uint32_t log_xyz;            // hit log of an illuminant session on X, Y, Z planes (with bin_log, X/Y/Z kernels): a record is the hit's slot
                                // in ONE plane | CMF code << kLogWlShift, and the per-tile pass applies the code's CMF row
   uint32_t log_plane_stride;   // ... floats between the X, Y and Z planes (fallback atomics of a full log)
+  uint32_t no_land;            // 1: production-mode layer with prob >= 1 that is not the last — every exit continues, nothing reaches the image
   double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
   double* landed;              // persistent landed-weight tally (until readback / take_landed)
   HaloExitRecord* exits;

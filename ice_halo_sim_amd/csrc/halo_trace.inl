@@ -454,7 +454,7 @@ struct PixCache {
 // flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
 // sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
-constexpr int kAccDirect = 0, kAccBin = 1, kAccLog = 2;   // halo_trace_kernel ACC
+constexpr int kAccDirect = 0, kAccBin = 1, kAccLog = 2, kAccNone = 3;   // halo_trace_kernel ACC (None: a layer whose every exit continues — nothing lands)
 constexpr int kHitBuf = 1536;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
 constexpr int kBinMaxTiles = 512;
@@ -496,6 +496,7 @@ struct ExitQueues<false> {
 };
 template <bool MONO, bool SMALLC>
 struct AccCtx {
+  bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
@@ -1099,6 +1100,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     if (!queued) return;
   }
   PROBE_MARK(pr, kPhEmitGate);
+  if (MODE == kModePlain && cache.none) return;   // (never reached with an exit in hand: prob >= 1 passed it on above)
   if (queued) {
     if (P.prob >= 1.0f) return;   // dispatch-uniform: every candidate of this layer continues, nothing goes to the image
     const bool out = live && !pass;
@@ -1638,9 +1640,10 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES_FILTER 3
 #endif
 template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GEOM == kGeomOne || GEOM == kGeomOneHex) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
-  constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog;
+__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+  constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog, NONE = ACC == kAccNone;
   static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
+  static_assert(!NONE || (MODE == kModePlain && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
@@ -1651,7 +1654,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GE
   constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
-  constexpr bool QUEUE = MODE == kModePlain && ACC != kAccBin && (GEOM == kGeomOne || GEOM == kGeomOneHex);
+  constexpr bool QUEUE = MODE == kModePlain && ACC != kAccBin && ACC != kAccNone && (GEOM == kGeomOne || GEOM == kGeomOneHex);
   __shared__ __attribute__((aligned(16))) ExitQueues<QUEUE> s_queue;
   AccCtx<MONO, SMALLC> acc;
   acc.q = nullptr;
@@ -1659,6 +1662,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GE
     acc.q = &s_queue.q[threadIdx.x >> 6];
     if ((threadIdx.x & 63u) == 0u) acc.q->n = 0u;
   }
+  acc.none = NONE;
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
@@ -1692,7 +1696,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GE
     for (uint32_t i = threadIdx.x; i < sizeof(FilterDev) / 4u; i += kBlock) dst[i] = src[i];
     filter = reinterpret_cast<const FilterDev*>(&s_filter);
   }
-  if (P.aggregate == 1u || P.aggregate == 3u) {
+  if (!NONE && (P.aggregate == 1u || P.aggregate == 3u)) {
     for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) T.cache.tag[i] = 0u;
     for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN * (MONO ? 1 : 3); i += kBlock) T.cache.val[i] = 0.0f;
   }
@@ -1808,7 +1812,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GE
 #ifdef HALO_PROBE
   probe_start(pr);
 #endif
-  if (P.aggregate == 1u || P.aggregate == 3u) {
+  if (!NONE && (P.aggregate == 1u || P.aggregate == 3u)) {
     __syncthreads();
     for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];
@@ -1858,6 +1862,12 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? ((ACC != kAccDirect || GE
 // (the instantiations of the three MODEs compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
 template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
+  if constexpr (MODE == kModePlain && (GEOM == kGeomOne || GEOM == kGeomOneHex)) {
+    if (P.no_land != 0u) {   // every exit of this layer continues: no cache, no queue, no accumulation code
+      hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccNone>), grid, block, 0, stream, P);
+      return;
+    }
+  }
   if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode: scalar planes, or X/Y/Z planes of an illuminant session
     if (P.bin_log != 0u) {
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
@@ -1879,7 +1889,7 @@ template <int MODE>
 static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
   dim3 grid(blocks), block(kBlock);
   if constexpr (MODE == kModePlain) {
-    if (geom == kGeomOneHex && (P.bin_list == nullptr || P.bin_log != 0u)) {
+    if (geom == kGeomOneHex && (P.bin_list == nullptr || P.bin_log != 0u || P.no_land != 0u)) {
       launch_mono<MODE, kGeomOneHex>(P, grid, block, stream, mono);
       return hipGetLastError();
     }

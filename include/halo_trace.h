@@ -333,7 +333,7 @@ typedef struct HaloRouteInfo {
   uint32_t launches;     /* trace-kernel launches since halo_begin */
   uint32_t mode_mask;    /* bit m: a launch ran the MODE m instantiation (0 production, 1 + path/filter/colour, 2 + exit capture) */
   uint32_t geom_mask;    /* bit g: GEOM g (0 one shape per dispatch, 1 pool of 4.1 KB records, 2 pool of prism records, 3 one shape = regular hexagonal prism) */
-  uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels, 4 hit log, 5 hit log of an illuminant session (X, Y, Z made in the per-tile pass) */
+  uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels, 4 hit log, 5 hit log of an illuminant session (X, Y, Z made in the per-tile pass), 6 none (a layer whose every exit continues) */
   uint32_t source_mask;  /* bit 0 generated roots, 1 continuation pool (layer >= 1), 2 host-injected rays */
   uint32_t plane_cnt;    /* accumulation planes of the session (1 discrete, 3 X/Y/Z, M per-entry) */
   uint32_t plane_copies; /* privatised copies of each plane */

@@ -140,7 +140,7 @@ def test_config3_two_layer_multi_scatter_at_production_launch_sizes():
         st = run_session(hb, sc, rd, wl, n)
         route = hb.last_route()
         assert route.mode_mask == 1 and route.source_mask == 0b011 and route.geom_mask == 1 << 3   # regular prisms: the literal-normal instantiation
-        assert route.accum_mask == abi.ACCUM_SCALAR | abi.ACCUM_LOG   # 600 k roots: direct atomics; >= 2.5 Mi continuations: the hit log
+        assert route.accum_mask == abi.ACCUM_NONE | abi.ACCUM_LOG   # first layer (prob 1): nothing lands, the no-accumulation kernel; >= 2.5 Mi continuations: the hit log
         assert st[1].root_count == st[0].continuation_count >= (5 << 19)
         cont_h.append(st[0].continuation_count)
         launches += st[1].launches
