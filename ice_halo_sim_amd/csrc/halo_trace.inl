@@ -454,7 +454,7 @@ struct PixCache {
 // flush reserves the segment, the 8-byte stores of a tile land in one or two lines — and halo_bin_accumulate_kernel then
 // sums each tile's list in a 64 KB LDS tile and adds it to the plane with plain stores.  Lists that run over (a tile much
 // hotter than average) fall back to the direct atomic, so capacity is a speed matter only.
-constexpr int kAccDirect = 0, kAccBin = 1, kAccLog = 2, kAccNone = 3;   // halo_trace_kernel ACC (None: a layer whose every exit continues — nothing lands)
+constexpr int kAccDirect = 0, kAccBin = 1, kAccLog = 2, kAccNone = 3, kAccLogFinal = 4;   // halo_trace_kernel ACC (None: a layer whose every exit continues — nothing lands)
 constexpr int kHitBuf = 1536;                 // staged hits per workgroup (16 KB)
 constexpr uint32_t kBinTileLog2 = 14u;         // slots per tile: 64 KB of fp32 in the accumulate pass
 constexpr int kBinMaxTiles = 512;
@@ -496,6 +496,7 @@ struct ExitQueues<false> {
 };
 template <bool MONO, bool SMALLC>
 struct AccCtx {
+  bool last;         // kAccLogFinal kernels: the scene's last layer — no candidate continues, the append code is compiled out
   bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
   PixCache<MONO, SMALLC>* cache;
@@ -1073,7 +1074,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   bool pass = false;
   if (live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
   if (pass) {
-    if (!P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
+    if (!(MODE == kModePlain && cache.last) && !P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
       // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
       const uint64_t mask = __ballot(1);
       const uint32_t lane = __lane_id();
@@ -1641,7 +1642,7 @@ HD float wave_sum(float v) {
 #endif
 template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
-  constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog, NONE = ACC == kAccNone;
+  constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
   static_assert(!NONE || (MODE == kModePlain && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
@@ -1663,6 +1664,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
     if ((threadIdx.x & 63u) == 0u) acc.q->n = 0u;
   }
   acc.none = NONE;
+  acc.last = LAST;
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
@@ -1870,6 +1872,12 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
   }
   if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode: scalar planes, or X/Y/Z planes of an illuminant session
     if (P.bin_log != 0u) {
+      if constexpr (GEOM == kGeomOne || GEOM == kGeomOneHex) {
+        if (mono && P.final_layer != 0u) {   // the last layer's one-shape scalar kernels carry no continuation-append code
+          hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLogFinal>), grid, block, 0, stream, P);
+          return;
+        }
+      }
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
       else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
