@@ -338,11 +338,11 @@ struct Hits {
   int count;
 };
 
-HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz) {
+HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1) {   // lens >= 0: the dispatch's lens, known at compile time
   Hits r;
   r.count = 0;
   r.px0 = r.py0 = r.px1 = r.py1 = 0;
-  const int t = p.proj_type;
+  const int t = lens >= 0 ? lens : p.proj_type;
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT ||
       t == HALO_LENS_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
     if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
@@ -496,6 +496,7 @@ struct ExitQueues<false> {
 };
 template <bool MONO, bool SMALLC>
 struct AccCtx {
+  int lens;          // >= 0: instantiated for this lens (the projection's dispatch folds away)
   bool last;         // kAccLogFinal kernels: the scene's last layer — no candidate continues, the append code is compiled out
   bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
@@ -991,7 +992,7 @@ template <int MODE, bool MONO, bool SMALLC>
 HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
   const ProjDev& pj = P.proj;
-  Hits h = project_exit(pj, wx, wy, wz);
+  Hits h = project_exit(pj, wx, wy, wz, MODE == kModePlain ? cache.lens : -1);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
@@ -1014,8 +1015,8 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
 
 // The culls of project_exit that need no projection: false = this exit cannot land (conservative at cz ~ 0, where the
 // projection itself decides).
-HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz) {
-  const int t = p.proj_type;
+HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens = -1) {
+  const int t = lens >= 0 ? lens : p.proj_type;
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT || t == HALO_LENS_FISHEYE_STEREOGRAPHIC ||
       t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
     if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
@@ -1107,7 +1108,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     const bool out = live && !pass;
     sums.exit_w += out ? w : 0.0f;
     sums.exit_n += out ? 1u : 0u;
-    const bool want = out && exit_may_land(P.proj, wx, wy, wz);
+    const bool want = out && exit_may_land(P.proj, wx, wy, wz, cache.lens);
     const uint64_t m = __ballot(want);
     ExitQueue& Q = *cache.q;
     if (want) {
@@ -1640,7 +1641,9 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES_FILTER
 #define HALO_MIN_WAVES_FILTER 3
 #endif
-template <int MODE, int GEOM, bool MONO, int ACC>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log)
+// LENS >= 0: instantiated for that lens — the projection's dispatch over 11 lens types (uniform branches, and the SGPRs their
+// parameters hold) folds away: configs[1] 2.96 -> 2.73 ms per launch.  Done for the kernels and lenses of the shipped examples.
+template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
@@ -1665,6 +1668,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
   }
   acc.none = NONE;
   acc.last = LAST;
+  acc.lens = LENS;
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
@@ -1862,6 +1866,19 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
 
 // host-callable launcher pieces: each halo_trace_m<MODE>.hip translation unit instantiates the kernels of one MODE
 // (the instantiations of the three MODEs compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
+// The lens-specialised instantiations: the lenses of the reference's shipped examples (config_example.json: linear, dual fisheye
+// equal area; the BASELINE configurations: fisheye equal area; bench_config_stoch.json: rectangular), generic otherwise.
+template <int MODE, int GEOM, bool MONO, int ACC>
+static void launch_lens(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream) {
+  switch (P.proj.proj_type) {
+    case HALO_LENS_LINEAR: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_LINEAR>), grid, block, 0, stream, P); break;
+    case HALO_LENS_FISHEYE_EQUAL_AREA: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_FISHEYE_EQUAL_AREA>), grid, block, 0, stream, P); break;
+    case HALO_LENS_DUAL_FISHEYE_EQUAL_AREA: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_DUAL_FISHEYE_EQUAL_AREA>), grid, block, 0, stream, P); break;
+    case HALO_LENS_RECTANGULAR: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_RECTANGULAR>), grid, block, 0, stream, P); break;
+    default: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P); break;
+  }
+}
+
 template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
   if constexpr (MODE == kModePlain && (GEOM == kGeomOne || GEOM == kGeomOneHex)) {
@@ -1874,11 +1891,12 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
     if (P.bin_log != 0u) {
       if constexpr (GEOM == kGeomOne || GEOM == kGeomOneHex) {
         if (mono && P.final_layer != 0u) {   // the last layer's one-shape scalar kernels carry no continuation-append code
-          hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLogFinal>), grid, block, 0, stream, P);
+          launch_lens<MODE, GEOM, true, kAccLogFinal>(P, grid, block, stream);
           return;
         }
       }
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
+      else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) launch_lens<MODE, GEOM, false, kAccLog>(P, grid, block, stream);   // illuminant sessions over sampled crystals
       else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
     }
