@@ -58,13 +58,13 @@ def workload(cfg):
         return dict(scene=scenes.config2_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[1]: single-scatter hex column (prism h=1.3, zenith gauss(90,0.3)), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,3,true,kAccLog> (regular-prism instantiation, exit queue, hit log) + halo_split_kernel<1024,16> + halo_bin_accumulate_range_kernel",
+                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA> (regular-prism search, exit queue, hit log, last layer, lens as a template constant) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
                     metric="rays/sec (whole node) at 9 wavelengths, single-scatter hex column")
     if cfg == "2":
         return dict(scene=scenes.config3_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[2]: two-layer full multi-scattering (plate h=0.3 zenith gauss(0,0.8) prob 1.0 over random column h=1.3), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,3,true,kAccLog> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16> + halo_bin_accumulate_range_kernel",
+                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
                     metric="root rays/sec (whole node) at 9 wavelengths, two-layer full multi-scattering")
     if cfg in ("4", "4p"):
         full = {"type": "uniform", "mean": 0.0, "std": 360.0}
@@ -72,12 +72,12 @@ def workload(cfg):
         if cfg == "4":
             e = scenes.stochastic_prism_entry()
             what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,2,false,kAccLog> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
+            kern = "halo_trace_kernel<0,2,false,kAccLog,RECTANGULAR> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
         else:
             e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
                              scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)
             what = "stochastic pyramid (config_example crystal 5, upper Miller (2,0,3), six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,1,false,kAccLog> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
+            kern = "halo_trace_kernel<0,1,false,kAccLog,RECTANGULAR> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
         return dict(scene=scenes.scene([(0.0, [e])], max_hits=8),
                     render=scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL),
                     wls=[scenes.wl_illuminant("D65", 31)], rays=25_000_000,
