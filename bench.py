@@ -72,12 +72,12 @@ def workload(cfg):
         if cfg == "4":
             e = scenes.stochastic_prism_entry()
             what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,2,false,kAccLog,RECTANGULAR> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
+            kern = "halo_trace_kernel<0,2,false,kAccLog> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
         else:
             e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6),
                              scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)
             what = "stochastic pyramid (config_example crystal 5, upper Miller (2,0,3), six gauss(1,0.15) face distances)"
-            kern = "halo_trace_kernel<0,1,false,kAccLog,RECTANGULAR> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
+            kern = "halo_trace_kernel<0,1,false,kAccLog> (X/Y/Z hit log) + halo_split_kernel<1024,16,512> + halo_log_accumulate_kernel<3>"
         return dict(scene=scenes.scene([(0.0, [e])], max_hits=8),
                     render=scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL),
                     wls=[scenes.wl_illuminant("D65", 31)], rays=25_000_000,

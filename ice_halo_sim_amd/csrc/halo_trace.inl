@@ -1642,7 +1642,8 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES_FILTER 3
 #endif
 // LENS >= 0: instantiated for that lens — the projection's dispatch over 11 lens types (uniform branches, and the SGPRs their
-// parameters hold) folds away: configs[1] 2.96 -> 2.73 ms per launch.  Done for the kernels and lenses of the shipped examples.
+// parameters hold) folds away: configs[1] 2.96 -> 2.73 ms per launch.  Done for the last-layer one-shape scalar kernels and the
+// lenses of the shipped examples.
 template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
@@ -1896,8 +1897,7 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
         }
       }
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
-      else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) launch_lens<MODE, GEOM, false, kAccLog>(P, grid, block, stream);   // illuminant sessions over sampled crystals
-      else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
+      else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);   // (a lens-specialised pool kernel gains nothing: configs[4] 4.31 vs 4.32 ms)
       return;
     }
   }
