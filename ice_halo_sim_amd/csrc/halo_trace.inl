@@ -1375,7 +1375,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float dwz = P.s_lat * x + P.c_lat * z;
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
-    if (HEX || P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // (HEX dispatches always come with the slab-wise entry table)
+    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     w = (P.wl_pool_size == 1u) ? wl0.e.spd_weight : P.wl_pool[wl_idx].spd_weight;
     PROBE_MARK(pr, kPhEntry);
@@ -1415,7 +1415,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     PROBE_MARK(pr, kPhRotation);
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
-    if (HEX || P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // (HEX dispatches always come with the slab-wise entry table)
+    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     PROBE_MARK(pr, kPhEntry);
   } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)

