@@ -184,7 +184,10 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const bool active = s < 2 || side_active;
   const uint32_t act_mask = team_ballot(active);
   // --- vertices: candidate triples in lexicographic order, 32 per round; kept in serial order ---
+  // (the kept vertices live in registers while the list grows — lane v holds vertex v and vertex 32 + v — and go to LDS once, for
+  // the face phase: the serial filter below runs ~25 times per crystal and used to read and write the list in LDS each time)
   int nv = 0;
+  double k0[3] = {0.0, 0.0, 0.0}, k1[3] = {0.0, 0.0, 0.0};
   const int total = 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0)) + (upper ? 20 : 0) + (lower ? 20 : 0);
   for (int base = 0; base < total; base += kTeam) {
     int i, j, k;
@@ -204,21 +207,30 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       todo &= todo - 1u;
       const double cx = team_bcast(x[0], src), cy = team_bcast(x[1], src), cz = team_bcast(x[2], src);
       bool dup = false;
-      for (int v = lane; v < nv; v += kTeam) {
-        const double dx = T.verts[v][0] - cx, dy = T.verts[v][1] - cy, dz = T.verts[v][2] - cz;
-        if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;
-        if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = true;
+      if (lane < nv) {
+        const double dx = k0[0] - cx, dy = k0[1] - cy, dz = k0[2] - cz;
+        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = true;
+      }
+      if (lane + kTeam < nv) {
+        const double dx = k1[0] - cx, dy = k1[1] - cy, dz = k1[2] - cz;
+        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = true;
       }
       if (team_ballot(dup) == 0u && nv < geom::kPyrMaxVerts) {
-        if (lane == 0) {
-          T.verts[nv][0] = cx;
-          T.verts[nv][1] = cy;
-          T.verts[nv][2] = cz;
+        if (lane == (nv & (kTeam - 1))) {
+          if (nv < kTeam) {
+            k0[0] = cx, k0[1] = cy, k0[2] = cz;
+          } else {
+            k1[0] = cx, k1[1] = cy, k1[2] = cz;
+          }
         }
         nv++;
       }
     }
   }
+  if (lane < nv)
+    for (int a = 0; a < 3; a++) T.verts[lane][a] = k0[a];
+  if (lane + kTeam < nv)
+    for (int a = 0; a < 3; a++) T.verts[lane + kTeam][a] = k1[a];
   // --- faces: vertices on plane s (ascending vertex order), then CCW order ---
   int cnt = 0;
   if (valid && active) {
