@@ -153,6 +153,7 @@ def pmc_valu(cfg, rays_per_launch):
         return None
     return {"valu_active_frac": active * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
             "waves_per_simd": (wave * 4.0 / busy / 32.0) if wave else None,
+            "note": "valu_active_frac = SQ_ACTIVE_INST_VALU x 4 / 32 SIMDs / SQ_BUSY_CYCLES; values slightly above 1 mean saturated (the x4 assumes 4-cycle issue)",
             "source": "profiles/%s_bench%s_pmc_{insts,cycles}.txt (counter means over every launch of the kernel in that pass)" % (PROFILE_ROUND, cfg)}
 
 
