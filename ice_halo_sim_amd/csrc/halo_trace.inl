@@ -338,14 +338,15 @@ struct Hits {
   int count;
 };
 
-HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1) {   // lens >= 0: the dispatch's lens, known at compile time
+HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1) {   // lens / vis >= 0: the dispatch's lens / visible range, known at compile time
   Hits r;
   r.count = 0;
   r.px0 = r.py0 = r.px1 = r.py1 = 0;
   const int t = lens >= 0 ? lens : p.proj_type;
+  const int vr = vis >= 0 ? vis : p.visible_range;
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT ||
       t == HALO_LENS_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
-    if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
+    if ((vr == HALO_VISIBLE_UPPER && wz > 0.0f) || (vr == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
     float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
     float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
     float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
@@ -496,7 +497,8 @@ struct ExitQueues<false> {
 };
 template <bool MONO, bool SMALLC>
 struct AccCtx {
-  int lens;          // >= 0: instantiated for this lens (the projection's dispatch folds away)
+  int lens, vis;     // >= 0: instantiated for this lens / visible range (the projection's dispatch folds away)
+  bool nogate;       // instantiated for prob <= 0: no candidate ever passes the gate, the gate stream and its code fold away
   bool last;         // kAccLogFinal kernels: the scene's last layer — no candidate continues, the append code is compiled out
   bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
@@ -992,7 +994,7 @@ template <int MODE, bool MONO, bool SMALLC>
 HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
   const ProjDev& pj = P.proj;
-  Hits h = project_exit(pj, wx, wy, wz, MODE == kModePlain ? cache.lens : -1);
+  Hits h = project_exit(pj, wx, wy, wz, MODE == kModePlain ? cache.lens : -1, MODE == kModePlain ? cache.vis : -1);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
@@ -1015,11 +1017,12 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
 
 // The culls of project_exit that need no projection: false = this exit cannot land (conservative at cz ~ 0, where the
 // projection itself decides).
-HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens = -1) {
+HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1) {
   const int t = lens >= 0 ? lens : p.proj_type;
+  const int vr = vis >= 0 ? vis : p.visible_range;
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT || t == HALO_LENS_FISHEYE_STEREOGRAPHIC ||
       t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
-    if ((p.visible_range == HALO_VISIBLE_UPPER && wz > 0.0f) || (p.visible_range == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
+    if ((vr == HALO_VISIBLE_UPPER && wz > 0.0f) || (vr == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
     return p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz) > -1e-6f;
   }
   return true;
@@ -1073,7 +1076,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
   // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
   bool pass = false;
-  if (live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
+  if (!(MODE == kModePlain && cache.nogate) && live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
   if (pass) {
     if (!(MODE == kModePlain && cache.last) && !P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
       // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
@@ -1108,7 +1111,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     const bool out = live && !pass;
     sums.exit_w += out ? w : 0.0f;
     sums.exit_n += out ? 1u : 0u;
-    const bool want = out && exit_may_land(P.proj, wx, wy, wz, cache.lens);
+    const bool want = out && exit_may_land(P.proj, wx, wy, wz, cache.lens, cache.vis);
     const uint64_t m = __ballot(want);
     ExitQueue& Q = *cache.q;
     if (want) {
@@ -1641,10 +1644,10 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES_FILTER
 #define HALO_MIN_WAVES_FILTER 3
 #endif
-// LENS >= 0: instantiated for that lens — the projection's dispatch over 11 lens types (uniform branches, and the SGPRs their
-// parameters hold) folds away: configs[1] 2.96 -> 2.73 ms per launch.  Done for the last-layer one-shape scalar kernels and the
-// lenses of the shipped examples.
-template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
+// LENS / VIS >= 0, NOGATE: instantiated for that lens, that visible range and prob <= 0 — the projection's dispatch over 11 lens
+// types (uniform branches, and the SGPRs their parameters hold), the visibility tests and the gate stream fold away: configs[1]
+// 2.96 -> 2.73 (lens) -> 2.60 ms per launch.  Done for the last-layer one-shape scalar kernels and the lenses of the shipped examples.
+template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1, int VIS = -1, bool NOGATE = false>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
 __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
@@ -1670,6 +1673,8 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
   acc.none = NONE;
   acc.last = LAST;
   acc.lens = LENS;
+  acc.vis = VIS;
+  acc.nogate = NOGATE;
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
@@ -1867,15 +1872,27 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
 
 // host-callable launcher pieces: each halo_trace_m<MODE>.hip translation unit instantiates the kernels of one MODE
 // (the instantiations of the three MODEs compile in parallel that way; halo_backend.cpp is plain C++ and never sees <<<>>>)
-// The lens-specialised instantiations: the lenses of the reference's shipped examples (config_example.json: linear, dual fisheye
-// equal area; the BASELINE configurations: fisheye equal area; bench_config_stoch.json: rectangular), generic otherwise.
+// The specialised instantiations of the last-layer kernels: lens, visible range and "prob <= 0" (the usual last layer: nothing
+// passes the gate) as template constants.  Lenses of the reference's shipped examples (config_example.json: linear, dual fisheye
+// equal area; the BASELINE configurations: fisheye equal area; bench_config_stoch.json: rectangular) x visible upper / full;
+// anything else runs the generic kernel.
+template <int MODE, int GEOM, bool MONO, int ACC, int LENS>
+static void launch_vis(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream) {
+  if (P.proj.visible_range == HALO_VISIBLE_UPPER) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_UPPER, true>), grid, block, 0, stream, P);
+  else if (P.proj.visible_range == HALO_VISIBLE_FULL) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+  else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P);
+}
 template <int MODE, int GEOM, bool MONO, int ACC>
 static void launch_lens(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream) {
+  if (P.prob > 0.0f) {
+    hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P);
+    return;
+  }
   switch (P.proj.proj_type) {
-    case HALO_LENS_LINEAR: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_LINEAR>), grid, block, 0, stream, P); break;
-    case HALO_LENS_FISHEYE_EQUAL_AREA: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_FISHEYE_EQUAL_AREA>), grid, block, 0, stream, P); break;
-    case HALO_LENS_DUAL_FISHEYE_EQUAL_AREA: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_DUAL_FISHEYE_EQUAL_AREA>), grid, block, 0, stream, P); break;
-    case HALO_LENS_RECTANGULAR: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, HALO_LENS_RECTANGULAR>), grid, block, 0, stream, P); break;
+    case HALO_LENS_LINEAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_LINEAR>(P, grid, block, stream); break;
+    case HALO_LENS_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_FISHEYE_EQUAL_AREA>(P, grid, block, stream); break;
+    case HALO_LENS_DUAL_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_DUAL_FISHEYE_EQUAL_AREA>(P, grid, block, stream); break;
+    case HALO_LENS_RECTANGULAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_RECTANGULAR>(P, grid, block, stream); break;
     default: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P); break;
   }
 }
