@@ -58,13 +58,13 @@ def workload(cfg):
         return dict(scene=scenes.config2_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[1]: single-scatter hex column (prism h=1.3, zenith gauss(90,0.3)), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA> (regular-prism search, exit queue, hit log, last layer, lens as a template constant) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
+                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA,UPPER,nogate> (regular-prism search, exit queue, hit log; last layer, lens, visible range and closed gate as template constants) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
                     metric="rays/sec (whole node) at 9 wavelengths, single-scatter hex column")
     if cfg == "2":
         return dict(scene=scenes.config3_scene(), render=scenes.config2_render(),
                     wls=[scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9], rays=50_000_000,
                     name="configs[2]: two-layer full multi-scattering (plate h=0.3 zenith gauss(0,0.8) prob 1.0 over random column h=1.3), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
-                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
+                    kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA,UPPER,nogate> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
                     metric="root rays/sec (whole node) at 9 wavelengths, two-layer full multi-scattering")
     if cfg in ("4", "4p"):
         full = {"type": "uniform", "mean": 0.0, "std": 360.0}
