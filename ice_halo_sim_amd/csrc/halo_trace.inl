@@ -1914,7 +1914,13 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
         }
       }
       if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
-      else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);   // (a lens-specialised pool kernel gains nothing: configs[4] 4.31 vs 4.32 ms)
+      else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) {
+        // illuminant sessions over sampled crystals: a full-sky render with a closed gate (bench_config_stoch.json's shape) knows both at
+        // compile time (configs[4] 5.52 -> 5.43 ms per step; its lens as a constant gains nothing more: 4.31 vs 4.32 ms per launch)
+        if (P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL)
+          hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog, -1, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
+      } else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
     }
   }
