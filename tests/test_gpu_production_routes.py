@@ -415,3 +415,30 @@ def test_xyz_hit_log_on_a_deterministic_crystal_equals_direct_xyz_atomics():
         assert rel_l2(img, ref[0]) <= 2e-5, (name, rel_l2(img, ref[0]))
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 71)
     _check_single_layer((out["log"][0], out["log"][1]), (img_o, landed_o))
+
+
+@pytest.mark.parametrize("prob", [0.0, 0.4, 1.0])
+def test_last_layer_gate_in_the_production_kernels(prob):
+    """A last layer with prob > 0: candidates that pass the gate are dropped ("continue" with no next layer, simulator.cpp:719-722).
+    The production kernels — exit queue with direct atomics, and the last-layer hit-log kernels (the specialised instantiation for
+    prob <= 0, the generic one otherwise) — against the emit-site capture kernel on the same rays."""
+    sc = scenes.scene([(prob, [scenes.column_crystal_entry()])], max_hits=7)
+    rd, wl, n = scenes.config2_render(), scenes.wl_discrete(550.0), 300_000
+    out = {}
+    for name, kw in (("direct", {}), ("log", {"hit_log": 1}), ("emit_site", {"capture_exits": 1})):
+        hb = hip_backend(seed=83, **kw)
+        st = run_session(hb, sc, rd, wl, n)
+        if "capture_exits" in kw:
+            hb.DrainExits()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (img, landed, st[0].exit_count, st[0].pixel_hits)
+    ref = out["emit_site"]
+    if prob >= 1.0:
+        assert ref[1] == 0.0 and ref[0].sum() == 0.0
+    for name in ("direct", "log"):
+        img, landed, exits, hits = out[name]
+        assert exits == ref[2] and abs(hits - ref[3]) <= 2 + 1e-5 * ref[3], (name, exits, ref[2], hits, ref[3])
+        assert landed == pytest.approx(ref[1], rel=2e-5, abs=1e-3)
+        if ref[0].sum() > 0:
+            assert rel_l2(block_mean(img, 4), block_mean(ref[0], 4)) <= 1e-3
