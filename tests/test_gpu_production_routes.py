@@ -442,3 +442,28 @@ def test_last_layer_gate_in_the_production_kernels(prob):
         assert landed == pytest.approx(ref[1], rel=2e-5, abs=1e-3)
         if ref[0].sum() > 0:
             assert rel_l2(block_mean(img, 4), block_mean(ref[0], 4)) <= 1e-3
+
+
+def test_middle_layer_through_the_hit_log():
+    """Two layers, prob 0.5 then 0: the FIRST layer both lands exits and continues rays, at 3 Mi roots — the non-final hit-log
+    kernel (exit queue push + continuation append side by side) — and the second layer runs the last-layer kernel on ~7 Mi
+    continuations.  Against the same scene on direct atomics: layer 0 traces the same rays (equal continuation count and exits);
+    the image agrees statistically (the second layer's ray order is nondeterministic on either route)."""
+    col = scenes.column_crystal_entry()
+    sc = scenes.scene([(0.5, [col]), (0.0, [col])], max_hits=7)
+    rd, wl, n = scenes.config2_render(), scenes.wl_discrete(550.0), 3 << 20
+    out = {}
+    for name, kw in (("log", {}), ("direct", {"hit_log": 0})):
+        hb = hip_backend(seed=89, **kw)
+        st = run_session(hb, sc, rd, wl, n)
+        r = hb.last_route()
+        assert r.mode_mask == 1 and r.accum_mask == (abi.ACCUM_LOG if name == "log" else abi.ACCUM_SCALAR), (name, r.accum_mask)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (img, landed, st)
+    a, b = out["log"], out["direct"]
+    assert a[2][0].continuation_count == b[2][0].continuation_count and a[2][0].exit_count == b[2][0].exit_count
+    assert a[2][1].root_count == a[2][0].continuation_count >= (2 << 20)
+    assert a[1] == pytest.approx(b[1], rel=2e-3)
+    assert a[0].sum(dtype=np.float64) == pytest.approx(b[0].sum(dtype=np.float64), rel=2e-3)
+    assert _pearson_blocks(a[0], b[0], 16) >= 0.999
