@@ -106,7 +106,12 @@ class HaloExitRecord(C.Structure):
 
 class HaloRouteInfo(C.Structure):
     _fields_ = [("launches", C.c_uint32), ("mode_mask", C.c_uint32), ("geom_mask", C.c_uint32), ("accum_mask", C.c_uint32),
-                ("source_mask", C.c_uint32), ("plane_cnt", C.c_uint32), ("plane_copies", C.c_uint32), ("shuffle_chunk", C.c_uint32)]
+                ("source_mask", C.c_uint32), ("plane_cnt", C.c_uint32), ("plane_copies", C.c_uint32), ("shuffle_chunk", C.c_uint32),
+                ("spec_mask", C.c_uint32), ("generic_launches", C.c_uint32)]
+
+
+MODE_PLAIN, MODE_FILTER, MODE_CAPTURE, MODE_GENERIC, MODE_COLOR = 1, 2, 4, 8, 16   # HaloRouteInfo.mode_mask bits
+SPEC_LAST, SPEC_LENS, SPEC_VIS, SPEC_NOGATE = 1, 2, 4, 8                           # HaloRouteInfo.spec_mask bits
 
 
 ACCUM_XYZ, ACCUM_SCALAR, ACCUM_BIN1, ACCUM_BIN2, ACCUM_LOG, ACCUM_LOG_XYZ, ACCUM_NONE = 1, 2, 4, 8, 16, 32, 64   # HaloRouteInfo.accum_mask bits

@@ -10,7 +10,7 @@ PROBE = bool(os.environ.get("HALO_PROBE"))   # phase-probe build (tools/phase_pr
 # HALO_BUILD_TAG=x builds libhalo_hip_x.so in build_x/ (A/B experiments: load it with HALO_LIB=...); HALO_DEFS="-DA=1 -DB" adds macros
 TAG = "probe" if PROBE else os.environ.get("HALO_BUILD_TAG", "")
 LIB = os.path.join(HERE, "libhalo_hip_%s.so" % TAG if TAG else "libhalo_hip.so")
-SOURCES = ["halo_trace_m0.hip", "halo_trace_m1.hip", "halo_trace_m2.hip", "halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp",
+SOURCES = ["halo_trace_m0.hip", "halo_trace_m1.hip", "halo_trace_m2.hip", "halo_trace_m3.hip", "halo_trace_m4.hip", "halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp",
            "halo_host.cpp"]
 NO_CONTRACT = {"halo_shapegen.hip"}   # geometry shared with the host: same rounding on both sides
 HEADERS = ["halo_device.h", "halo_trace.inl", "halo_geom.h", "halo_host.hpp", "cie_tables.inc", os.path.join("..", "..", "include", "halo_trace.h")]

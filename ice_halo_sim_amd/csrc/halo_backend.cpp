@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,7 +21,7 @@
 #include "halo_host.hpp"
 
 namespace halo {
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono);
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
@@ -91,6 +93,7 @@ struct HaloBackend {
   uint32_t hit_log_cap = 0;    // test knob: records per log region (0 = sized from the launch); the tile lists then get half their even share
   int hex_fast = 1;            // 1: regular hexagonal prisms of one-shape dispatches run the literal-normal next-face search
   int entry_fast = 1;          // 1: full prisms of one-shape dispatches take the slab-wise entry pick (EntryFastDev)
+  int filter_fast = 1;         // 1: filtered / colour-tagged dispatches with max_hits <= 16 run the production-shaped kernels (FastTables); 0: the generic ones
   int async = 0;               // 1: final-layer dispatches are queued without a host sync; stats via halo_collect_stats
   uint32_t shuffle_chunk_log2 = 5;   // Recombine's shuffle moves chunks of 2^k pool entries (k = 0: per ray, like the reference)
   HaloRouteInfo route{};       // kernels that served the current / last session (halo_last_route)
@@ -119,6 +122,7 @@ struct HaloBackend {
   DevBuf<float> lanes;                       // class_count x W x H
   int lanes_w = 0, lanes_h = 0;
   DevBuf<FilterDev> filter_dev;
+  std::unique_ptr<FastTables> fast_scratch;  // host staging of a dispatch's fast filter tables (20 KB: not on the stack)
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
@@ -349,6 +353,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "host_shapes") b->host_shapes = v ? 1 : 0;
   else if (k == "entry_fast") b->entry_fast = v ? 1 : 0;
   else if (k == "hex_fast") b->hex_fast = v ? 1 : 0;
+  else if (k == "filter_fast") b->filter_fast = v ? 1 : 0;
   else if (k == "hit_log") b->hit_log = static_cast<int>(v);
   else if (k == "hit_log_cap") b->hit_log_cap = static_cast<uint32_t>(std::max<int64_t>(v, 0));
   else if (k == "gen_serial") b->gen_serial = v ? 1 : 0;
@@ -456,14 +461,26 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   //    the per-tile pass applies the CMF (halo_log_accumulate_kernel<3>): no plane per entry, no two-level split, a 3-plane fold
   //    (images above 512 Ki pixels: on small ones most hits land in the pixel cache, and the X/Y/Z cache pays three fp32 LDS adds — the
   //    slow kind on gfx950 — per hit where a scalar plane pays one: the reference's 512x256 D65 scene runs 2.8 vs 8.0 G rays/s)
-  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > (1u << 19);
+  uint32_t s_log2 = 6;  // columns per plane row: at least one fold tile
+  while ((static_cast<size_t>(kMonoRows) << s_log2) < npix) s_log2++;
+  // the log's tile layout has limits (halo_trace_layer: log_layout_ok): X/Y/Z records keep the slot in 23 bits of which the per-tile pass
+  // takes <= 4 Ki-slot tiles x 512, scalar planes 16 Ki-slot tiles x 256.  A session the log cannot serve keeps the routes it had before
+  // (one plane per pool entry + binned lists; privatised copies for the direct atomics).
+  const bool log_xyz_fits = s_log2 <= 11u, log_mono_fits = s_log2 <= 12u;
+  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > (1u << 19) && log_xyz_fits;
   b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
   // privatised copies spread the direct atomics of hot pixels; per-entry planes spread them already, and a session whose
   // launches all go through the hit log (copy 0 only) would just make the closing fold read seven empty copies
-  const bool all_logged = plain_scene && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (2ull << 20) && (discrete || b->xyz_log) &&
-                          (b->mono_session || b->xyz_log);
+  // ("all" cannot be known here: a layer's rays are dealt out to its crystal entries, and an entry's launch under 2 Mi rays adds directly.
+  // So the copies go only when every layer has ONE entry — a layer is then launches of the whole batch, and what may still fall under the
+  // threshold, a last chunk or a thin continuation layer, is little work by definition)
+  bool one_entry_layers = true;
+  for (int l = 0; l < scene->layer_count; l++) one_entry_layers = one_entry_layers && scene->layers[l].entry_count == 1;
+  const bool fast_scene = plain_scene || (!b->capture && b->filter_fast && scene->max_hits <= 16);   // (a dispatch whose tables do not fit the fast form still adds directly: copy 0 only, correct, slower)
+  const bool all_logged = fast_scene && one_entry_layers && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (2ull << 20) &&
+                          (discrete ? log_mono_fits : b->xyz_log) && (b->mono_session || b->xyz_log);
   b->plane_copies = (b->mono_by_wl || all_logged) ? 1u : static_cast<uint32_t>(b->mono_copies);
   b->plane_coef.clear();
   for (uint32_t m = 0; m < b->plane_cnt; m++) {
@@ -471,8 +488,6 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     else b->plane_coef.push_back({m == 0 ? 1.0f : 0.0f, m == 1 ? 1.0f : 0.0f, m == 2 ? 1.0f : 0.0f});
   }
   {
-    uint32_t s_log2 = 6;  // at least one fold tile of columns
-    while ((static_cast<size_t>(kMonoRows) << s_log2) < npix) s_log2++;
     const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
     if (b->mono.cap < need) {
       HIPCHK(b, b->mono.reserve(need));
@@ -719,6 +734,29 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
     }
 
+    // Which kernels: capture (tests) > filter / colour in their fast form (paths <= 16 faces, tables fit) > the generic filter kernels > plain
+    int mode = 0;
+    FastTables* fast_host = nullptr;
+    if (b->capture) mode = 2;
+    else if (use_filter || use_color) {
+      mode = 3;
+      if (b->filter_fast && b->scene.max_hits <= 16) {
+        b->fast_scratch.reset(new FastTables());
+        std::memset(b->fast_scratch.get(), 0, sizeof(FastTables));
+        const HaloColorSet* cs = (use_color && E.color_id > 0) ? &b->color_sets[static_cast<size_t>(E.color_id - 1)] : nullptr;
+        if (host::BuildFastTables(use_filter ? &b->filters[static_cast<size_t>(E.filter_id - 1)] : nullptr, cs, E.axis, *b->fast_scratch)) {
+          fast_host = b->fast_scratch.get();
+          fast_host->class_cnt = use_color ? cd.class_cnt : 0u;
+          for (uint32_t c = 0; c < fast_host->class_cnt; c++) {
+            fast_host->class_bits[c] = cd.class_bits[c];
+            fast_host->class_all[c] = cd.class_all[c];
+          }
+          mode = use_color ? 4 : 1;
+        }
+      }
+    }
+    const bool fast_mode = mode == 0 || mode == 1 || mode == 4;   // production-shaped kernels: exit queue, hit log, regular-prism search
+
     const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
     for (uint64_t off = 0; off < n_ci;) {
@@ -757,13 +795,16 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       if (use_filter) hs.filter = fd;
       if (use_color) hs.color = cd;
+      if (fast_host) std::memcpy(&hs.fast, fast_host, sizeof(FastTables));
       for (double& v : hs.sums) v = 0.0;
       if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
-      HIPCHK(b, hipMemcpyAsync(ds, &hs, sizeof(DispatchSlot), hipMemcpyHostToDevice, b->stream));
+      // (the fast filter tables are the slot's last member and travel only with the dispatches that use them)
+      HIPCHK(b, hipMemcpyAsync(ds, &hs, fast_host ? sizeof(DispatchSlot) : offsetof(DispatchSlot, fast), hipMemcpyHostToDevice, b->stream));
       P.lut = ds->lut;
       P.wl_pool = ds->wl;
       P.filter = use_filter ? &ds->filter : nullptr;
       P.color = use_color ? &ds->color : nullptr;
+      P.fast = fast_host ? &ds->fast : nullptr;
       P.lanes = b->lanes.ptr;
       P.lane_stride = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
       P.sums = ds->sums;
@@ -826,10 +867,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint32_t log_t_log2 = b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
       const uint32_t log_tiles = 1u << log_t_log2;
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && !b->mono_by_wl && b->mono_s_log2 <= 12u);
-      const bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && !b->capture && P.filter == nullptr && P.color == nullptr &&
+      bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && fast_mode &&
                            (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
                            (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
-      const bool use_log_xyz = use_log && b->xyz_log;
+      bool use_log_xyz = use_log && b->xyz_log;
+      uint64_t log_cap = 0;
       if (use_log) {
         // a region takes 4 records per ray of its workgroup (configs[1]: 1.2 logged per ray), 8 for full-sky renders (5-6 per ray),
         // and a tile list twice its even share of that; what runs over falls back to direct atomics
@@ -843,12 +885,31 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
           cap = b->hit_log_cap;
           c2 = std::max<uint64_t>(cap * static_cast<uint64_t>(blocks) / (2ull * log_tiles), 64ull);
         }
+        // The log's capacity is a speed matter only (what runs over is added directly), so it gives way to the memory there is: the
+        // regions and lists still to be allocated take at most half of what is free (the continuation and shape pools of later layers
+        // want theirs), and a reserve that fails all the same sends this launch down the direct route instead of failing the trace.
+        {
+          size_t free_b = 0, total_b = 0;
+          const uint64_t have = (b->bin_list.cap + b->bin_list2.cap) * sizeof(HitRec);
+          uint64_t need = (cap * static_cast<uint64_t>(blocks) + c2 * log_tiles) * sizeof(HitRec);
+          if (need > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need - have > free_b / 2u) {
+            const double shrink = static_cast<double>(have + free_b / 2u) / static_cast<double>(need);
+            cap = std::max<uint64_t>(static_cast<uint64_t>(static_cast<double>(cap) * shrink), 1024ull);
+            c2 = std::max<uint64_t>(static_cast<uint64_t>(static_cast<double>(c2) * shrink), 1024ull);
+          }
+        }
         cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
+        log_cap = cap;
+        if (b->bin_list.reserve(cap * static_cast<uint64_t>(blocks)) != hipSuccess || b->bin_list2.reserve(c2 * log_tiles) != hipSuccess) {
+          (void)hipGetLastError();   // out of memory: not this launch's route
+          use_log = use_log_xyz = false;
+        }
+      }
+      if (use_log) {
+        const uint64_t cap = log_cap;
         HIPCHK(b, b->bin_cnt.reserve(std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u)));
         HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(512) * 16u));
         HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), b->stream));
-        HIPCHK(b, b->bin_list.reserve(cap * static_cast<uint64_t>(blocks)));
-        HIPCHK(b, b->bin_list2.reserve(c2 * log_tiles));
         P.bin_list = b->bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
         P.bin_tiles = log_tiles;
@@ -893,16 +954,35 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
         P.mono_copy_mask = b->plane_copies - 1u;
       }
-      P.no_land = (P.prob >= 1.0f && !P.final_layer && !b->capture && P.filter == nullptr && P.color == nullptr && b->aggregate == 1) ? 1u : 0u;
+      P.no_land = (P.prob >= 1.0f && !P.final_layer && fast_mode && b->aggregate == 1) ? 1u : 0u;
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hs.efast.hex_regular) ? 3 : geom;
-      hipError_t le = launch_trace(P, blocks, b->stream, b->capture != 0, launch_geom, b->mono_session);
+      hipError_t le = launch_trace(P, blocks, b->stream, mode, launch_geom, b->mono_session);
       b->mono_dirty = true;
       b->route.launches++;
-      b->route.mode_mask |= 1u << (b->capture ? 2 : ((P.filter != nullptr || P.color != nullptr) ? 1 : 0));
-      b->route.geom_mask |= 1u << launch_geom;
-      b->route.accum_mask |= P.no_land ? 64u : use_log ? (use_log_xyz ? 32u : 16u) : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
+      b->route.mode_mask |= 1u << mode;
+      // the masks name the instantiation launch_mode / launch_mono pick (halo_trace.inl), not the request: the regular-prism search exists for
+      // the production-shaped kernels off the binned route, the no-accumulation kernels for their one-shape dispatches
+      const bool ran_hex = launch_geom == 3 && fast_mode && (P.bin_list == nullptr || P.bin_log != 0u || P.no_land != 0u);
+      const bool ran_none = P.no_land != 0u && geom == 0;
+      b->route.geom_mask |= 1u << (launch_geom == 3 && !ran_hex ? 0 : launch_geom);
+      b->route.accum_mask |= ran_none ? 64u : use_log ? (use_log_xyz ? 32u : 16u) : (use_bin ? (two_level ? 8u : 4u) : (b->mono_session ? 2u : 1u));
+      // specialisations (plain kernels only; launch_lens / launch_vis / launch_mono): bit 0 last-layer kernel (no continuation code), 1 lens as a
+      // constant, 2 visible range as a constant, 3 closed gate as a constant
+      {
+        const bool one = geom == 0, lens_known = P.proj.proj_type == HALO_LENS_LINEAR || P.proj.proj_type == HALO_LENS_FISHEYE_EQUAL_AREA ||
+                                                 P.proj.proj_type == HALO_LENS_DUAL_FISHEYE_EQUAL_AREA || P.proj.proj_type == HALO_LENS_RECTANGULAR;
+        const bool vis_known = P.proj.visible_range == HALO_VISIBLE_UPPER || P.proj.visible_range == HALO_VISIBLE_FULL;
+        uint32_t spec = 0u;
+        if (fast_mode && use_log && one && !ran_none && b->mono_session && P.final_layer) {
+          spec |= 1u;
+          if (mode == 0 && P.prob <= 0.0f && lens_known && vis_known) spec |= 2u | 4u | 8u;
+        }
+        if (mode == 0 && use_log && !one && !b->mono_session && P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL) spec |= 4u | 8u;
+        b->route.spec_mask |= spec;
+        if (spec == 0u) b->route.generic_launches++;
+      }
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
       if (use_log) {
@@ -1029,18 +1109,20 @@ int halo_reduce_accumulator(halo_handle_t b, void* nccl_comm, int root, int this
   if (!b->acc || b->acc_w <= 0) return fail(b, HALO_FATAL, "reduce_accumulator before any session");
   // ncclReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, root, comm, stream) — rccl.h:550
   typedef int (*nccl_reduce_fn)(const void*, void*, size_t, int, int, int, void*, hipStream_t);
-  static nccl_reduce_fn reduce = nullptr;
-  if (!reduce) {
+  static nccl_reduce_fn reduce = nullptr;   // looked up once, whichever GPU's thread gets here first (one thread per GPU is a supported use)
+  static std::once_flag reduce_once;
+  std::call_once(reduce_once, [] {
     void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (lib) reduce = reinterpret_cast<nccl_reduce_fn>(dlsym(lib, "ncclReduce"));
-    if (!reduce) return fail(b, HALO_UNAVAILABLE, "RCCL (librccl.so: ncclReduce) cannot be loaded");
-  }
+  });
+  if (!reduce) return fail(b, HALO_UNAVAILABLE, "RCCL (librccl.so: ncclReduce) cannot be loaded");
   HIPCHK(b, hipSetDevice(b->device));
   int rc = fold_if_dirty(b);   // an unfinished session still owes its planes to the accumulator
   if (rc != HALO_OK) return rc;
   const size_t n = static_cast<size_t>(b->acc_w) * static_cast<size_t>(b->acc_h) * 3 + 4;
+  if (n > b->acc_floats) return fail(b, HALO_FATAL, "reduce_accumulator: the bound accumulator is smaller than width*height*3+4 floats");
   const int nr = reduce(b->acc, b->acc, n, 7 /* ncclFloat32 */, 0 /* ncclSum */, root, nccl_comm, b->stream);
   if (nr != 0) return fail(b, HALO_FATAL, "ncclReduce failed with code " + std::to_string(nr));
   if (this_rank != root) HIPCHK(b, hipMemsetAsync(b->acc, 0, n * sizeof(float), b->stream));   // drained, in stream order
@@ -1243,6 +1325,28 @@ int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int
   if (!rp || !out || n < 0 || n > HALO_MAX_HITS) return HALO_FATAL;
   std::vector<uint8_t> v = host::ReduceRaypath(std::vector<uint8_t>(rp, rp + n), static_cast<uint8_t>(symmetry), sigma_a, d_applicable != 0);
   std::copy(v.begin(), v.end(), out);
+  return HALO_OK;
+}
+int halo_host_filter_fast_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int32_t n, const float dir[3], int32_t crystal_id, int32_t* pass) {
+  if (!f || !axis || !pass || n < 0 || n > 16 || (n && !path) || !dir) return HALO_FATAL;
+  // the tables of the (filter, axis) asked about last are kept: the tests sweep thousands of paths per filter
+  struct Cache {
+    HaloFilter f;
+    HaloAxis axis;
+    bool valid = false, fits = false;
+    FastTables tables;
+  };
+  static thread_local std::unique_ptr<Cache> cache;
+  if (!cache) cache.reset(new Cache());
+  if (!cache->valid || std::memcmp(&cache->f, f, sizeof(HaloFilter)) != 0 || std::memcmp(&cache->axis, axis, sizeof(HaloAxis)) != 0) {
+    std::memset(&cache->tables, 0, sizeof(FastTables));
+    cache->f = *f;
+    cache->axis = *axis;
+    cache->fits = host::BuildFastTables(f, nullptr, *axis, cache->tables);
+    cache->valid = true;
+  }
+  if (!cache->fits) return HALO_FATAL;
+  *pass = host::FastFilterCheck(cache->tables, path, static_cast<uint32_t>(n), dir, static_cast<uint32_t>(crystal_id)) ? 1 : 0;
   return HALO_OK;
 }
 double halo_host_refractive_index(double wl) { return host::IceRefractiveIndex(wl); }

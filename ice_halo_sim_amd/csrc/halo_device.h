@@ -148,6 +148,39 @@ struct ColorDev {
   ColorTermDev terms[HALO_COLOR_MAX_TERMS];
 };
 
+// Fast form of the emit-gate filter and of the raypath-colour predicates for paths of at most 16 faces (max_hits <= 16): what the
+// kFilter / kColor production kernels evaluate.  Nothing is symmetry-reduced on the device.  A raypath term matches exactly the
+// sequences whose reduction (Crystal::ReduceRaypath, crystal.cpp:536-600) equals the term's canonical form; each of them is one of
+// the <= 24 images of that form under the P / B / D group, so the host lists the members (FastTables::orbit: every image whose own
+// reduction IS the canonical form — the reference's predicate, including the cases where its reduction is not a perfect orbit
+// invariant) and the kernel compares the packed path with them; an entry/exit term becomes a 32 x 32 bit matrix over face numbers
+// (row = entry face, bit = exit face).  All of it is dispatch-uniform and read with scalar loads.
+constexpr int kFastOrbitCap = 768;   // 128-bit members over all raypath terms of a dispatch (filter + colour predicates)
+constexpr int kFastEeCap = 24;       // entry/exit matrices
+struct FastTerm {
+  uint32_t type;            // HALO_FILTER_*
+  uint32_t len;             // raypath: length of the canonical sequence
+  uint32_t min_len, max_len;
+  uint32_t orbit_off, orbit_n;   // raypath: members in FastTables::orbit
+  uint32_t ee_off;          // entry/exit: matrix in FastTables::ee
+  uint32_t crystal_id;
+  float dir[3], radii_c;
+  uint32_t bit;             // colour predicates: the mask bit this predicate sets
+  uint32_t pad[3];
+};
+static_assert(sizeof(FastTerm) == 64, "read with scalar loads");
+struct FastTables {
+  uint32_t has_filter, is_complex, action, or_count;
+  uint32_t color_terms, class_cnt, pad0, pad1;
+  uint8_t and_counts[HALO_FILTER_MAX_OR];
+  uint64_t class_bits[HALO_COLOR_MAX_CLASSES];
+  uint32_t class_all[HALO_COLOR_MAX_CLASSES];
+  FastTerm fterm[HALO_FILTER_MAX_TERMS];
+  FastTerm cterm[HALO_COLOR_MAX_TERMS];
+  uint64_t orbit[kFastOrbitCap][2];   // {hi, lo}, the path register's layout: newest face in the low byte of lo
+  uint32_t ee[kFastEeCap][32];
+};
+
 // Continuation pool sharding.  One device counter saturates at ~88 M returning atomics/s (measured, MI355X), and every
 // wave appends once per emit site — so the pool is cut into kContShards regions, block b appends to region b % kContShards
 // through that region's own counter (64 B apart: same-line atomics serialise), and the next layer reads logical index j
@@ -171,6 +204,7 @@ struct DispatchSlot {
   alignas(16) uint32_t seg[kContShards + 4];
   alignas(16) ColorDev color;
   alignas(16) EntryFastDev efast;
+  alignas(16) FastTables fast;
 };
 
 // Everything one (layer, crystal-entry) dispatch needs; passed by value as the kernel argument.
@@ -250,6 +284,7 @@ struct DispatchParams {
   uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
   const FilterDev* filter;     // nullptr = pass-all
   const ColorDev* color;       // nullptr = no raypath colour: no masks carried, no lanes
+  const FastTables* fast;      // kFilter / kColor kernels: the filter and the colour predicates in their fast form (else nullptr)
   float* lanes;                // class_cnt x lane_stride Y lanes
   uint32_t lane_stride;        // W*H
 };

@@ -250,6 +250,171 @@ FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis) {
   return d;
 }
 
+std::vector<std::array<uint64_t, 2>> RaypathMembers(const std::vector<uint8_t>& canon, uint8_t symmetry, int sigma_a, bool d_applicable) {
+  std::vector<std::array<uint64_t, 2>> out;
+  if (canon.empty() || canon.size() > 16) return out;   // longer than the path register: no path of a fast kernel can match
+  auto pack = [](const std::vector<uint8_t>& q) {
+    std::array<uint64_t, 2> w = {0ull, 0ull};   // {hi, lo}: element 0 is the oldest face, the last element sits in the low byte of lo
+    for (size_t i = 0; i < q.size(); i++) {
+      const size_t pos = q.size() - 1 - i;      // byte position from the low end
+      w[pos < 8 ? 1 : 0] |= static_cast<uint64_t>(q[i]) << (8 * (pos % 8));
+    }
+    return w;
+  };
+  // reduce(p) is one of the images of p under {rotations} x {D} x {B}, so every p with reduce(p) == canon is an image of canon
+  for (int rot = 0; rot < kFnPeriod; rot++)
+    for (int dd = 0; dd < 2; dd++)
+      for (int bb = 0; bb < 2; bb++) {
+        std::vector<uint8_t> q = canon;
+        for (uint8_t& x : q) {
+          if (x >= 3) {
+            const int pyr = x / 10;
+            int pri = x % 10 - 3;
+            pri = ((pri + rot) % kFnPeriod + kFnPeriod) % kFnPeriod;
+            if (dd) pri = ((sigma_a - pri) % kFnPeriod + kFnPeriod) % kFnPeriod;
+            x = static_cast<uint8_t>(pyr * 10 + pri + 3);
+          }
+          if (bb) {
+            if (x <= 2) x = static_cast<uint8_t>(3 - x);
+            else if (x >= 13 && x <= 18) x = static_cast<uint8_t>(x + 10);
+            else if (x >= 23 && x <= 28) x = static_cast<uint8_t>(x - 10);
+          }
+        }
+        if (ReduceRaypath(q, symmetry, sigma_a, d_applicable) != canon) continue;
+        const auto w = pack(q);
+        if (std::find(out.begin(), out.end(), w) == out.end()) out.push_back(w);
+      }
+  return out;
+}
+
+bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, FastTables& out) {
+  const bool dap = IsDApplicable(axis);
+  const int sigma_a = dap ? ComputeSigmaA(axis.roll.center) : 0;
+  uint32_t orbit_used = 0, ee_used = 0;
+  bool fits = true;
+  auto fill = [&](const HaloFilterTerm& t, uint8_t symmetry, FastTerm& o) {
+    o = FastTerm{};
+    o.type = static_cast<uint32_t>(t.type);
+    if (t.type == HALO_FILTER_RAYPATH) {
+      std::vector<uint8_t> rp;
+      for (int i = 0; i < t.raypath_len && i < kFilterPathCap; i++) rp.push_back(t.raypath[i]);
+      const std::vector<uint8_t> canon = ReduceRaypath(rp, symmetry, sigma_a, dap);
+      o.len = static_cast<uint32_t>(canon.size());
+      const auto members = RaypathMembers(canon, symmetry, sigma_a, dap);
+      if (orbit_used + members.size() > static_cast<size_t>(kFastOrbitCap)) {
+        fits = false;
+        return;
+      }
+      o.orbit_off = orbit_used;
+      o.orbit_n = static_cast<uint32_t>(members.size());
+      for (const auto& m : members) {
+        out.orbit[orbit_used][0] = m[0];
+        out.orbit[orbit_used][1] = m[1];
+        orbit_used++;
+      }
+    } else if (t.type == HALO_FILTER_ENTRY_EXIT) {  // DeviceFilterMatchSimple filter_shared.h:180-224 as a matrix over (entry face, exit face)
+      o.min_len = t.min_len;
+      o.max_len = t.max_len;
+      if (ee_used >= static_cast<uint32_t>(kFastEeCap)) {
+        fits = false;
+        return;
+      }
+      o.ee_off = ee_used;
+      std::vector<uint8_t> want;
+      if (t.has_entry) want.push_back(static_cast<uint8_t>(t.entry));
+      if (t.has_exit) want.push_back(static_cast<uint8_t>(t.exit_face));
+      const std::vector<uint8_t> canon = ReduceRaypath(want, symmetry, sigma_a, dap);
+      for (uint32_t e = 0; e < 32; e++) {
+        uint32_t row = 0;
+        for (uint32_t x = 0; x < 32; x++) {
+          std::vector<uint8_t> q;
+          if (t.has_entry) q.push_back(static_cast<uint8_t>(e));
+          if (t.has_exit) q.push_back(static_cast<uint8_t>(x));
+          if (q.empty() || ReduceRaypath(q, symmetry, sigma_a, dap) == canon) row |= 1u << x;
+        }
+        out.ee[ee_used][e] = row;
+      }
+      ee_used++;
+    } else if (t.type == HALO_FILTER_DIRECTION) {  // FillDirection device_filter_desc.cpp:57-65
+      const float lon = t.az * kDegToRad, lat = t.el * kDegToRad;
+      o.dir[0] = std::cos(lat) * std::cos(lon);
+      o.dir[1] = std::cos(lat) * std::sin(lon);
+      o.dir[2] = std::sin(lat);
+      o.radii_c = std::cos(t.radii * kDegToRad);
+    } else if (t.type == HALO_FILTER_CRYSTAL) {
+      o.crystal_id = static_cast<uint32_t>(t.crystal_id);
+    }
+  };
+  out.has_filter = 0;
+  out.is_complex = out.action = out.or_count = 0;
+  out.color_terms = 0;
+  if (filter != nullptr) {
+    const uint8_t sym = static_cast<uint8_t>(filter->symmetry & 7);
+    out.has_filter = 1;
+    out.is_complex = filter->is_complex ? 1u : 0u;
+    out.action = filter->action ? 1u : 0u;
+    if (!filter->is_complex) {
+      fill(filter->terms[0], sym, out.fterm[0]);
+    } else {
+      out.or_count = static_cast<uint32_t>(std::min(filter->or_count, HALO_FILTER_MAX_OR));
+      int k = 0;
+      for (uint32_t o = 0; o < out.or_count; o++) {
+        out.and_counts[o] = static_cast<uint8_t>(filter->and_counts[o]);
+        for (int a = 0; a < filter->and_counts[o] && k < HALO_FILTER_MAX_TERMS; a++, k++) fill(filter->terms[k], sym, out.fterm[k]);
+      }
+    }
+  }
+  if (colors != nullptr) {
+    out.color_terms = static_cast<uint32_t>(std::min(colors->term_count, HALO_COLOR_MAX_TERMS));
+    for (uint32_t k = 0; k < out.color_terms; k++) {
+      fill(colors->terms[k].predicate, static_cast<uint8_t>(colors->terms[k].symmetry & 7), out.cterm[k]);
+      out.cterm[k].bit = static_cast<uint32_t>(colors->terms[k].bit & 0xFF);
+    }
+  }
+  return fits;
+}
+
+bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t L, const float dir[3], uint32_t crystal_id) {
+  uint64_t hi = 0, lo = 0;   // the kernels' path register: newest face in the low byte
+  for (uint32_t i = 0; i < L; i++) {
+    hi = (hi << 8) | (lo >> 56);
+    lo = (lo << 8) | path[i];
+  }
+  auto term = [&](const FastTerm& t) {
+    if (t.type == HALO_FILTER_NONE) return true;
+    if (t.type == HALO_FILTER_RAYPATH) {
+      if (L != t.len) return false;
+      for (uint32_t k = 0; k < t.orbit_n; k++)
+        if (lo == F.orbit[t.orbit_off + k][1] && (L <= 8u || hi == F.orbit[t.orbit_off + k][0])) return true;
+      return false;
+    }
+    if (t.type == HALO_FILTER_ENTRY_EXIT) {
+      if (L == 0u || L < t.min_len) return false;
+      if (t.max_len != 0u && L > t.max_len) return false;
+      const uint32_t sh = 8u * (L - 1u);
+      const uint32_t first = static_cast<uint32_t>((sh < 64u ? lo >> sh : hi >> (sh - 64u)) & 0xFFull), last = static_cast<uint32_t>(lo & 0xFFull);
+      return first < 32u && last < 32u && ((F.ee[t.ee_off][first & 31u] >> last) & 1u) != 0u;
+    }
+    if (t.type == HALO_FILTER_DIRECTION) return t.dir[0] * dir[0] + t.dir[1] * dir[1] + t.dir[2] * dir[2] > t.radii_c;
+    if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;
+    return false;
+  };
+  bool m;
+  if (!F.is_complex) {
+    m = term(F.fterm[0]);
+  } else {
+    m = false;
+    uint32_t idx = 0;
+    for (uint32_t o = 0; o < F.or_count; o++) {
+      bool all = true;
+      for (uint32_t a = 0; a < F.and_counts[o]; a++) all = term(F.fterm[idx + a]) && all;
+      idx += F.and_counts[o];
+      m = m || all;
+    }
+  }
+  return F.action == 0u ? m : !m;
+}
+
 bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out) {
   std::memset(&out, 0, sizeof(out));
   if (s.face_cnt != kEntryFastFaces || s.slab_cnt != 4 || s.single_cnt != 0 || s.tri_cnt < 8 || s.tri_cnt > kEntryFastTris) return false;

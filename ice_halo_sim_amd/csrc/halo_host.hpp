@@ -45,6 +45,14 @@ std::vector<uint64_t> Partition(const float* proportions, int n, uint64_t ray_nu
 // canonical sequences reduced by Crystal::ReduceRaypath (crystal.cpp:536-600).
 FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis);
 std::vector<uint8_t> ReduceRaypath(const std::vector<uint8_t>& rp, uint8_t symmetry, int sigma_a, bool d_applicable);
+// Fast form of a filter (nullptr = none) and of a crystal entry's colour predicates for the kernels that hold the path in a
+// 128-bit register (halo_device.h FastTables).  false = it does not fit (member / matrix pools full): the caller takes the
+// generic kernels.  `out` must be zero-initialised by the caller only for the class table, which this function leaves alone.
+bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, FastTables& out);
+// The members of a raypath term: every sequence whose reduction equals `canon` (packed {hi, lo}, newest face in the low byte).
+std::vector<std::array<uint64_t, 2>> RaypathMembers(const std::vector<uint8_t>& canon, uint8_t symmetry, int sigma_a, bool d_applicable);
+// The fast tables evaluated on the host, step for step like halo_trace.inl fast_filter (test hook).
+bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t len, const float dir[3], uint32_t crystal_id);
 int ComputeSigmaA(float roll_center_deg);       // crystal.cpp:720-726
 bool IsDApplicable(const HaloAxis& axis);       // crystal.cpp:728-730
 

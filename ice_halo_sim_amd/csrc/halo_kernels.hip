@@ -523,13 +523,20 @@ hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log
 hipError_t launch_trace_m0(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
 hipError_t launch_trace_m1(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
 hipError_t launch_trace_m2(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
+hipError_t launch_trace_m3(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
+hipError_t launch_trace_m4(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono);
 
-// MODE: capture (tests) > filter / raypath colour (path recorded) > plain
-// geom: 0 = one shape per dispatch, 1 = shape pool, 2 = shape pool of prisms (compact LDS slots)
-hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, bool capture, int geom, bool mono) {
-  if (capture) return launch_trace_m2(P, blocks, stream, geom, mono);
-  if (P.filter != nullptr || P.color != nullptr) return launch_trace_m1(P, blocks, stream, geom, mono);
-  return launch_trace_m0(P, blocks, stream, geom, mono);
+// mode: halo_trace.inl kMode* — 0 plain, 1 filter (fast form), 2 capture (tests), 3 generic filter / colour, 4 filter + colour (fast form)
+// geom: 0 = one shape per dispatch, 1 = shape pool, 2 = shape pool of prisms (compact LDS slots), 3 = one regular hexagonal prism
+hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono) {
+  switch (mode) {
+    case 0: return launch_trace_m0(P, blocks, stream, geom, mono);
+    case 1: return launch_trace_m1(P, blocks, stream, geom, mono);
+    case 2: return launch_trace_m2(P, blocks, stream, geom, mono);
+    case 3: return launch_trace_m3(P, blocks, stream, geom, mono);
+    case 4: return launch_trace_m4(P, blocks, stream, geom, mono);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace halo

@@ -487,6 +487,17 @@ struct ExitQueue {
   uint32_t wl[kExitQ];
   uint32_t n;
 };
+struct ExitQueueMask {   // raypath colour (kModeColor): the exit's component mask rides along
+  uint32_t lo[kExitQ], hi[kExitQ];
+};
+template <bool ON>
+struct ExitQueueMasks {
+  ExitQueueMask q[kBlock / 64];
+};
+template <>
+struct ExitQueueMasks<false> {
+  uint32_t unused;
+};
 template <bool ON>
 struct ExitQueues {
   ExitQueue q[kBlock / 64];
@@ -502,6 +513,9 @@ struct AccCtx {
   bool last;         // kAccLogFinal kernels: the scene's last layer — no candidate continues, the append code is compiled out
   bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
+  ExitQueueMask* qm; // ... its colour-mask planes (kModeColor)
+  const FastTables* fast;   // kModeFilter / kModeColor: the dispatch's filter + colour predicates (dispatch-uniform, scalar loads)
+  const uint32_t* fast_ee;  // ... the first kFastEeLds entry/exit matrices, staged in LDS
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
   uint32_t* log_n;   // hit-log kernels: the workgroup's log cursor (LDS); nullptr otherwise
@@ -889,7 +903,86 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// the fused kernel.  MODE: 0 = production, 1 = + raypath recording and emit-gate filter, 2 = + exit capture (tests)
+// The same predicates in their fast form (halo_device.h FastTables), for max_hits <= 16 — the kModeFilter / kModeColor kernels.
+// Nothing is reduced here: the host listed, per raypath term, the sequences whose reduction is the term's canonical form, and
+// turned every entry/exit term into a bit matrix over (entry face, exit face).  Terms, counts and the path LENGTH are
+// wave-uniform (every lane of an interaction has recorded the same number of faces; the rare stray lane is evaluated by a
+// second, uniformly branched call), so the walk over clauses and terms is scalar control flow over scalar loads, and the only
+// per-lane work is one 64-bit compare per member, one table word per entry/exit term, three FMAs per direction term.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFastEeLds = 8u;   // entry/exit matrices staged in LDS (1 KB); a dispatch with more reads the rest from HBM
+HD bool fast_term(const FastTables& F, const uint32_t* ee_lds, const FastTerm& t, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
+  const uint32_t type = t.type;
+  if (type == HALO_FILTER_NONE) return true;
+  if (type == HALO_FILTER_RAYPATH) {  // DeviceFilterMatchSimple :156-178
+    if (L != t.len) return false;
+    const uint32_t n = t.orbit_n, off = t.orbit_off;
+    bool m = false;
+    if (L <= 8u) {
+      for (uint32_t k = 0u; k < n; ++k) m = m || (reg.lo == F.orbit[off + k][1]);
+    } else {
+      for (uint32_t k = 0u; k < n; ++k) m = m || (reg.lo == F.orbit[off + k][1] && reg.hi == F.orbit[off + k][0]);
+    }
+    return m;
+  }
+  if (type == HALO_FILTER_ENTRY_EXIT) {  // :180-224
+    if (L == 0u || L < t.min_len) return false;
+    if (t.max_len != 0u && L > t.max_len) return false;
+    const uint32_t sh = 8u * (L - 1u);   // scalar
+    const uint32_t first = static_cast<uint32_t>((sh < 64u ? reg.lo >> sh : reg.hi >> (sh - 64u)) & 0xFFull);
+    const uint32_t last = static_cast<uint32_t>(reg.lo & 0xFFull);
+    const uint32_t row = t.ee_off < kFastEeLds ? ee_lds[t.ee_off * 32u + (first & 31u)] : F.ee[t.ee_off][first & 31u];
+    return first < 32u && last < 32u && ((row >> last) & 1u) != 0u;
+  }
+  if (type == HALO_FILTER_DIRECTION) return t.dir[0] * wx + t.dir[1] * wy + t.dir[2] * wz > t.radii_c;  // :226-229
+  if (type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;                                    // :231-233
+  return false;
+}
+
+HD bool fast_filter(const FastTables& F, const uint32_t* ee_lds, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
+  bool m;
+  if (!F.is_complex) {
+    m = fast_term(F, ee_lds, F.fterm[0], L, reg, wx, wy, wz, crystal_id);
+  } else {  // OR over AND-clauses, every clause and term visited (uniform trip counts); an empty complex filter matches nothing (:263-291)
+    m = false;
+    uint32_t idx = 0u;
+    const uint32_t oc = F.or_count;
+    for (uint32_t o = 0u; o < oc; ++o) {
+      const uint32_t n = F.and_counts[o];
+      bool all = true;
+      for (uint32_t a = 0u; a < n; ++a) all = fast_term(F, ee_lds, F.fterm[idx + a], L, reg, wx, wy, wz, crystal_id) && all;
+      idx += n;
+      m = m || all;
+    }
+  }
+  return (F.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+}
+
+HD uint64_t fast_color_bits(const FastTables& F, const uint32_t* ee_lds, uint64_t carried, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {  // ApplyLayerColorBits cu:498-527
+  uint64_t m = carried;
+  const uint32_t n = F.color_terms;
+  for (uint32_t k = 0u; k < n; ++k) {
+    const uint32_t bit = F.cterm[k].bit;
+    if (bit < 64u && fast_term(F, ee_lds, F.cterm[k], L, reg, wx, wy, wz, crystal_id)) m |= 1ull << bit;
+  }
+  return m;
+}
+
+HD void fan_lanes_fast(const DispatchParams& P, const FastTables& F, uint64_t mask, uint32_t pix, float y_val) {  // FanColorClassLanes cu:535-556
+  const uint32_t n = F.class_cnt;
+  for (uint32_t k = 0u; k < n; ++k) {
+    const uint64_t bits = F.class_bits[k];
+    if (bits == 0ull) continue;
+    const uint64_t matched = mask & bits;
+    const bool ok = F.class_all[k] ? (matched == bits) : (matched != 0ull);
+    if (ok) atomic_add_f32(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, y_val);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused kernel.  MODE: 0 = production; 1 = + emit-gate filter, 4 = + filter and raypath colour — both in their fast form
+// (path in a 128-bit register, FastTables), built like the production kernels: exit queue, hit log, regular-prism search;
+// 2 = + exit capture (tests), 3 = the generic filter / colour kernels (paths up to 64 faces, symmetry reduction on the device)
 // ------------------------------------------------------------------------------------------------
 // Per-face view of the fan-triangle table of a dispatch's ONE shape (deterministic crystals), built by the workgroup when it
 // stages the shape: the entry pick then walks the faces (8 for a prism) and only the triangles of the face it lands in,
@@ -909,7 +1002,13 @@ struct LdsTables {
   FaceIndex fidx;
   __attribute__((aligned(16))) EntryFastDev efast;   // staged only when P.entry_fast != nullptr (full prism, one shape per dispatch)
 };
-constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2;
+constexpr int kModePlain = 0, kModeFilter = 1, kModeCapture = 2, kModeGeneric = 3, kModeColor = 4;
+template <int MODE>
+struct ModeTraits {
+  static constexpr bool kFast = MODE == kModePlain || MODE == kModeFilter || MODE == kModeColor;   // production-shaped kernels
+  static constexpr bool kFastPath = MODE == kModeFilter || MODE == kModeColor;                      // ... that keep a path register
+  static constexpr bool kTables = MODE == kModeCapture || MODE == kModeGeneric;                     // FilterDev / ColorDev in LDS, device-side reduction
+};
 template <bool ON>
 struct FilterSlot {
   FilterDev f;
@@ -994,13 +1093,14 @@ template <int MODE, bool MONO, bool SMALLC>
 HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
   const ProjDev& pj = P.proj;
-  Hits h = project_exit(pj, wx, wy, wz, MODE == kModePlain ? cache.lens : -1, MODE == kModePlain ? cache.vis : -1);
+  Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px0);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
-    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
+    if (ModeTraits<MODE>::kTables && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
+    if constexpr (MODE == kModeColor) fan_lanes_fast(P, *cache.fast, cmask, pix, cmf_y * w);
     sums.landed += w;  // bump_landed: primary hit only (scatter_accum.hpp:96-108)
     sums.pix_n++;
     primary = static_cast<int>(pix);
@@ -1008,7 +1108,8 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
   if (h.count == 2 && h.px1 >= 0 && h.px1 < pj.img_w && h.py1 >= 0 && h.py1 < pj.img_h) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px1);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
-    if (MODE != kModePlain && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
+    if (ModeTraits<MODE>::kTables && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
+    if constexpr (MODE == kModeColor) fan_lanes_fast(P, *cache.fast, cmask, pix, cmf_y * w);
     sums.pix_n++;
   }
   PROBE_MARK(pr, kPhAccum);
@@ -1030,7 +1131,7 @@ HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens =
 
 // Pop exits off the wave's queue, one per active lane and round, until fewer than 64 are left (`all`: until it is empty).
 // Called where every lane that took part in the pushes is active (their counts agree).
-template <bool MONO, bool SMALLC>
+template <int MODE, bool MONO, bool SMALLC>
 HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, RaySums& sums, bool all, Probe& pr) {
   ExitQueue& Q = *cache.q;
   const uint64_t m = __ballot(1);
@@ -1042,11 +1143,13 @@ HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, 
       const uint32_t i = qn - 1u - k;
       const uint32_t wl = Q.wl[i];
       float cx = 0.0f, cy = 0.0f, cz = 0.0f;
-      if (!MONO) {   // X/Y/Z planes: the popping lane is not the ray's, so the CMF row comes from the pool (<= 8 KB, cache-resident)
+      if (!MONO || MODE == kModeColor) {   // X/Y/Z planes (and the colour lanes' Y): the popping lane is not the ray's, so the CMF row comes from the pool (<= 8 KB, cache-resident)
         const WlEntryDev e = P.wl_pool[wl];
         cx = e.cmf_x, cy = e.cmf_y, cz = e.cmf_z;
       }
-      land_exit<kModePlain, MONO, SMALLC>(P, cache, nullptr, 0ull, Q.x[i], Q.y[i], Q.z[i], Q.w[i], cx, cy, cz, wl, sums, pr);
+      uint64_t cm = 0ull;
+      if constexpr (MODE == kModeColor) cm = static_cast<uint64_t>(cache.qm->lo[i]) | (static_cast<uint64_t>(cache.qm->hi[i]) << 32);
+      land_exit<MODE, MONO, SMALLC>(P, cache, nullptr, cm, Q.x[i], Q.y[i], Q.z[i], Q.w[i], cx, cy, cz, wl, sums, pr);
     }
     qn -= min(na, qn);
   }
@@ -1058,27 +1161,47 @@ HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, 
 template <int MODE, bool MONO, bool SMALLC>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, bool live,
                   float lx, float ly, float lz, float w, float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const PathView& pv, RaySums& sums, Probe& pr) {
+                  const PathView& pv, uint32_t uni_len, RaySums& sums, Probe& pr) {
   // `live`: this lane has an outgoing candidate.  Kernels with an exit queue call this with every lane of the interaction loop
   // (the push is a wave-wide step); the others branch around it here.
-  const bool queued = MODE == kModePlain && cache.q != nullptr;
+  const bool queued = ModeTraits<MODE>::kFast && cache.q != nullptr;
   if (!queued && !live) return;
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
   float wx = R[0] * lx + R[1] * ly + R[2] * lz;
   float wy = R[3] * lx + R[4] * ly + R[5] * lz;
   float wz = R[6] * lx + R[7] * ly + R[8] * lz;
   // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
-  if (MODE != kModePlain && filter != nullptr) {
+  if (ModeTraits<MODE>::kTables && filter != nullptr) {
     if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
   }
   uint64_t cmask = carried;
-  if (MODE != kModePlain && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
+  if (ModeTraits<MODE>::kTables && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
+  if constexpr (ModeTraits<MODE>::kFastPath) {
+    // every lane of this interaction has recorded uni_len faces — except a stray (one fewer): evaluated by a second call that the
+    // wave takes only when it holds one
+    const FastTables& F = *cache.fast;
+    const uint64_t odd = __ballot(live && pv.len != uni_len);
+    bool ok = true;
+    if (F.has_filter) ok = fast_filter(F, cache.fast_ee, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
+    if (MODE == kModeColor) cmask = fast_color_bits(F, cache.fast_ee, carried, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
+    if (odd != 0ull) {
+      bool ok2 = true;
+      if (F.has_filter) ok2 = fast_filter(F, cache.fast_ee, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
+      uint64_t cm2 = carried;
+      if (MODE == kModeColor) cm2 = fast_color_bits(F, cache.fast_ee, carried, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
+      const bool is_odd = pv.len != uni_len;
+      ok = is_odd ? ok2 : ok;
+      cmask = is_odd ? cm2 : cmask;
+    }
+    live = live && ok;
+    if (!queued && !live) return;
+  }
   // prob gate (CollectData simulator.cpp:719): one draw per outgoing candidate; u in [0,1) so prob<=0 never
   // passes and prob>=1 always does — the draw is skipped there without changing any outcome.
   bool pass = false;
-  if (!(MODE == kModePlain && cache.nogate) && live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
+  if (!(ModeTraits<MODE>::kFast && cache.nogate) && live && P.prob > 0.0f) pass = (P.prob >= 1.0f) ? true : (uniform(gate) < P.prob);
   if (pass) {
-    if (!(MODE == kModePlain && cache.last) && !P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
+    if (!(ModeTraits<MODE>::kFast && cache.last) && !P.final_layer) {  // "continue" with no next layer is dropped (simulator.cpp:719-722)
       // wave64 ballot compaction: one atomic per wave per emit site, lanes take consecutive slots
       const uint64_t mask = __ballot(1);
       const uint32_t lane = __lane_id();
@@ -1096,7 +1219,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
         P.cont_out[2u * st + slot] = wz;
         P.cont_out[3u * st + slot] = w;
         reinterpret_cast<uint32_t*>(P.cont_out)[4u * st + slot] = wl_idx;
-        if (MODE != kModePlain && color != nullptr) {  // the mask rides with the continuation (cu:922,1129)
+        if (MODE == kModeColor || (ModeTraits<MODE>::kTables && color != nullptr)) {  // the mask rides with the continuation (cu:922,1129)
           reinterpret_cast<uint32_t*>(P.cont_out)[5u * st + slot] = static_cast<uint32_t>(cmask);
           reinterpret_cast<uint32_t*>(P.cont_out)[6u * st + slot] = static_cast<uint32_t>(cmask >> 32);
         }
@@ -1105,7 +1228,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     if (!queued) return;
   }
   PROBE_MARK(pr, kPhEmitGate);
-  if (MODE == kModePlain && cache.none) return;   // (never reached with an exit in hand: prob >= 1 passed it on above)
+  if (ModeTraits<MODE>::kFast && cache.none) return;   // (never reached with an exit in hand: prob >= 1 passed it on above)
   if (queued) {
     if (P.prob >= 1.0f) return;   // dispatch-uniform: every candidate of this layer continues, nothing goes to the image
     const bool out = live && !pass;
@@ -1121,9 +1244,13 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
       Q.z[i] = wz;
       Q.w[i] = w;
       Q.wl[i] = wl_idx;
+      if constexpr (MODE == kModeColor) {
+        cache.qm->lo[i] = static_cast<uint32_t>(cmask);
+        cache.qm->hi[i] = static_cast<uint32_t>(cmask >> 32);
+      }
     }
     sums.qn += static_cast<uint32_t>(__popcll(m));
-    if (sums.qn >= 64u) drain_exits<MONO, SMALLC>(P, cache, sums, false, pr);
+    if (sums.qn >= 64u) drain_exits<MODE, MONO, SMALLC>(P, cache, sums, false, pr);
     return;
   }
   const int primary = land_exit<MODE, MONO, SMALLC>(P, cache, color, cmask, wx, wy, wz, w, cmf_x, cmf_y, cmf_z, wl_idx, sums, pr);
@@ -1407,7 +1534,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
     w = P.cont_in[3u * st + src];
     wl_idx = reinterpret_cast<const uint32_t*>(P.cont_in)[4u * st + src];
-    if (MODE != kModePlain && color != nullptr)
+    if (MODE == kModeColor || (ModeTraits<MODE>::kTables && color != nullptr))
       carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[5u * st + src]) |
                 (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[6u * st + src]) << 32);
     float lon, lat, roll;
@@ -1446,7 +1573,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   const float n_idx = wle.n_idx;
   const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
 
-  uint8_t path[MODE != kModePlain ? kFilterPathCap : 1];
+  uint8_t path[ModeTraits<MODE>::kTables ? kFilterPathCap : 1];
   PathView pv = {path, 0u, {0ull, 0ull}};
   if (MODE != kModePlain) {
     pv.reg.lo = sh->face_number[face];
@@ -1460,7 +1587,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     hex_d_basal = T.efast.hex_d_basal;
     hex_d_side = T.efast.hex_d_side;
   }
-  const bool queued = MODE == kModePlain && acc.q != nullptr;
+  const bool queued = ModeTraits<MODE>::kFast && acc.q != nullptr;
   if (queued) sums.qn = acc.q->n;   // parked there between passes (ExitQueue)
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
@@ -1491,7 +1618,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const bool live = !done && (stray || has_exit);
     emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, live, stray ? d[0] : (entering ? rlx : rfx), stray ? d[1] : (entering ? rly : rfy),
                                   stray ? d[2] : (entering ? rlz : rfz), stray ? w : (entering ? w_refl : w_refr), cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid,
-                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, sums, pr);
+                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, i + 1u, sums, pr);
     PROBE_MARK(pr, kPhEmitGate);
     done = done || stray;
     if (i + 1u == P.max_hits) break;
@@ -1572,11 +1699,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       face = hit;
       if (MODE != kModePlain) {
         const uint8_t fn = sh->face_number[face];
-        if (pv.len < 16u) {
+        if (ModeTraits<MODE>::kFastPath || pv.len < 16u) {   // (the fast kernels serve max_hits <= 16)
           pv.reg = pk_shl8(pv.reg);
           pv.reg.lo |= fn;
         } else if (pv.len < kFilterPathCap) {
-          path[pv.len] = fn;
+          if constexpr (ModeTraits<MODE>::kTables) path[pv.len] = fn;
         }
         pv.len++;
       }
@@ -1648,10 +1775,11 @@ HD float wave_sum(float v) {
 // types (uniform branches, and the SGPRs their parameters hold), the visibility tests and the gate stream fold away: configs[1]
 // 2.96 -> 2.73 (lens) -> 2.60 ms per launch.  Done for the last-layer one-shape scalar kernels and the lenses of the shipped examples.
 template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1, int VIS = -1, bool NOGATE = false>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
-__global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : HALO_MIN_WAVES) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : (MODE == kModePlain ? HALO_MIN_WAVES : 4)) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
-  static_assert(!LOG || MODE == kModePlain, "the hit log is a production-mode route");
-  static_assert(!NONE || (MODE == kModePlain && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
+  static_assert(!LOG || ModeTraits<MODE>::kFast, "the hit log is a production-mode route");
+  static_assert(!NONE || (ModeTraits<MODE>::kFast && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
+  static_assert(MODE == kModePlain || (LENS < 0 && VIS < 0 && !NOGATE), "lens / visible-range / closed-gate specialisations exist for the plain kernels only");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
@@ -1662,13 +1790,24 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
   constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
-  constexpr bool QUEUE = MODE == kModePlain && ACC != kAccBin && ACC != kAccNone && (GEOM == kGeomOne || GEOM == kGeomOneHex);
+  constexpr bool QUEUE = ModeTraits<MODE>::kFast && ACC != kAccBin && ACC != kAccNone && (GEOM == kGeomOne || GEOM == kGeomOneHex);
   __shared__ __attribute__((aligned(16))) ExitQueues<QUEUE> s_queue;
+  __shared__ __attribute__((aligned(16))) ExitQueueMasks<QUEUE && MODE == kModeColor> s_queue_mask;
+  __shared__ uint32_t s_fast_ee[ModeTraits<MODE>::kFastPath ? kFastEeLds * 32u : 1u];
   AccCtx<MONO, SMALLC> acc;
   acc.q = nullptr;
+  acc.qm = nullptr;
+  acc.fast = nullptr;
+  acc.fast_ee = nullptr;
   if constexpr (QUEUE) {
     acc.q = &s_queue.q[threadIdx.x >> 6];
     if ((threadIdx.x & 63u) == 0u) acc.q->n = 0u;
+    if constexpr (MODE == kModeColor) acc.qm = &s_queue_mask.q[threadIdx.x >> 6];
+  }
+  if constexpr (ModeTraits<MODE>::kFastPath) {
+    acc.fast = P.fast;
+    acc.fast_ee = s_fast_ee;
+    for (uint32_t i = threadIdx.x; i < kFastEeLds * 32u; i += kBlock) s_fast_ee[i] = P.fast->ee[i >> 5][i & 31u];
   }
   acc.none = NONE;
   acc.last = LAST;
@@ -1687,22 +1826,22 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
     acc.hits = &s_hits.b;
     if (threadIdx.x == 0) s_hits.b.n = 0u;
   }
-  __shared__ __attribute__((aligned(16))) FilterSlot<MODE != kModePlain> s_filter;
+  __shared__ __attribute__((aligned(16))) FilterSlot<ModeTraits<MODE>::kTables> s_filter;
   constexpr bool POOL = GEOM != kGeomOne && GEOM != kGeomOneHex;
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, ShapeDev, 1> s_shape;  // deterministic: the dispatch's one shape
-  __shared__ __attribute__((aligned(16))) ColorSlot<MODE != kModePlain> s_color;
+  __shared__ __attribute__((aligned(16))) ColorSlot<ModeTraits<MODE>::kTables> s_color;
   const ColorDev* color = nullptr;
-  if (MODE != kModePlain && P.color != nullptr) {
+  if (ModeTraits<MODE>::kTables && P.color != nullptr) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.color);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_color);
     for (uint32_t i = threadIdx.x; i < sizeof(ColorDev) / 4u; i += kBlock) dst[i] = src[i];
     color = reinterpret_cast<const ColorDev*>(&s_color);
   }
   const FilterDev* filter = nullptr;
-  if (MODE != kModePlain && P.filter != nullptr) {
+  if (ModeTraits<MODE>::kTables && P.filter != nullptr) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.filter);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&s_filter);
     for (uint32_t i = threadIdx.x; i < sizeof(FilterDev) / 4u; i += kBlock) dst[i] = src[i];
@@ -1814,7 +1953,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == 0 ? (((ACC != kAccDirect && A
   }
   if constexpr (QUEUE) {   // what the last passes left on the wave's exit queue
     sums.qn = acc.q->n;
-    drain_exits<MONO, SMALLC>(P, acc, sums, true, pr);
+    drain_exits<MODE, MONO, SMALLC>(P, acc, sums, true, pr);
   }
   if constexpr (BIN) {
     __syncthreads();
@@ -1899,17 +2038,18 @@ static void launch_lens(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
 
 template <int MODE, int GEOM>
 static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream, bool mono) {
-  if constexpr (MODE == kModePlain && (GEOM == kGeomOne || GEOM == kGeomOneHex)) {
+  if constexpr (ModeTraits<MODE>::kFast && (GEOM == kGeomOne || GEOM == kGeomOneHex)) {
     if (P.no_land != 0u) {   // every exit of this layer continues: no cache, no queue, no accumulation code
       hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccNone>), grid, block, 0, stream, P);
       return;
     }
   }
-  if constexpr (MODE == kModePlain) {   // the hit log exists for the production mode: scalar planes, or X/Y/Z planes of an illuminant session
+  if constexpr (ModeTraits<MODE>::kFast) {   // the hit log exists for the production-shaped kernels: scalar planes, or X/Y/Z planes of an illuminant session
     if (P.bin_log != 0u) {
       if constexpr (GEOM == kGeomOne || GEOM == kGeomOneHex) {
         if (mono && P.final_layer != 0u) {   // the last layer's one-shape scalar kernels carry no continuation-append code
-          launch_lens<MODE, GEOM, true, kAccLogFinal>(P, grid, block, stream);
+          if constexpr (MODE == kModePlain) launch_lens<MODE, GEOM, true, kAccLogFinal>(P, grid, block, stream);
+          else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLogFinal>), grid, block, 0, stream, P);
           return;
         }
       }
@@ -1917,9 +2057,13 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
       else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) {
         // illuminant sessions over sampled crystals: a full-sky render with a closed gate (bench_config_stoch.json's shape) knows both at
         // compile time (configs[4] 5.52 -> 5.43 ms per step; its lens as a constant gains nothing more: 4.31 vs 4.32 ms per launch)
-        if (P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL)
-          hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog, -1, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
+        if constexpr (MODE == kModePlain) {
+          if (P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL) {
+            hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog, -1, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       } else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog>), grid, block, 0, stream, P);
       return;
     }
@@ -1937,7 +2081,7 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
 template <int MODE>
 static hipError_t launch_mode(const DispatchParams& P, int blocks, hipStream_t stream, int geom, bool mono) {
   dim3 grid(blocks), block(kBlock);
-  if constexpr (MODE == kModePlain) {
+  if constexpr (ModeTraits<MODE>::kFast) {
     if (geom == kGeomOneHex && (P.bin_list == nullptr || P.bin_log != 0u || P.no_land != 0u)) {
       launch_mono<MODE, kGeomOneHex>(P, grid, block, stream, mono);
       return hipGetLastError();

@@ -1,4 +1,4 @@
-// halo_trace_m1.hip — the kModeFilter instantiations of halo_trace_kernel (see halo_trace.inl).
+// halo_trace_m1.hip — the kModeFilter instantiations of halo_trace_kernel (see halo_trace.inl): emit-gate filter in its fast form.
 #include "halo_trace.inl"
 
 namespace halo {

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 3   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
-                                halo_drain_exits, option "shuffle_chunk", exit records carry full 64-face paths */
+#define HALO_ABI_VERSION 4   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
+                                halo_drain_exits, option "shuffle_chunk", exit records carry full 64-face paths; 4: HaloRouteInfo
+                                names the kernel mode (5 modes) and its specialisation, option "filter_fast" */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 
@@ -331,13 +332,18 @@ int halo_last_sample_counts(halo_handle_t h, uint64_t* crystal_samples, uint64_t
  * a test that means to check the production binned shape-pool kernel asserts that it really ran. */
 typedef struct HaloRouteInfo {
   uint32_t launches;     /* trace-kernel launches since halo_begin */
-  uint32_t mode_mask;    /* bit m: a launch ran the MODE m instantiation (0 production, 1 + path/filter/colour, 2 + exit capture) */
+  uint32_t mode_mask;    /* bit m: a launch ran the MODE m instantiation: 0 production; 1 production + emit-gate filter, 4 production + filter and
+                            raypath colour (both for max_hits <= 16: path in a register, predicates as host-built member tables); 2 + exit capture
+                            (tests); 3 the generic filter / colour kernels (paths to 64 faces, or tables that do not fit the fast form) */
   uint32_t geom_mask;    /* bit g: GEOM g (0 one shape per dispatch, 1 pool of 4.1 KB records, 2 pool of prism records, 3 one shape = regular hexagonal prism) */
   uint32_t accum_mask;   /* bit 0 direct X/Y/Z planes, 1 direct scalar plane(s), 2 binned one level, 3 binned two levels, 4 hit log, 5 hit log of an illuminant session (X, Y, Z made in the per-tile pass), 6 none (a layer whose every exit continues) */
   uint32_t source_mask;  /* bit 0 generated roots, 1 continuation pool (layer >= 1), 2 host-injected rays */
   uint32_t plane_cnt;    /* accumulation planes of the session (1 discrete, 3 X/Y/Z, M per-entry) */
   uint32_t plane_copies; /* privatised copies of each plane */
   uint32_t shuffle_chunk;/* pool entries that move together through Recombine's shuffle */
+  uint32_t spec_mask;    /* specialised instantiations that ran — bit 0: last-layer kernel (no continuation-append code), 1: lens as a compile-time
+                            constant, 2: visible range as a constant, 3: closed gate (prob <= 0) as a constant */
+  uint32_t generic_launches; /* launches that ran an instantiation with none of those specialisations */
 } HaloRouteInfo;
 int halo_last_route(halo_handle_t h, HaloRouteInfo* out);
 int halo_sync(halo_handle_t h);
@@ -409,6 +415,12 @@ int halo_host_build_proj_params(const HaloRender* render, void* proj_params_76_b
 int halo_host_partition(const float* proportions, int n, uint64_t ray_num, double* carry, uint64_t* out_counts);
 /* Crystal::ReduceRaypath(rp, symmetry, sigma_a, d_applicable) — crystal.cpp:536-600 (hexagonal families, fn_period 6). */
 int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int32_t sigma_a, int32_t d_applicable, uint8_t* out);
+/* The emit-gate filter predicate as the production filter kernels evaluate it — DeviceFilterCheck, shared/filter_shared.h:308-315, on the
+ * host-built member tables (csrc/halo_device.h FastTables; max_hits <= 16): filter `f` for a crystal with orientation `axis`, asked about an
+ * exit with face-number path `path[0..n)` (n <= 16), world direction `dir` and crystal id `crystal_id`.  Writes 1 / 0 to *pass.  HALO_FATAL
+ * when the filter does not fit the fast form (the backend then runs the generic kernels).  A host-side test hook: the tests compare it with
+ * the reduction-based predicate (halo_host_reduce_raypath) over every short face sequence. */
+int halo_host_filter_fast_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int32_t n, const float dir[3], int32_t crystal_id, int32_t* pass);
 /* IceRefractiveIndex::Get — optics.cpp:180-197. */
 double halo_host_refractive_index(double wavelength_nm);
 /* GetIlluminantSpd(type, wavelength) — util/illuminant.cpp:113-134 (HALO_ILLUM_*; 0 outside the tabulated range). */
@@ -451,7 +463,7 @@ HALO_STATIC_ASSERT(sizeof(HaloWl) == 16, "HaloWl");
 HALO_STATIC_ASSERT(sizeof(HaloHostRays) == 4 * sizeof(void*), "HaloHostRays");
 HALO_STATIC_ASSERT(sizeof(HaloLayerStats) == 56, "HaloLayerStats");
 HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 40 + HALO_PATH_CAP, "HaloExitRecord");
-HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 32, "HaloRouteInfo");
+HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 40, "HaloRouteInfo");
 HALO_STATIC_ASSERT(sizeof(HaloDisplay) == 28, "HaloDisplay");
 HALO_STATIC_ASSERT(sizeof(HaloGeomTables) == 4 + HALO_MAX_FACES * 20 + 4 + HALO_MAX_TRIS * (36 + 12 + 4 + 4), "HaloGeomTables");
 #endif /* HALO_TRACE_H_ */
