@@ -1315,6 +1315,15 @@ struct HoBackend {
   double carry[HALO_MAX_LAYERS][HALO_MAX_ENTRIES];
   /* accumulator */
   float* xyz;
+  /* option "acc64" (not the reference's arithmetic — a checker's precaution, off by default): pixel hits are summed in double, first in a
+   * small per-thread pixel cache, then in xyz64 / lanes64, and reach the float image at readback.  The reference adds every hit into a
+   * float image (accum_shared.h:56-62), which stops being exact once a pixel is large: a 6 Mi-ray session on a 512x256 image already
+   * reads 0.12 % high in sum(Y) against landed weight x cmf_y — rounding noise of the accumulator, not of the algorithm, and larger than
+   * the 3e-3 image tolerance of the production-size parity tests.  The per-thread caches also take the hot pixels off the shared image
+   * (the contended omp atomics were what kept the all-cores CPU baseline from scaling). */
+  int acc64;
+  double* xyz64;
+  double* lanes64;
   int acc_w, acc_h;
   double landed;
   /* continuation pool: 5 floats per ray (d, w, wl_idx) */
@@ -1341,6 +1350,8 @@ struct HoBackend {
   uint64_t exit_n, exit_cap;
 };
 
+static void materialise_acc64(HoBackend* b);
+
 HoBackend* ho_create(uint32_t seed) {
   HoBackend* b = (HoBackend*)calloc(1, sizeof(HoBackend));
   b->seed = seed;
@@ -1351,6 +1362,8 @@ HoBackend* ho_create(uint32_t seed) {
 void ho_destroy(HoBackend* b) {
   if (!b) return;
   free(b->xyz);
+  free(b->xyz64);
+  free(b->lanes64);
   free(b->cont);
   free(b->cont_in);
   free(b->exits);
@@ -1365,6 +1378,7 @@ int ho_set_option(HoBackend* b, const char* key, int64_t v) {
   if (!strcmp(key, "capture_exits")) b->capture = (int)v;
   else if (!strcmp(key, "geom_clock")) b->geom_clock = (int)(v > 0 ? v : 32);
   else if (!strcmp(key, "threads")) b->threads = (int)(v > 0 ? v : 1);
+  else if (!strcmp(key, "acc64")) b->acc64 = v ? 1 : 0;
   else if (!strcmp(key, "rank")) {
     uint64_t base = (uint64_t)v << 40; /* disjoint 64-bit counter ranges per shard */
     b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
@@ -1421,6 +1435,7 @@ int ho_set_color(HoBackend* b, const HaloColorSet* sets, int32_t n_sets, const H
 /* TraceBackend::ReadbackClassLanes trace_backend.hpp:471-493: copy + zero */
 int ho_readback_class_lanes(HoBackend* b, float* lanes, int width, int height, int class_count) {
   if (class_count != b->color_class_count || width != b->lanes_w || height != b->lanes_h || !b->lanes) return HALO_FATAL;
+  materialise_acc64(b);
   size_t n = (size_t)class_count * width * height;
   memcpy(lanes, b->lanes, n * sizeof(float));
   memset(b->lanes, 0, n * sizeof(float));
@@ -1440,6 +1455,8 @@ int ho_begin(HoBackend* b, const HaloScene* scene, const HaloRender* render, con
     b->acc_w = render->width;
     b->acc_h = render->height;
     b->xyz = (float*)calloc((size_t)b->acc_w * b->acc_h * 3, sizeof(float));
+    free(b->xyz64);
+    b->xyz64 = NULL;
     b->landed = 0.0;
   }
   if (b->color_class_count > 0 && (!b->lanes || b->lanes_w != render->width || b->lanes_h != render->height)) {
@@ -1447,6 +1464,8 @@ int ho_begin(HoBackend* b, const HaloScene* scene, const HaloRender* render, con
     b->lanes_w = render->width;
     b->lanes_h = render->height;
     b->lanes = (float*)calloc((size_t)b->color_class_count * b->lanes_w * b->lanes_h, sizeof(float));
+    free(b->lanes64);
+    b->lanes64 = NULL;
   }
   b->in_session = 1;
   b->layer_idx = 0;
@@ -1490,13 +1509,53 @@ typedef struct {
   const HaloColorSet* color; /* NULL = this entry sets no colour bits */
 } HoCiCtx;
 
+#define HO_PC_LOG2 13
+typedef struct { /* option "acc64": one thread's pixel cache, direct-mapped; pix < 0 = free */
+  int64_t pix[1 << HO_PC_LOG2];
+  double v[1 << HO_PC_LOG2][3];
+} HoPixCache;
+
 typedef struct { /* per-thread output sink */
   HoBackend* b;
+  HoPixCache* pc; /* NULL = add into the float image directly (the reference's arithmetic) */
   double landed;
   double exit_w_sum;
   uint64_t exit_count;
   uint64_t pixel_hits;
 } HoSink;
+
+static void pixcache_flush_slot(HoBackend* b, HoPixCache* pc, uint32_t slot) {
+  double* dst = b->xyz64 + (size_t)pc->pix[slot] * 3;
+  for (int k = 0; k < 3; k++) {
+    double v = pc->v[slot][k];
+    pc->v[slot][k] = 0.0;
+    if (v != 0.0) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+      dst[k] += v;
+    }
+  }
+  pc->pix[slot] = -1;
+}
+
+/* option "acc64": what the double accumulators hold goes into the float image (called by every reader of b->xyz / b->lanes) */
+static void materialise_acc64(HoBackend* b) {
+  if (b->xyz64) {
+    size_t n = (size_t)b->acc_w * b->acc_h * 3;
+    for (size_t i = 0; i < n; i++) {
+      b->xyz[i] = (float)((double)b->xyz[i] + b->xyz64[i]);
+      b->xyz64[i] = 0.0;
+    }
+  }
+  if (b->lanes64 && b->lanes) {
+    size_t n = (size_t)b->color_class_count * b->lanes_w * b->lanes_h;
+    for (size_t i = 0; i < n; i++) {
+      b->lanes[i] = (float)((double)b->lanes[i] + b->lanes64[i]);
+      b->lanes64[i] = 0.0;
+    }
+  }
+}
 
 static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const float exit_world[3], float w, uint64_t cmask, int32_t* primary_pix) {
   /* EmitToDeviceXyz cuda_trace_backend.cu:433-480 == ScatterOutgoingToXyz scatter_accum.hpp:47-110 */
@@ -1508,6 +1567,17 @@ static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const f
       size_t pix = (size_t)py * (size_t)b->proj.img_w + (size_t)px;
       float* dst = b->xyz + pix * 3; /* AccumXyzToPixel accum_shared.h:56-62 */
       float a0 = wle->cmf[0] * w, a1 = wle->cmf[1] * w, a2 = wle->cmf[2] * w;
+      if (sink->pc) {
+        HoPixCache* pc = sink->pc;
+        uint32_t slot = ((uint32_t)pix * 2654435761u) >> (32 - HO_PC_LOG2);
+        if (pc->pix[slot] != (int64_t)pix) {
+          if (pc->pix[slot] >= 0) pixcache_flush_slot(b, pc, slot);
+          pc->pix[slot] = (int64_t)pix;
+        }
+        pc->v[slot][0] += (double)a0;
+        pc->v[slot][1] += (double)a1;
+        pc->v[slot][2] += (double)a2;
+      } else {
 #ifdef _OPENMP
 #pragma omp atomic
       dst[0] += a0;
@@ -1520,6 +1590,7 @@ static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const f
       dst[1] += a1;
       dst[2] += a2;
 #endif
+      }
       /* FanColorClassLanes cu:535-556: primary AND overlap hits feed every class the mask satisfies */
       for (int k = 0; k < b->color_class_count; k++) {
         uint64_t bits = b->color_classes[k].bits;
@@ -1529,10 +1600,18 @@ static void emit_pixel(HoBackend* b, HoSink* sink, const HoWlEntry* wle, const f
         if (ok) {
           float* lane = b->lanes + (size_t)k * (size_t)b->proj.img_w * (size_t)b->proj.img_h + pix;
           float yv = wle->cmf[1] * w;
+          if (sink->pc) {
+            double* l64 = b->lanes64 + (size_t)k * (size_t)b->proj.img_w * (size_t)b->proj.img_h + pix;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+            *l64 += (double)yv;
+          } else {
 #ifdef _OPENMP
 #pragma omp atomic
 #endif
           *lane += yv;
+          }
         }
       }
       sink->pixel_hits++;
@@ -1840,6 +1919,8 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     for (int ci = 0; ci < L->entry_count; ci++) per_ci[ci] = 0;
     per_ci[0] = n;
   }
+  if (b->acc64 && !b->xyz64) b->xyz64 = (double*)calloc((size_t)b->acc_w * b->acc_h * 3, sizeof(double));
+  if (b->acc64 && b->lanes && !b->lanes64) b->lanes64 = (double*)calloc((size_t)b->color_class_count * b->lanes_w * b->lanes_h, sizeof(double));
   HoSink total;
   memset(&total, 0, sizeof(total));
   uint64_t ci_start = 0;
@@ -1901,10 +1982,22 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
       HoSink sink;
       memset(&sink, 0, sizeof(sink));
       sink.b = b;
+      if (b->acc64) {
+        sink.pc = (HoPixCache*)malloc(sizeof(HoPixCache));
+        for (int k = 0; k < (1 << HO_PC_LOG2); k++) {
+          sink.pc->pix[k] = -1;
+          sink.pc->v[k][0] = sink.pc->v[k][1] = sink.pc->v[k][2] = 0.0;
+        }
+      }
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 4096)
 #endif
       for (int64_t t = 0; t < (int64_t)n_ci; t++) run_ray(c, &sink, (uint32_t)t);
+      if (sink.pc) {
+        for (uint32_t k = 0; k < (1u << HO_PC_LOG2); k++)
+          if (sink.pc->pix[k] >= 0) pixcache_flush_slot(b, sink.pc, k);
+        free(sink.pc);
+      }
 #ifdef _OPENMP
 #pragma omp critical
 #endif
@@ -1970,6 +2063,7 @@ int ho_drain_exits(HoBackend* b, HaloExitRecord* out, uint64_t cap, uint64_t* co
 
 int ho_readback_xyz64(HoBackend* b, float* xyz, int width, int height, double* landed) {
   if (!b->xyz || width != b->acc_w || height != b->acc_h) return HALO_FATAL;
+  materialise_acc64(b);
   size_t n = (size_t)width * height * 3;
   memcpy(xyz, b->xyz, n * sizeof(float));
   memset(b->xyz, 0, n * sizeof(float));
@@ -2022,6 +2116,7 @@ float ho_linear_to_srgb(float linear) { /* color_space.cpp:51-56 */
 
 int ho_consumer_fold(HoBackend* b) { /* ConsumeDeviceFused render.cpp:138-149 */
   if (!b->xyz) return HALO_FATAL;
+  materialise_acc64(b);
   size_t n = (size_t)b->acc_w * b->acc_h * 3;
   if (!b->cons_sum || b->cons_w != b->acc_w || b->cons_h != b->acc_h) {
     free(b->cons_sum);
