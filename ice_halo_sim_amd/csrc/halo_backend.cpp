@@ -744,7 +744,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         b->fast_scratch.reset(new FastTables());
         std::memset(b->fast_scratch.get(), 0, sizeof(FastTables));
         const HaloColorSet* cs = (use_color && E.color_id > 0) ? &b->color_sets[static_cast<size_t>(E.color_id - 1)] : nullptr;
-        if (host::BuildFastTables(use_filter ? &b->filters[static_cast<size_t>(E.filter_id - 1)] : nullptr, cs, E.axis, *b->fast_scratch)) {
+        if (host::BuildFastTables(use_filter ? &b->filters[static_cast<size_t>(E.filter_id - 1)] : nullptr, cs, E.axis, static_cast<uint32_t>(E.crystal_config_id), *b->fast_scratch)) {
           fast_host = b->fast_scratch.get();
           fast_host->class_cnt = use_color ? cd.class_cnt : 0u;
           for (uint32_t c = 0; c < fast_host->class_cnt; c++) {
@@ -977,7 +977,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         uint32_t spec = 0u;
         if (fast_mode && use_log && one && !ran_none && b->mono_session && P.final_layer) {
           spec |= 1u;
-          if (mode == 0 && P.prob <= 0.0f && lens_known && vis_known) spec |= 2u | 4u | 8u;
+          if ((mode == 0 || mode == 1) && P.prob <= 0.0f && lens_known && vis_known) spec |= 2u | 4u | 8u;
         }
         if (mode == 0 && use_log && !one && !b->mono_session && P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL) spec |= 4u | 8u;
         b->route.spec_mask |= spec;
@@ -1333,16 +1333,18 @@ int halo_host_filter_fast_check(const HaloFilter* f, const HaloAxis* axis, const
   struct Cache {
     HaloFilter f;
     HaloAxis axis;
+    int32_t crystal_id = 0;
     bool valid = false, fits = false;
     FastTables tables;
   };
   static thread_local std::unique_ptr<Cache> cache;
   if (!cache) cache.reset(new Cache());
-  if (!cache->valid || std::memcmp(&cache->f, f, sizeof(HaloFilter)) != 0 || std::memcmp(&cache->axis, axis, sizeof(HaloAxis)) != 0) {
+  if (!cache->valid || std::memcmp(&cache->f, f, sizeof(HaloFilter)) != 0 || std::memcmp(&cache->axis, axis, sizeof(HaloAxis)) != 0 || cache->crystal_id != crystal_id) {
     std::memset(&cache->tables, 0, sizeof(FastTables));
     cache->f = *f;
     cache->axis = *axis;
-    cache->fits = host::BuildFastTables(f, nullptr, *axis, cache->tables);
+    cache->crystal_id = crystal_id;
+    cache->fits = host::BuildFastTables(f, nullptr, *axis, static_cast<uint32_t>(crystal_id), cache->tables);
     cache->valid = true;
   }
   if (!cache->fits) return HALO_FATAL;

@@ -155,29 +155,32 @@ struct ColorDev {
 // reduction IS the canonical form — the reference's predicate, including the cases where its reduction is not a perfect orbit
 // invariant) and the kernel compares the packed path with them; an entry/exit term becomes a 32 x 32 bit matrix over face numbers
 // (row = entry face, bit = exit face).  All of it is dispatch-uniform and read with scalar loads.
-constexpr int kFastOrbitCap = 768;   // 128-bit members over all raypath terms of a dispatch (filter + colour predicates)
+constexpr int kFastOrbitCap = 1024;  // members over all raypath terms of a dispatch (filter + colour predicates), each term's list padded to a multiple of 8
 constexpr int kFastEeCap = 24;       // entry/exit matrices
-struct FastTerm {
-  uint32_t type;            // HALO_FILTER_*
-  uint32_t len;             // raypath: length of the canonical sequence
-  uint32_t min_len, max_len;
-  uint32_t orbit_off, orbit_n;   // raypath: members in FastTables::orbit
-  uint32_t ee_off;          // entry/exit: matrix in FastTables::ee
+struct FastTerm {           // 8 dwords, read with ONE scalar load (s_load_dwordx8)
+  uint32_t w0;              // type (HALO_FILTER_*) | last << 8 | bit << 16 | len << 24
+                            //   last: 1 = last term of its AND-clause (the clause walk is one flat loop over the terms); bit: colour predicates, the
+                            //   mask bit this predicate sets; len: raypath, length of the canonical sequence (255 = longer than any path here)
+  uint32_t w1;              // min_len | max_len << 8 (entry/exit; 0 = unbounded above, 255 = beyond any path here) | orbit_n << 16
+  uint32_t w2;              // orbit_off | ee_off << 16 — raypath: members in FastTables::orbit_lo / orbit_hi (orbit_n a multiple of 8, padded
+                            //   with ~0); entry/exit: matrix in FastTables::ee, 0xFFFF = neither face constrained
   uint32_t crystal_id;
   float dir[3], radii_c;
-  uint32_t bit;             // colour predicates: the mask bit this predicate sets
-  uint32_t pad[3];
 };
-static_assert(sizeof(FastTerm) == 64, "read with scalar loads");
+static_assert(sizeof(FastTerm) == 32, "read with one s_load_dwordx8");
 struct FastTables {
-  uint32_t has_filter, is_complex, action, or_count;
-  uint32_t color_terms, class_cnt, pad0, pad1;
-  uint8_t and_counts[HALO_FILTER_MAX_OR];
+  // What the filter says about an exit whose path has L faces, two bits per L (bits 2L, 2L+1), folded on the host from everything that
+  // is known before the launch — the lengths the path terms can match at all, the dispatch's crystal id: 0 = every such exit fails,
+  // 1 = every such exit passes, 2 = evaluate the terms.  (A raypath filter costs nothing at the lengths it cannot match, an all-pass
+  // or all-fail filter nothing at all.)
+  uint64_t len_mode;
+  uint32_t has_filter, action, term_cnt, color_terms, class_cnt, pad0;
   uint64_t class_bits[HALO_COLOR_MAX_CLASSES];
   uint32_t class_all[HALO_COLOR_MAX_CLASSES];
-  FastTerm fterm[HALO_FILTER_MAX_TERMS];
+  FastTerm fterm[HALO_FILTER_MAX_TERMS + HALO_FILTER_MAX_OR];   // (+ one pass-all term per empty AND-clause)
   FastTerm cterm[HALO_COLOR_MAX_TERMS];
-  uint64_t orbit[kFastOrbitCap][2];   // {hi, lo}, the path register's layout: newest face in the low byte of lo
+  uint64_t orbit_lo[kFastOrbitCap];   // the path register's layout: newest face in the low byte of lo
+  uint64_t orbit_hi[kFastOrbitCap];
   uint32_t ee[kFastEeCap][32];
 };
 

@@ -287,34 +287,59 @@ std::vector<std::array<uint64_t, 2>> RaypathMembers(const std::vector<uint8_t>& 
   return out;
 }
 
-bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, FastTables& out) {
+namespace {
+struct FastTermView {   // the packed fields of a FastTerm (halo_device.h)
+  uint32_t type, last, bit, len, min_len, max_len, orbit_n, orbit_off, ee_off;
+};
+FastTermView ViewTerm(const FastTerm& t) {
+  return {t.w0 & 0xFFu, (t.w0 >> 8) & 0xFFu, (t.w0 >> 16) & 0xFFu, t.w0 >> 24, t.w1 & 0xFFu, (t.w1 >> 8) & 0xFFu, t.w1 >> 16, t.w2 & 0xFFFFu, t.w2 >> 16};
+}
+void PackTerm(const FastTermView& v, FastTerm& t) {
+  t.w0 = (v.type & 0xFFu) | ((v.last & 0xFFu) << 8) | ((v.bit & 0xFFu) << 16) | ((v.len & 0xFFu) << 24);
+  t.w1 = (v.min_len & 0xFFu) | ((v.max_len & 0xFFu) << 8) | (v.orbit_n << 16);
+  t.w2 = (v.orbit_off & 0xFFFFu) | (v.ee_off << 16);
+}
+}  // namespace
+
+bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, uint32_t crystal_id, FastTables& out) {
   const bool dap = IsDApplicable(axis);
   const int sigma_a = dap ? ComputeSigmaA(axis.roll.center) : 0;
   uint32_t orbit_used = 0, ee_used = 0;
   bool fits = true;
-  auto fill = [&](const HaloFilterTerm& t, uint8_t symmetry, FastTerm& o) {
-    o = FastTerm{};
+  auto fill = [&](const HaloFilterTerm& t, uint8_t symmetry, uint32_t last, uint32_t bit, FastTerm& out_term) {
+    out_term = FastTerm{};
+    FastTermView o{};
     o.type = static_cast<uint32_t>(t.type);
+    o.last = last;
+    o.bit = bit;
+    o.ee_off = 0xFFFFu;
+    struct Packer {   // writes the packed words on every way out of the lambda
+      FastTermView& v;
+      FastTerm& t;
+      ~Packer() { PackTerm(v, t); }
+    } packer{o, out_term};
     if (t.type == HALO_FILTER_RAYPATH) {
       std::vector<uint8_t> rp;
       for (int i = 0; i < t.raypath_len && i < kFilterPathCap; i++) rp.push_back(t.raypath[i]);
       const std::vector<uint8_t> canon = ReduceRaypath(rp, symmetry, sigma_a, dap);
-      o.len = static_cast<uint32_t>(canon.size());
+      o.len = static_cast<uint32_t>(std::min<size_t>(canon.size(), 255));
       const auto members = RaypathMembers(canon, symmetry, sigma_a, dap);
-      if (orbit_used + members.size() > static_cast<size_t>(kFastOrbitCap)) {
+      const size_t padded = (members.size() + 7u) & ~size_t(7);   // the kernel compares eight members per scalar load; ~0 is no path
+      if (orbit_used + padded > static_cast<size_t>(kFastOrbitCap)) {
         fits = false;
         return;
       }
       o.orbit_off = orbit_used;
-      o.orbit_n = static_cast<uint32_t>(members.size());
-      for (const auto& m : members) {
-        out.orbit[orbit_used][0] = m[0];
-        out.orbit[orbit_used][1] = m[1];
+      o.orbit_n = static_cast<uint32_t>(padded);
+      for (size_t k = 0; k < padded; k++) {
+        out.orbit_hi[orbit_used] = k < members.size() ? members[k][0] : ~0ull;
+        out.orbit_lo[orbit_used] = k < members.size() ? members[k][1] : ~0ull;
         orbit_used++;
       }
     } else if (t.type == HALO_FILTER_ENTRY_EXIT) {  // DeviceFilterMatchSimple filter_shared.h:180-224 as a matrix over (entry face, exit face)
-      o.min_len = t.min_len;
-      o.max_len = t.max_len;
+      o.min_len = std::min<uint32_t>(t.min_len, 255u);                       // (paths here have at most 16 faces)
+      o.max_len = t.max_len == 0u ? 0u : std::min<uint32_t>(t.max_len, 255u);
+      if (!t.has_entry && !t.has_exit) return;   // no face constraint (ee_off 0xFFFF): the length bounds are the whole term
       if (ee_used >= static_cast<uint32_t>(kFastEeCap)) {
         fits = false;
         return;
@@ -330,45 +355,72 @@ bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const
           std::vector<uint8_t> q;
           if (t.has_entry) q.push_back(static_cast<uint8_t>(e));
           if (t.has_exit) q.push_back(static_cast<uint8_t>(x));
-          if (q.empty() || ReduceRaypath(q, symmetry, sigma_a, dap) == canon) row |= 1u << x;
+          if (ReduceRaypath(q, symmetry, sigma_a, dap) == canon) row |= 1u << x;
         }
         out.ee[ee_used][e] = row;
       }
       ee_used++;
     } else if (t.type == HALO_FILTER_DIRECTION) {  // FillDirection device_filter_desc.cpp:57-65
       const float lon = t.az * kDegToRad, lat = t.el * kDegToRad;
-      o.dir[0] = std::cos(lat) * std::cos(lon);
-      o.dir[1] = std::cos(lat) * std::sin(lon);
-      o.dir[2] = std::sin(lat);
-      o.radii_c = std::cos(t.radii * kDegToRad);
+      out_term.dir[0] = std::cos(lat) * std::cos(lon);
+      out_term.dir[1] = std::cos(lat) * std::sin(lon);
+      out_term.dir[2] = std::sin(lat);
+      out_term.radii_c = std::cos(t.radii * kDegToRad);
     } else if (t.type == HALO_FILTER_CRYSTAL) {
-      o.crystal_id = static_cast<uint32_t>(t.crystal_id);
+      out_term.crystal_id = static_cast<uint32_t>(t.crystal_id);
     }
   };
-  out.has_filter = 0;
-  out.is_complex = out.action = out.or_count = 0;
-  out.color_terms = 0;
+  out.has_filter = out.action = out.term_cnt = out.color_terms = 0;
+  out.len_mode = 0x5555555555555555ull;   // no filter: every length passes
   if (filter != nullptr) {
     const uint8_t sym = static_cast<uint8_t>(filter->symmetry & 7);
     out.has_filter = 1;
-    out.is_complex = filter->is_complex ? 1u : 0u;
     out.action = filter->action ? 1u : 0u;
+    uint32_t k = 0;
     if (!filter->is_complex) {
-      fill(filter->terms[0], sym, out.fterm[0]);
-    } else {
-      out.or_count = static_cast<uint32_t>(std::min(filter->or_count, HALO_FILTER_MAX_OR));
-      int k = 0;
-      for (uint32_t o = 0; o < out.or_count; o++) {
-        out.and_counts[o] = static_cast<uint8_t>(filter->and_counts[o]);
-        for (int a = 0; a < filter->and_counts[o] && k < HALO_FILTER_MAX_TERMS; a++, k++) fill(filter->terms[k], sym, out.fterm[k]);
+      fill(filter->terms[0], sym, 1u, 0u, out.fterm[k++]);
+    } else {  // OR over AND-clauses as one flat list; an AND-clause without terms is true (filter_shared.h:263-291) = one pass-all term
+      const int oc = std::min(filter->or_count, HALO_FILTER_MAX_OR);
+      int src = 0;
+      for (int o = 0; o < oc; o++) {
+        const int n = filter->and_counts[o];
+        if (n <= 0) {
+          HaloFilterTerm none{};
+          none.type = HALO_FILTER_NONE;
+          fill(none, sym, 1u, 0u, out.fterm[k++]);
+        }
+        for (int a = 0; a < n && src < HALO_FILTER_MAX_TERMS; a++, src++) fill(filter->terms[src], sym, (a == n - 1) ? 1u : 0u, 0u, out.fterm[k++]);
       }
+    }
+    out.term_cnt = k;
+    out.len_mode = 0;
+    // fold what is known before the launch, per path length: 0 false, 1 true, 2 depends on the exit
+    for (uint32_t L = 0; L <= 16; L++) {
+      int m = 0, all = 1;   // OR accumulator (false), AND accumulator (true)
+      for (uint32_t i = 0; i < k; i++) {
+        const FastTermView t = ViewTerm(out.fterm[i]);
+        int v = 2;
+        if (t.type == HALO_FILTER_NONE) v = 1;
+        else if (t.type == HALO_FILTER_RAYPATH) v = (L != t.len || t.orbit_n == 0) ? 0 : 2;
+        else if (t.type == HALO_FILTER_ENTRY_EXIT) {
+          if (L == 0 || L < t.min_len || (t.max_len != 0 && L > t.max_len)) v = 0;
+          else v = t.ee_off == 0xFFFFu ? 1 : 2;
+        } else if (t.type == HALO_FILTER_CRYSTAL) v = crystal_id == out.fterm[i].crystal_id ? 1 : 0;
+        else if (t.type != HALO_FILTER_DIRECTION) v = 0;   // unknown type: never matches
+        all = (all == 0 || v == 0) ? 0 : ((all == 1 && v == 1) ? 1 : 2);
+        if (t.last) {
+          m = (m == 1 || all == 1) ? 1 : ((m == 0 && all == 0) ? 0 : 2);
+          all = 1;
+        }
+      }
+      if (m != 2 && out.action) m = 1 - m;
+      out.len_mode |= static_cast<uint64_t>(m) << (2 * L);
     }
   }
   if (colors != nullptr) {
     out.color_terms = static_cast<uint32_t>(std::min(colors->term_count, HALO_COLOR_MAX_TERMS));
     for (uint32_t k = 0; k < out.color_terms; k++) {
-      fill(colors->terms[k].predicate, static_cast<uint8_t>(colors->terms[k].symmetry & 7), out.cterm[k]);
-      out.cterm[k].bit = static_cast<uint32_t>(colors->terms[k].bit & 0xFF);
+      fill(colors->terms[k].predicate, static_cast<uint8_t>(colors->terms[k].symmetry & 7), 0u, static_cast<uint32_t>(colors->terms[k].bit & 0xFF), out.cterm[k]);
     }
   }
   return fits;
@@ -380,36 +432,35 @@ bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t L, const
     hi = (hi << 8) | (lo >> 56);
     lo = (lo << 8) | path[i];
   }
-  auto term = [&](const FastTerm& t) {
+  const uint32_t lm = static_cast<uint32_t>(F.len_mode >> (2 * L)) & 3u;
+  if (lm != 2u) return lm == 1u;
+  auto term = [&](const FastTerm& raw) {
+    const FastTermView t = ViewTerm(raw);
     if (t.type == HALO_FILTER_NONE) return true;
     if (t.type == HALO_FILTER_RAYPATH) {
       if (L != t.len) return false;
       for (uint32_t k = 0; k < t.orbit_n; k++)
-        if (lo == F.orbit[t.orbit_off + k][1] && (L <= 8u || hi == F.orbit[t.orbit_off + k][0])) return true;
+        if (lo == F.orbit_lo[t.orbit_off + k] && (L <= 8u || hi == F.orbit_hi[t.orbit_off + k])) return true;
       return false;
     }
     if (t.type == HALO_FILTER_ENTRY_EXIT) {
       if (L == 0u || L < t.min_len) return false;
       if (t.max_len != 0u && L > t.max_len) return false;
+      if (t.ee_off == 0xFFFFu) return true;
       const uint32_t sh = 8u * (L - 1u);
       const uint32_t first = static_cast<uint32_t>((sh < 64u ? lo >> sh : hi >> (sh - 64u)) & 0xFFull), last = static_cast<uint32_t>(lo & 0xFFull);
       return first < 32u && last < 32u && ((F.ee[t.ee_off][first & 31u] >> last) & 1u) != 0u;
     }
-    if (t.type == HALO_FILTER_DIRECTION) return t.dir[0] * dir[0] + t.dir[1] * dir[1] + t.dir[2] * dir[2] > t.radii_c;
-    if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;
+    if (t.type == HALO_FILTER_DIRECTION) return raw.dir[0] * dir[0] + raw.dir[1] * dir[1] + raw.dir[2] * dir[2] > raw.radii_c;
+    if (t.type == HALO_FILTER_CRYSTAL) return crystal_id == raw.crystal_id;
     return false;
   };
-  bool m;
-  if (!F.is_complex) {
-    m = term(F.fterm[0]);
-  } else {
-    m = false;
-    uint32_t idx = 0;
-    for (uint32_t o = 0; o < F.or_count; o++) {
-      bool all = true;
-      for (uint32_t a = 0; a < F.and_counts[o]; a++) all = term(F.fterm[idx + a]) && all;
-      idx += F.and_counts[o];
+  bool m = false, all = true;
+  for (uint32_t k = 0; k < F.term_cnt; k++) {
+    all = term(F.fterm[k]) && all;
+    if (ViewTerm(F.fterm[k]).last) {
       m = m || all;
+      all = true;
     }
   }
   return F.action == 0u ? m : !m;
@@ -455,6 +506,7 @@ bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out) {
     bool reg = true;
     for (int k = 0; k < 4 && reg; k++) reg = s.slab[k][0] == want[k][0] && s.slab[k][1] == want[k][1] && s.slab[k][2] == want[k][2] && s.slab[k][3] == s.slab[k][4];
     for (int k = 2; k < 4 && reg; k++) reg = s.slab[k][3] == s.slab[1][3];
+    for (int f = 0; f < kEntryFastFaces && reg; f++) reg = s.face_number[f] == f + 1;   // the path recorder of the filter kernels counts on it
     out.hex_regular = reg ? 1u : 0u;
     out.hex_d_basal = s.slab[0][3];
     out.hex_d_side = s.slab[1][3];

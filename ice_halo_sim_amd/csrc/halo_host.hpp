@@ -47,8 +47,9 @@ FilterDev BuildFilter(const HaloFilter& f, const HaloAxis& axis);
 std::vector<uint8_t> ReduceRaypath(const std::vector<uint8_t>& rp, uint8_t symmetry, int sigma_a, bool d_applicable);
 // Fast form of a filter (nullptr = none) and of a crystal entry's colour predicates for the kernels that hold the path in a
 // 128-bit register (halo_device.h FastTables).  false = it does not fit (member / matrix pools full): the caller takes the
-// generic kernels.  `out` must be zero-initialised by the caller only for the class table, which this function leaves alone.
-bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, FastTables& out);
+// generic kernels.  `crystal_id`: the dispatch's crystal (crystal terms are constants of the dispatch and fold into len_mode).  The class table
+// of `out` is the caller's.
+bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const HaloAxis& axis, uint32_t crystal_id, FastTables& out);
 // The members of a raypath term: every sequence whose reduction equals `canon` (packed {hi, lo}, newest face in the low byte).
 std::vector<std::array<uint64_t, 2>> RaypathMembers(const std::vector<uint8_t>& canon, uint8_t symmetry, int sigma_a, bool d_applicable);
 // The fast tables evaluated on the host, step for step like halo_trace.inl fast_filter (test hook).

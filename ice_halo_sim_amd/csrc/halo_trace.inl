@@ -514,7 +514,7 @@ struct AccCtx {
   bool none;         // kAccNone kernels: every outgoing candidate continues (prob >= 1, not the last layer), nothing is projected
   ExitQueue* q;      // this wave's exit queue; nullptr = project and accumulate at the emit site
   ExitQueueMask* qm; // ... its colour-mask planes (kModeColor)
-  const FastTables* fast;   // kModeFilter / kModeColor: the dispatch's filter + colour predicates (dispatch-uniform, scalar loads)
+  const FastTables __attribute__((address_space(4)))* fast;   // kModeFilter / kModeColor: the dispatch's filter + colour predicates (dispatch-uniform, scalar loads)
   const uint32_t* fast_ee;  // ... the first kFastEeLds entry/exit matrices, staged in LDS
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
@@ -911,64 +911,126 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
 // per-lane work is one 64-bit compare per member, one table word per entry/exit term, three FMAs per direction term.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kFastEeLds = 8u;   // entry/exit matrices staged in LDS (1 KB); a dispatch with more reads the rest from HBM
-HD bool fast_term(const FastTables& F, const uint32_t* ee_lds, const FastTerm& t, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
-  const uint32_t type = t.type;
+// The tables are read through the CONSTANT address space: a plain global pointer makes every one of these dispatch-uniform reads a
+// vector load + v_readfirstlane behind a full memory wait — the kernel stores to global memory, so the compiler cannot prove the
+// tables unclobbered (measured: the all-pass crystal-id filter at 1.37x the plain kernel) — while constant-space loads are scalar
+// (s_load through the scalar cache), invariant and hoistable.  The tables are written by the dispatch's H2D copy, before the launch.
+typedef const FastTables __attribute__((address_space(4))) FastTablesC;
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint64_t u64x8 __attribute__((ext_vector_type(8)));
+typedef uint64_t u64x4 __attribute__((ext_vector_type(4)));
+struct FastTermS {   // one term in scalar registers: ONE s_load_dwordx8 (field packing: halo_device.h FastTerm)
+  u32x8 r;
+  HD uint32_t type() const { return r[0] & 0xFFu; }
+  HD uint32_t last() const { return (r[0] >> 8) & 0xFFu; }
+  HD uint32_t bit() const { return (r[0] >> 16) & 0xFFu; }
+  HD uint32_t len() const { return r[0] >> 24; }
+  HD uint32_t min_len() const { return r[1] & 0xFFu; }
+  HD uint32_t max_len() const { return (r[1] >> 8) & 0xFFu; }
+  HD uint32_t orbit_n() const { return r[1] >> 16; }
+  HD uint32_t orbit_off() const { return r[2] & 0xFFFFu; }
+  HD uint32_t ee_off() const { return r[2] >> 16; }
+  HD uint32_t crystal_id() const { return r[3]; }
+  HD float dir(int k) const { return __uint_as_float(r[4 + k]); }
+  HD float radii_c() const { return __uint_as_float(r[7]); }
+};
+static_assert(offsetof(FastTerm, crystal_id) == 12 && offsetof(FastTerm, dir) == 16 && offsetof(FastTerm, radii_c) == 28, "FastTermS mirrors FastTerm");
+HD FastTermS load_term(const FastTerm __attribute__((address_space(4)))* t) {
+  FastTermS o;
+  o.r = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(t);
+  return o;
+}
+
+HD bool fast_term(FastTablesC& F, const uint32_t* ee_lds, const FastTermS& t, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
+  const uint32_t type = t.type();
   if (type == HALO_FILTER_NONE) return true;
   if (type == HALO_FILTER_RAYPATH) {  // DeviceFilterMatchSimple :156-178
-    if (L != t.len) return false;
-    const uint32_t n = t.orbit_n, off = t.orbit_off;
+    if (L != t.len()) return false;
+    const uint32_t n = t.orbit_n(), off = t.orbit_off();
     bool m = false;
-    if (L <= 8u) {
-      for (uint32_t k = 0u; k < n; ++k) m = m || (reg.lo == F.orbit[off + k][1]);
+    if (L <= 8u) {   // eight members per scalar load (lists are padded to a multiple of eight with ~0)
+      for (uint32_t k = 0u; k < n; k += 8u) {
+        const u64x8 v = *reinterpret_cast<const u64x8 __attribute__((address_space(4)))*>(&F.orbit_lo[off + k]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = m || (reg.lo == v[j]);
+      }
     } else {
-      for (uint32_t k = 0u; k < n; ++k) m = m || (reg.lo == F.orbit[off + k][1] && reg.hi == F.orbit[off + k][0]);
+      for (uint32_t k = 0u; k < n; k += 4u) {
+        const u64x4 lo = *reinterpret_cast<const u64x4 __attribute__((address_space(4)))*>(&F.orbit_lo[off + k]);
+        const u64x4 hi = *reinterpret_cast<const u64x4 __attribute__((address_space(4)))*>(&F.orbit_hi[off + k]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) m = m || (reg.lo == lo[j] && reg.hi == hi[j]);
+      }
     }
     return m;
   }
   if (type == HALO_FILTER_ENTRY_EXIT) {  // :180-224
-    if (L == 0u || L < t.min_len) return false;
-    if (t.max_len != 0u && L > t.max_len) return false;
+    if (L == 0u || L < t.min_len()) return false;
+    if (t.max_len() != 0u && L > t.max_len()) return false;
+    const uint32_t eo = t.ee_off();
+    if (eo == 0xFFFFu) return true;   // neither face constrained
     const uint32_t sh = 8u * (L - 1u);   // scalar
     const uint32_t first = static_cast<uint32_t>((sh < 64u ? reg.lo >> sh : reg.hi >> (sh - 64u)) & 0xFFull);
     const uint32_t last = static_cast<uint32_t>(reg.lo & 0xFFull);
-    const uint32_t row = t.ee_off < kFastEeLds ? ee_lds[t.ee_off * 32u + (first & 31u)] : F.ee[t.ee_off][first & 31u];
+    const uint32_t row = eo < kFastEeLds ? ee_lds[eo * 32u + (first & 31u)] : F.ee[eo][first & 31u];
     return first < 32u && last < 32u && ((row >> last) & 1u) != 0u;
   }
-  if (type == HALO_FILTER_DIRECTION) return t.dir[0] * wx + t.dir[1] * wy + t.dir[2] * wz > t.radii_c;  // :226-229
-  if (type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id;                                    // :231-233
+  if (type == HALO_FILTER_DIRECTION) return t.dir(0) * wx + t.dir(1) * wy + t.dir(2) * wz > t.radii_c();  // :226-229
+  if (type == HALO_FILTER_CRYSTAL) return crystal_id == t.crystal_id();                                      // :231-233
   return false;
 }
 
-HD bool fast_filter(const FastTables& F, const uint32_t* ee_lds, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
-  bool m;
-  if (!F.is_complex) {
-    m = fast_term(F, ee_lds, F.fterm[0], L, reg, wx, wy, wz, crystal_id);
-  } else {  // OR over AND-clauses, every clause and term visited (uniform trip counts); an empty complex filter matches nothing (:263-291)
-    m = false;
-    uint32_t idx = 0u;
-    const uint32_t oc = F.or_count;
-    for (uint32_t o = 0u; o < oc; ++o) {
-      const uint32_t n = F.and_counts[o];
-      bool all = true;
-      for (uint32_t a = 0u; a < n; ++a) all = fast_term(F, ee_lds, F.fterm[idx + a], L, reg, wx, wy, wz, crystal_id) && all;
-      idx += n;
-      m = m || all;
-    }
-  }
-  return (F.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+// The filter's header and its first term: four scalar loads issued together at the emit site, one wait.  Measured alternatives, 10 M rays,
+// plain kernel 0.70 ms — all-pass crystal filter / one-term direction filter / 3-clause complex filter: this form 0.785 / 0.839 / 0.981 ms;
+// read once per ray pass and held across the interaction loop 0.811 / 0.863 / 1.027 (13 more live scalar registers: spills); requested at
+// the top of every interaction, ahead of the Fresnel block, with len_mode once per kernel 0.806 / 0.856 / 1.016; field by field where the
+// walk needs them (a scalar-cache round trip each) 0.823 / 0.828 / 1.263; as vector loads through a plain global pointer 0.970 / 0.980 / 1.594.
+struct FastHdr {
+  uint64_t len_mode;
+  uint32_t term_cnt, action;
+  FastTermS t0;
+};
+HD FastHdr load_fast_hdr(FastTablesC& F) {
+  FastHdr h;
+  h.len_mode = F.len_mode;
+  h.term_cnt = F.term_cnt;
+  h.action = F.action;
+  h.t0 = load_term(&F.fterm[0]);
+  return h;
 }
 
-HD uint64_t fast_color_bits(const FastTables& F, const uint32_t* ee_lds, uint64_t carried, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {  // ApplyLayerColorBits cu:498-527
+// `lm`: what the host already knows about exits of this length (FastTables::len_mode): 0 all fail, 1 all pass, 2 ask the terms
+HD bool fast_filter(FastTablesC& F, const uint32_t* ee_lds, const FastHdr& H, uint32_t lm, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
+  if (lm != 2u) return lm == 1u;
+  // OR over AND-clauses as one flat walk (FastTerm::last closes a clause); every term visited: uniform trip count (:263-291)
+  const uint32_t n = H.term_cnt;
+  if (n == 0u) return H.action != 0u;   // an empty complex filter matches nothing
+  bool all = fast_term(F, ee_lds, H.t0, L, reg, wx, wy, wz, crystal_id);
+  bool m = H.t0.last() ? all : false;
+  all = H.t0.last() ? true : all;
+  for (uint32_t k = 1u; k < n; ++k) {
+    const FastTermS t = load_term(&F.fterm[k]);
+    all = fast_term(F, ee_lds, t, L, reg, wx, wy, wz, crystal_id) && all;
+    if (t.last()) {
+      m = m || all;
+      all = true;
+    }
+  }
+  return (H.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+}
+
+HD uint64_t fast_color_bits(FastTablesC& F, const uint32_t* ee_lds, uint64_t carried, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {  // ApplyLayerColorBits cu:498-527
   uint64_t m = carried;
   const uint32_t n = F.color_terms;
   for (uint32_t k = 0u; k < n; ++k) {
-    const uint32_t bit = F.cterm[k].bit;
-    if (bit < 64u && fast_term(F, ee_lds, F.cterm[k], L, reg, wx, wy, wz, crystal_id)) m |= 1ull << bit;
+    const FastTermS t = load_term(&F.cterm[k]);
+    const uint32_t bit = t.bit();
+    if (bit < 64u && fast_term(F, ee_lds, t, L, reg, wx, wy, wz, crystal_id)) m |= 1ull << bit;
   }
   return m;
 }
 
-HD void fan_lanes_fast(const DispatchParams& P, const FastTables& F, uint64_t mask, uint32_t pix, float y_val) {  // FanColorClassLanes cu:535-556
+HD void fan_lanes_fast(const DispatchParams& P, FastTablesC& F, uint64_t mask, uint32_t pix, float y_val) {  // FanColorClassLanes cu:535-556
   const uint32_t n = F.class_cnt;
   for (uint32_t k = 0u; k < n; ++k) {
     const uint64_t bits = F.class_bits[k];
@@ -1161,7 +1223,7 @@ HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, 
 template <int MODE, bool MONO, bool SMALLC>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, bool live,
                   float lx, float ly, float lz, float w, float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const PathView& pv, uint32_t uni_len, RaySums& sums, Probe& pr) {
+                  const PathView& pv, uint32_t uni_len, bool odd_lane, RaySums& sums, Probe& pr) {
   // `live`: this lane has an outgoing candidate.  Kernels with an exit queue call this with every lane of the interaction loop
   // (the push is a wave-wide step); the others branch around it here.
   const bool queued = ModeTraits<MODE>::kFast && cache.q != nullptr;
@@ -1179,19 +1241,18 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   if constexpr (ModeTraits<MODE>::kFastPath) {
     // every lane of this interaction has recorded uni_len faces — except a stray (one fewer): evaluated by a second call that the
     // wave takes only when it holds one
-    const FastTables& F = *cache.fast;
-    const uint64_t odd = __ballot(live && pv.len != uni_len);
-    bool ok = true;
-    if (F.has_filter) ok = fast_filter(F, cache.fast_ee, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
+    FastTablesC& F = *cache.fast;
+    const FastHdr fh = load_fast_hdr(F);
+    const uint64_t odd = __ballot(live && odd_lane);
+    const uint64_t len_mode = fh.len_mode;   // (has_filter = 0 comes as "every length passes")
+    bool ok = fast_filter(F, cache.fast_ee, fh, static_cast<uint32_t>(len_mode >> (2u * uni_len)) & 3u, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
     if (MODE == kModeColor) cmask = fast_color_bits(F, cache.fast_ee, carried, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
     if (odd != 0ull) {
-      bool ok2 = true;
-      if (F.has_filter) ok2 = fast_filter(F, cache.fast_ee, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
+      const bool ok2 = fast_filter(F, cache.fast_ee, fh, static_cast<uint32_t>(len_mode >> (2u * (uni_len - 1u))) & 3u, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
       uint64_t cm2 = carried;
       if (MODE == kModeColor) cm2 = fast_color_bits(F, cache.fast_ee, carried, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
-      const bool is_odd = pv.len != uni_len;
-      ok = is_odd ? ok2 : ok;
-      cmask = is_odd ? cm2 : cmask;
+      ok = odd_lane ? ok2 : ok;
+      cmask = odd_lane ? cm2 : cmask;
     }
     live = live && ok;
     if (!queued && !live) return;
@@ -1576,7 +1637,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   uint8_t path[ModeTraits<MODE>::kTables ? kFilterPathCap : 1];
   PathView pv = {path, 0u, {0ull, 0ull}};
   if (MODE != kModePlain) {
-    pv.reg.lo = sh->face_number[face];
+    pv.reg.lo = (HEX && ModeTraits<MODE>::kFastPath) ? static_cast<uint32_t>(face) + 1u : sh->face_number[face];
     pv.len = 1u;
   }
 
@@ -1618,7 +1679,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const bool live = !done && (stray || has_exit);
     emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, live, stray ? d[0] : (entering ? rlx : rfx), stray ? d[1] : (entering ? rly : rfy),
                                   stray ? d[2] : (entering ? rlz : rfz), stray ? w : (entering ? w_refl : w_refr), cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid,
-                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, i + 1u, sums, pr);
+                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, i + 1u, stray, sums, pr);
     PROBE_MARK(pr, kPhEmitGate);
     done = done || stray;
     if (i + 1u == P.max_hits) break;
@@ -1697,13 +1758,17 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       p[1] += t_best * d[1];
       p[2] += t_best * d[2];
       face = hit;
-      if (MODE != kModePlain) {
+      if constexpr (ModeTraits<MODE>::kFastPath) {   // (max_hits <= 16: the register holds every path; its length is the loop counter)
+        const uint32_t fn = HEX ? static_cast<uint32_t>(face) + 1u : sh->face_number[face];   // regular prism: numbers 1..8 in face order (BuildEntryFast checks)
+        pv.reg = pk_shl8(pv.reg);
+        pv.reg.lo |= fn;
+      } else if (MODE != kModePlain) {
         const uint8_t fn = sh->face_number[face];
-        if (ModeTraits<MODE>::kFastPath || pv.len < 16u) {   // (the fast kernels serve max_hits <= 16)
+        if (pv.len < 16u) {
           pv.reg = pk_shl8(pv.reg);
           pv.reg.lo |= fn;
         } else if (pv.len < kFilterPathCap) {
-          if constexpr (ModeTraits<MODE>::kTables) path[pv.len] = fn;
+          path[pv.len] = fn;
         }
         pv.len++;
       }
@@ -1779,7 +1844,7 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || ModeTraits<MODE>::kFast, "the hit log is a production-mode route");
   static_assert(!NONE || (ModeTraits<MODE>::kFast && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
-  static_assert(MODE == kModePlain || (LENS < 0 && VIS < 0 && !NOGATE), "lens / visible-range / closed-gate specialisations exist for the plain kernels only");
+  static_assert(MODE == kModePlain || MODE == kModeFilter || (LENS < 0 && VIS < 0 && !NOGATE), "lens / visible-range / closed-gate specialisations exist for the plain and the filter kernels");
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
@@ -1805,7 +1870,7 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
     if constexpr (MODE == kModeColor) acc.qm = &s_queue_mask.q[threadIdx.x >> 6];
   }
   if constexpr (ModeTraits<MODE>::kFastPath) {
-    acc.fast = P.fast;
+    acc.fast = (const FastTables __attribute__((address_space(4)))*)(P.fast);
     acc.fast_ee = s_fast_ee;
     for (uint32_t i = threadIdx.x; i < kFastEeLds * 32u; i += kBlock) s_fast_ee[i] = P.fast->ee[i >> 5][i & 31u];
   }
@@ -2048,7 +2113,7 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
     if (P.bin_log != 0u) {
       if constexpr (GEOM == kGeomOne || GEOM == kGeomOneHex) {
         if (mono && P.final_layer != 0u) {   // the last layer's one-shape scalar kernels carry no continuation-append code
-          if constexpr (MODE == kModePlain) launch_lens<MODE, GEOM, true, kAccLogFinal>(P, grid, block, stream);
+          if constexpr (MODE == kModePlain || MODE == kModeFilter) launch_lens<MODE, GEOM, true, kAccLogFinal>(P, grid, block, stream);
           else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLogFinal>), grid, block, 0, stream, P);
           return;
         }
