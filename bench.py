@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — rays/s of the MI355X trace hot path on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4p] [--repeats R]
+  python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4p|ref:<name>] [--repeats R] [--scaling weak|strong]
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
 (one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch of the selected configuration:
 
@@ -13,10 +13,21 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
              gauss(1, 0.15) face distances, D65, rectangular 2048x1024 full sky, max_hits 8), D65 pool of 31 wavelengths,
              25 M rays per GPU per step (200 M over 8 GPUs)
   --config 4p the pyramidal variant of the same (examples/config_example.json crystal 5 with the same face distances)
+  --config ref:<name>  a config DOCUMENT of the reference, through the JSON reader (ice_halo_sim_amd.config), at its own resolution:
+             ref:bench_light_single_ms, ref:ms_multi_crystal, ref:ms_multi_crystal_complex_filter, ref:ms_multi_crystal_filtered_bd —
+             the reference's published GPU benchmark scenes (doc/performance-testing.md:465-468; fixture tests/golden/ref_e2e_configs.json),
+             one step = 4 sessions x 50 M root rays (>= 200 M rays per timed step, the reference's steady-state rule) — and
+             ref:config_example, examples/config_example.json as shipped (README quick start: 9 wavelengths x 50 M rays, renderer 4;
+             fixture tests/golden/ref_example_configs.json)
+
+With the default configuration on one GPU the JSON line also carries `other_configs`: short runs (1 warm-up + 3 timed steps, one
+repeat) of configs 2, 4, 4p and of the five reference documents — metric, ms/step, route and roofline of each — so that the
+driver's record holds them; the headline fields are those of configs[1] alone.
 
 Rays shard by index range (disjoint RNG counter ranges per rank, no data-path collective); every step ends with ONE RCCL
 sum-reduce of the W*H*3(+4) fp32 accumulator to rank 0 (the reference's drain point, simulator.cpp:1409-1477).  Per-GPU work
-is fixed -> "scaling": "weak".
+is fixed -> "scaling": "weak" (the default); --scaling strong fixes the TOTAL instead (configs[3]'s "400 M rays sharded across 8"
+read as a fixed job: rays per rank = rays / N).
 
 Timing follows the reference's protocol (doc/performance-testing.md:109-131: >= 5 repeats, median + CoV): after W warm-up
 steps the timed region — EXACTLY K steps between barrier + synchronize — is run R times (default 5); `value` and
@@ -44,7 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r02"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
+PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
 
 # The reference's legacy CPU path measured by the survey in the build container (compiled with shims, 6 worker
 # threads, config_example-shaped scene): the only number that relates the oracle ("port") to the real reference.
@@ -83,7 +94,44 @@ def workload(cfg):
                     wls=[scenes.wl_illuminant("D65", 31)], rays=25_000_000,
                     name="configs[4]: " + what + ", full-sphere axis, D65 pool of 31 wavelengths, %d root rays per GPU per step (200 M over 8 GPUs), max_hits 8, rectangular 2048x1024 visible full",
                     kernel=kern, metric="rays/sec (whole node), stochastic-geometry crystal, 31 wavelengths")
+    if cfg.startswith("ref:"):
+        return ref_workload(cfg[4:])
     raise SystemExit("unknown --config %r" % cfg)
+
+
+REF_SCENES = ("bench_light_single_ms", "ms_multi_crystal", "ms_multi_crystal_complex_filter", "ms_multi_crystal_filtered_bd")
+
+
+def ref_workload(name):
+    """A config document of the reference as a workload: the scene, the filters and the FIRST renderer of the document at its own
+    resolution (examples/config_example.json: renderer 4, the one the survey's configs[0] names), its light source as written."""
+    from ice_halo_sim_amd import config
+    golden = os.path.join(ROOT, "tests", "golden")
+    if name == "config_example":
+        doc = json.load(open(os.path.join(golden, "ref_example_configs.json")))[name]
+        where = "examples/config_example.json as shipped (README.md:46-48)"
+    else:
+        docs = json.load(open(os.path.join(golden, "ref_e2e_configs.json")))
+        if name not in docs:
+            raise SystemExit("unknown reference document %r" % name)
+        doc = docs[name]
+        where = "test/e2e/configs/%s.json (doc/performance-testing.md:465-468)" % name
+    job = config.load_config(doc)
+    rid = 4 if name == "config_example" else sorted(job.renders)[0]
+    rd = job.renders[rid]
+    if name == "config_example":
+        wls, rays = list(job.wavelengths), job.per_wavelength_ray_num()      # 9 x 50 M
+        what = "%d wavelengths x %%d root rays per GPU per step" % len(wls)
+    else:
+        wls, rays = list(job.wavelengths) * 4, 50_000_000                     # the document's light source, 4 sessions x 50 M
+        what = "%d sessions x %%d root rays per GPU per step (light source as written: %s)" % (len(wls), "illuminant pool" if job.wavelengths[0].illuminant >= 0 else "discrete")
+    filt = sum(1 for l in range(job.scene.layer_count) for e in range(job.scene.layers[l].entry_count) if job.scene.layers[l].entries[e].filter_id > 0)
+    return dict(scene=job.scene, render=rd, wls=wls, rays=rays, filters=job.filters,
+                colors=(job.color_sets, job.color_classes) if job.color_classes else None, geom_clock=job.geom_clock,
+                name="ref:%s — %s, renderer %d (%dx%d), %d scattering layer(s), %d filtered crystal entr%s, max_hits %d, " % (
+                    name, where, rid, rd.width, rd.height, job.scene.layer_count, filt, "y" if filt == 1 else "ies", job.scene.max_hits) + what,
+                kernel="halo_trace_kernel (instantiations by route: see config.route) + its accumulation passes",
+                metric="root rays/sec, reference document %s" % name)
 
 
 def cpu_baseline(wk, budget_s=12.0):
@@ -92,7 +140,11 @@ def cpu_baseline(wk, budget_s=12.0):
     cores = os.cpu_count() or 1
     threads = min(cores, 128)
     sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
-    ob = OracleBackend(seed=42, threads=threads)
+    ob = OracleBackend(seed=42, threads=threads, acc64=1)   # per-thread pixel caches: the shared float image's contended atomics kept the all-cores run from scaling
+    if wk.get("geom_clock"):
+        ob.set_option("geom_clock", wk["geom_clock"])
+    if wk.get("filters"):
+        ob.set_filters(wk["filters"])
     t0 = time.perf_counter()
     run_session(ob, sc, rd, wls[0], 100_000)  # calibration (also warms the LUT/page cache)
     rate = 100_000 / max(time.perf_counter() - t0, 1e-6)
@@ -157,15 +209,161 @@ def pmc_valu(cfg, rays_per_launch):
             "source": "profiles/%s_bench%s_pmc_{insts,cycles}.txt (counter means over every launch of the kernel in that pass)" % (PROFILE_ROUND, cfg)}
 
 
+def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
+    """One configuration on this rank's GPU: `warmup` untimed steps, then `repeats` timed regions of exactly `steps` steps each (barrier +
+    synchronize on both sides, MAX over ranks).  Returns the JSON object of the configuration on rank 0, None elsewhere."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    world, rank, local_rank = ctx["world"], ctx["rank"], ctx["local_rank"]
+    from ice_halo_sim_amd.dist import ShardedTracer
+
+    wk = workload(cfg)
+    sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
+    n_cfg = args.rays_per_wl or wk["rays"]
+    strong = args.scaling == "strong"
+    n = -(-n_cfg // world) if strong else n_cfg        # strong: the configuration's rays are the whole job, cut into `world` shards
+    tracer = ShardedTracer(sc, rd, seed=42, device=local_rank, rank=rank, world=world, **{"async": 1})
+    if wk.get("geom_clock"):
+        tracer.backend.set_option("geom_clock", wk["geom_clock"])
+    if wk.get("filters"):
+        tracer.backend.set_filters(wk["filters"])
+    if wk.get("colors"):
+        tracer.backend.set_color(*wk["colors"])
+    if args.blocks_per_cu > 0:
+        tracer.backend.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.aggregate >= 0:
+        tracer.backend.set_option("aggregate", args.aggregate)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        tracer.backend.set_option(k, int(v))
+    layers = sc.layer_count
+    first_layer = {"ms": 0.0, "launches": 0, "hits": 0, "cont": 0}     # non-final layers return their tallies synchronously
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        for wl in wls:
+            sts = tracer.trace_session_layers(wl, n)        # this rank's shard of the batch
+            for st in sts[:-1]:
+                first_layer["ms"] += st.kernel_ms
+                first_layer["launches"] += st.launches
+                first_layer["hits"] += st.pixel_hits
+                first_layer["cont"] += st.continuation_count
+        tracer.reduce_to_root()                              # one RCCL sum-reduce at the drain point
+
+    for _ in range(warmup):
+        step()
+    tracer.zero()
+    tracer.backend.collect_stats()                            # drop the warm-up tallies
+    for k in first_layer:
+        first_layer[k] = 0
+    times = []
+    for _ in range(max(repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()                                           # dispatches are queued; nothing waits on the host per launch
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times.append(float(t.item()))
+    st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
+    route = tracer.backend.last_route()
+    dt = statistics.median(times)
+    cov = (statistics.pstdev(times) / statistics.mean(times)) if len(times) > 1 else 0.0
+
+    reps = len(times)
+    rays_per_rank_step = len(wls) * n
+    rays_per_rank = reps * steps * rays_per_rank_step
+    launches, kernel_ms, pixel_hits, exits = int(st.launches), float(st.kernel_ms), int(st.pixel_hits), int(st.exit_count)
+    # the DEVICE's own root tally must equal the rays claimed (nothing skipped inside the timed region)
+    assert int(st.root_count) == rays_per_rank + first_layer["cont"], (int(st.root_count), rays_per_rank, first_layer["cont"])
+
+    img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
+    tracer.backend.close()
+    del tracer
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    # the dominant kernel: the last layer's launches (single-scatter: the only layer; multi-scatter: the transit-source layer)
+    dom_launches = launches - first_layer["launches"]
+    dom_ms = kernel_ms - first_layer["ms"]
+    dom_hits = pixel_hits - first_layer["hits"]
+    dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
+    avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
+    # ALGORITHMIC bytes (DESIGN.md §4): 3 ch x 4 B x (read + write) per in-frame pixel hit; a transit-source launch also
+    # reads its 20-byte continuation records (and the layer before wrote them: 20 B out + 20 B in per continuation);
+    # a shape-pool launch reads one sampled-crystal record per 32 rays (and the generator wrote it)
+    alg = dom_hits * 24.0
+    if layers > 1:
+        alg += dom_rays * 40.0
+    shape_rec = {"4": 1360.0, "4p": 4112.0}.get(cfg)
+    if shape_rec:
+        alg += dom_rays / 32.0 * shape_rec * 2.0
+    alg_per_launch = alg / max(dom_launches, 1)
+    achieved = alg_per_launch / max(avg_launch_s, 1e-12) / 1e9
+    total_rays_step = rays_per_rank_step * world
+    out = {
+        "metric": wk["metric"],
+        "value": total_rays_step * steps / dt,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt * 1e3 / steps,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": wk["name"] % n,
+                   "rays_per_step_per_gpu": rays_per_rank_step, "resolution": [rd.width, rd.height],
+                   "sharding": "root-ray index ranges, 1 RCCL reduce of %d floats per step" % (rd.width * rd.height * 3 + 4),
+                   "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed,
+                   "route": {"mode_mask": route.mode_mask, "geom_mask": route.geom_mask, "accum_mask": route.accum_mask,
+                             "source_mask": route.source_mask, "planes": route.plane_cnt, "plane_copies": route.plane_copies,
+                             "spec_mask": route.spec_mask, "generic_launches": route.generic_launches}},
+        "repeats": {"n": reps, "protocol": "reference doc/performance-testing.md:109-131 (>= 5 repeats, median + CoV); each repeat times exactly --steps steps",
+                    "median_ms_per_step": dt * 1e3 / steps, "cov": cov,
+                    "ms_per_step_all": [x * 1e3 / steps for x in times]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(cfg),
+                     "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % (PROFILE_ROUND, cfg),
+                     "kernel": wk["kernel"], "launches": dom_launches,
+                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
+                     "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
+                     "valu": pmc_valu(cfg, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
+                     "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+    }
+    if layers > 1:
+        traced = rays_per_rank + first_layer["cont"]
+        out["multi_scatter"] = {"root_rays_per_s": out["value"], "traced_rays_per_s": traced / (reps * steps) * world / (dt / steps),
+                                "continuations_per_root": first_layer["cont"] / max(rays_per_rank, 1),
+                                "first_layer_kernel_ms_per_launch": first_layer["ms"] / max(first_layer["launches"], 1),
+                                "last_layer_kernel_ms_per_launch": avg_launch_s * 1e3}
+    if with_cpu and world == 1:
+        out["cpu_baseline"] = cpu_baseline(wk)
+    return out
+
+
+OTHER_CONFIGS = ("2", "4", "4p") + tuple("ref:" + n for n in REF_SCENES) + ("ref:config_example",)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="1", choices=["1", "2", "4", "4p"])
+    ap.add_argument("--config", default="1", help="1 | 2 | 4 | 4p | ref:<document> (see the module docstring)")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (median reported)")
     ap.add_argument("--rays-per-wl", type=int, default=0, help="root rays per session per GPU per step (0 = the configuration's own)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: per-GPU work fixed; strong: the configuration's rays are the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="default configuration on one GPU: skip the short runs of the other configurations")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--aggregate", type=int, default=-1)
     ap.add_argument("--opt", action="append", default=[], help="backend option key=value (repeatable)")
@@ -193,126 +391,21 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=dist_backend)
+    ctx = {"torch": torch, "dist": dist, "world": world, "rank": rank, "local_rank": local_rank}
 
-    from ice_halo_sim_amd.dist import ShardedTracer
-
-    wk = workload(args.config)
-    sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
-    n = args.rays_per_wl or wk["rays"]
-    tracer = ShardedTracer(sc, rd, seed=42, device=local_rank, rank=rank, world=world, **{"async": 1})
-    if args.blocks_per_cu > 0:
-        tracer.backend.set_option("blocks_per_cu", args.blocks_per_cu)
-    if args.aggregate >= 0:
-        tracer.backend.set_option("aggregate", args.aggregate)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        tracer.backend.set_option(k, int(v))
-    layers = sc.layer_count
-    first_layer = {"ms": 0.0, "launches": 0, "hits": 0, "cont": 0}     # non-final layers return their tallies synchronously
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step():
-        for wl in wls:
-            sts = tracer.trace_session_layers(wl, n)        # this rank's shard of the batch
-            for st in sts[:-1]:
-                first_layer["ms"] += st.kernel_ms
-                first_layer["launches"] += st.launches
-                first_layer["hits"] += st.pixel_hits
-                first_layer["cont"] += st.continuation_count
-        tracer.reduce_to_root()                              # one RCCL sum-reduce at the drain point
-
-    for _ in range(args.warmup):
-        step()
-    tracer.zero()
-    tracer.backend.collect_stats()                            # drop the warm-up tallies
-    for k in first_layer:
-        first_layer[k] = 0
-    times = []
-    for _ in range(max(args.repeats, 1)):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()                                           # dispatches are queued; nothing waits on the host per launch
-        barrier()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        times.append(float(t.item()))
-    st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
-    route = tracer.backend.last_route()
-    dt = statistics.median(times)
-    cov = (statistics.pstdev(times) / statistics.mean(times)) if len(times) > 1 else 0.0
-
-    reps = len(times)
-    rays_per_rank_step = len(wls) * n
-    rays_per_rank = reps * args.steps * rays_per_rank_step
-    launches, kernel_ms, pixel_hits, exits = int(st.launches), float(st.kernel_ms), int(st.pixel_hits), int(st.exit_count)
-    assert int(st.root_count) == rays_per_rank + first_layer["cont"], (int(st.root_count), rays_per_rank, first_layer["cont"])
-
-    img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
+    out = measure(args.config, args, ctx, args.steps, args.warmup, args.repeats, with_cpu=not args.no_cpu_baseline)
+    if args.config == "1" and world == 1 and not args.no_others and not args.rays_per_wl:
+        others = {}
+        for cfg in OTHER_CONFIGS:
+            r = measure(cfg, args, ctx, 3, 1, 1, with_cpu=False)
+            others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+                           "workload": r["config"]["workload"], "resolution": r["config"]["resolution"], "exits_per_root": r["config"]["exits_per_root"],
+                           "route": r["config"]["route"],
+                           "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "kernel_rays_per_s")}}
+            if "multi_scatter" in r:
+                others[cfg]["multi_scatter"] = r["multi_scatter"]
+        out["other_configs"] = others
     if rank == 0:
-        # the dominant kernel: the last layer's launches (single-scatter: the only layer; multi-scatter: the transit-source layer)
-        dom_launches = launches - first_layer["launches"]
-        dom_ms = kernel_ms - first_layer["ms"]
-        dom_hits = pixel_hits - first_layer["hits"]
-        dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
-        avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
-        # ALGORITHMIC bytes: 3 ch x 4 B x (read + write) per in-frame pixel hit; a transit-source launch also
-        # reads its 20-byte continuation records (and the layer before wrote them: 20 B out + 20 B in per continuation);
-        # a shape-pool launch reads one sampled-crystal record per 32 rays (and the generator wrote it)
-        alg = dom_hits * 24.0
-        if layers > 1:
-            alg += dom_rays * 40.0
-        shape_rec = {"4": 1360.0, "4p": 4112.0}.get(args.config)
-        if shape_rec:
-            alg += dom_rays / 32.0 * shape_rec * 2.0
-        alg_per_launch = alg / max(dom_launches, 1)
-        achieved = alg_per_launch / max(avg_launch_s, 1e-12) / 1e9
-        total_rays_step = rays_per_rank_step * world
-        out = {
-            "metric": wk["metric"],
-            "value": total_rays_step * args.steps / dt,
-            "unit": "rays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": wk["name"] % n,
-                       "rays_per_step_per_gpu": rays_per_rank_step, "resolution": [rd.width, rd.height],
-                       "sharding": "root-ray index ranges, 1 RCCL reduce of %d floats per step" % (rd.width * rd.height * 3 + 4),
-                       "exits_per_root": exits / max(rays_per_rank, 1), "landed_weight_rank0_image": landed,
-                       "route": {"mode_mask": route.mode_mask, "geom_mask": route.geom_mask, "accum_mask": route.accum_mask,
-                                 "source_mask": route.source_mask, "planes": route.plane_cnt, "plane_copies": route.plane_copies}},
-            "repeats": {"n": reps, "protocol": "reference doc/performance-testing.md:109-131 (>= 5 repeats, median + CoV); each repeat times exactly --steps steps",
-                        "median_ms_per_step": dt * 1e3 / args.steps, "cov": cov,
-                        "ms_per_step_all": [x * 1e3 / args.steps for x in times]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(args.config),
-                         "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % (PROFILE_ROUND, args.config),
-                         "kernel": wk["kernel"], "launches": dom_launches,
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
-                         "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
-                         "valu": pmc_valu(args.config, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
-                         "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
-        }
-        if layers > 1:
-            traced = rays_per_rank + first_layer["cont"]
-            out["multi_scatter"] = {"root_rays_per_s": out["value"], "traced_rays_per_s": traced / (reps * args.steps) * world / (dt / args.steps),
-                                    "continuations_per_root": first_layer["cont"] / max(rays_per_rank, 1),
-                                    "first_layer_kernel_ms_per_launch": first_layer["ms"] / max(first_layer["launches"], 1),
-                                    "last_layer_kernel_ms_per_launch": avg_launch_s * 1e3}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wk)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,7 +26,7 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t s_log2, bool interleaved, hipStream_t stream);
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, hipStream_t stream);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
@@ -851,10 +851,15 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const bool two_level = bin_tiles > 512u;
       const bool bin_shape_ok = two_level ? (fan_log2 <= 8u && (bin_slots & 16383ull) == 0ull)
                                           : (bin_tiles >= 8u && (bin_tiles & (bin_tiles - 1u)) == 0u);
+      // The hit log over the scalar planes of a per-entry-plane session (small images: the reference's 512x256 D65 scenes): every plane gets
+      // 2^t interleaved tiles of <= 16 Ki slots, and the split pass feeds at most 512 lists — 64 planes up to 128 Ki pixels, 32 up to 256 Ki.
+      const uint32_t wl_t_log2 = b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u;
+      const bool log_planes_ok = b->mono_by_wl && (static_cast<uint64_t>(b->plane_cnt) << wl_t_log2) <= 512ull &&
+                                 (static_cast<uint64_t>(b->plane_cnt) << (b->mono_s_log2 + 10u)) <= (1ull << 31) && b->hit_log != 0 && b->bin <= 0;
       const bool use_bin = b->mono_session && b->aggregate == 1 && !b->capture && bin_shape_ok && bin_slots <= (1ull << 31) &&
-                           // own choice: only where the hit log cannot go (one plane per pool entry) — the log beats the binned route on every
-                           // one-plane full-sky launch measured (tools/bin_vs_log_probe.py: dual fisheye 50 M rays 5.13 -> 4.42 ms)
-                           (b->bin < 0 ? (b->mono_by_wl && bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
+                           // own choice: only where the hit log cannot go (one plane per pool entry on a larger image) — the log beats the binned route
+                           // on every launch measured (tools/bin_vs_log_probe.py: dual fisheye 50 M rays 5.13 -> 4.42 ms)
+                           (b->bin < 0 ? (b->mono_by_wl && !log_planes_ok && bin_geom_ok && b->render.visible == HALO_VISIBLE_FULL && m >= (2ull << 20)) : b->bin != 0);
       const uint32_t lists1 = two_level ? ((bin_tiles + (1u << fan_log2) - 1u) >> fan_log2) : bin_tiles;
       uint32_t cap2 = 0u;
       // Hit log (halo_trace.inl log_hit): global fp32 atomics retire memory-side at 21 G/s on this part, which bounded every big
@@ -864,9 +869,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Tiles: as many as the split pass feeds whatever the image size — the per-tile pass has one workgroup per tile — of at least
       // 256 and at most 16 Ki slots (X/Y/Z: 4 Ki) of ONE plane: 512 for X/Y/Z; for a scalar plane 128 where that keeps them within
       // 16 Ki slots (longer runs in the split pass: 0.23 vs 0.25 ms at configs[1]).
-      const uint32_t log_t_log2 = b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
-      const uint32_t log_tiles = 1u << log_t_log2;
-      const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && !b->mono_by_wl && b->mono_s_log2 <= 12u);
+      const uint32_t log_t_log2 = log_planes_ok ? wl_t_log2 : b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
+      const uint32_t log_planes = log_planes_ok ? b->plane_cnt : 1u;
+      const uint32_t log_tiles = log_planes << log_t_log2;   // lists the split pass feeds
+      const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && (log_planes_ok || (!b->mono_by_wl && b->mono_s_log2 <= 12u)));
       bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && fast_mode &&
                            (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
                            (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
@@ -989,7 +995,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
                                                            b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
-                                                       b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
+                                                       b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {

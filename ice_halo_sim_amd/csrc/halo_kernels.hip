@@ -121,10 +121,10 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
   // kMix: interleaved tiles (TileMap, s = mix_log2, t = fan_log2); else contiguous ranges of 2^tile_log2 slots
   auto tile_of = [&](uint32_t x) {
     const uint32_t sl = x & slot_mask;
-    if (kMix) {
+    if (kMix) {   // interleaved tiles of ONE plane; the planes of a per-entry-plane session lie back to back, each with its own 2^fan_log2 tiles
       uint32_t tile, local;
-      TileMap{mix_log2, fan_log2}.split(sl, tile, local);
-      return tile;
+      TileMap{mix_log2, fan_log2}.split(sl & ((1u << (mix_log2 + 10u)) - 1u), tile, local);
+      return ((sl >> (mix_log2 + 10u)) << fan_log2) | tile;
     }
     return (sl >> tile_log2) & fmask;
   };
@@ -266,10 +266,11 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   constexpr uint32_t kTileLog2 = CH == 3u ? 12u : 14u;
   __shared__ __attribute__((aligned(16))) double acc[CH][1u << kTileLog2];   // fp64: see halo_bin_accumulate_kernel
   __shared__ float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][3];
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = blockIdx.x;   // plane << tiles_log2 | tile of that plane (CH = 1: the scalar planes of a per-entry-plane session lie back to back)
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
   const TileMap map{s_log2, tiles_log2};
+  const uint32_t tile_in = tile & ((1u << tiles_log2) - 1u), plane_of_tile = tile >> tiles_log2, in_plane = (1u << (s_log2 + 10u)) - 1u;
   const uint32_t slots = 1u << (s_log2 + 10u - tiles_log2);   // <= 1 << kTileLog2
   for (uint32_t c = 0; c < CH; ++c)
     for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[c][j] = 0.0;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   constexpr uint32_t kU = 4u, kSlotMask = CH == 3u ? (1u << kLogWlShift) - 1u : 0xFFFFFFFFu;
   auto add = [&](uint2 h) {
     uint32_t t_unused, s;
-    map.split(h.x & kSlotMask, t_unused, s);
+    map.split(h.x & kSlotMask & in_plane, t_unused, s);
     const double w = static_cast<double>(__uint_as_float(h.y));
     if constexpr (CH == 3u) {
       const uint32_t code = h.x >> kLogWlShift;
@@ -309,10 +310,10 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   for (; i < n; i += kBinBlock) add(src[i]);
   __syncthreads();
   for (uint32_t c = 0; c < CH; ++c) {
-    float* dst = planes + static_cast<size_t>(c) * plane_stride;
+    float* dst = planes + static_cast<size_t>(c) * plane_stride + (static_cast<size_t>(plane_of_tile) << (s_log2 + 10u));
     for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) {
       const float v = static_cast<float>(acc[c][j]);
-      if (v != 0.0f) dst[map.slot_of(tile, j)] += v;
+      if (v != 0.0f) dst[map.slot_of(tile_in, j)] += v;
     }
   }
 }
@@ -320,9 +321,19 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 // hit-log route, one scalar plane: regions -> `tiles` (a power of two <= 256) tiles -> the plane.  Contiguous tiles (plain float4
 // write-out, 3-5 % faster at configs[1] / [2]) where the lists have room for an uneven image — renders that cull most exits,
 // ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
+// `planes` > 1: the scalar planes of a per-entry-plane illuminant session (back to back), `tiles` interleaved tiles EACH, planes x tiles <= 512.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t s_log2, bool interleaved, hipStream_t stream) {
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
+  if (planes > 1u) {
+    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles * planes), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
+                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2);
+    return hipGetLastError();
+  }
   if (interleaved)
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});

@@ -114,24 +114,28 @@ def test_filter_production_kernels_vs_oracle(case):
     print("%s: mode %d geom %d accum %d; exits %d; block-mean rel L2 %s" % (case, r.mode_mask, r.geom_mask, r.accum_mask, h["st"][0].exit_count, err))
 
 
-@pytest.mark.parametrize("wl_kind", ["d65_xyz", "d65_planes_binned", "d65_planes_direct"])
+@pytest.mark.parametrize("wl_kind", ["d65_xyz", "d65_planes_log64", "d65_planes_log31", "d65_planes_binned", "d65_planes_direct"])
 def test_filter_production_kernels_illuminant_sessions(wl_kind):
     """The complex filter on an illuminant session, the plane layouts a filtered dispatch can meet on a small image: X/Y/Z planes
-    (sessions under 8 Mi rays: `<kModeFilter, hex, MONO=false, kAccDirect>`); one scalar plane per pool entry with binned
-    accumulation (>= 8 Mi rays, full-sky render, the reference's default pool of 64 = 512 tiles: `<kModeFilter, one, true, kAccBin>`);
-    and per-entry planes with direct atomics (a pool of 31: 248 tiles are not a power of two, the binned route does not apply)."""
+    (sessions under 8 Mi rays: `<kModeFilter, hex, MONO=false, kAccDirect>`); one scalar plane per pool entry (>= 8 Mi rays) with the hit
+    log over the planes (the backend's choice on the reference's 512x256 scenes: `<kModeFilter, hex, true, kAccLogFinal>`, 64 x 8 or 31 x 8
+    interleaved tiles), with binned accumulation (option bin = 1, 64 planes = 512 tiles: `<kModeFilter, one, true, kAccBin>`), and with
+    direct atomics (option hit_log = 0; a pool of 31 is 248 tiles, not a power of two, so the binned route does not apply)."""
     col = scenes.column_crystal_entry()
     sc = scenes.scene([(0.0, [_with(col, 4)])], max_hits=7)
     rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
-    pool = 64 if wl_kind == "d65_planes_binned" else 31
+    pool = 64 if wl_kind in ("d65_planes_binned", "d65_planes_log64") else 31
     wl = scenes.wl_illuminant("D65", pool)
     n = (5 << 20) if wl_kind == "d65_xyz" else (9 << 20)
-    h = _render(hip_backend(seed=33), sc, rd, wl, n, _filter_table())
+    opts = {"d65_planes_binned": {"bin": 1}, "d65_planes_direct": {"hit_log": 0}}.get(wl_kind, {})
+    h = _render(hip_backend(seed=33, **opts), sc, rd, wl, n, _filter_table())
     o = _render(OracleBackend(seed=33, threads=THREADS, acc64=1), sc, rd, wl, n, _filter_table())
     r = h["route"]
     assert r.mode_mask == abi.MODE_FILTER, r.mode_mask
     assert r.plane_cnt == (3 if wl_kind == "d65_xyz" else pool)
-    assert r.accum_mask == {"d65_xyz": abi.ACCUM_XYZ, "d65_planes_binned": abi.ACCUM_BIN1, "d65_planes_direct": abi.ACCUM_SCALAR}[wl_kind], r.accum_mask
+    assert r.accum_mask == {"d65_xyz": abi.ACCUM_XYZ, "d65_planes_binned": abi.ACCUM_BIN1, "d65_planes_direct": abi.ACCUM_SCALAR}.get(wl_kind, abi.ACCUM_LOG), r.accum_mask
+    if wl_kind.startswith("d65_planes_log"):
+        assert r.geom_mask == 1 << 3 and r.spec_mask & abi.SPEC_LAST
     err = _single_layer_checks(h, o, wl_kind)
     print("%s: accum %d geom %d, block-mean rel L2 %s" % (wl_kind, r.accum_mask, r.geom_mask, err))
 
