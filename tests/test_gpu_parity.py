@@ -308,6 +308,43 @@ def test_pyramid_crystal_parity():
     assert paths & {13, 14, 15, 16, 17, 18} and paths & {23, 24, 25, 26, 27, 28}  # pyramidal face numbers appear
 
 
+@pytest.mark.parametrize("case", ["gauss_legacy_latitude", "zigzag_azimuth_laplacian_roll", "laplacian_azimuth_zigzag_roll", "gauss_legacy_wide"])
+def test_orientation_distributions_off_the_lut_path(case):
+    """The orientation sampler's branches that no other scene takes (sample_lat_lon_roll pcg_shared.h:392-440, get_dist :290-308): the
+    legacy Gaussian latitude (lat path 3: Box-Muller draw + NormalizeLatitude with its pole fold, math.cpp:511) and zigzag / Laplacian
+    draws on azimuth and roll — per ray against the oracle (same streams: same orientation, so the same exits)."""
+    uni = {"type": "uniform", "mean": 0, "std": 360}
+    ax = {
+        "gauss_legacy_latitude": scenes.axis(zenith={"type": "gauss_legacy", "mean": 90, "std": 2.0}, azimuth=uni, roll=uni),
+        "gauss_legacy_wide": scenes.axis(zenith={"type": "gauss_legacy", "mean": 10, "std": 40.0}, azimuth=uni, roll={"type": "gauss", "mean": 30, "std": 5}),   # folds over the pole often
+        "zigzag_azimuth_laplacian_roll": scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 1.0}, azimuth={"type": "zigzag", "mean": 20, "std": 60},
+                                                     roll={"type": "laplacian", "mean": 0, "std": 15}),
+        "laplacian_azimuth_zigzag_roll": scenes.axis(zenith={"type": "uniform", "mean": 45, "std": 30}, azimuth={"type": "laplacian", "mean": -40, "std": 25},
+                                                     roll={"type": "zigzag", "mean": 10, "std": 20}),
+    }[case]
+    e = scenes.entry(scenes.prism_crystal(1.3, [1.0] * 6), ax, 1.0, 3)
+    if case.startswith("gauss_legacy"):
+        assert e.axis.latitude.type == abi.DIST_GAUSS_LEGACY
+    sc = scenes.scene([(0.0, [e])], max_hits=7)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    r = run_both(sc, rd, scenes.wl_discrete(530.0), 100_000, seed=17)
+    frac, pix, path = match_exits(r["eh"], r["eo"])
+    assert frac >= 0.998 and pix >= 0.995 and path >= 0.999, (frac, pix, path)
+    assert abs(r["lh"] - r["lo"]) <= 1e-4 * r["lo"]
+    assert rel_l2(block_mean(r["ih"]), block_mean(r["io"])) <= 3e-3
+    # ... and on the production kernels (no capture), 2.5 Mi rays
+    hb = hip_backend(seed=17)
+    ob = OracleBackend(seed=17, threads=min(os.cpu_count() or 1, 128), acc64=1)
+    n = 5 << 19
+    sh, so = run_session(hb, sc, rd, scenes.wl_discrete(530.0), n), run_session(ob, sc, rd, scenes.wl_discrete(530.0), n)
+    assert hb.last_route().mode_mask == abi.MODE_PLAIN
+    (ih, lh), (io, lo) = hb.ReadbackXyzAccum(), ob.ReadbackXyzAccum()
+    hb.close()
+    ob.close()
+    assert sh[0].exit_count == pytest.approx(so[0].exit_count, rel=1e-4)
+    assert abs(lh - lo) <= 1e-4 * lo and rel_l2(block_mean(ih), block_mean(io)) <= 3e-3
+
+
 def test_multi_entry_layer_partition_parity():
     e1 = scenes.column_crystal_entry()
     e2 = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 0.8}), 5.0, 6)
@@ -455,6 +492,10 @@ def test_full_size_image_l2_vs_oracle():
     hb = hip_backend(seed=2024)
     ob = OracleBackend(seed=2024, threads=min(os.cpu_count() or 1, 128))
     sh = run_session(hb, sc, rd, scenes.wl_discrete(570.0), n)
+    r = hb.last_route()
+    # the headline instantiation, by name: halo_trace_kernel<0, 3 (regular prism), true, kAccLogFinal, FISHEYE_EQUAL_AREA, UPPER, nogate> + hit log
+    assert (r.mode_mask, r.geom_mask, r.accum_mask, r.launches) == (abi.MODE_PLAIN, 1 << 3, abi.ACCUM_LOG, 1), (r.mode_mask, r.geom_mask, r.accum_mask, r.launches)
+    assert r.spec_mask == abi.SPEC_LAST | abi.SPEC_LENS | abi.SPEC_VIS | abi.SPEC_NOGATE and r.generic_launches == 0, (r.spec_mask, r.generic_launches)
     ih, lh = hb.ReadbackXyzAccum()
     # The oracle adds every hit into a float32 pixel one by one: in ONE 20 M-ray session the sun-disc pixels pass 5e5 and
     # hits lighter than half an ulp (0.016) vanish — it reads 0.37 % low there.  Drain it every 1 M rays into float64

@@ -371,6 +371,12 @@ def test_exit_queue_kernel_lands_what_the_emit_site_kernels_land(lens, visible, 
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 19)
     assert q[1] == pytest.approx(landed_o, rel=2e-4, abs=1.0)
     assert q[3] == pytest.approx(st_o[0].exit_count, rel=2e-4, abs=20)
+    # ... and the oracle's IMAGE: what the queue kernels put on the pixels, channel by channel (same rays: 8x8 block means to 3e-3)
+    if img_o.sum() > 0:
+        assert rel_l2(block_mean(q[0]), block_mean(img_o)) <= 3e-3
+        tot = float(img_o.sum(dtype=np.float64))
+        for ch in range(3):
+            assert q[0][..., ch].sum(dtype=np.float64) == pytest.approx(img_o[..., ch].sum(dtype=np.float64), rel=3e-4, abs=1e-5 * tot)
 
 
 @pytest.mark.parametrize("size", [(256, 128), (512, 256), (1024, 512)])
@@ -467,3 +473,43 @@ def test_middle_layer_through_the_hit_log():
     assert a[1] == pytest.approx(b[1], rel=2e-3)
     assert a[0].sum(dtype=np.float64) == pytest.approx(b[0].sum(dtype=np.float64), rel=2e-3)
     assert _pearson_blocks(a[0], b[0], 16) >= 0.999
+
+
+@pytest.mark.parametrize("lens", [abi.LENS_LINEAR, abi.LENS_FISHEYE_EQUAL_AREA, abi.LENS_DUAL_FISHEYE_EQUAL_AREA, abi.LENS_RECTANGULAR])
+@pytest.mark.parametrize("visible", [abi.VISIBLE_UPPER, abi.VISIBLE_FULL])
+def test_lens_specialised_last_layer_kernels_vs_oracle(lens, visible):
+    """The instantiations that carry the lens, the visible range and the closed gate as template constants
+    (`halo_trace_kernel<0,3,true,kAccLogFinal,LENS,VIS,true>`: the lenses of the reference's shipped examples) at a launch size where the
+    backend picks them (3 Mi rays, prob 0 on the last layer), against the oracle: halo_last_route must report the specialisation
+    (spec_mask: last layer | lens | visible range | closed gate, no generic launch), then exits, landed weight, image."""
+    sc = scenes.config2_scene()
+    dual = lens == abi.LENS_DUAL_FISHEYE_EQUAL_AREA
+    rd = scenes.render(lens, 1024, 512, fov=180.0 if lens != abi.LENS_LINEAR else 90.0, el=30.0 if lens != abi.LENS_RECTANGULAR else 0.0, visible=visible,
+                       overlap=0.0872 if dual else 0.0)
+    wl, n = scenes.wl_discrete(610.0), 3 << 20
+    hb = hip_backend(seed=77)
+    st = run_session(hb, sc, rd, wl, n)
+    r = hb.last_route()
+    hip = hb.ReadbackXyzAccum()
+    hb.close()
+    assert r.mode_mask == abi.MODE_PLAIN and r.geom_mask == 1 << 3 and r.accum_mask == abi.ACCUM_LOG, (r.mode_mask, r.geom_mask, r.accum_mask)
+    assert r.spec_mask == abi.SPEC_LAST | abi.SPEC_LENS | abi.SPEC_VIS | abi.SPEC_NOGATE and r.generic_launches == 0, (r.spec_mask, r.generic_launches)
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 77, acc64=1)
+    assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=1e-4)
+    err = _check_single_layer(hip, (img_o, landed_o))
+    print("lens %d visible %d: spec %d, block-mean rel L2 %.2e" % (lens, visible, r.spec_mask, err))
+
+
+def test_unspecialised_lens_runs_the_generic_last_layer_kernel():
+    """... and a lens outside that list (fisheye stereographic) reports the generic last-layer kernel — the route info tells the two apart."""
+    sc = scenes.config2_scene()
+    rd = scenes.render(abi.LENS_FISHEYE_STEREOGRAPHIC, 1024, 512, fov=180.0, el=30.0, visible=abi.VISIBLE_UPPER)
+    wl, n = scenes.wl_discrete(610.0), 3 << 20
+    hb = hip_backend(seed=78)
+    st = run_session(hb, sc, rd, wl, n)
+    r = hb.last_route()
+    hip = hb.ReadbackXyzAccum()
+    hb.close()
+    assert r.spec_mask == abi.SPEC_LAST and r.generic_launches == 0 and r.accum_mask == abi.ACCUM_LOG, (r.spec_mask, r.generic_launches, r.accum_mask)
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 78, acc64=1)
+    _check_single_layer(hip, (img_o, landed_o))
