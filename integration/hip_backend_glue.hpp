@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <random>
 #include <type_traits>
 #include <utility>
 #include <variant>
@@ -242,18 +243,18 @@ inline SceneTables ToHalo(const SceneConfig& s, const RaypathColorConfig* color)
 // =====================================================================================================================
 class HipBackendGlue final : public TraceBackend {
  public:
-  // CreateBackend (simulator.cpp:854-919): seed = effective_seed_ (:782-798); device = the process's GPU (one engine per
+  // CreateBackend (simulator.cpp:854-919) knows no seed: like the reference's backends (cuda_trace_backend.cu:1931-1943,
+  // cpu_trace_backend.cpp:252-257) the engine is seeded ONCE, by the first BeginSession's SessionSpec::seed (0 = non-deterministic), and its
+  // ray counters then run on across sessions.  `seed` != 0 here pins it instead (tests).  device = the process's GPU (one engine per
   // process; a multi-GPU launcher passes its local rank).  Throws BackendUnavailableError without a gfx950 device.
-  explicit HipBackendGlue(uint32_t seed, int device = 0) {
-    try {
-      be_ = std::make_unique<halo::HipTraceBackend>(device, seed);
-    } catch (const halo::BackendUnavailableError& e) {
-      throw BackendUnavailableError(e.what());
-    }
+  explicit HipBackendGlue(uint32_t seed = 0u, int device = 0) : device_(device), pinned_seed_(seed) {
+    if (halo_device_count() <= device) throw BackendUnavailableError("no gfx950 device for the HIP trace backend");
+    if (seed != 0u) Create(seed);
   }
 
   // --- TraceBackend::BeginSession (trace_backend.hpp:374-378) ----------------------------------------------------------
   void BeginSession(const SessionSpec& spec) override {
+    if (!be_) Create(spec.seed != 0u ? spec.seed : static_cast<uint32_t>(std::random_device{}()) | 1u);   // seeded once per instance
     hip_glue::SceneTables t = hip_glue::ToHalo(*spec.scene, spec.raypath_color.get());       // SessionSpec::raypath_color
     if (!t.representable) throw BackendUnavailableError("scene exceeds the HIP backend's table caps (layers/entries/filter or colour terms)");
     const HaloRender rd = hip_glue::ToHalo(*spec.render);
@@ -337,8 +338,8 @@ class HipBackendGlue final : public TraceBackend {
   uint32_t WlPoolSize() const override { return kWlPoolSizeDefault; }
 
   // --- sample-count getters (trace_backend.hpp:587, :625): real counts of what the kernels drew in the last session ----------
-  size_t GetLastBatchStochasticCrystalSampleCount() const override { return be_->GetLastBatchStochasticCrystalSampleCount(); }
-  size_t GetLastBatchStochasticOrientationSampleCount() const override { return be_->GetLastBatchStochasticOrientationSampleCount(); }
+  size_t GetLastBatchStochasticCrystalSampleCount() const override { return be_ ? be_->GetLastBatchStochasticCrystalSampleCount() : 0; }
+  size_t GetLastBatchStochasticOrientationSampleCount() const override { return be_ ? be_->GetLastBatchStochasticOrientationSampleCount() : 0; }
   // GetLastColorDegradeCounts (trace_backend.hpp:632): nothing degrades silently here — a scene beyond the colour caps is
   // refused in BeginSession (BackendUnavailableError -> per-Run fallback to the legacy path, simulator.cpp:1049-1062)
   ColorDegradeCounts GetLastColorDegradeCounts() const override { return {}; }
@@ -360,6 +361,15 @@ class HipBackendGlue final : public TraceBackend {
       throw BackendUnavailableError(e.what());
     }
   }
+  void Create(uint32_t seed) {
+    try {
+      be_ = std::make_unique<halo::HipTraceBackend>(device_, seed);
+    } catch (const halo::BackendUnavailableError& e) {
+      throw BackendUnavailableError(e.what());
+    }
+  }
+  int device_ = 0;
+  uint32_t pinned_seed_ = 0u;
   std::unique_ptr<halo::HipTraceBackend> be_;
 };
 
