@@ -169,7 +169,7 @@ class HipTraceBackend:
     def generate_shapes(self, crystal, first_index, n, on_device=True):
         """`n` sampled instances of `crystal` as HaloGeomTables (device generator or the host builder)."""
         out = (abi.HaloGeomTables * n)()
-        self._check(self._L.halo_generate_shapes(self._h, C.byref(crystal), int(first_index), int(n), 1 if on_device else 0, out))
+        self._check(self._L.halo_generate_shapes(self._h, C.byref(crystal), int(first_index), int(n), int(on_device), out))   # 0 host | 1 general records | 2 prism records
         return out
 
     def last_sample_counts(self):

@@ -1055,7 +1055,30 @@ int halo_generate_shapes(halo_handle_t b, const HaloCrystal* crystal, uint64_t f
   if (!b || !crystal || (!out && n)) return HALO_FATAL;
   if (crystal->kind != HALO_CRYSTAL_PRISM && crystal->kind != HALO_CRYSTAL_PYRAMID) return fail(b, HALO_FATAL, "unknown crystal kind");
   std::vector<ShapeDev> pool(n);
-  if (on_device) {
+  if (on_device == 2 && crystal->kind == HALO_CRYSTAL_PRISM) {   // the prism-pool generator (1360-byte ShapePrism records, one team of 16 lanes per crystal)
+    HIPCHK(b, hipSetDevice(b->device));
+    DevBuf<ShapePrism> dev;
+    HIPCHK(b, dev.reserve(n));
+    std::vector<ShapePrism> recs(n);
+    hipError_t ge = launch_shapegen(dev.ptr, true, n, b->seed, host::MakeRecipe(*crystal), first_index, b->stream, b->gen_serial != 0);
+    if (ge == hipSuccess) ge = hipMemcpyAsync(recs.data(), dev.ptr, static_cast<size_t>(n) * sizeof(ShapePrism), hipMemcpyDeviceToHost, b->stream);
+    if (ge == hipSuccess) ge = hipStreamSynchronize(b->stream);
+    dev.release();
+    if (ge != hipSuccess) return hip_fail(b, ge, "halo_prismgen_team_kernel");
+    for (uint32_t k = 0; k < n; k++) {   // same members, shorter rows: widen to the general record
+      const ShapePrism& r = recs[k];
+      ShapeDev& d = pool[k];
+      std::memset(&d, 0, sizeof(d));
+      d.face_cnt = r.face_cnt, d.tri_cnt = r.tri_cnt, d.slab_cnt = r.slab_cnt, d.single_cnt = r.single_cnt;
+      std::memcpy(d.face, r.face, sizeof(r.face));
+      std::memcpy(d.slab, r.slab, sizeof(r.slab));
+      std::memcpy(d.tri_v, r.tri_v, sizeof(r.tri_v));
+      std::memcpy(d.tri_na, r.tri_na, sizeof(r.tri_na));
+      std::memcpy(d.tri_face, r.tri_face, sizeof(r.tri_face));
+      std::memcpy(d.face_number, r.face_number, sizeof(r.face_number));
+      std::memcpy(d.single, r.single, sizeof(r.single));
+    }
+  } else if (on_device) {
     HIPCHK(b, hipSetDevice(b->device));
     DevBuf<ShapeDev> dev;
     HIPCHK(b, dev.reserve(n));

@@ -69,6 +69,13 @@ __device__ __forceinline__ uint32_t team_ballot(bool p) {
 __device__ __forceinline__ double team_bcast(double v, int src) {   // value of team lane `src`
   return __shfl(v, static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(src)));
 }
+// LDS written by one lane of a team and read by others: the wave runs in lockstep, but nothing makes the compiler keep LDS accesses of
+// different lanes in program order across divergent regions — publish with a workgroup-scope fence + a wave barrier (like stage_shape's
+// callers in halo_trace.inl).
+__device__ __forceinline__ void team_publish() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ double team_max(double v) {
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
@@ -152,6 +159,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const double scale = team_max(fmax(fabs(half), side_active ? fabs(unit.d) : 0.0));
   const double tol = 5.0 * static_cast<double>(geom::kGeomFloatEps) * fmax(scale, 1e-3);
   if (s < 20) T.unit[s] = unit;
+  team_publish();
   // --- cone apexes: extreme z over the feasible concurrences of each cone's own six planes ---
   double z_top = half, z_bot = -half;
   for (int c = 0; c < 2; c++) {
@@ -181,6 +189,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   if (s == 0) raw = unit = geom::Plane3{0.0, 0.0, 1.0, -z_top};
   if (s == 1) raw = unit = geom::Plane3{0.0, 0.0, -1.0, z_bot};
   if (s < 2) T.unit[s] = unit;
+  team_publish();
   const bool active = s < 2 || side_active;
   const uint32_t act_mask = team_ballot(active);
   // --- vertices: candidate triples in lexicographic order, 32 per round; kept in serial order ---
@@ -231,6 +240,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     for (int a = 0; a < 3; a++) T.verts[lane][a] = k0[a];
   if (lane + kTeam < nv)
     for (int a = 0; a < 3; a++) T.verts[lane + kTeam][a] = k1[a];
+  team_publish();
   // --- faces: vertices on plane s (ascending vertex order), then CCW order ---
   int cnt = 0;
   if (valid && active) {
@@ -248,6 +258,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   }
   const int my_tris = on_n > 0 ? on_n - 2 : 0;
   if (s < 20) T.tri_cnt[s] = my_tris;
+  team_publish();
   int tri_start = 0, tri_total = 0;
   for (int q = 0; q < 20; q++) {
     const int c = T.tri_cnt[q];
@@ -264,15 +275,46 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     nrm[0] = static_cast<float>(unit.a);
     nrm[1] = static_cast<float>(unit.b);
     nrm[2] = static_cast<float>(unit.c);
-    float loop[HALO_MAX_FACE_VTX][3];
-    for (int q = 0; q < on_n; q++)
-      for (int a = 0; a < 3; a++) loop[q][a] = static_cast<float>(T.verts[T.on[s][q]][a]);
-    geom::EmitFace(out, cur, plane, nrm, geom::kPyrFaceNumber[s], loop, on_n);
+    // geom::EmitFace with the corner loop read where it lies (vertex list and face order in LDS) instead of through a per-lane copy of
+    // 16 x 3 floats (192 B of scratch per lane): the same statements on the same values
+    {
+      const int fid_e = cur.fid;
+      const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);
+      const float dn = (len > geom::kGeomFloatEps) ? plane[3] / len : 0.0f;
+      out.face[fid_e][0] = nrm[0];
+      out.face[fid_e][1] = nrm[1];
+      out.face[fid_e][2] = nrm[2];
+      out.face[fid_e][3] = dn;
+      cur.d_last = dn;
+      out.face_number[fid_e] = static_cast<uint8_t>(geom::kPyrFaceNumber[s]);
+      float v0[3];
+      for (int a = 0; a < 3; a++) v0[a] = static_cast<float>(T.verts[T.on[s][0]][a]);
+      for (int k = 1; k + 1 < on_n && on_n >= 3 && cur.tri < static_cast<int>(sizeof(out.tri_na) / 16u); k++) {
+        const int t = cur.tri;
+        float v[9];
+        for (int a = 0; a < 3; a++) {
+          v[a] = v0[a];
+          v[3 + a] = static_cast<float>(T.verts[T.on[s][k]][a]);
+          v[6 + a] = static_cast<float>(T.verts[T.on[s][k + 1]][a]);
+        }
+        for (int a = 0; a < 9; a++) out.tri_v[t][a] = v[a];
+        const float ea[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
+        const float eb[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+        const float cn[3] = {-eb[1] * ea[2] + ea[1] * eb[2], eb[0] * ea[2] - ea[0] * eb[2], -eb[0] * ea[1] + ea[0] * eb[1]};  // Cross3 math.cpp:36
+        const float mag = sqrtf(cn[0] * cn[0] + cn[1] * cn[1] + cn[2] * cn[2]);
+        out.tri_na[t][3] = mag / 2.0f;
+        for (int c = 0; c < 3; c++) out.tri_na[t][c] = (mag > 0.0f) ? cn[c] / mag : 0.0f;
+        out.tri_face[t] = static_cast<uint8_t>(fid_e);
+        cur.tri++;
+      }
+      cur.fid++;
+    }
     T.fn[fid][0] = nrm[0];
     T.fn[fid][1] = nrm[1];
     T.fn[fid][2] = nrm[2];
     T.fn[fid][3] = cur.d_last;
   }
+  team_publish();
   // opposite-face slabs (geom::FinalizeSlabs): face i pairs with the first later face whose unit normal is its exact negative
   const int face_cnt = __popc(present);
   int mate = -1;
@@ -311,11 +353,275 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Prism pools: one TEAM of 16 lanes builds one crystal (four teams per wave64, sixteen per workgroup), the record assembled in LDS and
+// written out with coalesced 16-byte stores.
+//
+// The serial builder above (one thread per crystal) spent its time waiting: a chain of dependent fp64 steps per lane, 640 B of scratch
+// per lane for its candidate / ring / loop arrays, and 1360-byte records 64 lanes wide written 4 bytes at a time — 11.5 % VALU-active,
+// 3.6x the records' bytes at the memory controller (profiles/r02_bench4_pmc_*), 1.13 ms per 781 K crystals, a fifth of configs[4]'s
+// step.  The same steps across a team (geom::SolveHex / BuildPrismShape / EmitFace / FinalizeSlabs, statement by statement):
+//   scalars     lane q draws scalar q (height, six face distances)                         (geom::DrawShapeScalarOne)
+//   corners     lane t < 12 intersects side pair t and tests it against the other four sides; the feasible ones are then taken IN ORDER
+//               (ballot, lowest lane first), broadcast and tested against the kept corners — the serial duplicate filter, unchanged
+//   sides       lane i < 6 counts the kept corners on side i; ring corner k = lane k's intersection of consecutive present sides
+//   triangles   lane t (and t + 16) builds fan triangle t of the face it belongs to; lanes 0..7 the face rows; lanes 0..2 the slabs
+// Every number comes from the same expression on the same operands as on the host (this file is compiled without contraction), so
+// the record is bit-identical to the host builder's (tests/test_gpu_parity.py::test_device_crystal_generator_equals_host_builder).
+constexpr int kPTeam = 16, kPTeamsPerBlock = 16, kPTeamBlock = kPTeam * kPTeamsPerBlock;
+struct PrismTeamLds {
+  __attribute__((aligned(16))) ShapePrism rec;
+  float c[6][2];   // ring corners (float, as the tables take them)
+};
+__device__ __forceinline__ uint32_t pteam_ballot(bool p) {
+  const unsigned long long b = __ballot(p);
+  return static_cast<uint32_t>(b >> (threadIdx.x & 48u)) & 0xFFFFu;
+}
+__device__ __forceinline__ double pteam_bcast(double v, int src) { return __shfl(v, src, kPTeam); }
+
+__global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePrism* __restrict__ pool, uint32_t n_crystals, uint32_t seed, const geom::CrystalRecipe rc,
+                                                                        uint64_t first_index) {
+  __shared__ PrismTeamLds s_team[kPTeamsPerBlock];
+  const int lane = static_cast<int>(threadIdx.x & 15u);
+  PrismTeamLds& T = s_team[threadIdx.x >> 4];
+  const uint32_t crystal = blockIdx.x * kPTeamsPerBlock + (threadIdx.x >> 4);
+  const bool live = crystal < n_crystals;   // team-uniform
+  {   // the record starts as zeros (rows beyond the counts are never read, but the pool then holds no stale bytes either)
+    float4* z = reinterpret_cast<float4*>(&T.rec);
+    for (uint32_t i = static_cast<uint32_t>(lane); i < sizeof(ShapePrism) / 16u; i += kPTeam) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  // --- shape scalars: slots [h, -, -, d0..d5] ---
+  float sc[9];
+  {
+    const float mine = lane < 9 ? geom::DrawShapeScalarOne(seed, rc, first_index + (live ? crystal : 0u), lane) : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 9; q++) sc[q] = __shfl(mine, q, kPTeam);
+  }
+  const float h = fabsf(sc[0]);
+  bool valid = live && (h > geom::kGeomFloatEps);
+  const double k_r = geom::kGeomSqrt3 / 4.0, k_d = geom::kGeomSqrt3 / 8.0;
+  double r[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) r[i] = k_r * static_cast<double>(sc[3 + i]);
+  // --- geom::SolveHex ---
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) scale = fmax(scale, fabs(r[i]));
+  const double tol = 5.0 * static_cast<double>(geom::kGeomFloatEps) * scale;
+  // candidate t: the t-th pair i < j, j != i + 3, in the serial loop's order
+  // (pairs (0,1) (0,2) (0,4) (0,5) (1,2) (1,3) (1,5) (2,3) (2,4) (3,4) (3,5) (4,5), a nibble each; the 60-degree tables by selects: a
+  // table indexed by a lane-varying value would live in scratch)
+  auto c6 = [](int i) { return i == 0 ? 1.0 : i == 1 ? 0.5 : i == 2 ? -0.5 : i == 3 ? -1.0 : i == 4 ? -0.5 : 0.5; };
+  auto s6 = [](int i) {
+    const double sv = 0.86602540378443864676;
+    return (i == 1 || i == 2) ? sv : (i == 4 || i == 5) ? -sv : 0.0;
+  };
+  geom::Pt2 q{0.0, 0.0};
+  bool feasible = false;
+  if (valid && lane < 12) {
+    const int i = static_cast<int>((0x433221110000ull >> (4 * lane)) & 15ull), j = static_cast<int>((0x554435325421ull >> (4 * lane)) & 15ull);
+    double ri = 0.0, rj = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {   // r[i], r[j] without a private array (dynamic indexing would put r[] in scratch)
+      ri = (m == i) ? r[m] : ri;
+      rj = (m == j) ? r[m] : rj;
+    }
+    const double det = c6(i) * s6(j) - s6(i) * c6(j);   // geom::Meet (never 0 for these pairs)
+    q.x = (ri * s6(j) - rj * s6(i)) / det;
+    q.y = (c6(i) * rj - c6(j) * ri) / det;
+    bool ok = true;
+#pragma unroll
+    for (int m = 0; m < 6; m++)
+      if (m != i && m != j && geom::Cos6(m) * q.x + geom::Sin6(m) * q.y > r[m] + tol) ok = false;
+    feasible = ok;
+  }
+  // kept corners: lane c holds corner c (at most 12); the feasible candidates join in the serial order
+  int nc = 0;
+  double kx = 0.0, ky = 0.0;
+  uint32_t todo = pteam_ballot(feasible);
+  while (__ballot(todo != 0u) != 0ull) {   // (the four teams of a wave may differ: the loop runs for the longest list)
+    const bool mine_left = todo != 0u;
+    const int src = mine_left ? __ffs(todo) - 1 : 0;
+    todo &= todo - 1u;
+    const double cx = pteam_bcast(q.x, src), cy = pteam_bcast(q.y, src);
+    const bool dup = mine_left && lane < nc && sqrt((kx - cx) * (kx - cx) + (ky - cy) * (ky - cy)) <= tol;
+    if (mine_left && pteam_ballot(dup) == 0u && nc < 12) {
+      if (lane == nc) {
+        kx = cx;
+        ky = cy;
+      }
+      nc++;
+    }
+  }
+  // a side is present iff at least two kept corners sit on it
+  int on = 0;
+  {
+    int nc_max = nc;
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) nc_max = max(nc_max, __shfl_xor(nc_max, off));   // uniform trip count over the wave's teams
+    double ci = 0.0, si = 0.0, rr = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      ci = (m == lane) ? geom::Cos6(m) : ci;
+      si = (m == lane) ? geom::Sin6(m) : si;
+      rr = (m == lane) ? r[m] : rr;
+    }
+    for (int c = 0; c < nc_max; c++) {
+      const double cx = pteam_bcast(kx, c), cy = pteam_bcast(ky, c);
+      if (c < nc && lane < 6 && fabs(ci * cx + si * cy - rr) <= tol) on++;
+    }
+  }
+  const uint32_t pmask = pteam_ballot(valid && lane < 6 && on >= 2);   // present sides
+  const int n = __popc(pmask);
+  // walk the present sides in order: side_k = the k-th present side
+  auto kth = [&](int k) {   // index of the k-th set bit of pmask (k < n)
+    uint32_t m = pmask;
+    for (int t = 0; t < k; t++) m &= m - 1u;
+    return m ? __ffs(m) - 1 : 0;
+  };
+  const int sk = lane < n ? kth(lane) : 0, sk1 = lane < n ? kth((lane + 1) % max(n, 1)) : 0;
+  const bool opp = lane < n && ((sk - sk1) == 3 || (sk - sk1) == -3);
+  const bool bounded = n >= 3 && pteam_ballot(opp) == 0u;
+  valid = valid && bounded;   // (n < 3 or unbounded: the empty crystal, counts stay 0)
+  if (valid && lane < n) {    // ring corner k: consecutive present sides meet
+    double ri = 0.0, rj = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      ri = (m == sk) ? r[m] : ri;
+      rj = (m == sk1) ? r[m] : rj;
+    }
+    const double det = c6(sk) * s6(sk1) - s6(sk) * c6(sk1);
+    geom::Pt2 g{0.0, 0.0};
+    if (det != 0.0) {
+      g.x = (ri * s6(sk1) - rj * s6(sk)) / det;
+      g.y = (c6(sk) * rj - c6(sk1) * ri) / det;
+    }
+    T.c[lane][0] = static_cast<float>(g.x);
+    T.c[lane][1] = static_cast<float>(g.y);
+  }
+  team_publish();
+  // --- geom::BuildPrismShape's emission ---
+  if (valid) {
+    const float zt = 0.5f * h, zb = -0.5f * h;
+    ShapePrism& R = T.rec;
+    // face rows: lane 0 top (number 1), lane 1 bottom (2), lane 2 + i side i (3 + i) at compact id 2 + rank(i)
+    float dn_mine = 0.0f;
+    int fid_mine = -1;
+    if (lane < 8) {
+      const int i = lane - 2;
+      const bool side = lane >= 2;
+      if (!side || ((pmask >> i) & 1u)) {
+        float plane[4], nrm[3];
+        if (!side) {
+          plane[0] = 0.0f, plane[1] = 0.0f, plane[2] = lane == 0 ? 1.0f : -1.0f, plane[3] = -zt;
+          nrm[0] = 0.0f, nrm[1] = 0.0f, nrm[2] = plane[2];
+          fid_mine = lane;
+        } else {
+          nrm[0] = static_cast<float>(c6(i)), nrm[1] = static_cast<float>(s6(i)), nrm[2] = 0.0f;
+          plane[0] = 0.5f * static_cast<float>(c6(i)), plane[1] = 0.5f * static_cast<float>(s6(i)), plane[2] = 0.0f;
+          float di = 0.0f;
+#pragma unroll
+          for (int m = 0; m < 6; m++) di = (m == i) ? sc[3 + m] : di;
+          plane[3] = -static_cast<float>(k_d * static_cast<double>(di));
+          fid_mine = 2 + __popc(pmask & ((1u << i) - 1u));
+        }
+        const float len = sqrtf(plane[0] * plane[0] + plane[1] * plane[1] + plane[2] * plane[2]);   // geom::EmitFace
+        dn_mine = (len > geom::kGeomFloatEps) ? plane[3] / len : 0.0f;
+        R.face[fid_mine][0] = nrm[0];
+        R.face[fid_mine][1] = nrm[1];
+        R.face[fid_mine][2] = nrm[2];
+        R.face[fid_mine][3] = dn_mine;
+        R.face_number[fid_mine] = static_cast<uint8_t>(side ? 3 + i : 1 + lane);
+      }
+    }
+    // fan triangles, in the serial order: top (n - 2), bottom (n - 2), then two per present side
+    const int nb = n - 2, total = 4 * n - 4;
+    for (int t = lane; t < total; t += kPTeam) {
+      float l0[3], l1[3], l2[3];
+      int fid;
+      if (t < 2 * nb) {
+        const bool top = t < nb;
+        const int k = (top ? t : t - nb) + 1;
+        const int i0 = top ? 0 : n - 1, i1 = top ? k : n - 1 - k, i2 = top ? k + 1 : n - 2 - k;
+        const float z = top ? zt : zb;
+        l0[0] = T.c[i0][0], l0[1] = T.c[i0][1], l0[2] = z;
+        l1[0] = T.c[i1][0], l1[1] = T.c[i1][1], l1[2] = z;
+        l2[0] = T.c[i2][0], l2[1] = T.c[i2][1], l2[2] = z;
+        fid = top ? 0 : 1;
+      } else {
+        const int sidx = (t - 2 * nb) >> 1, half = (t - 2 * nb) & 1;
+        const float* a = T.c[(sidx - 1 + n) % n];
+        const float* b = T.c[sidx];
+        // loop = (a, zb), (b, zb), (b, zt), (a, zt); triangles (0, 1, 2) and (0, 2, 3)
+        l0[0] = a[0], l0[1] = a[1], l0[2] = zb;
+        if (half == 0) {
+          l1[0] = b[0], l1[1] = b[1], l1[2] = zb;
+          l2[0] = b[0], l2[1] = b[1], l2[2] = zt;
+        } else {
+          l1[0] = b[0], l1[1] = b[1], l1[2] = zt;
+          l2[0] = a[0], l2[1] = a[1], l2[2] = zt;
+        }
+        fid = 2 + sidx;
+      }
+      float* v = R.tri_v[t];
+      for (int a3 = 0; a3 < 3; a3++) {
+        v[a3] = l0[a3];
+        v[3 + a3] = l1[a3];
+        v[6 + a3] = l2[a3];
+      }
+      const float ea[3] = {l1[0] - l0[0], l1[1] - l0[1], l1[2] - l0[2]};
+      const float eb[3] = {l2[0] - l0[0], l2[1] - l0[1], l2[2] - l0[2]};
+      const float nrm[3] = {-eb[1] * ea[2] + ea[1] * eb[2], eb[0] * ea[2] - ea[0] * eb[2], -eb[0] * ea[1] + ea[0] * eb[1]};  // Cross3 math.cpp:36
+      const float mag = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+      R.tri_na[t][3] = mag / 2.0f;
+      for (int c3 = 0; c3 < 3; c3++) R.tri_na[t][c3] = (mag > 0.0f) ? nrm[c3] / mag : 0.0f;
+      R.tri_face[t] = static_cast<uint8_t>(fid);
+    }
+    // geom::FinalizeSlabs: slab 0 = the basal pair, then sides i < 3 whose opposite i + 3 is present too, in side order; the rest single
+    const uint32_t pair = pmask & (pmask >> 3) & 7u;              // bit i: sides i and i + 3 both present
+    const uint32_t single = pmask & ~(pair | (pair << 3));
+    const float dn_opp = __shfl(dn_mine, (lane + 3) & 15, kPTeam);   // side i + 3 sits in lane i + 5
+    const float dn_bot = __shfl(dn_mine, 1, kPTeam);
+    const int fid_opp = __shfl(fid_mine, (lane + 3) & 15, kPTeam);
+    if (lane == 0) {
+      float* s0 = R.slab[0];
+      s0[0] = 0.0f, s0[1] = 0.0f, s0[2] = 1.0f, s0[3] = dn_mine, s0[4] = dn_bot;
+      reinterpret_cast<uint32_t*>(s0)[5] = 0u;
+      reinterpret_cast<uint32_t*>(s0)[6] = 1u;
+      s0[7] = 0.0f;
+      R.face_cnt = 2 + n;
+      R.tri_cnt = min(total, static_cast<int>(sizeof(R.tri_na) / 16u));
+      R.slab_cnt = 1 + __popc(pair);
+      R.single_cnt = __popc(single);
+    }
+    if (lane >= 2 && lane < 8) {
+      const int i = lane - 2;
+      if (i < 3 && ((pair >> i) & 1u)) {
+        float* sr = R.slab[1 + __popc(pair & ((1u << i) - 1u))];
+        sr[0] = static_cast<float>(c6(i)), sr[1] = static_cast<float>(s6(i)), sr[2] = 0.0f, sr[3] = dn_mine, sr[4] = dn_opp;
+        reinterpret_cast<uint32_t*>(sr)[5] = static_cast<uint32_t>(fid_mine);
+        reinterpret_cast<uint32_t*>(sr)[6] = static_cast<uint32_t>(fid_opp);
+        sr[7] = 0.0f;
+      }
+      if ((single >> i) & 1u) R.single[__popc(single & ((1u << i) - 1u))] = static_cast<uint8_t>(fid_mine);
+    }
+  }
+  team_publish();
+  if (live) {   // the record leaves in 16-byte pieces, 256 contiguous bytes per team and round
+    const float4* src = reinterpret_cast<const float4*>(&T.rec);
+    float4* dst = reinterpret_cast<float4*>(pool + crystal);
+    for (uint32_t i = static_cast<uint32_t>(lane); i < sizeof(ShapePrism) / 16u; i += kPTeam) dst[i] = src[i];
+  }
+}
+
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid) {
   if (n == 0) return hipSuccess;
   const dim3 grid((n + kGenBlock - 1) / kGenBlock), block(kGenBlock);
-  if (prism_records) hipLaunchKernelGGL(halo_shapegen_kernel<ShapePrism>, grid, block, 0, stream, static_cast<ShapePrism*>(pool), n, seed, rc, first_index);
+  if (prism_records && rc.c.kind == HALO_CRYSTAL_PRISM && !serial_pyramid)
+    hipLaunchKernelGGL(halo_prismgen_team_kernel, dim3((n + kPTeamsPerBlock - 1) / kPTeamsPerBlock), dim3(kPTeamBlock), 0, stream, static_cast<ShapePrism*>(pool), n, seed, rc,
+                       first_index);
+  else if (prism_records) hipLaunchKernelGGL(halo_shapegen_kernel<ShapePrism>, grid, block, 0, stream, static_cast<ShapePrism*>(pool), n, seed, rc, first_index);
   else if (rc.c.kind == HALO_CRYSTAL_PYRAMID && !serial_pyramid)
     hipLaunchKernelGGL(halo_pyrgen_team_kernel, dim3((n + kTeamsPerBlock - 1) / kTeamsPerBlock), dim3(kTeamBlock), 0, stream, static_cast<ShapeDev*>(pool), n, seed, rc,
                        first_index);

@@ -402,8 +402,9 @@ int halo_host_pyramid_geometry(float wedge_upper_deg, float wedge_lower_deg, flo
                                const float dist[6], HaloGeomTables* out);
 /* Sample crystal instances [first_index, first_index + n) of `crystal` from the backend's shape-scalar stream
  * (MakeCrystal simulator.cpp:448 + SyncGroupSampler :361-393 + closed-form geometry) into `out[n]`:
- * on_device = 1 runs the device generator the trace path uses for stochastic crystals, 0 the host builder.
- * Both are the same code (csrc/halo_geom.h); the tables are bit-equal whenever the draws involve no libm call
+ * on_device = 1 runs the device generator of the general (4.1 KB) records, 2 — prisms only — the generator of the prism pools' 1360-byte
+ * records (one team of 16 lanes per crystal: what a stochastic-prism trace really runs), 0 the host builder.
+ * All of them are the same geometry (csrc/halo_geom.h); the tables are bit-equal whenever the draws involve no libm call
  * (fixed / uniform distributions) and equal to float rounding otherwise.  Parity-test hook. */
 int halo_generate_shapes(halo_handle_t h, const HaloCrystal* crystal, uint64_t first_index, uint32_t n, int on_device,
                          HaloGeomTables* out);
