@@ -1223,7 +1223,7 @@ HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, 
 template <int MODE, bool MONO, bool SMALLC>
 HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const FilterDev* filter, const ColorDev* color, uint64_t carried, Stream& gate, const float* R, bool live,
                   float lx, float ly, float lz, float w, float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, uint32_t root, uint32_t seq,
-                  const PathView& pv, uint32_t uni_len, bool odd_lane, RaySums& sums, Probe& pr) {
+                  const PathView& pv, uint32_t uni_len, RaySums& sums, Probe& pr) {
   // `live`: this lane has an outgoing candidate.  Kernels with an exit queue call this with every lane of the interaction loop
   // (the push is a wave-wide step); the others branch around it here.
   const bool queued = ModeTraits<MODE>::kFast && cache.q != nullptr;
@@ -1239,21 +1239,11 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   uint64_t cmask = carried;
   if (ModeTraits<MODE>::kTables && color != nullptr) cmask = color_bits(*color, carried, pv, wx, wy, wz, P.crystal_id);
   if constexpr (ModeTraits<MODE>::kFastPath) {
-    // every lane of this interaction has recorded uni_len faces — except a stray (one fewer): evaluated by a second call that the
-    // wave takes only when it holds one
+    // every lane of this interaction has recorded uni_len faces (a stray lane emits where it strays, before its path would differ)
     FastTablesC& F = *cache.fast;
     const FastHdr fh = load_fast_hdr(F);
-    const uint64_t odd = __ballot(live && odd_lane);
-    const uint64_t len_mode = fh.len_mode;   // (has_filter = 0 comes as "every length passes")
-    bool ok = fast_filter(F, cache.fast_ee, fh, static_cast<uint32_t>(len_mode >> (2u * uni_len)) & 3u, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
+    const bool ok = fast_filter(F, cache.fast_ee, fh, static_cast<uint32_t>(fh.len_mode >> (2u * uni_len)) & 3u, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
     if (MODE == kModeColor) cmask = fast_color_bits(F, cache.fast_ee, carried, uni_len, pv.reg, wx, wy, wz, P.crystal_id);
-    if (odd != 0ull) {
-      const bool ok2 = fast_filter(F, cache.fast_ee, fh, static_cast<uint32_t>(len_mode >> (2u * (uni_len - 1u))) & 3u, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
-      uint64_t cm2 = carried;
-      if (MODE == kModeColor) cm2 = fast_color_bits(F, cache.fast_ee, carried, uni_len - 1u, pv.reg, wx, wy, wz, P.crystal_id);
-      ok = odd_lane ? ok2 : ok;
-      cmask = odd_lane ? cm2 : cmask;
-    }
     live = live && ok;
     if (!queued && !live) return;
   }
@@ -1641,8 +1631,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     pv.len = 1u;
   }
 
-  bool stray = false, done = false;
-  uint32_t stray_seq = 0u;
+  bool done = false;
   float hex_d_basal = 0.0f, hex_d_side = 0.0f;
   if constexpr (HEX) {
     hex_d_basal = T.efast.hex_d_basal;
@@ -1650,45 +1639,80 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   }
   const bool queued = ModeTraits<MODE>::kFast && acc.q != nullptr;
   if (queued) sums.qn = acc.q->n;   // parked there between passes (ExitQueue)
-  for (uint32_t i = 0u; i < P.max_hits; ++i) {
-    // --- Fresnel split at `face` (HitSurface optics.cpp:18-53) ---
-    const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
-    const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
-    const float rr = cos_t > 0.0f ? n_idx : inv_n;
-    const float dd = (1.0f - rr * rr) * fast_rcp(cos_t * cos_t) + rr * rr;
-    const bool tir = dd <= 0.0f;
+  // Fresnel split for relative index rr (HitSurface optics.cpp:18-53): reflected / refracted directions and weights
+  struct Split {
+    float rl[3], rf[3], w_refl, w_refr;
+    bool tir;
+  };
+  auto fresnel = [&](float cos_t, float rr, float rr2, float one_m_rr2, const float4& fn) {
+    Split o;
+    const float dd = one_m_rr2 * fast_rcp(cos_t * cos_t) + rr2;
+    o.tir = dd <= 0.0f;
     const float sq = fast_sqrt(fmaxf(dd, 0.0f));
     float Rs = (rr - sq) * fast_rcp(rr + sq);
     Rs *= Rs;
     float Rp = (1.0f - rr * sq) * fast_rcp(1.0f + rr * sq);
     Rp *= Rp;
-    const float w_refl = (Rs + Rp) * 0.5f * w;
-    const float w_refr = w - w_refl;
+    o.w_refl = (Rs + Rp) * 0.5f * w;
+    o.w_refr = w - o.w_refl;
     const float k_refl = 2.0f * cos_t;
     const float k_refr = (rr - sq) * cos_t;
-    const float rlx = d[0] - k_refl * fn.x, rly = d[1] - k_refl * fn.y, rlz = d[2] - k_refl * fn.z;
-    const float rfx = rr * d[0] - k_refr * fn.x, rfy = rr * d[1] - k_refr * fn.y, rfz = rr * d[2] - k_refr * fn.z;
-    // On a convex body exactly one child stays inside: the refracted one when entering (cos<0), the reflected
-    // one otherwise; the other child leaves through `face` and is the outgoing candidate.
-    const bool entering = cos_t < 0.0f;
-    const bool has_exit = entering || !tir;
+    o.rl[0] = d[0] - k_refl * fn.x, o.rl[1] = d[1] - k_refl * fn.y, o.rl[2] = d[2] - k_refl * fn.z;
+    o.rf[0] = rr * d[0] - k_refr * fn.x, o.rf[1] = rr * d[1] - k_refr * fn.y, o.rf[2] = rr * d[2] - k_refr * fn.z;
+    return o;
+  };
+  const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
+  for (uint32_t i = 0u; i < P.max_hits; ++i) {
+    // --- Fresnel split at `face` ---
+    const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
+    const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
+    // On a convex body exactly one child stays inside: the refracted one when entering (cos < 0), the reflected one otherwise; the other
+    // child leaves through `face` and is the outgoing candidate.  A ray ENTERS at most once, at its first interaction: every later face
+    // was picked by the search below with n.d > eps, i.e. it is hit from inside.  So only the first turn of the loop (a wave-uniform
+    // branch) carries the selects between the two cases; the others know the refracted child leaves, the reflected one stays and the
+    // relative index is n — eight v_cndmask (1.6x the cost of an FMA on this part, tools/valu_rate_bench) and the rr arithmetic less.
+    float ex[3], in[3], ex_w, in_w;
+    uint32_t ex_seq, in_seq;
+    bool has_exit;
+    if (i == 0u) {
+      const bool entering = cos_t < 0.0f;
+      const float rr = cos_t > 0.0f ? n_idx : inv_n;
+      const Split sp = fresnel(cos_t, rr, rr * rr, 1.0f - rr * rr, fn);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        ex[a] = entering ? sp.rl[a] : sp.rf[a];
+        in[a] = entering ? sp.rf[a] : sp.rl[a];
+      }
+      ex_w = entering ? sp.w_refl : sp.w_refr;
+      in_w = entering ? sp.w_refr : sp.w_refl;
+      ex_seq = entering ? 0u : 1u;
+      in_seq = entering ? 1u : 0u;
+      has_exit = entering || !sp.tir;
+    } else {
+      const Split sp = fresnel(cos_t, n_idx, n2, one_m_n2, fn);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        ex[a] = sp.rf[a];
+        in[a] = sp.rl[a];
+      }
+      ex_w = sp.w_refr;
+      in_w = sp.w_refl;
+      ex_seq = 2u * i + 1u;
+      in_seq = 2u * i;
+      has_exit = !sp.tir;
+    }
     PROBE_MARK(pr, kPhFresnel);
-    // A ray that found no face ahead in the previous interaction (`stray`, below) has its turn at the emit site now, as it is,
-    // and then idles to the end of the loop: the loop body holds ONE copy of the emit code, and every lane that entered the
-    // loop is still there at every emit (the exit queue's push is a wave-wide step).
-    const bool live = !done && (stray || has_exit);
-    emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, live, stray ? d[0] : (entering ? rlx : rfx), stray ? d[1] : (entering ? rly : rfy),
-                                  stray ? d[2] : (entering ? rlz : rfz), stray ? w : (entering ? w_refl : w_refr), cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid,
-                                  stray ? stray_seq : 2u * i + (entering ? 0u : 1u), pv, i + 1u, stray, sums, pr);
+    // every lane that entered the loop is still here at every emit (the exit queue's push is a wave-wide step): `live` says who has a candidate
+    emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, !done && has_exit, ex[0], ex[1], ex[2], ex_w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, ex_seq, pv,
+                                  i + 1u, sums, pr);
     PROBE_MARK(pr, kPhEmitGate);
-    done = done || stray;
     if (i + 1u == P.max_hits) break;
     if (!queued && done) break;
-    const uint32_t inward_seq = 2u * i + (entering ? 1u : 0u);
-    d[0] = entering ? rfx : rlx;
-    d[1] = entering ? rfy : rly;
-    d[2] = entering ? rfz : rlz;
-    w = entering ? w_refr : w_refl;
+    const uint32_t inward_seq = in_seq;
+    d[0] = in[0];
+    d[1] = in[1];
+    d[2] = in[2];
+    w = in_w;
     // --- next face on the convex body (PropagateSlab optics.cpp:64-158) ---
     // min over candidate faces of t = num/den (den > eps > 0) without dividing: num_i/den_i < num_b/den_b
     // <=> num_i*den_b < num_b*den_i.  One reciprocal at the end.
@@ -1747,13 +1771,19 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     }
     }
     const float t_best = num_b * fast_rcp(den_b);
-    if (!done && (hit < 0 || t_best <= -kSlabEps)) {
-      // no face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678) — emitted by the
-      // next turn of the loop
-      stray = true;
-      stray_seq = inward_seq;
+    // No face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678).  Rare — a wave holds such a lane
+    // once in thousands of passes — so it does not ride through the loop's emit site as a special case (selects on every operand of every
+    // emit): the wave branches here when it has one, and the lane's exit goes out at once through the plain emit (filter, gate,
+    // projection and accumulation at the site, no queue), with the path it has recorded so far.
+    const bool stray = !done && (hit < 0 || t_best <= -kSlabEps);
+    if (__ballot(stray) != 0ull) {
+      AccCtx<MONO, SMALLC> direct = acc;
+      direct.q = nullptr;
+      emit_gate<MODE, MONO, SMALLC>(P, direct, filter, color, carried, gate, R, stray, d[0], d[1], d[2], w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, inward_seq, pv, i + 1u,
+                                    sums, pr);
+      done = done || stray;
     }
-    if (!stray) {
+    if (!done) {
       p[0] += t_best * d[0];
       p[1] += t_best * d[1];
       p[2] += t_best * d[2];
