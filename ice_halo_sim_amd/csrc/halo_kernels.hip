@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
                                                                         uint32_t tiles_log2, uint32_t s_log2) {
   constexpr uint32_t kTileLog2 = CH == 3u ? 12u : 14u;
   __shared__ __attribute__((aligned(16))) double acc[CH][1u << kTileLog2];   // fp64: see halo_bin_accumulate_kernel
-  __shared__ float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][3];
+  __shared__ __attribute__((aligned(16))) float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][4];   // rows of 16 bytes: one LDS read per record
   const uint32_t tile = blockIdx.x;   // plane << tiles_log2 | tile of that plane (CH = 1: the scalar planes of a per-entry-plane session lie back to back)
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
@@ -280,6 +280,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
       s_cmf[j][0] = unit ? (j == pool_size ? 1.0f : 0.0f) : pool[j].cmf_x;
       s_cmf[j][1] = unit ? (j == pool_size + 1u ? 1.0f : 0.0f) : pool[j].cmf_y;
       s_cmf[j][2] = unit ? (j == pool_size + 2u ? 1.0f : 0.0f) : pool[j].cmf_z;
+      s_cmf[j][3] = 0.0f;
     }
   }
   __syncthreads();
@@ -291,14 +292,16 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
     const double w = static_cast<double>(__uint_as_float(h.y));
     if constexpr (CH == 3u) {
       const uint32_t code = h.x >> kLogWlShift;
-      const float cx = s_cmf[code][0], cy = s_cmf[code][1], cz = s_cmf[code][2];
-      if (cx != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(cx) * w);
-      if (cy != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(cy) * w);
-      if (cz != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(cz) * w);
+      const float4 c4 = *reinterpret_cast<const float4*>(s_cmf[code]);
+      if (c4.x != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(c4.x) * w);
+      if (c4.y != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(c4.y) * w);
+      if (c4.z != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(c4.z) * w);
     } else {
       unsafeAtomicAdd(&acc[0][s], w);
     }
   };
+  // (Requesting the next batch before this one is added — the pass sits at s_waitcnt for 60 % of its wave cycles — changes nothing:
+  // 1.00 -> 1.03 ms per 137 M records at configs[4].  What it waits for is the LDS)
   uint32_t i = threadIdx.x;
   for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
     uint2 h[kU];

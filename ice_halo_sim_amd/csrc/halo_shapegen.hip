@@ -76,6 +76,14 @@ __device__ __forceinline__ void team_publish() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+// sqrt(d2) <= lim, as the serial builders evaluate it — but the fp64 square root (a long software sequence on this part) only when d2 is
+// within a few ulps of lim^2, where its rounding could decide; everywhere else the comparison of the squares gives the same answer.
+__device__ __forceinline__ bool within(double d2, double lim) {
+  const double l2 = lim * lim;
+  if (d2 > l2 * (1.0 + 1e-12)) return false;
+  if (d2 < l2 * (1.0 - 1e-12)) return true;
+  return sqrt(d2) <= lim;
+}
 __device__ __forceinline__ double team_max(double v) {
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
@@ -218,11 +226,11 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       bool dup = false;
       if (lane < nv) {
         const double dx = k0[0] - cx, dy = k0[1] - cy, dz = k0[2] - cz;
-        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = true;
+        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) dup = true;
       }
       if (lane + kTeam < nv) {
         const double dx = k1[0] - cx, dy = k1[1] - cy, dz = k1[2] - cz;
-        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = true;
+        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) dup = true;
       }
       if (team_ballot(dup) == 0u && nv < geom::kPyrMaxVerts) {
         if (lane == (nv & (kTeam - 1))) {
@@ -444,7 +452,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
     const int src = mine_left ? __ffs(todo) - 1 : 0;
     todo &= todo - 1u;
     const double cx = pteam_bcast(q.x, src), cy = pteam_bcast(q.y, src);
-    const bool dup = mine_left && lane < nc && sqrt((kx - cx) * (kx - cx) + (ky - cy) * (ky - cy)) <= tol;
+    const bool dup = mine_left && lane < nc && within((kx - cx) * (kx - cx) + (ky - cy) * (ky - cy), tol);
     if (mine_left && pteam_ballot(dup) == 0u && nc < 12) {
       if (lane == nc) {
         kx = cx;
