@@ -5,6 +5,16 @@
 
 namespace halo {
 
+// Tile sums in 32.32 fixed point.  An fp64 LDS add is the slow kind here (tools/lds_atomic_bench.hip: ds_add_f64 1.5 T adds/s, ds_add_u64
+// 2.9 T), and these passes are LDS-bound (the index unit ~70 % busy, profiles/r03_bench4_pmc_lds.txt) — so a record's weight becomes a
+// 64-bit integer, weight x 2^32 truncated: resolution 2.3e-10 (the lightest exits that matter carry ~1e-7), range 2.1e9 per slot and launch
+// (a launch is at most 2^32 rays of weight <= 1, spread over the slots), and integer sums do not depend on the order of the adds.
+__device__ __forceinline__ long long fix32(float v) {   // v >= 0 (weights); exact below 2^31, saturating above
+  const float c = fminf(v, 2147483520.0f);
+  return static_cast<long long>(static_cast<double>(c) * 4294967296.0);
+}
+__device__ __forceinline__ float unfix32(long long a) { return static_cast<float>(static_cast<double>(a) * (1.0 / 4294967296.0)); }
+
 // kBinSplit workgroups per image tile: each sums its share of the tile's hit list in a 64 KB LDS tile (8 independent
 // loads in flight per thread — the loop is load-latency-bound otherwise) and adds the non-zero slots to the plane.
 constexpr int kBinBlock = 1024;
@@ -14,13 +24,13 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* _
   // fp64 sums, and not for precision: on gfx950 ds_add_f32 retires ~0.3 lanes per clock per CU (200 G adds/s chip-wide) while
   // ds_add_f64 runs at 1500 G/s and ds_add_u32 at 4600 G/s (tools/lds_atomic_bench.hip) — the fp32 LDS atomic is the slow one,
   // and this pass is one LDS add per hit.  128 KB of the CU's 160 KB: one workgroup of 16 waves per CU.
-  __shared__ double acc[1u << kBinTileLog2];
+  __shared__ unsigned long long acc[1u << kBinTileLog2];   // 32.32 fixed point (fix32)
   const uint32_t tile = blockIdx.x / kBinSplit, part = blockIdx.x % kBinSplit;
   const uint32_t n = min(cnt[tile * kBinCntStride], cap);
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kBinSplit);
   const uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n) * (part + 1u) / kBinSplit);
   if (hi <= lo) return;
-  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0.0;
+  for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) acc[j] = 0ull;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
   constexpr uint32_t kU = 8u;
@@ -30,15 +40,15 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* _
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x >> tiles_log2], static_cast<double>(__uint_as_float(h[u].y)));
+    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x >> tiles_log2], static_cast<unsigned long long>(fix32(__uint_as_float(h[u].y))));
   }
   for (; i < hi; i += kBinBlock) {
     const uint2 h = src[i];
-    unsafeAtomicAdd(&acc[h.x >> tiles_log2], static_cast<double>(__uint_as_float(h.y)));
+    atomicAdd(&acc[h.x >> tiles_log2], static_cast<unsigned long long>(fix32(__uint_as_float(h.y))));
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) {
-    const float v = static_cast<float>(acc[j]);
+    const float v = unfix32(static_cast<long long>(acc[j]));
     if (v != 0.0f) atomic_add_f32(plane + ((static_cast<size_t>(j) << tiles_log2) | tile), v);
   }
 }
@@ -213,12 +223,12 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
 // atomics of the trace / split kernels are ordered before it on the stream).
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
                                                                                const uint32_t* __restrict__ cnt, uint32_t tile_log2) {
-  __shared__ __attribute__((aligned(16))) double acc[1u << kBinTileLog2];   // fp64: see halo_bin_accumulate_kernel; tile_log2 <= kBinTileLog2
+  __shared__ __attribute__((aligned(16))) unsigned long long acc[1u << kBinTileLog2];   // 32.32 fixed point (fix32); tile_log2 <= kBinTileLog2
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
   const uint32_t slots = 1u << tile_log2, mask = slots - 1u;
-  for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[j] = 0.0;
+  for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[j] = 0ull;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
   constexpr uint32_t kU = 4u;
@@ -228,17 +238,17 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) unsafeAtomicAdd(&acc[h[u].x & mask], static_cast<double>(__uint_as_float(h[u].y)));
+    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x & mask], static_cast<unsigned long long>(fix32(__uint_as_float(h[u].y))));
   }
   for (; i < n; i += kBinBlock) {
     const uint2 h = src[i];
-    unsafeAtomicAdd(&acc[h.x & mask], static_cast<double>(__uint_as_float(h.y)));
+    atomicAdd(&acc[h.x & mask], static_cast<unsigned long long>(fix32(__uint_as_float(h.y))));
   }
   __syncthreads();
   float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << tile_log2));
   for (uint32_t j = threadIdx.x; j < slots / 4u; j += kBinBlock) {
-    const float4 v = make_float4(static_cast<float>(acc[4u * j]), static_cast<float>(acc[4u * j + 1u]), static_cast<float>(acc[4u * j + 2u]),
-                                 static_cast<float>(acc[4u * j + 3u]));
+    const float4 v = make_float4(unfix32(static_cast<long long>(acc[4u * j])), unfix32(static_cast<long long>(acc[4u * j + 1u])),
+                                 unfix32(static_cast<long long>(acc[4u * j + 2u])), unfix32(static_cast<long long>(acc[4u * j + 3u])));
     if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
       float4 q = dst[j];
       q.x += v.x;
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
                                                                         const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
                                                                         uint32_t tiles_log2, uint32_t s_log2) {
   constexpr uint32_t kTileLog2 = CH == 3u ? 12u : 14u;
-  __shared__ __attribute__((aligned(16))) double acc[CH][1u << kTileLog2];   // fp64: see halo_bin_accumulate_kernel
+  __shared__ __attribute__((aligned(16))) unsigned long long acc[CH][1u << kTileLog2];   // 32.32 fixed point (fix32)
   __shared__ __attribute__((aligned(16))) float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][4];   // rows of 16 bytes: one LDS read per record
   const uint32_t tile = blockIdx.x;   // plane << tiles_log2 | tile of that plane (CH = 1: the scalar planes of a per-entry-plane session lie back to back)
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   const uint32_t tile_in = tile & ((1u << tiles_log2) - 1u), plane_of_tile = tile >> tiles_log2, in_plane = (1u << (s_log2 + 10u)) - 1u;
   const uint32_t slots = 1u << (s_log2 + 10u - tiles_log2);   // <= 1 << kTileLog2
   for (uint32_t c = 0; c < CH; ++c)
-    for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[c][j] = 0.0;
+    for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[c][j] = 0ull;
   if constexpr (CH == 3u) {
     for (uint32_t j = threadIdx.x; j < pool_size + 3u; j += kBinBlock) {
       const bool unit = j >= pool_size;
@@ -285,37 +295,58 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   }
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
-  constexpr uint32_t kU = 4u, kSlotMask = CH == 3u ? (1u << kLogWlShift) - 1u : 0xFFFFFFFFu;
+  constexpr uint32_t kU = CH == 3u ? 8u : 4u, kSlotMask = CH == 3u ? (1u << kLogWlShift) - 1u : 0xFFFFFFFFu;
   auto add = [&](uint2 h) {
     uint32_t t_unused, s;
     map.split(h.x & kSlotMask & in_plane, t_unused, s);
-    const double w = static_cast<double>(__uint_as_float(h.y));
+    const float w = __uint_as_float(h.y);
     if constexpr (CH == 3u) {
       const uint32_t code = h.x >> kLogWlShift;
       const float4 c4 = *reinterpret_cast<const float4*>(s_cmf[code]);
-      if (c4.x != 0.0f) unsafeAtomicAdd(&acc[0][s], static_cast<double>(c4.x) * w);
-      if (c4.y != 0.0f) unsafeAtomicAdd(&acc[1][s], static_cast<double>(c4.y) * w);
-      if (c4.z != 0.0f) unsafeAtomicAdd(&acc[2][s], static_cast<double>(c4.z) * w);
+      if (c4.x != 0.0f) atomicAdd(&acc[0][s], static_cast<unsigned long long>(fix32(c4.x * w)));
+      if (c4.y != 0.0f) atomicAdd(&acc[1][s], static_cast<unsigned long long>(fix32(c4.y * w)));
+      if (c4.z != 0.0f) atomicAdd(&acc[2][s], static_cast<unsigned long long>(fix32(c4.z * w)));
     } else {
-      unsafeAtomicAdd(&acc[0][s], w);
+      atomicAdd(&acc[0][s], static_cast<unsigned long long>(fix32(w)));
     }
   };
-  // (Requesting the next batch before this one is added — the pass sits at s_waitcnt for 60 % of its wave cycles — changes nothing:
-  // 1.00 -> 1.03 ms per 137 M records at configs[4].  What it waits for is the LDS)
+  // Where the time goes (configs[4], 137 M records, 1.00 ms): without the adds the pass takes 0.27 ms, without the write-out 0.94 — the
+  // three fp64 LDS adds per record are 0.67 ms, 41 % of the rate tools/lds_atomic_bench.hip reaches, with the LDS index unit busy 13 % of the
+  // time (SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES, profiles/r03_bench4_pmc_lds.txt): a latency chain, not a throughput limit.  One workgroup per
+  // CU (96 KB of tiles) is four waves per SIMD, and each record was its own chain: CMF row read from LDS -> wait -> three adds.  So a batch's
+  // rows are all requested first, then its adds issued back to back.  (Requesting the next batch's global loads early changes nothing.)
   uint32_t i = threadIdx.x;
   for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
     uint2 h[kU];
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
+    if constexpr (CH == 3u) {
+      float4 c4[kU];
+      uint32_t sl[kU];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) add(h[u]);
+      for (uint32_t u = 0; u < kU; ++u) {
+        uint32_t t_unused;
+        map.split(h[u].x & kSlotMask & in_plane, t_unused, sl[u]);
+        c4[u] = *reinterpret_cast<const float4*>(s_cmf[h[u].x >> kLogWlShift]);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kU; ++u) {
+        const float w = __uint_as_float(h[u].y);
+        if (c4[u].x != 0.0f) atomicAdd(&acc[0][sl[u]], static_cast<unsigned long long>(fix32(c4[u].x * w)));
+        if (c4[u].y != 0.0f) atomicAdd(&acc[1][sl[u]], static_cast<unsigned long long>(fix32(c4[u].y * w)));
+        if (c4[u].z != 0.0f) atomicAdd(&acc[2][sl[u]], static_cast<unsigned long long>(fix32(c4[u].z * w)));
+      }
+    } else {
+#pragma unroll
+      for (uint32_t u = 0; u < kU; ++u) add(h[u]);
+    }
   }
   for (; i < n; i += kBinBlock) add(src[i]);
   __syncthreads();
   for (uint32_t c = 0; c < CH; ++c) {
     float* dst = planes + static_cast<size_t>(c) * plane_stride + (static_cast<size_t>(plane_of_tile) << (s_log2 + 10u));
     for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) {
-      const float v = static_cast<float>(acc[c][j]);
+      const float v = unfix32(static_cast<long long>(acc[c][j]));
       if (v != 0.0f) dst[map.slot_of(tile_in, j)] += v;
     }
   }
