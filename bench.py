@@ -99,7 +99,36 @@ def workload(cfg):
                     kernel=kern, metric="rays/sec (whole node), stochastic-geometry crystal, 31 wavelengths")
     if cfg.startswith("ref:"):
         return ref_workload(cfg[4:])
+    if cfg.startswith("filter:"):
+        return filter_workload(cfg[7:])
     raise SystemExit("unknown --config %r" % cfg)
+
+
+FILTER_CASES = ("none", "raypath_P", "entry_exit_PBD", "direction_out", "complex_PBD", "crystal_all_pass")
+
+
+def filter_workload(name):
+    """configs[1] with an emit-gate filter on its crystal entry (the filters of tools/perf_probe.py / tests' _filter_table): what the
+    production filter kernels (kModeFilter) cost next to the plain kernel of the same scene.  `none` = configs[1] itself."""
+    from ice_halo_sim_amd import scenes
+    T = scenes.filter_term
+    table = {"raypath_P": scenes.simple_filter(T("raypath", raypath=[3, 5]), "P"),
+             "entry_exit_PBD": scenes.simple_filter(T("entry_exit", entry=3, exit=5, min_len=2, max_len=4), "PBD"),
+             "direction_out": scenes.simple_filter(T("direction", az=180, el=20, radii=2.0), "", "filter_out"),
+             "complex_PBD": scenes.complex_filter([[T("raypath", raypath=[1, 3, 2])], [T("entry_exit", entry=1), T("crystal", crystal_id=3)],
+                                                   [T("raypath", raypath=[3, 1, 5, 7, 4])]], "PBD"),
+             "crystal_all_pass": scenes.simple_filter(T("crystal", crystal_id=99), "", "filter_out")}
+    if name != "none" and name not in table:
+        raise SystemExit("unknown filter case %r (one of %s)" % (name, ", ".join(FILTER_CASES)))
+    wk = workload("1")
+    col = scenes.column_crystal_entry()
+    col.filter_id = 0 if name == "none" else 1
+    wk.update(scene=scenes.scene([(0.0, [col])], max_hits=7), filters=[] if name == "none" else [table[name]],
+              name="filter:%s — configs[1]'s scene with %s on its crystal entry, " % (name, "no filter" if name == "none" else "the emit-gate filter `%s`" % name) +
+                   "9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
+              kernel="halo_trace_kernel<kModeFilter,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA,UPPER,nogate> + split + per-tile sums" if name != "none" else wk["kernel"],
+              metric="rays/sec, configs[1] under the emit-gate filter %s" % name)
+    return wk
 
 
 REF_SCENES = ("bench_light_single_ms", "ms_multi_crystal", "ms_multi_crystal_complex_filter", "ms_multi_crystal_filtered_bd")
@@ -193,7 +222,7 @@ def pmc_traffic_per_launch(cfg):
     counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (64 B tallied per 128-B
     request), so it is doubled; WRITE_SIZE is uncalibrated and taken as reported.  Sum of the per-dispatch means of the
     group's kernels."""
-    tag = "%s_bench%s" % (PROFILE_ROUND, cfg)
+    tag = "%s_bench%s" % (PROFILE_ROUND, cfg.replace(":", "_"))
     tot, seen = 0.0, False
     for k in GROUP_KERNELS:
         f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE", k), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE", k)
@@ -203,19 +232,66 @@ def pmc_traffic_per_launch(cfg):
     return tot if seen else None
 
 
+def _micro_costs():
+    """SIMD cycles per wave64 instruction from the committed micro-benchmark output (profiles/<round>_micro_valu_rate_bench.txt,
+    tools/valu_rate_bench.hip run on the GPU box): {instruction label: cycles}."""
+    path = os.path.join(ROOT, "profiles", "%s_micro_valu_rate_bench.txt" % PROFILE_ROUND)
+    out = {}
+    if os.path.exists(path):
+        for line in open(path):
+            if "cycles per wave64 instruction" in line:
+                name = line[:38].strip()
+                out[name] = float(line.split("ms")[1].split("cycles")[0])
+    return out
+
+
 def pmc_valu(cfg, rays_per_launch):
-    """VALU occupancy of the trace kernel from the committed PMC passes (per-dispatch means are per counter instance = one
-    shader engine = 32 SIMDs): instructions per 64-ray wave pass from SQ_INSTS_VALU; VALU-active fraction =
-    SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / 32 SIMDs / SQ_BUSY_CYCLES of the same pass — measured cycles, no clock assumed."""
-    insts = _pmc_mean("%s_bench%s_pmc_insts.txt" % (PROFILE_ROUND, cfg), "SQ_INSTS_VALU")
-    cyc = "%s_bench%s_pmc_cycles.txt" % (PROFILE_ROUND, cfg)
+    """Compute-side reading of the trace kernel from the committed PMC passes (per-dispatch means are per counter instance = one shader
+    engine = 8 CUs = 32 SIMDs).
+      issue_frac = sum over instruction classes of (dynamic count x measured cost of the class) / (32 SIMDs x SQ_BUSY_CYCLES): the share of
+        the SIMDs' cycles that the kernel's own VALU instructions need at the rates tools/valu_rate_bench.hip measures on this part (an
+        fp32 FMA is 2.8 cycles per wave64 instruction, a v_cndmask or v_cmp 4.5-4.8, an integer multiply 4.8, a transcendental 8.4) —
+        counts by class from SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / INT32 / INT64 / CVT, the unclassified rest (moves, selects, compares,
+        logic, lane moves) priced at the static mix of the kernel's hot loop.
+      The older figure, SQ_ACTIVE_INST_VALU x 4 / 32 / SQ_BUSY_CYCLES, is kept as valu_active_frac: it charges every instruction four
+        cycles and reads slightly above 1 when the pipe is saturated."""
+    tag = "%s_bench%s" % (PROFILE_ROUND, cfg.replace(":", "_"))
+    insts = _pmc_mean(tag + "_pmc_insts.txt", "SQ_INSTS_VALU")
+    cyc = tag + "_pmc_cycles.txt"
     active, busy, wave = _pmc_mean(cyc, "SQ_ACTIVE_INST_VALU"), _pmc_mean(cyc, "SQ_BUSY_CYCLES"), _pmc_mean(cyc, "SQ_WAVE_CYCLES")
     if not insts or not active or not busy:
         return None
-    return {"valu_active_frac": active * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
-            "waves_per_simd": (wave * 4.0 / busy / 32.0) if wave else None,
-            "note": "valu_active_frac = SQ_ACTIVE_INST_VALU x 4 / 32 SIMDs / SQ_BUSY_CYCLES; values slightly above 1 mean saturated (the x4 assumes 4-cycle issue)",
-            "source": "profiles/%s_bench%s_pmc_{insts,cycles}.txt (counter means over every launch of the kernel in that pass)" % (PROFILE_ROUND, cfg)}
+    out = {"valu_active_frac": active * 4.0 / 32.0 / busy, "valu_insts_per_wave_ray": insts * 32.0 / (rays_per_launch / 64.0),
+           "waves_per_simd": (wave * 4.0 / busy / 32.0) if wave else None,
+           "source": "profiles/%s_pmc_{insts,cycles,classes,wait}.txt (counter means over every launch of the kernel in that pass)" % tag}
+    cls = tag + "_pmc_classes.txt"
+    keys = ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "INT64", "CVT")
+    counts = {k: _pmc_mean(cls, "SQ_INSTS_VALU_" + k) for k in keys}
+    total = _pmc_mean(cls, "SQ_INSTS_VALU")
+    costs = _micro_costs()
+    if total and all(v is not None for v in counts.values()) and costs:
+        c = lambda name, default: costs.get(name, default)
+        fma = c("v_fma_f32", 2.81)
+        price = {"ADD_F32": fma, "MUL_F32": fma, "FMA_F32": fma,
+                 "TRANS_F32": (c("v_rcp_f32", 8.6) + c("v_sqrt_f32", 8.3) + c("v_rsq_f32", 8.2)) / 3.0,
+                 # integer adds / shifts / logic next to integer multiplies, 3 : 1 in the PCG hash that dominates this class
+                 "INT32": 0.75 * c("v_add_u32", 3.2) + 0.25 * c("v_mul_lo_u32", 4.8), "INT64": c("v_mad_u64_u32", 5.9), "CVT": c("v_cvt_i32_f32", 4.2)}
+        # the unclassified instructions, by the static mix of the interaction loop (v_cndmask 27 %, v_cmp 22 %, v_mov 22 %, logic / shifts 19 %, lane moves 10 %)
+        other = 0.27 * c("v_cndmask_b32_e64 (sgpr mask)", 4.45) + 0.22 * c("v_cmp_gt_f32", 4.86) + 0.22 * c("v_mov_b32", 2.65) + \
+            0.19 * c("v_xor_b32", 3.1) + 0.10 * c("v_readlane_b32", 4.56)
+        classified = sum(counts.values())
+        cycles = sum(counts[k] * price[k] for k in keys) + max(total - classified, 0.0) * other
+        out["issue_frac"] = cycles / (32.0 * busy)
+        out["census"] = {k: counts[k] / total for k in keys}
+        out["census"]["other (moves, selects, compares, logic, lane moves)"] = max(total - classified, 0.0) / total
+        out["cost_cycles_per_wave64_instruction"] = dict(price, other=other)
+    w = tag + "_pmc_wait.txt"
+    wa, wi, aa = _pmc_mean(w, "SQ_WAIT_ANY"), _pmc_mean(w, "SQ_WAIT_INST_ANY"), _pmc_mean(w, "SQ_ACTIVE_INST_ANY")
+    wv = _pmc_mean(w, "SQ_WAVE_CYCLES")
+    if wa and wi and aa and wv:
+        out["wave_cycles"] = {"issuing": aa / wv, "ready_but_pipe_busy": wi / wv, "parked_at_waitcnt": wa / wv}
+    out["note"] = "issue_frac ~ 0.9 with ready waves waiting for the pipe a quarter of the time = VALU-issue-bound; valu_active_frac (4 cycles per instruction) reads above 1 then"
+    return out
 
 
 def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):

@@ -172,9 +172,13 @@ struct FastTables {
   // What the filter says about an exit whose path has L faces, two bits per L (bits 2L, 2L+1), folded on the host from everything that
   // is known before the launch — the lengths the path terms can match at all, the dispatch's crystal id: 0 = every such exit fails,
   // 1 = every such exit passes, 2 = evaluate the terms.  (A raypath filter costs nothing at the lengths it cannot match, an all-pass
-  // or all-fail filter nothing at all.)
+  // or all-fail filter nothing at all.)  3 = the filter is ONE direction term (the common "mask the sun" filter): its constants ride in this
+  // header (dir0, radii0), so the whole evaluation is the header's one scalar load and three FMAs.
+  // The first eight dwords are what every emit reads: ONE s_load_dwordx8.
   uint64_t len_mode;
-  uint32_t has_filter, action, term_cnt, color_terms, class_cnt, pad0;
+  uint32_t term_cnt, action;
+  float dir0[3], radii0;
+  uint32_t has_filter, color_terms, class_cnt, pad0;
   uint64_t class_bits[HALO_COLOR_MAX_CLASSES];
   uint32_t class_all[HALO_COLOR_MAX_CLASSES];
   FastTerm fterm[HALO_FILTER_MAX_TERMS + HALO_FILTER_MAX_OR];   // (+ one pass-all term per empty AND-clause)

@@ -371,6 +371,7 @@ bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const
     }
   };
   out.has_filter = out.action = out.term_cnt = out.color_terms = 0;
+  out.dir0[0] = out.dir0[1] = out.dir0[2] = out.radii0 = 0.0f;
   out.len_mode = 0x5555555555555555ull;   // no filter: every length passes
   if (filter != nullptr) {
     const uint8_t sym = static_cast<uint8_t>(filter->symmetry & 7);
@@ -414,7 +415,12 @@ bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const
         }
       }
       if (m != 2 && out.action) m = 1 - m;
+      if (m == 2 && k == 1 && ViewTerm(out.fterm[0]).type == HALO_FILTER_DIRECTION) m = 3;   // one direction term: evaluated from the header
       out.len_mode |= static_cast<uint64_t>(m) << (2 * L);
+    }
+    if (k == 1 && ViewTerm(out.fterm[0]).type == HALO_FILTER_DIRECTION) {
+      for (int a = 0; a < 3; a++) out.dir0[a] = out.fterm[0].dir[a];
+      out.radii0 = out.fterm[0].radii_c;
     }
   }
   if (colors != nullptr) {
@@ -433,6 +439,10 @@ bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t L, const
     lo = (lo << 8) | path[i];
   }
   const uint32_t lm = static_cast<uint32_t>(F.len_mode >> (2 * L)) & 3u;
+  if (lm == 3u) {
+    const bool m = F.dir0[0] * dir[0] + F.dir0[1] * dir[1] + F.dir0[2] * dir[2] > F.radii0;
+    return F.action == 0u ? m : !m;
+  }
   if (lm != 2u) return lm == 1u;
   auto term = [&](const FastTerm& raw) {
     const FastTermView t = ViewTerm(raw);

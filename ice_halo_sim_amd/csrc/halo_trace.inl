@@ -980,35 +980,44 @@ HD bool fast_term(FastTablesC& F, const uint32_t* ee_lds, const FastTermS& t, ui
   return false;
 }
 
-// The filter's header and its first term: four scalar loads issued together at the emit site, one wait.  Measured alternatives, 10 M rays,
-// plain kernel 0.70 ms — all-pass crystal filter / one-term direction filter / 3-clause complex filter: this form 0.785 / 0.839 / 0.981 ms;
+// The filter's header: the first eight dwords of FastTables, ONE scalar load at the emit site.  It decides most exits by itself (len_mode:
+// every exit of this length fails / passes; or the filter is one direction term whose constants it carries); only when the terms must be
+// asked does the walk load them (one more load for the first term).  Measured alternatives, 10 M rays, plain kernel 0.70 ms — all-pass
+// crystal filter / one-term direction filter / 3-clause complex filter: header + first term as four loads at the emit 0.785 / 0.839 / 0.981 ms;
 // read once per ray pass and held across the interaction loop 0.811 / 0.863 / 1.027 (13 more live scalar registers: spills); requested at
-// the top of every interaction, ahead of the Fresnel block, with len_mode once per kernel 0.806 / 0.856 / 1.016; field by field where the
-// walk needs them (a scalar-cache round trip each) 0.823 / 0.828 / 1.263; as vector loads through a plain global pointer 0.970 / 0.980 / 1.594.
+// the top of every interaction, ahead of the Fresnel block 0.806 / 0.856 / 1.016; field by field where the walk needs them (a
+// scalar-cache round trip each) 0.823 / 0.828 / 1.263; as vector loads through a plain global pointer 0.970 / 0.980 / 1.594.
 struct FastHdr {
   uint64_t len_mode;
   uint32_t term_cnt, action;
-  FastTermS t0;
+  float dir0[3], radii0;
 };
 HD FastHdr load_fast_hdr(FastTablesC& F) {
+  const u32x8 r = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(&F);
   FastHdr h;
-  h.len_mode = F.len_mode;
-  h.term_cnt = F.term_cnt;
-  h.action = F.action;
-  h.t0 = load_term(&F.fterm[0]);
+  h.len_mode = static_cast<uint64_t>(r[0]) | (static_cast<uint64_t>(r[1]) << 32);
+  h.term_cnt = r[2];
+  h.action = r[3];
+  h.dir0[0] = __uint_as_float(r[4]);
+  h.dir0[1] = __uint_as_float(r[5]);
+  h.dir0[2] = __uint_as_float(r[6]);
+  h.radii0 = __uint_as_float(r[7]);
   return h;
 }
+static_assert(offsetof(FastTables, len_mode) == 0 && offsetof(FastTables, term_cnt) == 8 && offsetof(FastTables, action) == 12 && offsetof(FastTables, dir0) == 16 &&
+              offsetof(FastTables, radii0) == 28, "load_fast_hdr reads the first eight dwords");
 
-// `lm`: what the host already knows about exits of this length (FastTables::len_mode): 0 all fail, 1 all pass, 2 ask the terms
+// `lm`: what the host already knows about exits of this length (FastTables::len_mode): 0 all fail, 1 all pass, 2 ask the terms, 3 one direction term (header)
 HD bool fast_filter(FastTablesC& F, const uint32_t* ee_lds, const FastHdr& H, uint32_t lm, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {
+  if (lm == 3u) {
+    const bool m = H.dir0[0] * wx + H.dir0[1] * wy + H.dir0[2] * wz > H.radii0;   // :226-229
+    return (H.action == 0u) ? m : !m;
+  }
   if (lm != 2u) return lm == 1u;
   // OR over AND-clauses as one flat walk (FastTerm::last closes a clause); every term visited: uniform trip count (:263-291)
   const uint32_t n = H.term_cnt;
-  if (n == 0u) return H.action != 0u;   // an empty complex filter matches nothing
-  bool all = fast_term(F, ee_lds, H.t0, L, reg, wx, wy, wz, crystal_id);
-  bool m = H.t0.last() ? all : false;
-  all = H.t0.last() ? true : all;
-  for (uint32_t k = 1u; k < n; ++k) {
+  bool m = false, all = true;
+  for (uint32_t k = 0u; k < n; ++k) {
     const FastTermS t = load_term(&F.fterm[k]);
     all = fast_term(F, ee_lds, t, L, reg, wx, wy, wz, crystal_id) && all;
     if (t.last()) {
@@ -1016,7 +1025,7 @@ HD bool fast_filter(FastTablesC& F, const uint32_t* ee_lds, const FastHdr& H, ui
       all = true;
     }
   }
-  return (H.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315)
+  return (H.action == 0u) ? m : !m;  // Check = Match XOR filter_out (:308-315); an empty complex filter matches nothing
 }
 
 HD uint64_t fast_color_bits(FastTablesC& F, const uint32_t* ee_lds, uint64_t carried, uint32_t L, Pk128 reg, float wx, float wy, float wz, uint32_t crystal_id) {  // ApplyLayerColorBits cu:498-527

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats of `bench.py --config CFG`, then PMC passes in their own runs
 # (counters are never collected together with trace domains other than --kernel-trace).
 # Output: gpurun_out/prof_<tag>/<round>_bench<cfg>_*.txt — copy the summaries into profiles/.
-#   tools/collect_profiles.sh <round> <cfg> [rays-per-session] [tag]
+#   tools/collect_profiles.sh <round> <cfg> [rays-per-session] [tag]      (cfg may also be filter:<case>)
 # cfg: 1 | 2 | 4 | 4p | ref:<document>; tag names the output files (default <round>_bench<cfg>, ':' dropped)
 set -u
 ROUND=${1:-r03}
