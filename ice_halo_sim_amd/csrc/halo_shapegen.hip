@@ -223,14 +223,17 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       const int src = __ffs(todo) - 1;
       todo &= todo - 1u;
       const double cx = team_bcast(x[0], src), cy = team_bcast(x[1], src), cz = team_bcast(x[2], src);
+      // (the serial builder's box pre-test |d| <= 4 tol per axis is implied by the distance test; this loop runs ~40 times per crystal
+      // and is the largest block of the kernel, so it carries nothing it does not need — and the second kept vertex per lane only once
+      // more than 32 are kept, which the wave decides for both of its teams)
       bool dup = false;
-      if (lane < nv) {
+      {
         const double dx = k0[0] - cx, dy = k0[1] - cy, dz = k0[2] - cz;
-        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) dup = true;
+        dup = lane < nv && within(dx * dx + dy * dy + dz * dz, 2.0 * tol);
       }
-      if (lane + kTeam < nv) {
+      if (__ballot(nv > kTeam) != 0ull) {
         const double dx = k1[0] - cx, dy = k1[1] - cy, dz = k1[2] - cz;
-        if (!(fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) && within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) dup = true;
+        dup = dup || (lane + kTeam < nv && within(dx * dx + dy * dy + dz * dz, 2.0 * tol));
       }
       if (team_ballot(dup) == 0u && nv < geom::kPyrMaxVerts) {
         if (lane == (nv & (kTeam - 1))) {
