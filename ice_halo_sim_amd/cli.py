@@ -16,6 +16,8 @@ from . import config
 from .backend import BackendUnavailableError, HipTraceBackend
 
 DISPATCH_RAYS = 1 << 26  # rays per TraceLayer call (the reference's GPU dispatch is 2^18, server.cpp:151; we batch far larger)
+DISPATCH_RAYS_MULTI = 1 << 24  # ... for scenes with more than one scattering layer: the continuation pools are sized for roots x max_hits,
+                               # and a one-shot CLI run pays for their allocation (64 Mi roots x 8 hits: two pools of 10 GB, 0.5 s of hipMalloc)
 
 
 def run_job(job, render_id=None, seed=42, device=0, max_rays=None, progress=None):
@@ -49,7 +51,7 @@ def run_job(job, render_id=None, seed=42, device=0, max_rays=None, progress=None
     for wl in job.wavelengths:
         left = per_wl
         while left > 0:
-            n = min(left, DISPATCH_RAYS)
+            n = min(left, DISPATCH_RAYS if job.scene.layer_count == 1 else DISPATCH_RAYS_MULTI)
             be.BeginSession(job.scene, render, wl, n)
             for li in range(job.scene.layer_count):
                 be.TraceLayer(n if li == 0 else 0)
