@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Prism pools: one TEAM of 16 lanes builds one crystal (four teams per wave64, sixteen per workgroup), the record assembled in LDS and
+// Prism pools: one TEAM of 8 lanes builds one crystal (eight teams per wave64, sixteen per workgroup), the record assembled in LDS and
 // written out with coalesced 16-byte stores.
 //
 // The serial builder above (one thread per crystal) spent its time waiting: a chain of dependent fp64 steps per lane, 640 B of scratch
@@ -373,95 +373,110 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
 // 3.6x the records' bytes at the memory controller (profiles/r02_bench4_pmc_*), 1.13 ms per 781 K crystals, a fifth of configs[4]'s
 // step.  The same steps across a team (geom::SolveHex / BuildPrismShape / EmitFace / FinalizeSlabs, statement by statement):
 //   scalars     lane q draws scalar q (height, six face distances)                         (geom::DrawShapeScalarOne)
-//   corners     lane t < 12 intersects side pair t and tests it against the other four sides; the feasible ones are then taken IN ORDER
+//   corners     lane t intersects side pairs t and t + 8 (12 in all) and tests them against the other four sides; the feasible ones are then taken IN ORDER
 //               (ballot, lowest lane first), broadcast and tested against the kept corners — the serial duplicate filter, unchanged
 //   sides       lane i < 6 counts the kept corners on side i; ring corner k = lane k's intersection of consecutive present sides
-//   triangles   lane t (and t + 16) builds fan triangle t of the face it belongs to; lanes 0..7 the face rows; lanes 0..2 the slabs
+//   triangles   lane t (and t + 8, t + 16) builds fan triangle t of the face it belongs to; lanes 0..7 the face rows; lanes 2..4 the slabs
 // Every number comes from the same expression on the same operands as on the host (this file is compiled without contraction), so
 // the record is bit-identical to the host builder's (tests/test_gpu_parity.py::test_device_crystal_generator_equals_host_builder).
-constexpr int kPTeam = 16, kPTeamsPerBlock = 16, kPTeamBlock = kPTeam * kPTeamsPerBlock;
+constexpr int kPTeam = 8, kPTeamsPerBlock = 16, kPTeamBlock = kPTeam * kPTeamsPerBlock;   // 128 threads: 16 crystals, 22.8 KB of LDS
 struct PrismTeamLds {
   __attribute__((aligned(16))) ShapePrism rec;
   float c[6][2];   // ring corners (float, as the tables take them)
 };
 __device__ __forceinline__ uint32_t pteam_ballot(bool p) {
   const unsigned long long b = __ballot(p);
-  return static_cast<uint32_t>(b >> (threadIdx.x & 48u)) & 0xFFFFu;
+  return static_cast<uint32_t>(b >> (threadIdx.x & 56u)) & 0xFFu;
 }
 __device__ __forceinline__ double pteam_bcast(double v, int src) { return __shfl(v, src, kPTeam); }
 
 __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePrism* __restrict__ pool, uint32_t n_crystals, uint32_t seed, const geom::CrystalRecipe rc,
                                                                         uint64_t first_index) {
   __shared__ PrismTeamLds s_team[kPTeamsPerBlock];
-  const int lane = static_cast<int>(threadIdx.x & 15u);
-  PrismTeamLds& T = s_team[threadIdx.x >> 4];
-  const uint32_t crystal = blockIdx.x * kPTeamsPerBlock + (threadIdx.x >> 4);
+  const int lane = static_cast<int>(threadIdx.x & 7u);
+  PrismTeamLds& T = s_team[threadIdx.x >> 3];
+  const uint32_t crystal = blockIdx.x * kPTeamsPerBlock + (threadIdx.x >> 3);
   const bool live = crystal < n_crystals;   // team-uniform
   {   // the record starts as zeros (rows beyond the counts are never read, but the pool then holds no stale bytes either)
     float4* z = reinterpret_cast<float4*>(&T.rec);
     for (uint32_t i = static_cast<uint32_t>(lane); i < sizeof(ShapePrism) / 16u; i += kPTeam) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  // --- shape scalars: slots [h, -, -, d0..d5] ---
-  float sc[9];
+  // --- shape scalars: lane 0 draws the height (slot 0), lanes 1..6 the six face distances (slots 3..8) ---
+  float h_raw, dist[6];
   {
-    const float mine = lane < 9 ? geom::DrawShapeScalarOne(seed, rc, first_index + (live ? crystal : 0u), lane) : 0.0f;
+    const float mine = lane < 7 ? geom::DrawShapeScalarOne(seed, rc, first_index + (live ? crystal : 0u), lane == 0 ? 0 : lane + 2) : 0.0f;
+    h_raw = __shfl(mine, 0, kPTeam);
 #pragma unroll
-    for (int q = 0; q < 9; q++) sc[q] = __shfl(mine, q, kPTeam);
+    for (int i = 0; i < 6; i++) dist[i] = __shfl(mine, 1 + i, kPTeam);
   }
-  const float h = fabsf(sc[0]);
+  const float h = fabsf(h_raw);
   bool valid = live && (h > geom::kGeomFloatEps);
   const double k_r = geom::kGeomSqrt3 / 4.0, k_d = geom::kGeomSqrt3 / 8.0;
   double r[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) r[i] = k_r * static_cast<double>(sc[3 + i]);
+  for (int i = 0; i < 6; i++) r[i] = k_r * static_cast<double>(dist[i]);
   // --- geom::SolveHex ---
   double scale = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; i++) scale = fmax(scale, fabs(r[i]));
   const double tol = 5.0 * static_cast<double>(geom::kGeomFloatEps) * scale;
-  // candidate t: the t-th pair i < j, j != i + 3, in the serial loop's order
-  // (pairs (0,1) (0,2) (0,4) (0,5) (1,2) (1,3) (1,5) (2,3) (2,4) (3,4) (3,5) (4,5), a nibble each; the 60-degree tables by selects: a
-  // table indexed by a lane-varying value would live in scratch)
+  // (the 60-degree tables by selects: a table indexed by a lane-varying value would live in scratch)
   auto c6 = [](int i) { return i == 0 ? 1.0 : i == 1 ? 0.5 : i == 2 ? -0.5 : i == 3 ? -1.0 : i == 4 ? -0.5 : 0.5; };
   auto s6 = [](int i) {
     const double sv = 0.86602540378443864676;
     return (i == 1 || i == 2) ? sv : (i == 4 || i == 5) ? -sv : 0.0;
   };
-  geom::Pt2 q{0.0, 0.0};
-  bool feasible = false;
-  if (valid && lane < 12) {
-    const int i = static_cast<int>((0x433221110000ull >> (4 * lane)) & 15ull), j = static_cast<int>((0x554435325421ull >> (4 * lane)) & 15ull);
-    double ri = 0.0, rj = 0.0;
+  auto rsel = [&](int i) {   // r[i] without a private array
+    double v = 0.0;
 #pragma unroll
-    for (int m = 0; m < 6; m++) {   // r[i], r[j] without a private array (dynamic indexing would put r[] in scratch)
-      ri = (m == i) ? r[m] : ri;
-      rj = (m == j) ? r[m] : rj;
+    for (int m = 0; m < 6; m++) v = (m == i) ? r[m] : v;
+    return v;
+  };
+  // candidate t: the t-th pair i < j, j != i + 3, in the serial loop's order: (0,1) (0,2) (0,4) (0,5) (1,2) (1,3) (1,5) (2,3) (2,4) (3,4) (3,5) (4,5),
+  // a nibble each; lane t takes candidates t and t + 8
+  geom::Pt2 q[2] = {{0.0, 0.0}, {0.0, 0.0}};
+  bool feasible[2] = {false, false};
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    const int t = lane + 8 * round;
+    if (valid && t < 12) {
+      const int i = static_cast<int>((0x433221110000ull >> (4 * t)) & 15ull), j = static_cast<int>((0x554435325421ull >> (4 * t)) & 15ull);
+      const double ri = rsel(i), rj = rsel(j);
+      const double det = c6(i) * s6(j) - s6(i) * c6(j);   // geom::Meet (never 0 for these pairs)
+      q[round].x = (ri * s6(j) - rj * s6(i)) / det;
+      q[round].y = (c6(i) * rj - c6(j) * ri) / det;
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < 6; m++)
+        if (m != i && m != j && geom::Cos6(m) * q[round].x + geom::Sin6(m) * q[round].y > r[m] + tol) ok = false;
+      feasible[round] = ok;
     }
-    const double det = c6(i) * s6(j) - s6(i) * c6(j);   // geom::Meet (never 0 for these pairs)
-    q.x = (ri * s6(j) - rj * s6(i)) / det;
-    q.y = (c6(i) * rj - c6(j) * ri) / det;
-    bool ok = true;
-#pragma unroll
-    for (int m = 0; m < 6; m++)
-      if (m != i && m != j && geom::Cos6(m) * q.x + geom::Sin6(m) * q.y > r[m] + tol) ok = false;
-    feasible = ok;
   }
-  // kept corners: lane c holds corner c (at most 12); the feasible candidates join in the serial order
+  // kept corners: lane c holds corners c and c + 8 (at most 12); the feasible candidates join in the serial order
   int nc = 0;
-  double kx = 0.0, ky = 0.0;
-  uint32_t todo = pteam_ballot(feasible);
-  while (__ballot(todo != 0u) != 0ull) {   // (the four teams of a wave may differ: the loop runs for the longest list)
-    const bool mine_left = todo != 0u;
-    const int src = mine_left ? __ffs(todo) - 1 : 0;
-    todo &= todo - 1u;
-    const double cx = pteam_bcast(q.x, src), cy = pteam_bcast(q.y, src);
-    const bool dup = mine_left && lane < nc && within((kx - cx) * (kx - cx) + (ky - cy) * (ky - cy), tol);
-    if (mine_left && pteam_ballot(dup) == 0u && nc < 12) {
-      if (lane == nc) {
-        kx = cx;
-        ky = cy;
+  double kx[2] = {0.0, 0.0}, ky[2] = {0.0, 0.0};
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    uint32_t todo = pteam_ballot(feasible[round]);
+    while (__ballot(todo != 0u) != 0ull) {   // (the eight teams of a wave may differ: the loop runs for the longest list)
+      const bool mine_left = todo != 0u;
+      const int src = mine_left ? __ffs(todo) - 1 : 0;
+      todo &= todo - 1u;
+      const double cx = pteam_bcast(q[round].x, src), cy = pteam_bcast(q[round].y, src);
+      const bool dup = mine_left && ((lane < nc && within((kx[0] - cx) * (kx[0] - cx) + (ky[0] - cy) * (ky[0] - cy), tol)) ||
+                                     (lane + kPTeam < nc && within((kx[1] - cx) * (kx[1] - cx) + (ky[1] - cy) * (ky[1] - cy), tol)));
+      if (mine_left && pteam_ballot(dup) == 0u && nc < 12) {
+        if (lane == (nc & (kPTeam - 1))) {
+          if (nc < kPTeam) {
+            kx[0] = cx;
+            ky[0] = cy;
+          } else {
+            kx[1] = cx;
+            ky[1] = cy;
+          }
+        }
+        nc++;
       }
-      nc++;
     }
   }
   // a side is present iff at least two kept corners sit on it
@@ -469,16 +484,11 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
   {
     int nc_max = nc;
 #pragma unroll
-    for (int off = 16; off < 64; off <<= 1) nc_max = max(nc_max, __shfl_xor(nc_max, off));   // uniform trip count over the wave's teams
-    double ci = 0.0, si = 0.0, rr = 0.0;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      ci = (m == lane) ? geom::Cos6(m) : ci;
-      si = (m == lane) ? geom::Sin6(m) : si;
-      rr = (m == lane) ? r[m] : rr;
-    }
+    for (int off = 8; off < 64; off <<= 1) nc_max = max(nc_max, __shfl_xor(nc_max, off));   // uniform trip count over the wave's teams
+    const double ci = c6(lane), si = s6(lane), rr = rsel(lane);   // (lanes 6, 7: unused values)
     for (int c = 0; c < nc_max; c++) {
-      const double cx = pteam_bcast(kx, c), cy = pteam_bcast(ky, c);
+      const double cx = c < kPTeam ? pteam_bcast(kx[0], c) : pteam_bcast(kx[1], c - kPTeam);
+      const double cy = c < kPTeam ? pteam_bcast(ky[0], c) : pteam_bcast(ky[1], c - kPTeam);
       if (c < nc && lane < 6 && fabs(ci * cx + si * cy - rr) <= tol) on++;
     }
   }
@@ -495,12 +505,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
   const bool bounded = n >= 3 && pteam_ballot(opp) == 0u;
   valid = valid && bounded;   // (n < 3 or unbounded: the empty crystal, counts stay 0)
   if (valid && lane < n) {    // ring corner k: consecutive present sides meet
-    double ri = 0.0, rj = 0.0;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      ri = (m == sk) ? r[m] : ri;
-      rj = (m == sk1) ? r[m] : rj;
-    }
+    const double ri = rsel(sk), rj = rsel(sk1);
     const double det = c6(sk) * s6(sk1) - s6(sk) * c6(sk1);
     geom::Pt2 g{0.0, 0.0};
     if (det != 0.0) {
@@ -518,7 +523,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
     // face rows: lane 0 top (number 1), lane 1 bottom (2), lane 2 + i side i (3 + i) at compact id 2 + rank(i)
     float dn_mine = 0.0f;
     int fid_mine = -1;
-    if (lane < 8) {
+    {
       const int i = lane - 2;
       const bool side = lane >= 2;
       if (!side || ((pmask >> i) & 1u)) {
@@ -532,7 +537,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
           plane[0] = 0.5f * static_cast<float>(c6(i)), plane[1] = 0.5f * static_cast<float>(s6(i)), plane[2] = 0.0f;
           float di = 0.0f;
 #pragma unroll
-          for (int m = 0; m < 6; m++) di = (m == i) ? sc[3 + m] : di;
+          for (int m = 0; m < 6; m++) di = (m == i) ? dist[m] : di;
           plane[3] = -static_cast<float>(k_d * static_cast<double>(di));
           fid_mine = 2 + __popc(pmask & ((1u << i) - 1u));
         }
@@ -591,9 +596,9 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
     // geom::FinalizeSlabs: slab 0 = the basal pair, then sides i < 3 whose opposite i + 3 is present too, in side order; the rest single
     const uint32_t pair = pmask & (pmask >> 3) & 7u;              // bit i: sides i and i + 3 both present
     const uint32_t single = pmask & ~(pair | (pair << 3));
-    const float dn_opp = __shfl(dn_mine, (lane + 3) & 15, kPTeam);   // side i + 3 sits in lane i + 5
+    const float dn_opp = __shfl(dn_mine, (lane + 3) & 7, kPTeam);   // side i + 3 sits in lane i + 5
     const float dn_bot = __shfl(dn_mine, 1, kPTeam);
-    const int fid_opp = __shfl(fid_mine, (lane + 3) & 15, kPTeam);
+    const int fid_opp = __shfl(fid_mine, (lane + 3) & 7, kPTeam);
     if (lane == 0) {
       float* s0 = R.slab[0];
       s0[0] = 0.0f, s0[1] = 0.0f, s0[2] = 1.0f, s0[3] = dn_mine, s0[4] = dn_bot;
@@ -605,7 +610,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
       R.slab_cnt = 1 + __popc(pair);
       R.single_cnt = __popc(single);
     }
-    if (lane >= 2 && lane < 8) {
+    if (lane >= 2) {
       const int i = lane - 2;
       if (i < 3 && ((pair >> i) & 1u)) {
         float* sr = R.slab[1 + __popc(pair & ((1u << i) - 1u))];
@@ -618,7 +623,7 @@ __global__ void __launch_bounds__(kPTeamBlock) halo_prismgen_team_kernel(ShapePr
     }
   }
   team_publish();
-  if (live) {   // the record leaves in 16-byte pieces, 256 contiguous bytes per team and round
+  if (live) {   // the record leaves in 16-byte pieces, 128 contiguous bytes per team and round
     const float4* src = reinterpret_cast<const float4*>(&T.rec);
     float4* dst = reinterpret_cast<float4*>(pool + crystal);
     for (uint32_t i = static_cast<uint32_t>(lane); i < sizeof(ShapePrism) / 16u; i += kPTeam) dst[i] = src[i];
