@@ -90,6 +90,45 @@ __device__ __forceinline__ double team_max(double v) {
   return v;
 }
 
+// geom::PyrOrderFace for the team kernel: the same ORDER without its eight fp64 divisions and its square root.  The serial form divides
+// the vertex sum by the count (centroid), normalises the first spoke, and sorts by a pseudo-angle |y| / (|x| + |y|) per quadrant — but only
+// the cyclic order around the centroid is used, and that is invariant under a positive scaling of the spokes and of the frame: here the
+// spokes are cnt * (v - centroid) = cnt * v - sum, the frame is the first spoke as it is, and the sort key is the float form of the same
+// pseudo-angle.  The vertices of a face are at least 2 tol apart after the duplicate filter — angular gaps of ~1e-4 against key errors of
+// ~1e-7 — so the order, hence the table, is the serial builder's (the bit-equality test holds it to that).
+__device__ __forceinline__ int order_face_fast(const double (*verts)[3], uint8_t* on, int cnt, const geom::Plane3& unit, double tol, float* key) {
+  double c[3] = {0, 0, 0};
+  for (int q = 0; q < cnt; q++)
+    for (int a = 0; a < 3; a++) c[a] += verts[on[q]][a];
+  const double k = static_cast<double>(cnt);
+  const double e1[3] = {k * verts[on[0]][0] - c[0], k * verts[on[0]][1] - c[1], k * verts[on[0]][2] - c[2]};
+  if (within(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], k * tol)) return 0;   // |v0 - centroid| <= tol: the face degenerates to a point
+  const double n[3] = {unit.a, unit.b, unit.c};
+  const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+  key[0] = 0.0f;
+  for (int q = 1; q < cnt; q++) {
+    const double r[3] = {k * verts[on[q]][0] - c[0], k * verts[on[q]][1] - c[1], k * verts[on[q]][2] - c[2]};
+    const double yd = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], xd = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
+    const float x = static_cast<float>(xd), y = static_cast<float>(yd);   // (products of crystal-size lengths: far inside float's range)
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float t = (ax + ay > 0.0f) ? ay / (ax + ay) : 0.0f;
+    key[q] = (y >= 0.0f) ? (x >= 0.0f ? t : 2.0f - t) : (x < 0.0f ? 2.0f + t : 4.0f - t);
+  }
+  for (int q = 1; q < cnt; q++) {  // stable insertion sort by key
+    const float ka = key[q];
+    const uint8_t kv = on[q];
+    int p = q - 1;
+    while (p >= 0 && key[p] > ka) {
+      key[p + 1] = key[p];
+      on[p + 1] = on[p];
+      p--;
+    }
+    key[p + 1] = ka;
+    on[p + 1] = kv;
+  }
+  return cnt;
+}
+
 // candidate triple number t of the restricted enumeration (see geom::BuildPyramidShape), lexicographic order
 __device__ __forceinline__ bool team_triple(int t, bool upper, bool lower, int& i, int& j, int& k) {
   const int pair_a[15] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4}, pair_b[15] = {1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
@@ -169,7 +208,11 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   if (s < 20) T.unit[s] = unit;
   team_publish();
   // --- cone apexes: extreme z over the feasible concurrences of each cone's own six planes ---
+  // The 20 triples of a cone are also the last candidates of the vertex enumeration below, and a concurrence that violates one of its own
+  // cone's planes cannot be a vertex: the survivors of this phase (a handful of the 40) are parked — in T.verts, which is free until the
+  // vertex list is final — in their list order, and the vertex phase takes them from there instead of solving and scanning all 40 again.
   double z_top = half, z_bot = -half;
+  int ns = 0;   // parked survivors (team-uniform)
   for (int c = 0; c < 2; c++) {
     if (!(c == 0 ? upper : lower)) continue;
     const int lo = (c == 0) ? 8 : 14;
@@ -177,18 +220,24 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     int i, j, k;
     bool found = false;
     double zc = 0.0;
+    double xs[3] = {0.0, 0.0, 0.0};
     if (lane < 20 && team_triple(30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0)) + ((c == 1 && upper) ? 20 : 0) + lane, upper, lower, i, j, k)) {
-      double x[3];
-      if (geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x)) {
+      if (geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], xs)) {
         bool ok = true;
-        for (int m = 0; m < 6 && ok; m++) ok = geom::EvalPlane(T.unit[lo + m], x) <= tol;
+        for (int m = 0; m < 6 && ok; m++) ok = geom::EvalPlane(T.unit[lo + m], xs) <= tol;
         if (ok) {
           found = true;
-          zc = x[2];
+          zc = xs[2];
         }
       }
     }
-    const bool any = team_ballot(found) != 0u;
+    const uint32_t fmask = team_ballot(found);
+    if (found) {
+      const int slot = ns + __popc(fmask & ((1u << lane) - 1u));
+      for (int a = 0; a < 3; a++) T.verts[slot][a] = xs[a];
+    }
+    ns += __popc(fmask);
+    const bool any = fmask != 0u;
     const double best = sign * team_max(found ? sign * zc : -1e300);
     if (!any) valid = false;
     if (c == 0) z_top = half + static_cast<double>(h1) * (best - half);
@@ -205,13 +254,21 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   // the face phase: the serial filter below runs ~25 times per crystal and used to read and write the list in LDS each time)
   int nv = 0;
   double k0[3] = {0.0, 0.0, 0.0}, k1[3] = {0.0, 0.0, 0.0};
-  const int total = 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0)) + (upper ? 20 : 0) + (lower ? 20 : 0);
+  const int total_nc = 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0));   // basal and prism-pair triples; the cone triples follow as parked survivors
+  const int total = total_nc + ns;
   for (int base = 0; base < total; base += kTeam) {
     int i, j, k;
     double x[3] = {0.0, 0.0, 0.0};
     bool feasible = false;
-    if (valid && base + lane < total && team_triple(base + lane, upper, lower, i, j, k)) {
-      if (geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x)) {
+    const int cand = base + lane;
+    bool solved = false;
+    if (valid && cand < total_nc && team_triple(cand, upper, lower, i, j, k)) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
+    if (valid && cand >= total_nc && cand < total) {
+      for (int a = 0; a < 3; a++) x[a] = T.verts[cand - total_nc][a];
+      solved = true;
+    }
+    {
+      if (solved) {
         bool ok = true;
         for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol over the active planes
           if ((act_mask >> m) & 1u) ok = ok && (T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d <= tol);
@@ -247,6 +304,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       }
     }
   }
+  team_publish();   // (the parked survivors have all been read)
   if (lane < nv)
     for (int a = 0; a < 3; a++) T.verts[lane][a] = k0[a];
   if (lane + kTeam < nv)
@@ -259,7 +317,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       if (fabs(unit.a * T.verts[v][0] + unit.b * T.verts[v][1] + unit.c * T.verts[v][2] + unit.d) <= 2.0 * tol && cnt < HALO_MAX_FACE_VTX) T.on[s][cnt++] = static_cast<uint8_t>(v);
   }
   int on_n = 0;
-  if (valid && active && cnt >= 3) on_n = geom::PyrOrderFace(T.verts, T.on[s], cnt, unit, tol, T.ang[s]);
+  if (valid && active && cnt >= 3) on_n = order_face_fast(T.verts, T.on[s], cnt, unit, tol, reinterpret_cast<float*>(T.ang[s]));
   const uint32_t present = team_ballot(on_n > 0);
   if (__popc(present) < 4) valid = false;
   // --- tables ---
