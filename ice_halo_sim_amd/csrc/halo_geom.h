@@ -35,14 +35,14 @@ constexpr double kGeomPiD = 3.14159265358979323846;
 constexpr uint32_t kNonceShape = 0x6A09E667u;   // domain of the shape-scalar stream (ours: the reference draws from mt19937)
 
 // exact 60-degree direction tables (geo3d_closedform.hpp:48-52)
-HALO_GEOM_HD double Cos6(int i) {
-  const double t[6] = {1.0, 0.5, -0.5, -1.0, -0.5, 0.5};
-  return t[i];
+// (selects, not tables: a local table indexed by a lane-dependent i is written to scratch and read back on the device)
+HALO_GEOM_HD double Cos6(int i) {   // 1, 1/2, -1/2, -1, -1/2, 1/2
+  const double m = (i == 0 || i == 3) ? 1.0 : 0.5;
+  return (i >= 2 && i <= 4) ? -m : m;
 }
-HALO_GEOM_HD double Sin6(int i) {
+HALO_GEOM_HD double Sin6(int i) {   // 0, s, s, 0, -s, -s
   const double s = 0.86602540378443864676;
-  const double t[6] = {0.0, s, s, 0.0, -s, -s};
-  return t[i];
+  return (i == 0 || i == 3) ? 0.0 : (i < 3 ? s : -s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -333,9 +333,10 @@ HALO_GEOM_HD bool Concurrence(const Plane3& p, const Plane3& q, const Plane3& r,
   const double det = p.a * (q.b * r.c - q.c * r.b) - p.b * (q.a * r.c - q.c * r.a) + p.c * (q.a * r.b - q.b * r.a);
   if (fabs(det) < 1e-9) return false;
   const double dx = -p.d, dy = -q.d, dz = -r.d;
-  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) / det;
-  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) / det;
-  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) / det;
+  const double inv = 1.0 / det;   // one fp64 division per concurrence (a long sequence on the device), not three
+  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) * inv;
+  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) * inv;
+  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) * inv;
   return true;
 }
 
@@ -360,21 +361,24 @@ constexpr int kPyrMaxVerts = 40;   // a hexagonal prism capped by two truncated 
 
 // Plane of slot s (2..7 prism sides, 8..13 upper cone, 14..19 lower cone) as FillHexCrystalCoef states it (geo3d.cpp:346-512);
 // a1 / a2 = cone slopes, half = h2 / 2, k8 = sqrt3 / 8.  One definition for the serial builder and the team builder.
-HALO_GEOM_HD Plane3 PyrRawPlane(int s, double a1, double a2, double half, double k8, const float dist[6]) {
+HALO_GEOM_HD Plane3 PyrRawPlaneOne(int s, double a1, double a2, double half, double k8, float dist_i) {   // dist_i = dist[(s - 2) % 6]
   if (s < 8) {
     const int i = s - 2;
-    return Plane3{0.5 * Cos6(i), 0.5 * Sin6(i), 0.0, -k8 * static_cast<double>(dist[i])};
+    return Plane3{0.5 * Cos6(i), 0.5 * Sin6(i), 0.0, -k8 * static_cast<double>(dist_i)};
   }
   if (s < 14) {
     const int i = s - 8;
-    return Plane3{0.5 * a1 * Cos6(i), 0.5 * a1 * Sin6(i), k8, -k8 * (half + a1 * static_cast<double>(dist[i]))};
+    return Plane3{0.5 * a1 * Cos6(i), 0.5 * a1 * Sin6(i), k8, -k8 * (half + a1 * static_cast<double>(dist_i))};
   }
   const int i = s - 14;
-  return Plane3{0.5 * a2 * Cos6(i), 0.5 * a2 * Sin6(i), -k8, -k8 * (half + a2 * static_cast<double>(dist[i]))};
+  return Plane3{0.5 * a2 * Cos6(i), 0.5 * a2 * Sin6(i), -k8, -k8 * (half + a2 * static_cast<double>(dist_i))};
+}
+HALO_GEOM_HD Plane3 PyrRawPlane(int s, double a1, double a2, double half, double k8, const float dist[6]) {
+  return PyrRawPlaneOne(s, a1, a2, half, k8, dist[(s - 2) % 6]);
 }
 HALO_GEOM_HD Plane3 PyrUnitPlane(const Plane3& raw) {
-  const double len = sqrt(raw.a * raw.a + raw.b * raw.b + raw.c * raw.c);
-  return Plane3{raw.a / len, raw.b / len, raw.c / len, raw.d / len};
+  const double inv = 1.0 / sqrt(raw.a * raw.a + raw.b * raw.b + raw.c * raw.c);
+  return Plane3{raw.a * inv, raw.b * inv, raw.c * inv, raw.d * inv};
 }
 constexpr int kPyrFaceNumber[20] = {1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28};
 
@@ -588,6 +592,9 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
 struct CrystalRecipe {   // HaloCrystal with the wedge trig already evaluated (host, once per dispatch)
   HaloCrystal c;
   double cot_u, cot_l;   // sqrt3/4 / tan(wedge); negative = illegal wedge (cone absent)
+  // draw plan (PlanShapeScalar, filled by host::MakeRecipe): scalar q of [h0, h1, h2, d0..d5] is the draw of distribution
+  // plan_src[q] (0..2 heights, 3..8 face distances) taken at stream slot plan_slot[q]; 0xFF = the crystal kind has no scalar q
+  uint8_t plan_slot[9], plan_src[9];
 };
 
 HALO_GEOM_HD bool BuildPyramidDispatch(const CrystalRecipe& rc, const float sc[9], const float dist[6], ShapeDev& out) {
@@ -647,14 +654,12 @@ HALO_GEOM_HD uint32_t DrawSlots(const HaloDist& d) {
     default: return 0u;
   }
 }
-// ONE of the nine scalars of DrawShapeScalars (slot `want` of [h0, h1, h2, d0..d5]; 0 for a slot the crystal kind does not
-// have): walks the same draw sequence, stepping the stream over the draws that are not asked for instead of evaluating them
-// (a Gaussian draw is a logf and a cosf).  Lets nine lanes draw the nine scalars side by side.
-HALO_GEOM_HD float DrawShapeScalarOne(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, int want) {
-  const HaloCrystal& c = rc.c;
-  const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
-  const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
-  ScalarStream rng{(hi == 0u) ? (seed ^ kNonceShape) : ((seed ^ kNonceShape) ^ PcgHash32(hi)), lo * 1000003u, 0u};
+// Where ONE of the nine scalars of DrawShapeScalars comes from (slot `want` of [h0, h1, h2, d0..d5]): walks the same draw
+// sequence without drawing — `src` = the distribution whose draw supplies it (itself, or the first member in draw order of its
+// sync group), `at` = the stream slot that draw starts at.  False for a slot the crystal kind does not have.  The walk depends
+// on the crystal description alone, so the host does it once per dispatch (CrystalRecipe::plan_*) and the team generators draw
+// their scalars side by side, one lane each, straight from the plan.
+HALO_GEOM_HD bool PlanShapeScalar(const HaloCrystal& c, int want, uint32_t& at, int& src) {
   const int n_h = (c.kind == HALO_CRYSTAL_PRISM) ? 1 : 3;
   // the slot whose draw `want` takes: itself, or the first member (in draw order) of its sync group
   int target = -1;
@@ -665,9 +670,10 @@ HALO_GEOM_HD float DrawShapeScalarOne(uint32_t seed, const CrystalRecipe& rc, ui
     if (slot == want) want_exists = true;
     if (target < 0 && (slot == want || (want_group != 0 && c.sync_group[slot] == want_group))) target = slot;
   }
-  if (!want_exists || target < 0) return 0.0f;
+  if (!want_exists || target < 0) return false;
   int seen_groups[9];
   int n_seen = 0;
+  uint32_t pos = 0u;
   for (int i = 0; i < n_h + 6; i++) {
     const int slot = (i < n_h) ? i : 3 + (i - n_h);
     const HaloDist& d = (i < n_h) ? c.height[i] : c.face_dist[i - n_h];
@@ -676,11 +682,33 @@ HALO_GEOM_HD float DrawShapeScalarOne(uint32_t seed, const CrystalRecipe& rc, ui
     if (group != 0)
       for (int q = 0; q < n_seen; q++) have = have || (seen_groups[q] == group);
     if (have) continue;                 // a later member of a group: reuses, draws nothing
-    if (slot == target) return Draw(rng, d);
-    rng.slot += DrawSlots(d);
+    if (slot == target) {
+      at = pos;
+      src = (i < n_h) ? i : 3 + (i - n_h);
+      return true;
+    }
+    pos += DrawSlots(d);
     if (group != 0) seen_groups[n_seen++] = group;
   }
-  return 0.0f;
+  return false;
+}
+HALO_GEOM_HD void FillDrawPlan(CrystalRecipe& rc) {
+  for (int q = 0; q < 9; q++) {
+    uint32_t at = 0u;
+    int src = 0;
+    const bool ok = PlanShapeScalar(rc.c, q, at, src);
+    rc.plan_slot[q] = ok ? static_cast<uint8_t>(at) : static_cast<uint8_t>(0xFF);
+    rc.plan_src[q] = ok ? static_cast<uint8_t>(src) : static_cast<uint8_t>(0);
+  }
+}
+// scalar `want` of crystal instance `shape_index` by the recipe's plan (the value DrawShapeScalars puts in sc[want])
+HALO_GEOM_HD float DrawShapeScalarOne(uint32_t seed, const CrystalRecipe& rc, uint64_t shape_index, int want) {
+  if (want < 0 || want >= 9 || rc.plan_slot[want] == 0xFF) return 0.0f;
+  const uint32_t lo = static_cast<uint32_t>(shape_index & 0xFFFFFFFFull);
+  const uint32_t hi = static_cast<uint32_t>(shape_index >> 32);
+  ScalarStream rng{(hi == 0u) ? (seed ^ kNonceShape) : ((seed ^ kNonceShape) ^ PcgHash32(hi)), lo * 1000003u, rc.plan_slot[want]};
+  const int src = rc.plan_src[want];
+  return Draw(rng, src < 3 ? rc.c.height[src] : rc.c.face_dist[src - 3]);
 }
 
 // S = ShapeDev (any crystal) or ShapePrism (prisms only: a pyramid recipe yields the empty shape)

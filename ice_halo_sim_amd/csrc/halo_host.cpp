@@ -88,6 +88,7 @@ geom::CrystalRecipe MakeRecipe(const HaloCrystal& c) {
   };
   r.cot_u = cot(c.wedge_upper_deg);
   r.cot_l = cot(c.wedge_lower_deg);
+  geom::FillDrawPlan(r);
   return r;
 }
 

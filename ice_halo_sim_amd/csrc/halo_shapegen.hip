@@ -40,26 +40,41 @@ __global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? HA
 // The serial builder (geom::BuildPyramidShape, one thread per crystal) keeps ~4 KB of per-lane arrays in scratch — planes,
 // vertices, per-face vertex lists — and ran at two waves per SIMD; at 1.4 ms per 125 K crystals it cost as much as the trace
 // of their 4 M rays.  Here the same steps are spread over a team and the arrays live in LDS:
-//   planes       lane s < 20 builds raw / unit plane s                                  (geom::PyrRawPlane / PyrUnitPlane)
-//   cone apexes  lane t < 20 solves triple t of its cone, team max                      (geom::Concurrence)
-//   vertices     the ~100 candidate triples in lexicographic order, 32 per round, one solve + feasibility scan per lane;
-//                feasible candidates are then taken IN ORDER (ballot, lowest lane first), broadcast, tested against the kept
-//                vertices (one per lane) and appended — the serial duplicate filter, unchanged
-//   faces        lane s: vertices on plane s, CCW order                                 (geom::PyrOrderFace)
+//   scalars      lane q < 9 draws scalar q from the recipe's draw plan (geom::DrawShapeScalarOne); lane s takes its face distance by shuffle
+//   planes       lane s < 20 builds raw / unit plane s                                  (geom::PyrRawPlaneOne / PyrUnitPlane)
+//   cone apexes  lane t < 20 solves triple t of its cone, team max; the feasible ones are parked for the vertex phase (geom::Concurrence)
+//   vertices     the 60 basal / prism-pair triples in lexicographic order, then the parked cone survivors, 32 per round: one solve +
+//                feasibility scan per lane, then the serial duplicate filter evaluated in parallel — every feasible lane tests its
+//                candidate against the kept vertices and the round's other candidates (float pre-test, fp64 only for near pairs),
+//                the lowest of each duplicate group is kept, in lane order = list order (see the loop for why that IS the serial filter)
+//   faces        lane v evaluates the planes at vertex v, one ballot per plane hands lane s the vertices on plane s; CCW order by float
+//                pseudo-angle keys (order_face_fast: geom::PyrOrderFace's order without its divisions)
 //   tables       lane s emits face row + fan triangles at offsets from a team prefix sum (geom::EmitFace), then pairs the
-//                opposite faces (geom::FinalizeSlabs' rule) with ballots
+//                opposite faces (geom::FinalizeSlabs' rule: the one slot that can hold the exact negative normal) with ballots
 // Every number is produced by the same expression on the same operands as in the serial builder, reductions are max / any
-// (order-free), and candidates are filtered in the serial order, so the record is bit-identical to the host's
+// (order-free), and candidates are kept in the serial order, so the record is bit-identical to the host's
 // (tests/test_gpu_parity.py::test_device_crystal_generator_equals_host_builder).
+// Round 3: 4.28 -> 2.69 ms per 781 K crystals (measured per phase with early exits: draw plan + no scratch tables 0.96 -> 0.24 ms,
+// parallel duplicate filter and branch-free plane scan 1.30 -> 1.14 ms, face collection stays ~0.65 ms, slab pairing 0.31 -> ~0.05 ms).
 constexpr int kTeam = 32, kTeamsPerBlock = 8, kTeamBlock = kTeam * kTeamsPerBlock;
 
 struct TeamLds {
   geom::Plane3 unit[20];
   double verts[geom::kPyrMaxVerts][3];
-  double ang[20][HALO_MAX_FACE_VTX];
-  uint8_t on[20][HALO_MAX_FACE_VTX];
-  float fn[20][4];      // emitted face rows by compact id (unit normal, plane constant)
-  int tri_cnt[20];      // fan triangles of slot s (0 when absent)
+  union {
+    struct {   // vertex phase
+      double cand[kTeam][3];                  // the round's feasible candidates
+      double park[geom::kPyrMaxVerts][3];     // feasible concurrences of the cones' own triples (<= 20 per cone), parked by the apex phase
+      float4 cand_f[kTeam];                   // float copies for the distance pre-test (w = unused)
+      float4 kept_f[geom::kPyrMaxVerts];
+    } vtx;
+    struct {   // face phase
+      float key[20][HALO_MAX_FACE_VTX];       // pseudo-angle sort keys
+      uint8_t on[20][HALO_MAX_FACE_VTX];
+      float fn[20][4];      // emitted face rows by compact id (unit normal, plane constant)
+      int tri_cnt[20];      // fan triangles of slot s (0 when absent)
+    } f;
+  };
 };
 
 __device__ __forceinline__ uint32_t team_ballot(bool p) {
@@ -111,7 +126,7 @@ __device__ __forceinline__ int order_face_fast(const double (*verts)[3], uint8_t
     const double yd = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], xd = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
     const float x = static_cast<float>(xd), y = static_cast<float>(yd);   // (products of crystal-size lengths: far inside float's range)
     const float ax = fabsf(x), ay = fabsf(y);
-    const float t = (ax + ay > 0.0f) ? ay / (ax + ay) : 0.0f;
+    const float t = (ax + ay > 0.0f) ? ay * __builtin_amdgcn_rcpf(ax + ay) : 0.0f;   // (1 ulp: the keys only have to order)
     key[q] = (y >= 0.0f) ? (x >= 0.0f ? t : 2.0f - t) : (x < 0.0f ? 2.0f + t : 4.0f - t);
   }
   for (int q = 1; q < cnt; q++) {  // stable insertion sort by key
@@ -129,42 +144,64 @@ __device__ __forceinline__ int order_face_fast(const double (*verts)[3], uint8_t
   return cnt;
 }
 
+template <class... T>
+constexpr unsigned long long PackOctal(T... v) {
+  unsigned long long out = 0ull;
+  int sh = 0;
+  ((out |= static_cast<unsigned long long>(v) << sh, sh += 3), ...);
+  return out;
+}
+template <class... T>
+constexpr unsigned long long PackOctal15(T... v) {
+  static_assert(sizeof...(v) == 15, "15 pairs");
+  return PackOctal(v...);
+}
+template <class... T>
+constexpr unsigned long long PackOctal20(T... v) {
+  static_assert(sizeof...(v) == 20, "20 triples");
+  return PackOctal(v...);
+}
 // candidate triple number t of the restricted enumeration (see geom::BuildPyramidShape), lexicographic order
 __device__ __forceinline__ bool team_triple(int t, bool upper, bool lower, int& i, int& j, int& k) {
-  const int pair_a[15] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4}, pair_b[15] = {1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
-  const int tri_a[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3}, tri_b[20] = {1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 2, 2, 2, 3, 3, 4, 3, 3, 4, 4},
-            tri_c[20] = {2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 3, 4, 5, 4, 5, 5, 4, 5, 5, 5};
+  // pairs (a < b) and triples (a < b < c) of 0..5 in lexicographic order, packed 3 bits per entry (register constants: an array indexed by
+  // the lane would be a load from constant memory in the middle of a dependent chain)
+  //   pair_a = 0,0,0,0,0,1,1,1,1,2,2,2,3,3,4   pair_b = 1,2,3,4,5,2,3,4,5,3,4,5,4,5,5
+  //   tri_a  = 0 x10, 1 x6, 2 x3, 3            tri_b  = 1,1,1,1,2,2,2,3,3,4,2,2,2,3,3,4,3,3,4,4      tri_c = 2,3,4,5,3,4,5,4,5,5,3,4,5,4,5,5,4,5,5,5
+  constexpr unsigned long long kPairA = PackOctal15(0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4), kPairB = PackOctal15(1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5);
+  constexpr unsigned long long kTriA = PackOctal20(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3), kTriB = PackOctal20(1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 2, 2, 2, 3, 3, 4, 3, 3, 4, 4),
+                               kTriC = PackOctal20(2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 3, 4, 5, 4, 5, 5, 4, 5, 5, 5);
+  auto pick = [](unsigned long long packed, int idx) { return static_cast<int>((packed >> (3 * idx)) & 7ull); };
   if (t < 30) {   // basal plane b with two planes of its cone (or two prism planes without one)
     const int b = t / 15, q = t % 15;
     const int lo = (b == 0) ? (upper ? 8 : 2) : (lower ? 14 : 2);
     i = b;
-    j = lo + pair_a[q];
-    k = lo + pair_b[q];
+    j = lo + pick(kPairA, q);
+    k = lo + pick(kPairB, q);
     return true;
   }
   t -= 30;
   const int per_pair = (upper ? 1 : 0) + (lower ? 1 : 0);
   if (t < 15 * per_pair) {   // prism planes i < j with cone plane i of the upper, then the lower cone
     const int q = t / per_pair, which = t % per_pair;
-    i = 2 + pair_a[q];
-    j = 2 + pair_b[q];
-    k = ((which == 0 && upper) ? 8 : 14) + pair_a[q];
+    i = 2 + pick(kPairA, q);
+    j = 2 + pick(kPairB, q);
+    k = ((which == 0 && upper) ? 8 : 14) + pick(kPairA, q);
     return true;
   }
   t -= 15 * per_pair;
   if (upper) {
     if (t < 20) {
-      i = 8 + tri_a[t];
-      j = 8 + tri_b[t];
-      k = 8 + tri_c[t];
+      i = 8 + pick(kTriA, t);
+      j = 8 + pick(kTriB, t);
+      k = 8 + pick(kTriC, t);
       return true;
     }
     t -= 20;
   }
   if (lower && t < 20) {
-    i = 14 + tri_a[t];
-    j = 14 + tri_b[t];
-    k = 14 + tri_c[t];
+    i = 14 + pick(kTriA, t);
+    j = 14 + pick(kTriB, t);
+    k = 14 + pick(kTriC, t);
     return true;
   }
   return false;
@@ -179,15 +216,11 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const bool live = crystal < n;                       // team-uniform
   ShapeDev& out = pool[live ? crystal : 0u];
   // --- shape scalars: lane q < 9 draws scalar q (a Gaussian draw is a logf + cosf), the team shares them ---
-  float sc[9];
-  {
-    const float mine = lane < 9 ? geom::DrawShapeScalarOne(seed, rc, first_index + (live ? crystal : 0u), lane) : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 9; q++) sc[q] = __shfl(mine, static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(q)));
-  }
-  float dist[6];
-  for (int i = 0; i < 6; i++) dist[i] = sc[3 + i];
-  const float h1 = fabsf(sc[0]), h2 = fabsf(sc[1]), h3 = fabsf(sc[2]);
+  // (no per-lane array of the nine: lane s takes the one face distance its plane uses straight from the lane that drew it)
+  const float mine = lane < 9 ? geom::DrawShapeScalarOne(seed, rc, first_index + (live ? crystal : 0u), lane) : 0.0f;
+  const int team_base = static_cast<int>(threadIdx.x & 32u);
+  const float h1 = fabsf(__shfl(mine, team_base | 0)), h2 = fabsf(__shfl(mine, team_base | 1)), h3 = fabsf(__shfl(mine, team_base | 2));
+  const float my_dist = __shfl(mine, team_base | (3 + (lane + 4) % 6));   // (s - 2) mod 6 for s = lane >= 2
   const double cot_u = rc.cot_u, cot_l = rc.cot_l;
   const bool upper = h1 > geom::kGeomFloatEps && cot_u >= 0.0;
   const bool lower = h3 > geom::kGeomFloatEps && cot_l >= 0.0;
@@ -200,7 +233,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const bool side_active = s >= 2 && s < 20 && ((s < 8) || (s < 14 ? upper : lower));
   geom::Plane3 raw = geom::Plane3{0.0, 0.0, 0.0, 0.0}, unit = raw;
   if (side_active) {
-    raw = geom::PyrRawPlane(s, a1, a2, half, k8, dist);
+    raw = geom::PyrRawPlaneOne(s, a1, a2, half, k8, my_dist);
     unit = geom::PyrUnitPlane(raw);
   }
   const double scale = team_max(fmax(fabs(half), side_active ? fabs(unit.d) : 0.0));
@@ -209,10 +242,13 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   team_publish();
   // --- cone apexes: extreme z over the feasible concurrences of each cone's own six planes ---
   // The 20 triples of a cone are also the last candidates of the vertex enumeration below, and a concurrence that violates one of its own
-  // cone's planes cannot be a vertex: the survivors of this phase (a handful of the 40) are parked — in T.verts, which is free until the
+  // cone's planes cannot be a vertex: the survivors of this phase (a handful of the 40) are parked — in LDS the face phase reuses later, so free until the
   // vertex list is final — in their list order, and the vertex phase takes them from there instead of solving and scanning all 40 again.
   double z_top = half, z_bot = -half;
   int ns = 0;   // parked survivors (team-uniform)
+  static_assert(geom::kPyrMaxVerts >= 40, "40 cone triples can be parked");
+  double (*const cand_lds)[3] = T.vtx.cand;
+  double (*const park)[3] = T.vtx.park;
   for (int c = 0; c < 2; c++) {
     if (!(c == 0 ? upper : lower)) continue;
     const int lo = (c == 0) ? 8 : 14;
@@ -234,7 +270,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     const uint32_t fmask = team_ballot(found);
     if (found) {
       const int slot = ns + __popc(fmask & ((1u << lane) - 1u));
-      for (int a = 0; a < 3; a++) T.verts[slot][a] = xs[a];
+      for (int a = 0; a < 3; a++) park[slot][a] = xs[a];
     }
     ns += __popc(fmask);
     const bool any = fmask != 0u;
@@ -250,12 +286,17 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const bool active = s < 2 || side_active;
   const uint32_t act_mask = team_ballot(active);
   // --- vertices: candidate triples in lexicographic order, 32 per round; kept in serial order ---
-  // (the kept vertices live in registers while the list grows — lane v holds vertex v and vertex 32 + v — and go to LDS once, for
-  // the face phase: the serial filter below runs ~25 times per crystal and used to read and write the list in LDS each time)
+  // The serial filter keeps a candidate unless a vertex kept before it lies within 2 tol.  Taking the feasible candidates one at a time
+  // (broadcast, test against the kept list, append) cost ~40 instructions per candidate, ~35 candidates per crystal: a third of the
+  // kernel.  Here a round's feasible candidates go to LDS, every feasible lane tests its own against the vertices kept in earlier rounds
+  // (a hit drops it, as in the serial filter) and against the round's other candidates, gathering the mask D of those within 2 tol; among
+  // the candidates that survive the first test the serial filter keeps exactly the lowest of each group when the groups are cliques
+  // (D equal for all members: every duplicate of a vertex is a duplicate of its other duplicates) — checked, and when it does not hold
+  // the greedy pass runs on the masks, which is the serial filter itself.  Kept candidates are appended in lane order = list order.
   int nv = 0;
-  double k0[3] = {0.0, 0.0, 0.0}, k1[3] = {0.0, 0.0, 0.0};
   const int total_nc = 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0));   // basal and prism-pair triples; the cone triples follow as parked survivors
   const int total = total_nc + ns;
+  const uint32_t below = (1u << lane) - 1u;
   for (int base = 0; base < total; base += kTeam) {
     int i, j, k;
     double x[3] = {0.0, 0.0, 0.0};
@@ -264,60 +305,111 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     bool solved = false;
     if (valid && cand < total_nc && team_triple(cand, upper, lower, i, j, k)) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
     if (valid && cand >= total_nc && cand < total) {
-      for (int a = 0; a < 3; a++) x[a] = T.verts[cand - total_nc][a];
+      for (int a = 0; a < 3; a++) x[a] = park[cand - total_nc][a];
       solved = true;
     }
-    {
-      if (solved) {
-        bool ok = true;
-        for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol over the active planes
-          if ((act_mask >> m) & 1u) ok = ok && (T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d <= tol);
-        feasible = ok;
+    if (solved) {
+      bool ok = true;
+      // EvalPlane(unit[m], x) <= tol over the active planes — over all twenty slots without a branch: the slots of an absent cone hold
+      // the zero plane, which evaluates to 0 <= tol
+#pragma unroll 5
+      for (int m = 0; m < 20; m++) ok = ok & (T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d <= tol);
+      feasible = ok;
+    }
+    const uint32_t fm = team_ballot(feasible);
+    // distance pre-test in float: a pair within 2 tol in fp64 is within thr in float whatever the vertices' magnitude (the float copies
+    // are off by <= 2^-24 of each coordinate, |difference error| <= 1.2e-7 * (|x|+|y|+|z|) =: m), so a pair the pre-test calls far IS far
+    // and only the pairs it calls near (real duplicates, nearly always) take the fp64 test of the serial filter
+    const float fx = static_cast<float>(x[0]), fy = static_cast<float>(x[1]), fz = static_cast<float>(x[2]);
+    const float thr = 3.0f * static_cast<float>(tol) + 1e-6f * (fabsf(fx) + fabsf(fy) + fabsf(fz));
+    const float thr2 = thr * thr;
+    if (feasible) {
+      for (int a = 0; a < 3; a++) cand_lds[lane][a] = x[a];
+      T.vtx.cand_f[lane] = make_float4(fx, fy, fz, 0.0f);
+    }
+    team_publish();
+    bool dupk = false;
+    uint32_t D = feasible ? (1u << lane) : 0u;   // (a candidate is within 2 tol of itself)
+    if (feasible) {
+      for (int v = 0; v < nv; v++) {
+        const float4 o = T.vtx.kept_f[v];
+        const float ex = o.x - fx, ey = o.y - fy, ez = o.z - fz;
+        if (ex * ex + ey * ey + ez * ez <= thr2) {
+          const double dx = T.verts[v][0] - x[0], dy = T.verts[v][1] - x[1], dz = T.verts[v][2] - x[2];
+          dupk = dupk || within(dx * dx + dy * dy + dz * dz, 2.0 * tol);
+        }
+      }
+      for (uint32_t m = fm & ~(1u << lane); m != 0u; m &= m - 1u) {
+        const int e = __ffs(m) - 1;
+        const float4 o = T.vtx.cand_f[e];
+        const float ex = o.x - fx, ey = o.y - fy, ez = o.z - fz;
+        if (ex * ex + ey * ey + ez * ez <= thr2) {
+          const double dx = cand_lds[e][0] - x[0], dy = cand_lds[e][1] - x[1], dz = cand_lds[e][2] - x[2];
+          if (within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) D |= 1u << e;
+        }
       }
     }
-    uint32_t todo = team_ballot(feasible);
-    while (todo != 0u) {   // (the two teams of a wave may differ: the loop runs for the longer list)
-      const int src = __ffs(todo) - 1;
-      todo &= todo - 1u;
-      const double cx = team_bcast(x[0], src), cy = team_bcast(x[1], src), cz = team_bcast(x[2], src);
-      // (the serial builder's box pre-test |d| <= 4 tol per axis is implied by the distance test; this loop runs ~40 times per crystal
-      // and is the largest block of the kernel, so it carries nothing it does not need — and the second kept vertex per lane only once
-      // more than 32 are kept, which the wave decides for both of its teams)
-      bool dup = false;
-      {
-        const double dx = k0[0] - cx, dy = k0[1] - cy, dz = k0[2] - cz;
-        dup = lane < nv && within(dx * dx + dy * dy + dz * dz, 2.0 * tol);
+    const bool in_r = feasible && !dupk;
+    const uint32_t rm = team_ballot(in_r);
+    D &= rm;
+    const int rep = in_r ? __ffs(D) - 1 : lane;   // (D holds the lane's own bit)
+    const uint32_t d_rep = static_cast<uint32_t>(__shfl(static_cast<int>(D), static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(rep))));
+    uint32_t keep = team_ballot(in_r && rep == lane);
+    if (__ballot(in_r && d_rep != D) != 0ull) {   // not cliques (vertices ~2 tol apart in a chain): the greedy pass, in list order
+      keep = 0u;
+      for (int e = 0; e < kTeam; e++) {
+        const uint32_t d_e = static_cast<uint32_t>(__shfl(static_cast<int>(D), static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(e))));
+        if (((rm >> e) & 1u) && (d_e & keep) == 0u) keep |= 1u << e;
       }
-      if (__ballot(nv > kTeam) != 0ull) {
-        const double dx = k1[0] - cx, dy = k1[1] - cy, dz = k1[2] - cz;
-        dup = dup || (lane + kTeam < nv && within(dx * dx + dy * dy + dz * dz, 2.0 * tol));
+    }
+    if ((keep >> lane) & 1u) {
+      const int pos = nv + __popc(keep & below);
+      if (pos < geom::kPyrMaxVerts) {
+        for (int a = 0; a < 3; a++) T.verts[pos][a] = x[a];
+        T.vtx.kept_f[pos] = make_float4(fx, fy, fz, 0.0f);
       }
-      if (team_ballot(dup) == 0u && nv < geom::kPyrMaxVerts) {
-        if (lane == (nv & (kTeam - 1))) {
-          if (nv < kTeam) {
-            k0[0] = cx, k0[1] = cy, k0[2] = cz;
-          } else {
-            k1[0] = cx, k1[1] = cy, k1[2] = cz;
-          }
-        }
-        nv++;
+    }
+    nv = min(nv + __popc(keep), geom::kPyrMaxVerts);
+    team_publish();
+  }
+  // --- faces: vertices on plane s (ascending vertex order), then CCW order ---
+  // Turned around: lane v evaluates the twenty planes at vertex v (the vertex in registers, the planes broadcast reads that do not depend on
+  // one another), a ballot per plane hands lane s the set of vertices on plane s.  (One lane per plane walking the vertex list — a
+  // dependent LDS read and a conditional LDS write per step — sat waiting: 0.62 ms of the kernel for ~200 instructions.)
+  uint32_t on_lo = 0u, on_hi = 0u;
+  {
+    const bool two = __ballot(nv > kTeam) != 0ull;   // more than 32 vertices in either team of the wave: lane v also holds vertex 32 + v
+    uint32_t pm0 = 0u, pm1 = 0u;
+    if (valid && lane < nv) {
+      const double vx = T.verts[lane][0], vy = T.verts[lane][1], vz = T.verts[lane][2];
+#pragma unroll 5
+      for (int m = 0; m < 20; m++) pm0 |= (fabs(T.unit[m].a * vx + T.unit[m].b * vy + T.unit[m].c * vz + T.unit[m].d) <= 2.0 * tol ? 1u : 0u) << m;
+    }
+    if (two && valid && lane + kTeam < nv) {
+      const double vx = T.verts[lane + kTeam][0], vy = T.verts[lane + kTeam][1], vz = T.verts[lane + kTeam][2];
+#pragma unroll 5
+      for (int m = 0; m < 20; m++) pm1 |= (fabs(T.unit[m].a * vx + T.unit[m].b * vy + T.unit[m].c * vz + T.unit[m].d) <= 2.0 * tol ? 1u : 0u) << m;
+    }
+#pragma unroll
+    for (int m = 0; m < 20; m++) {
+      const uint32_t b0 = team_ballot((pm0 >> m) & 1u);
+      if (s == m) on_lo = b0;
+    }
+    if (two) {
+#pragma unroll
+      for (int m = 0; m < 20; m++) {
+        const uint32_t b1 = team_ballot((pm1 >> m) & 1u);
+        if (s == m) on_hi = b1;
       }
     }
   }
-  team_publish();   // (the parked survivors have all been read)
-  if (lane < nv)
-    for (int a = 0; a < 3; a++) T.verts[lane][a] = k0[a];
-  if (lane + kTeam < nv)
-    for (int a = 0; a < 3; a++) T.verts[lane + kTeam][a] = k1[a];
-  team_publish();
-  // --- faces: vertices on plane s (ascending vertex order), then CCW order ---
   int cnt = 0;
-  if (valid && active) {
-    for (int v = 0; v < nv; v++)
-      if (fabs(unit.a * T.verts[v][0] + unit.b * T.verts[v][1] + unit.c * T.verts[v][2] + unit.d) <= 2.0 * tol && cnt < HALO_MAX_FACE_VTX) T.on[s][cnt++] = static_cast<uint8_t>(v);
+  if (valid && active) {   // the first HALO_MAX_FACE_VTX of them, ascending
+    for (uint32_t m = on_lo; m != 0u && cnt < HALO_MAX_FACE_VTX; m &= m - 1u) T.f.on[s][cnt++] = static_cast<uint8_t>(__ffs(m) - 1);
+    for (uint32_t m = on_hi; m != 0u && cnt < HALO_MAX_FACE_VTX; m &= m - 1u) T.f.on[s][cnt++] = static_cast<uint8_t>(kTeam + __ffs(m) - 1);
   }
   int on_n = 0;
-  if (valid && active && cnt >= 3) on_n = order_face_fast(T.verts, T.on[s], cnt, unit, tol, reinterpret_cast<float*>(T.ang[s]));
+  if (valid && active && cnt >= 3) on_n = order_face_fast(T.verts, T.f.on[s], cnt, unit, tol, T.f.key[s]);
   const uint32_t present = team_ballot(on_n > 0);
   if (__popc(present) < 4) valid = false;
   // --- tables ---
@@ -326,11 +418,11 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     return;   // (the other team of this wave carries on: nothing below synchronises across teams)
   }
   const int my_tris = on_n > 0 ? on_n - 2 : 0;
-  if (s < 20) T.tri_cnt[s] = my_tris;
+  if (s < 20) T.f.tri_cnt[s] = my_tris;
   team_publish();
   int tri_start = 0, tri_total = 0;
   for (int q = 0; q < 20; q++) {
-    const int c = T.tri_cnt[q];
+    const int c = T.f.tri_cnt[q];
     if (q < s) tri_start += c;
     tri_total += c;
   }
@@ -357,14 +449,14 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       cur.d_last = dn;
       out.face_number[fid_e] = static_cast<uint8_t>(geom::kPyrFaceNumber[s]);
       float v0[3];
-      for (int a = 0; a < 3; a++) v0[a] = static_cast<float>(T.verts[T.on[s][0]][a]);
+      for (int a = 0; a < 3; a++) v0[a] = static_cast<float>(T.verts[T.f.on[s][0]][a]);
       for (int k = 1; k + 1 < on_n && on_n >= 3 && cur.tri < static_cast<int>(sizeof(out.tri_na) / 16u); k++) {
         const int t = cur.tri;
         float v[9];
         for (int a = 0; a < 3; a++) {
           v[a] = v0[a];
-          v[3 + a] = static_cast<float>(T.verts[T.on[s][k]][a]);
-          v[6 + a] = static_cast<float>(T.verts[T.on[s][k + 1]][a]);
+          v[3 + a] = static_cast<float>(T.verts[T.f.on[s][k]][a]);
+          v[6 + a] = static_cast<float>(T.verts[T.f.on[s][k + 1]][a]);
         }
         for (int a = 0; a < 9; a++) out.tri_v[t][a] = v[a];
         const float ea[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]};
@@ -378,37 +470,33 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       }
       cur.fid++;
     }
-    T.fn[fid][0] = nrm[0];
-    T.fn[fid][1] = nrm[1];
-    T.fn[fid][2] = nrm[2];
-    T.fn[fid][3] = cur.d_last;
+    T.f.fn[fid][0] = nrm[0];
+    T.f.fn[fid][1] = nrm[1];
+    T.f.fn[fid][2] = nrm[2];
+    T.f.fn[fid][3] = cur.d_last;
   }
   team_publish();
   // opposite-face slabs (geom::FinalizeSlabs): face i pairs with the first later face whose unit normal is its exact negative
   const int face_cnt = __popc(present);
-  int mate = -1;
-  bool is_minus = false;
-  if (on_n > 0) {
-    for (int j2 = fid + 1; j2 < face_cnt && mate < 0; j2++)
-      if (nrm[0] == -T.fn[j2][0] && nrm[1] == -T.fn[j2][1] && nrm[2] == -T.fn[j2][2]) mate = j2;
-    for (int j2 = 0; j2 < fid && !is_minus; j2++)
-      if (T.fn[j2][0] == -nrm[0] && T.fn[j2][1] == -nrm[1] && T.fn[j2][2] == -nrm[2]) {
-        // j2 takes this face only if no face between them already matched j2's normal — distinct faces of a convex solid
-        // never share a normal, so the first match is the only one
-        is_minus = true;
-      }
-  }
+  // The serial rule scans the emitted faces for the first later one whose normal is the exact negative.  A face of this family has at
+  // most one such partner and it can only sit in one slot: the other basal face, the prism side three steps round, the other cone's face
+  // three steps round (equal cone slopes) — every other plane points somewhere else in the horizontal, and two present faces of a convex
+  // solid never share a normal (a legal wedge keeps a cone face's normal away from the basal one even in float).  So: look at that slot.
+  const int opp = s < 2 ? 1 - s : (s < 8 ? 2 + (s + 1) % 6 : (s < 14 ? 14 + (s - 5) % 6 : 8 + (s - 11) % 6));   // (s - 2 + 3) % 6 etc.
+  const float ox = __shfl(nrm[0], team_base | opp), oy = __shfl(nrm[1], team_base | opp), oz = __shfl(nrm[2], team_base | opp);
+  const bool paired = on_n > 0 && s < 20 && ((present >> opp) & 1u) && nrm[0] == -ox && nrm[1] == -oy && nrm[2] == -oz;
+  const int mate = (paired && opp > s) ? __popc(present & ((1u << opp) - 1u)) : -1;
+  const bool is_minus = paired && opp < s;
   const bool is_plus = on_n > 0 && mate >= 0 && !is_minus;
   const bool is_single = on_n > 0 && !is_plus && !is_minus;
   const uint32_t plus_mask = team_ballot(is_plus), single_mask = team_ballot(is_single);
-  const uint32_t below = (1u << s) - 1u;
   if (is_plus) {
     float* r = out.slab[__popc(plus_mask & below)];
     r[0] = nrm[0];
     r[1] = nrm[1];
     r[2] = nrm[2];
-    r[3] = T.fn[fid][3];
-    r[4] = T.fn[mate][3];
+    r[3] = T.f.fn[fid][3];
+    r[4] = T.f.fn[mate][3];
     reinterpret_cast<uint32_t*>(r)[5] = static_cast<uint32_t>(fid);
     reinterpret_cast<uint32_t*>(r)[6] = static_cast<uint32_t>(mate);
     r[7] = 0.0f;
