@@ -85,13 +85,17 @@ static_assert(sizeof(EntryFastDev) % 16 == 0, "copied as float4");
 
 // LDS slot of a general pool shape (the HBM record stays a ShapeDev).  A convex solid with V corners has 2 (V - 2) fan
 // triangles whatever its faces look like (Euler), and the pyramid family has at most 24 corners (two hexagonal rings per
-// cap) — 44 triangles; 48 rows instead of ShapeDev's 64 make the slot 3.2 KB, and a workgroup's eight slots plus its tables
-// then fit three times into a CU's LDS instead of twice.  stage_shape clamps to the slot's capacity like it always did.
+// cap) — 44 triangles, 48 rows.  The corner rows (tri_v, 36 B per triangle) are NOT staged: the entry pick reads one
+// triangle's nine floats per ray, so they stay in the pool record (HBM / L2, the lines the staging copy has just touched) and the
+// slot carries the pointer.  1.5 KB per slot instead of 3.2 KB: a workgroup's eight slots plus its tables take 34 KB, four
+// workgroups per CU instead of three, and the compiler targets 128 VGPRs instead of 146 — configs[4p] 2.88 -> 3.19 G rays/s on
+// one box.  stage_shape clamps to the slot's capacity like it always did.
 struct ShapeSlot48 {
   int32_t face_cnt, tri_cnt, slab_cnt, single_cnt;
   float face[kMaxFaces][4];
   float slab[kMaxSlabs][8];
-  float tri_v[48][9];
+  const float (*tri_v)[9];   // the record's corner rows (global memory)
+  uint64_t pad0;
   float tri_na[48][4];
   uint8_t tri_face[48];
   uint8_t face_number[kMaxFaces];

@@ -1116,7 +1116,7 @@ struct PoolSlotType<kGeomPoolPrism> {
   typedef ShapePrism type;
   typedef ShapePrism rec;
 };
-static_assert(offsetof(ShapeSlot48, tri_v) % 16 == 0 && offsetof(ShapeSlot48, tri_na) % 16 == 0 && offsetof(ShapeSlot48, slab) % 16 == 0 &&
+static_assert(offsetof(ShapeSlot48, tri_na) % 16 == 0 && offsetof(ShapeSlot48, slab) % 16 == 0 &&
               offsetof(ShapeSlot48, tri_face) % 4 == 0 && offsetof(ShapeSlot48, face_number) % 4 == 0 && offsetof(ShapeSlot48, single) % 4 == 0,
               "rows are copied as float4 / dwords");
 template <bool ON, typename SlotT, int N = kBlock / 32>
@@ -1146,9 +1146,13 @@ HD void stage_shape(SlotT* slot, const RecT* g, uint32_t l32) {
   const float4* gs = reinterpret_cast<const float4*>(g->slab);
   float4* ss = reinterpret_cast<float4*>(slot->slab);
   for (uint32_t i = l32; i < 2u * sc; i += 32u) ss[i] = gs[i];
-  const float4* gv = reinterpret_cast<const float4*>(g->tri_v);
-  float4* sv = reinterpret_cast<float4*>(slot->tri_v);
-  for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) sv[i] = gv[i];
+  if constexpr (sizeof(slot->tri_v) == sizeof(void*)) {   // the slot keeps a pointer to the record's corner rows
+    if (l32 == 0u) *reinterpret_cast<const float (**)[9]>(&slot->tri_v) = g->tri_v;
+  } else {
+    const float4* gv = reinterpret_cast<const float4*>(g->tri_v);
+    float4* sv = reinterpret_cast<float4*>(const_cast<float(*)[9]>(slot->tri_v));
+    for (uint32_t i = l32; i < (tc * 9u + 3u) / 4u; i += 32u) sv[i] = gv[i];
+  }
   const float4* gn = reinterpret_cast<const float4*>(g->tri_na);
   float4* sn = reinterpret_cast<float4*>(slot->tri_na);
   for (uint32_t i = l32; i < tc; i += 32u) sn[i] = gn[i];
