@@ -69,7 +69,7 @@ struct TeamLds {
       float4 kept_f[geom::kPyrMaxVerts];
     } vtx;
     struct {   // face phase
-      float key[20][HALO_MAX_FACE_VTX];       // pseudo-angle sort keys
+      double key[20][HALO_MAX_FACE_VTX];      // pseudo-angle sort keys (float keys of order_face_fast in the front half; doubles when geom::PyrOrderFace runs)
       uint8_t on[20][HALO_MAX_FACE_VTX];
       float fn[20][4];      // emitted face rows by compact id (unit normal, plane constant)
       int tri_cnt[20];      // fan triangles of slot s (0 when absent)
@@ -109,17 +109,23 @@ __device__ __forceinline__ double team_max(double v) {
 // the vertex sum by the count (centroid), normalises the first spoke, and sorts by a pseudo-angle |y| / (|x| + |y|) per quadrant — but only
 // the cyclic order around the centroid is used, and that is invariant under a positive scaling of the spokes and of the frame: here the
 // spokes are cnt * (v - centroid) = cnt * v - sum, the frame is the first spoke as it is, and the sort key is the float form of the same
-// pseudo-angle.  The vertices of a face are at least 2 tol apart after the duplicate filter — angular gaps of ~1e-4 against key errors of
-// ~1e-7 — so the order, hence the table, is the serial builder's (the bit-equality test holds it to that).
+// pseudo-angle (error ~2e-7).  That decides the order only where the keys are clearly apart: two corners 1e-4 apart on a sliver face can
+// subtend 1e-8 at the centroid.  So the function REFUSES (returns -1, list untouched) when two neighbouring keys — or the last key and the
+// full turn — are closer than 1e-4, or when the face is nearly a point, and the caller then runs geom::PyrOrderFace itself: the table is
+// the serial builder's in every case (tests/test_gpu_parity.py::test_device_crystal_generator_equals_host_builder: one crystal in 4000
+// of its "full apexes" recipe takes the refusal).
 __device__ __forceinline__ int order_face_fast(const double (*verts)[3], uint8_t* on, int cnt, const geom::Plane3& unit, double tol, float* key) {
   double c[3] = {0, 0, 0};
   for (int q = 0; q < cnt; q++)
     for (int a = 0; a < 3; a++) c[a] += verts[on[q]][a];
   const double k = static_cast<double>(cnt);
   const double e1[3] = {k * verts[on[0]][0] - c[0], k * verts[on[0]][1] - c[1], k * verts[on[0]][2] - c[2]};
-  if (within(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], k * tol)) return 0;   // |v0 - centroid| <= tol: the face degenerates to a point
+  const double lim = k * tol;
+  if (e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2] < 4.0 * lim * lim) return -1;   // |v0 - centroid| within 2 tol: the serial test decides
   const double n[3] = {unit.a, unit.b, unit.c};
   const double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
+  const uint32_t saved[3] = {reinterpret_cast<const uint32_t*>(on)[0], reinterpret_cast<const uint32_t*>(on)[1], reinterpret_cast<const uint32_t*>(on)[2]};
+  static_assert(HALO_MAX_FACE_VTX == 12, "a face's vertex list is three dwords");
   key[0] = 0.0f;
   for (int q = 1; q < cnt; q++) {
     const double r[3] = {k * verts[on[q]][0] - c[0], k * verts[on[q]][1] - c[1], k * verts[on[q]][2] - c[2]};
@@ -140,6 +146,12 @@ __device__ __forceinline__ int order_face_fast(const double (*verts)[3], uint8_t
     }
     key[p + 1] = ka;
     on[p + 1] = kv;
+  }
+  bool close = 4.0f - key[cnt - 1] < 1e-4f;
+  for (int q = 1; q < cnt; q++) close = close || (key[q] - key[q - 1] < 1e-4f);
+  if (close) {
+    for (int a = 0; a < 3; a++) reinterpret_cast<uint32_t*>(on)[a] = saved[a];
+    return -1;
   }
   return cnt;
 }
@@ -409,7 +421,10 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     for (uint32_t m = on_hi; m != 0u && cnt < HALO_MAX_FACE_VTX; m &= m - 1u) T.f.on[s][cnt++] = static_cast<uint8_t>(kTeam + __ffs(m) - 1);
   }
   int on_n = 0;
-  if (valid && active && cnt >= 3) on_n = order_face_fast(T.verts, T.f.on[s], cnt, unit, tol, T.f.key[s]);
+  if (valid && active && cnt >= 3) {
+    on_n = order_face_fast(T.verts, T.f.on[s], cnt, unit, tol, reinterpret_cast<float*>(T.f.key[s]));
+    if (on_n < 0) on_n = geom::PyrOrderFace(T.verts, T.f.on[s], cnt, unit, tol, T.f.key[s]);   // too close for float keys: the serial ordering itself
+  }
   const uint32_t present = team_ballot(on_n > 0);
   if (__popc(present) < 4) valid = false;
   // --- tables ---

@@ -701,6 +701,16 @@ def test_device_crystal_generator_equals_host_builder():
         ("prism gauss", scenes.prism_crystal(g(1.3, 0.2), [g(1.0, 0.2)] * 6), False, 3000),
         ("pyramid uniform", scenes.pyramid_crystal(u(0.3, 0.4), u(1.0, 0.8), u(0.3, 0.4), face_distance=[u(1.0, 0.5)] * 6), True, 1500),
         ("pyramid gauss", scenes.pyramid_crystal(g(0.2, 0.05), g(1.2, 0.2), g(0.5, 0.1), upper_miller=(2, 3), face_distance=[g(1.0, 0.1)] * 6), False, 1000),
+        # the draw plan (CrystalRecipe::plan_*): grouped scalars reuse the first member's draw, the stream steps over one slot per uniform and
+        # two per Gaussian draw that is not asked for
+        ("pyramid sync groups", scenes.pyramid_crystal(u(0.3, 0.4), u(1.0, 0.8), u(0.3, 0.4), face_distance=[u(1.0, 0.5)] * 6,
+                                                       sync_group=[1, 0, 1, 2, 3, 2, 3, 2, 3]), True, 1000),
+        ("pyramid mixed draws, groups", scenes.pyramid_crystal(u(0.3, 0.4), g(1.0, 0.2), u(0.3, 0.4), face_distance=[u(1.0, 0.5), g(1.0, 0.1)] * 3,
+                                                               sync_group=[0, 0, 0, 4, 0, 4, 0, 4, 0]), False, 1000),
+        # regular cross-section: six planes meet in each apex and shoulders coincide — every vertex is found by several triples, the
+        # duplicate filter's groups (cliques, checked; greedy pass otherwise) do real work
+        ("pyramid regular sides", scenes.pyramid_crystal(u(0.6, 0.8), u(1.0, 0.8), u(0.6, 0.8)), True, 1000),
+        ("pyramid full apexes", scenes.pyramid_crystal(1.0, u(1.0, 0.8), 1.0, face_distance=[u(1.0, 0.1)] * 6), True, 1000),
     ]
     for name, cr, exact, n in cases:
         dev = hb.generate_shapes(cr, 10_000_000_000, n, on_device=True)     # index above 2^32: hi word mixes into the seed
