@@ -68,6 +68,7 @@ def load_library():
         "halo_consumer_reset": (C.c_int, [H]),
         "halo_host_prism_geometry": (C.c_int, [C.c_float, f32p, C.POINTER(abi.HaloGeomTables)]),
         "halo_host_pyramid_geometry": (C.c_int, [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]),
+        "halo_host_shape_scalars": (C.c_int, [C.POINTER(abi.HaloCrystal), C.c_uint32, C.c_uint64, C.c_int, f32p]),
         "halo_host_build_lat_lut": (C.c_int, [C.POINTER(abi.HaloDist), f32p, f32p, f32p]),
         "halo_host_build_proj_params": (C.c_int, [C.POINTER(abi.HaloRender), C.c_void_p]),
         "halo_host_partition": (C.c_int, [f32p, C.c_int, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -91,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
     "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
-    "halo_host_pyramid_geometry", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
+    "halo_host_pyramid_geometry", "halo_host_shape_scalars", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
 ]
 

@@ -1329,6 +1329,16 @@ int halo_host_pyramid_geometry(float wu, float wl, float h1, float h2, float h3,
   if (!out || !dist) return HALO_FATAL;
   return host::BuildPyramid(wu, wl, h1, h2, h3, dist, *out) ? HALO_OK : HALO_UNAVAILABLE;
 }
+int halo_host_shape_scalars(const HaloCrystal* crystal, uint32_t seed, uint64_t shape_index, int via_plan, float out9[9]) {
+  if (!crystal || !out9) return HALO_FATAL;
+  const geom::CrystalRecipe rc = host::MakeRecipe(*crystal);
+  if (via_plan) {
+    for (int q = 0; q < 9; q++) out9[q] = geom::DrawShapeScalarOne(seed, rc, shape_index, q);
+  } else {
+    geom::DrawShapeScalars(seed, rc, shape_index, out9);
+  }
+  return HALO_OK;
+}
 int halo_host_build_lat_lut(const HaloDist* lat, float* theta, float* cdf, float* flip) {
   if (!lat || !theta || !cdf || !flip) return HALO_FATAL;
   host::LatLut l = host::BuildLatLut(*lat);

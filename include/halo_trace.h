@@ -400,6 +400,10 @@ int halo_host_prism_geometry(float h, const float dist[6], HaloGeomTables* out);
 /* Crystal::CreatePyramid(wedge_u, wedge_l, h1, h2, h3, dist) — crystal.cpp:379-426. */
 int halo_host_pyramid_geometry(float wedge_upper_deg, float wedge_lower_deg, float h1, float h2, float h3,
                                const float dist[6], HaloGeomTables* out);
+/* The nine shape scalars [h0, h1, h2, d0..d5] of crystal instance `shape_index` (SyncGroupSampler, simulator.cpp:361-393, over the PCG
+ * shape stream): via_plan = 0 walks the draw sequence as the host builder does, 1 draws each scalar from the per-dispatch draw plan the
+ * device generators use (one lane per scalar).  The two must agree bit for bit.  Parity-test hook, no device needed. */
+int halo_host_shape_scalars(const HaloCrystal* crystal, uint32_t seed, uint64_t shape_index, int via_plan, float out9[9]);
 /* Sample crystal instances [first_index, first_index + n) of `crystal` from the backend's shape-scalar stream
  * (MakeCrystal simulator.cpp:448 + SyncGroupSampler :361-393 + closed-form geometry) into `out[n]`:
  * on_device = 1 runs the device generator of the general (4.1 KB) records, 2 — prisms only — the generator of the prism pools' 1360-byte

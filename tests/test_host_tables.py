@@ -165,3 +165,39 @@ def test_graft_entry_build_runs():
     library, resolves every exported symbol and checks the ABI version against include/halo_trace.h (no GPU needed)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_shape_scalar_draw_plan_equals_the_sequential_sampler():
+    """SyncGroupSampler (simulator.cpp:361-393) two ways: the host builder walks the nine scalars in draw order (grouped slots reuse the
+    first member's raw value, a Gaussian draw takes two stream slots); the device generators draw scalar q on lane q from the dispatch's draw
+    plan (CrystalRecipe::plan_slot / plan_src, geom::PlanShapeScalar).  Every scalar must agree bit for bit over random group assignments,
+    distribution types and crystal kinds."""
+    L = backend.load_library()
+    rng = np.random.default_rng(5)
+    kinds = ["fixed", "uniform", "gauss", "zigzag", "laplacian"]
+
+    def dist():
+        k = kinds[rng.integers(len(kinds))]
+        if k == "fixed":
+            return float(rng.uniform(0.2, 1.5))
+        return {"type": k, "mean": float(rng.uniform(0.3, 1.3)), "std": float(rng.uniform(0.05, 0.6))}
+
+    n_grouped = 0
+    for trial in range(300):
+        groups = [int(g) for g in rng.choice([0, 0, 1, 2, 3], 9)]
+        if trial % 2:
+            cr = scenes.pyramid_crystal(dist(), dist(), dist(), face_distance=[dist() for _ in range(6)], sync_group=groups)
+        else:
+            cr = scenes.prism_crystal(dist(), [dist() for _ in range(6)], sync_group=groups)
+        for idx in (0, 7, 2**32 + 5, 10_000_000_123):
+            a, b = np.zeros(9, np.float32), np.zeros(9, np.float32)
+            assert L.halo_host_shape_scalars(C.byref(cr), 1234, idx, 0, fptr(a)) == 0
+            assert L.halo_host_shape_scalars(C.byref(cr), 1234, idx, 1, fptr(b)) == 0
+            assert a.tobytes() == b.tobytes(), (trial, groups, a, b)
+            if cr.kind == abi.CRYSTAL_PRISM:
+                assert a[1] == 0.0 and a[2] == 0.0          # a prism has one height
+            for g in set(groups) - {0}:
+                members = [q for q in range(9) if groups[q] == g and (cr.kind != abi.CRYSTAL_PRISM or q not in (1, 2))]
+                n_grouped += len(members) > 1
+                assert len({float(a[q]) for q in members}) <= 1, (groups, a)   # one raw draw per group
+    assert n_grouped > 500
