@@ -514,6 +514,20 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
       nv++;
     }
   };
+  // The argument above is about the exact solid.  The feasibility test has a tolerance, and where two rings of corners come within a few
+  // tolerances of each other (a cap a ten-thousandth of the way to its apex, a side face about to vanish) triples that meet OUTSIDE the
+  // exact solid pass it as well; the exhaustive enumeration meets them — early, and they then absorb the true corners on both sides as
+  // duplicates — the short lists do not, and keep two rings whose corners each face then claims in part: a table that is no polytope
+  // (fan triangles != 2 V - 4).  So the short lists are checked by that count and the exhaustive enumeration — the definition — runs
+  // when it fails (found by tests/test_gpu_fuzz.py, seed 488: one crystal in ~2500 of a recipe whose cap height crosses zero;
+  // tools/pyr_topology_scan.py: 11 of 30000 ordinary parameter draws disagreed with the exhaustive builder before, 1 now — and there the
+  // exhaustive table is no polytope itself).
+  int on[20][HALO_MAX_FACE_VTX];
+  int on_n[20];
+  int present = 0;
+  for (int pass = 0; pass < 2; pass++) {
+  nv = 0;
+  if (pass == 0) {
   for (int b = 0; b < 2; b++) {   // i = 0, 1: a basal plane with two planes of its cone (or two prism planes without one)
     const int lo = (b == 0) ? (upper ? 8 : 2) : (lower ? 14 : 2);
     for (int j = lo; j < lo + 6; j++)
@@ -531,11 +545,19 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
       for (int j = i + 1; j < lo + 6; j++)
         for (int k = j + 1; k < lo + 6; k++) try_triple(i, j, k);
   }
+  } else {
+    for (int i = 0; i < 20; i++) {
+      if (!active[i]) continue;
+      for (int j = i + 1; j < 20; j++) {
+        if (!active[j]) continue;
+        for (int k = j + 1; k < 20; k++)
+          if (active[k]) try_triple(i, j, k);
+      }
+    }
+  }
   // a face is present with >= 3 vertices on its plane; the crystal needs >= 4 present faces
   // (IsValidClosedFormPyramid crystal.cpp:93-101), so the loops are ordered in a first pass and emitted in a second
-  int on[20][HALO_MAX_FACE_VTX];
-  int on_n[20];
-  int present = 0;
+  present = 0;
   // membership of every vertex in every plane, vertex-major: one load of the vertex, the 20 planes from their register copies
   // (same expression as EvalPlane, same values; each face's list comes out in ascending vertex order as before)
   int member_cnt[20];
@@ -568,6 +590,10 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     if (PyrOrderFace(verts, on[s], cnt, unit[s], tol, ang) == 0) continue;
     on_n[s] = cnt;
     present++;
+  }
+  int tris = 0;
+  for (int s = 0; s < 20; s++) tris += on_n[s] > 0 ? on_n[s] - 2 : 0;
+  if (tris == 2 * nv - 4 && present >= 4) break;   // a polytope: the short lists found it
   }
   if (present < 4) return false;
   ShapeCursor cur;

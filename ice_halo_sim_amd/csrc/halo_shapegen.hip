@@ -305,20 +305,44 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   // the candidates that survive the first test the serial filter keeps exactly the lowest of each group when the groups are cliques
   // (D equal for all members: every duplicate of a vertex is a duplicate of its other duplicates) — checked, and when it does not hold
   // the greedy pass runs on the masks, which is the serial filter itself.  Kept candidates are appended in lane order = list order.
-  int nv = 0;
-  const int total_nc = 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0));   // basal and prism-pair triples; the cone triples follow as parked survivors
-  const int total = total_nc + ns;
+  // Two passes at most (geom::BuildPyramidShape): the short candidate lists first; if what they give is no polytope (fan triangles != 2 V - 4:
+  // corners of two rings within a few tolerances of each other, where triples that meet outside the exact solid pass the feasibility test
+  // too) the exhaustive enumeration of all C(20,3) triples — the definition — runs instead, 36 rounds of 32.
+  int nv = 0, on_n = 0, tri_start = 0, tri_total = 0;
+  uint32_t present = 0u;
   const uint32_t below = (1u << lane) - 1u;
+  auto build = [&](const bool exhaustive) __attribute__((always_inline)) {
+  nv = 0;
+  const int total_nc = exhaustive ? 1140 : 30 + 15 * ((upper ? 1 : 0) + (lower ? 1 : 0));   // basal and prism-pair triples; the cone triples follow as parked survivors
+  const int total = exhaustive ? 1140 : total_nc + ns;
   for (int base = 0; base < total; base += kTeam) {
     int i, j, k;
     double x[3] = {0.0, 0.0, 0.0};
     bool feasible = false;
     const int cand = base + lane;
     bool solved = false;
-    if (valid && cand < total_nc && team_triple(cand, upper, lower, i, j, k)) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
-    if (valid && cand >= total_nc && cand < total) {
-      for (int a = 0; a < 3; a++) x[a] = park[cand - total_nc][a];
-      solved = true;
+    if (exhaustive) {
+      if (cand < total) {   // triple number `cand` of 0 <= i < j < k < 20, lexicographic
+        int rem = cand;
+        i = 0;
+        while (rem >= (19 - i) * (18 - i) / 2) {
+          rem -= (19 - i) * (18 - i) / 2;
+          i++;
+        }
+        j = i + 1;
+        while (rem >= 19 - j) {
+          rem -= 19 - j;
+          j++;
+        }
+        k = j + 1 + rem;
+        if (((act_mask >> i) & (act_mask >> j) & (act_mask >> k) & 1u) != 0u) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
+      }
+    } else {
+      if (cand < total_nc && team_triple(cand, upper, lower, i, j, k)) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
+      if (cand >= total_nc && cand < total) {
+        for (int a = 0; a < 3; a++) x[a] = park[cand - total_nc][a];
+        solved = true;
+      }
     }
     if (solved) {
       bool ok = true;
@@ -420,26 +444,31 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     for (uint32_t m = on_lo; m != 0u && cnt < HALO_MAX_FACE_VTX; m &= m - 1u) T.f.on[s][cnt++] = static_cast<uint8_t>(__ffs(m) - 1);
     for (uint32_t m = on_hi; m != 0u && cnt < HALO_MAX_FACE_VTX; m &= m - 1u) T.f.on[s][cnt++] = static_cast<uint8_t>(kTeam + __ffs(m) - 1);
   }
-  int on_n = 0;
+  on_n = 0;
   if (valid && active && cnt >= 3) {
     on_n = order_face_fast(T.verts, T.f.on[s], cnt, unit, tol, reinterpret_cast<float*>(T.f.key[s]));
     if (on_n < 0) on_n = geom::PyrOrderFace(T.verts, T.f.on[s], cnt, unit, tol, T.f.key[s]);   // too close for float keys: the serial ordering itself
   }
-  const uint32_t present = team_ballot(on_n > 0);
+  present = team_ballot(on_n > 0);
+  if (s < 20) T.f.tri_cnt[s] = on_n > 0 ? on_n - 2 : 0;
+  team_publish();
+  tri_start = tri_total = 0;
+  for (int q = 0; q < 20; q++) {
+    const int c = T.f.tri_cnt[q];
+    if (q < s) tri_start += c;
+    tri_total += c;
+  }
+  };
+  if (valid) build(false);
+  if (valid && !(tri_total == 2 * nv - 4 && __popc(present) >= 4)) {   // no polytope: rare, and the two copies of the phases keep the usual path's registers to itself
+    team_publish();   // (the face phase's LDS is the vertex phase's staging area)
+    build(true);
+  }
   if (__popc(present) < 4) valid = false;
   // --- tables ---
   if (!valid) {
     if (live && lane == 0) out.face_cnt = out.tri_cnt = out.slab_cnt = out.single_cnt = 0;
     return;   // (the other team of this wave carries on: nothing below synchronises across teams)
-  }
-  const int my_tris = on_n > 0 ? on_n - 2 : 0;
-  if (s < 20) T.f.tri_cnt[s] = my_tris;
-  team_publish();
-  int tri_start = 0, tri_total = 0;
-  for (int q = 0; q < 20; q++) {
-    const int c = T.f.tri_cnt[q];
-    if (q < s) tri_start += c;
-    tri_total += c;
   }
   const int fid = __popc(present & ((1u << s) - 1u));
   float nrm[3] = {0.0f, 0.0f, 0.0f};

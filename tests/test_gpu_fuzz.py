@@ -1,0 +1,161 @@
+"""Randomised scenes, HIP vs the oracle ray by ray (capture on, one scattering layer so that the rays pair up deterministically).
+
+The hand-written parity tests and the reference's 61 e2e documents walk the features one or two at a time; this draws them together at
+random — crystal family and its stochastic parameters (sync groups included), the three axis distributions of every type, one to three
+crystal entries per layer, max_hits, sun, all eleven lenses with random view / field of view / visible range / lens shift, discrete
+wavelength or an illuminant pool, and (half of the cases) an emit-gate filter of any kind, symmetry and action, simple or complex.  Same
+per-ray bar as `test_reference_e2e_configs_parity`: exit counts, >= 99.7 % of the exits matched in direction and weight, their pixel and
+face path, the landed weight and the block-mean image.
+
+`FUZZ_SEEDS` (environment, e.g. `FUZZ_SEEDS=1000:1400`) runs another range — that is how the seeds below were first swept."""
+import os
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, scenes
+from tests._oracle_backend import OracleBackend, run_session
+from tests.test_gpu_parity import block_mean, hip_backend, match_exits, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+PYR_FACES = [1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17, 18, 23, 24, 25, 26, 27, 28]
+
+
+def _dist(rng, centre, spreads, kinds=("uniform", "gauss", "zigzag", "laplacian")):
+    return {"type": str(rng.choice(kinds)), "mean": float(centre), "std": float(rng.choice(spreads))}
+
+
+def _face_distances(rng):
+    r = rng.random()
+    if r < 0.45:
+        return None
+    if r < 0.7:
+        return [float(rng.uniform(0.6, 1.4)) for _ in range(6)]
+    return [_dist(rng, rng.uniform(0.8, 1.2), [0.05, 0.15, 0.4], ("uniform", "gauss")) for _ in range(6)]
+
+
+def _crystal(rng):
+    # sync groups tie heights to heights and face distances to face distances (a height drawn as a face distance is a legal document, but
+    # its crystals sit in the degenerate regime where even the exhaustive vertex enumeration yields no polytope: tools/pyr_topology_scan.py)
+    groups = ([int(g) for g in rng.choice([0, 0, 1], 3)] + [int(g) for g in rng.choice([0, 0, 0, 2, 3], 6)]) if rng.random() < 0.3 else None
+    if rng.random() < 0.55:
+        h = float(rng.choice([0.1, 0.3, 1.0, 1.3, 3.0])) if rng.random() < 0.6 else _dist(rng, rng.uniform(0.3, 2.0), [0.1, 0.5], ("uniform", "gauss"))
+        return scenes.prism_crystal(h, _face_distances(rng), sync_group=groups), list(range(1, 9))
+
+    def frac():
+        return float(rng.choice([0.0, 0.1, 0.5, 1.0])) if rng.random() < 0.6 else _dist(rng, rng.uniform(0.1, 0.8), [0.05, 0.3], ("uniform", "gauss"))
+    kw = {}
+    if rng.random() < 0.5:
+        kw["upper_miller"], kw["lower_miller"] = [(1, 1), (2, 3), (1, 2), (3, 2)][rng.integers(4)], [(1, 1), (2, 3), (1, 2)][rng.integers(3)]
+    else:
+        kw["upper_wedge"], kw["lower_wedge"] = float(rng.uniform(8, 80)), float(rng.uniform(8, 80))
+    ph = float(rng.choice([0.0, 0.4, 1.0, 2.0])) if rng.random() < 0.6 else _dist(rng, rng.uniform(0.3, 1.5), [0.1, 0.4], ("uniform", "gauss"))
+    return scenes.pyramid_crystal(frac(), ph, frac(), face_distance=_face_distances(rng), sync_group=groups, **kw), PYR_FACES
+
+
+def _axis(rng):
+    r = rng.random()
+    if r < 0.15:
+        return scenes.axis()
+    kinds = ("uniform", "gauss", "zigzag", "laplacian", "gauss_legacy")
+    zen = float(rng.choice([0.0, 90.0, 35.0])) if rng.random() < 0.15 else _dist(rng, rng.choice([0.0, 90.0, rng.uniform(0, 180)]), [0.3, 5.0, 40.0, 360.0], kinds)
+    az = None if rng.random() < 0.5 else (float(rng.uniform(0, 360)) if rng.random() < 0.3 else _dist(rng, rng.uniform(0, 360), [2.0, 60.0, 360.0]))
+    ro = None if rng.random() < 0.5 else (float(rng.uniform(0, 360)) if rng.random() < 0.3 else _dist(rng, rng.uniform(0, 360), [2.0, 60.0, 360.0]))
+    return scenes.axis(zenith=zen, azimuth=az, roll=ro)
+
+
+def _term(rng, faces):
+    kind = str(rng.choice(["raypath", "entry_exit", "direction", "crystal"]))
+    if kind == "raypath":
+        return scenes.filter_term("raypath", raypath=[int(rng.choice(faces)) for _ in range(int(rng.integers(1, 6)))])
+    if kind == "entry_exit":
+        lo = int(rng.integers(1, 4))
+        return scenes.filter_term("entry_exit", entry=int(rng.choice(faces)) if rng.random() < 0.7 else None, exit=int(rng.choice(faces)) if rng.random() < 0.7 else None,
+                                  min_len=lo, max_len=None if rng.random() < 0.4 else lo + int(rng.integers(0, 5)))
+    if kind == "direction":
+        return scenes.filter_term("direction", az=float(rng.uniform(0, 360)), el=float(rng.uniform(-60, 80)), radii=float(rng.choice([2.0, 15.0, 60.0])))
+    return scenes.filter_term("crystal", crystal_id=int(rng.integers(1, 5)))
+
+
+def _filter(rng, faces):
+    sym = "".join(c for c in "PBD" if rng.random() < 0.5)
+    action = "filter_in" if rng.random() < 0.6 else "filter_out"
+    if rng.random() < 0.7:
+        return scenes.simple_filter(_term(rng, faces), sym, action)
+    return scenes.complex_filter([[_term(rng, faces) for _ in range(int(rng.integers(1, 3)))] for _ in range(int(rng.integers(1, 4)))], sym, action)
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    entries, filters = [], []
+    for k in range(int(rng.choice([1, 1, 2, 3]))):
+        cr, faces = _crystal(rng)
+        fid = 0
+        if rng.random() < 0.5:
+            filters.append(_filter(rng, faces))
+            fid = len(filters)
+        entries.append(scenes.entry(cr, _axis(rng), float(rng.uniform(0.2, 3.0)), k + 1, fid))
+    sc = scenes.scene([(0.0, entries)], max_hits=int(rng.choice([1, 2, 4, 7, 8, 12])), sun_altitude=float(rng.uniform(-10, 85)), sun_azimuth=float(rng.uniform(0, 360)),
+                      sun_diameter=float(rng.choice([0.0, 0.5, 2.0])))
+    lens = int(rng.integers(0, 11))
+    w, h = [(64, 48), (200, 100), (333, 211), (512, 256), (640, 640)][rng.integers(5)]
+    fov = float(rng.uniform(20, 120)) if lens == abi.LENS_LINEAR else float(rng.choice([180.0, 120.0, 90.0, 200.0]))
+    rd = scenes.render(lens, w, h, fov=fov, az=float(rng.uniform(0, 360)), el=float(rng.uniform(-30, 90)), ro=float(rng.choice([0.0, rng.uniform(0, 360)])),
+                       visible=int(rng.integers(0, 3)), overlap=float(rng.choice([0.0, 0.1])), lens_shift=(int(rng.integers(-20, 21)), int(rng.integers(-20, 21))) if rng.random() < 0.3 else (0, 0))
+    wl = scenes.wl_discrete(float(rng.uniform(400, 700))) if rng.random() < 0.6 else scenes.wl_illuminant(str(rng.choice(["D65", "D50", "A", "E"])), int(rng.choice([1, 7, 31, 64])))
+    return sc, rd, wl, filters, int(rng.choice([8, 32, 64]))
+
+
+def run_case(seed, n=60_000):
+    sc, rd, wl, filters, clock = make_case(seed)
+    hb = hip_backend(seed=seed, capture_exits=1, geom_clock=clock)
+    ob = OracleBackend(seed=seed, capture_exits=1, threads=8, geom_clock=clock)
+    for b in (hb, ob):
+        b.set_filters(filters)
+    sh = run_session(hb, sc, rd, wl, n)
+    so = run_session(ob, sc, rd, wl, n)
+    eh, eo = hb.DrainExits(), ob.DrainExits()
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    hb.close()
+    ob.close()
+    L0 = sc.layers[0]
+    fixed = all(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
+                for i in range(L0.entry_count))
+    out = dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), n_exits=(len(eh), len(eo)), fixed_axes=fixed)
+    out["match"] = match_exits(eh, eo) if len(eo) and len(eh) else (1.0 if len(eh) == len(eo) else 0.0, 1.0, 1.0)
+    # what the exits that do not pair up (or pair up with another weight) can move the landed weight by, at most
+    n_un = int(round((1.0 - out["match"][0]) * (len(eh) + len(eo)))) + 1
+    wmax = max(float(eh["weight"].max()) if len(eh) else 0.0, float(eo["weight"].max()) if len(eo) else 0.0)
+    out["unmatched_weight"] = n_un * wmax if out["match"][0] < 1.0 else 0.0
+    out["l2"] = rel_l2(block_mean(ih, 4), block_mean(io, 4)) if io.sum() > 0 else 0.0
+    return out
+
+
+def check(seed, r):
+    """The per-ray bars are those of the e2e documents.  Three things a random scene does that the documents do not, found by sweeping
+    800 seeds (tools/diag_fuzz.py shows any seed in detail): (1) every axis FIXED — all rays then meet the crystal the same way, and if
+    that way grazes a face (sun 0.35 degrees below a plate's basal plane: cos of the incidence angle passes through zero across the sun's
+    disc, the transmitted weight 1 - R is ill-conditioned there) or a critical angle, the weights of 1-3 % of the exits move by more
+    than the 2e-4 bar on every ray that goes that way: 0.95 there; (2) small sparse images at 60 k rays, where ONE exit crossing a pixel
+    border is 1 % of a block-mean distance: that bar is 5e-2 here, the per-ray bars carry the comparison; (3) illuminant weights of
+    ~100 per exit: the landed weights may differ by what the unmatched exits weigh."""
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3, abs=20), (seed, r)
+    frac, pix, path = r["match"]
+    assert frac >= (0.95 if r["fixed_axes"] else 0.997) and pix >= 0.995 and path >= 0.998, (seed, r)
+    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3 + r["unmatched_weight"], (seed, r)
+    assert r["l2"] <= 5e-2, (seed, r)
+
+
+def _seeds():
+    spec = os.environ.get("FUZZ_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(100, 148))
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_scene_traces_the_same_rays_as_the_oracle(seed):
+    check(seed, run_case(seed))

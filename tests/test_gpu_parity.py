@@ -705,6 +705,10 @@ def test_device_crystal_generator_equals_host_builder():
         # duplicate filter's groups (cliques, checked; greedy pass otherwise) do real work
         ("pyramid regular sides", scenes.pyramid_crystal(u(0.6, 0.8), u(1.0, 0.8), u(0.6, 0.8)), True, 1000),
         ("pyramid full apexes", scenes.pyramid_crystal(1.0, u(1.0, 0.8), 1.0, face_distance=[u(1.0, 0.1)] * 6), True, 1000),
+        # caps a few tolerances high: the short candidate lists give no polytope for about half of these, the exhaustive enumeration runs
+        # (geom::BuildPyramidShape's second pass, the team kernel's 36-round pass)
+        ("pyramid sliver caps", scenes.pyramid_crystal(u(0.0002, 0.0002), u(1.0, 0.8), u(0.0002, 0.0003)), True, 600),
+        ("pyramid sliver caps, irregular", scenes.pyramid_crystal(u(0.0002, 0.0003), u(0.001, 0.002), u(0.3, 0.6), face_distance=[u(1.0, 0.4)] * 6), True, 600),
     ]
     for name, cr, exact, n in cases:
         dev = hb.generate_shapes(cr, 10_000_000_000, n, on_device=True)     # index above 2^32: hi word mixes into the seed
