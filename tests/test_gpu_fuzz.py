@@ -159,3 +159,56 @@ def _seeds():
 @pytest.mark.parametrize("seed", _seeds())
 def test_random_scene_traces_the_same_rays_as_the_oracle(seed):
     check(seed, run_case(seed))
+
+
+# ---- the same random scenes on the PRODUCTION kernels (capture off, launches big enough for the hit log) --------------------------------
+THREADS = max(8, min(os.cpu_count() or 8, 128))
+
+
+def run_production_case(seed, n=3 << 20):
+    """Capture off: plain / kModeFilter kernels with the exit queue, hit log or binned routes, pool or one-shape geometry as the scene
+    asks.  Same streams on both sides, so image, landed weight and exit count are compared like the single-layer production tests
+    (tests/test_gpu_filter_production.py), the oracle with its double accumulator."""
+    sc, rd, wl, filters, clock = make_case(seed)
+    hb = hip_backend(seed=seed, geom_clock=clock)
+    ob = OracleBackend(seed=seed, threads=THREADS, acc64=1, geom_clock=clock)
+    for b in (hb, ob):
+        b.set_filters(filters)
+    sh = run_session(hb, sc, rd, wl, n)
+    route = hb.last_route()
+    so = run_session(ob, sc, rd, wl, n)
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    hb.close()
+    ob.close()
+    L0 = sc.layers[0]
+    fixed = all(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
+                for i in range(L0.entry_count))
+    io = np.asarray(io, np.float32)
+    return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, accum_mask=route.accum_mask, fixed_axes=fixed,
+                l2=rel_l2(block_mean(ih, 8), block_mean(io, 8)) if io.sum() > 0 else 0.0,
+                sums=(ih.sum(axis=(0, 1), dtype=np.float64), io.sum(axis=(0, 1), dtype=np.float64)))
+
+
+def check_production(seed, r):
+    assert not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC)), (seed, r)      # max_hits <= 12: the production-shaped kernels
+    loose = 10.0 if r["fixed_axes"] else 1.0        # (every ray the same way: see check())
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 * loose, abs=20), (seed, r)
+    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
+    assert r["l2"] <= 3e-3 * loose, (seed, r)
+    tot = float(r["sums"][1].sum())
+    for ch in range(3):
+        assert r["sums"][0][ch] == pytest.approx(r["sums"][1][ch], rel=5e-4 * loose, abs=1e-5 * tot + 1e-6), (seed, ch, r)
+
+
+def _prod_seeds():
+    spec = os.environ.get("FUZZ_PROD_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(2000, 2016))
+
+
+@pytest.mark.parametrize("seed", _prod_seeds())
+def test_random_scene_on_the_production_kernels(seed):
+    check_production(seed, run_production_case(seed))
