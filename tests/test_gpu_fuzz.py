@@ -350,3 +350,74 @@ def _ms_prod_seeds():
 @pytest.mark.parametrize("seed", _ms_prod_seeds())
 def test_random_multi_scatter_scene_on_the_production_kernels(seed):
     check_ms_production(seed, run_ms_production_case(seed))
+
+
+# ---- raypath colour on the production kernels (kModeColor): masks -> classes -> Y lanes ----------------------------------------------------
+def make_color_tables(seed, sc):
+    """Random colour sets for the scene of `seed` (own generator: the scene itself stays what make_case draws): every crystal entry gets 1-3
+    predicates on distinct bits, then 1-4 classes over the bits in use ("any" / "all")."""
+    rng = np.random.default_rng(seed + 7777)
+    L0 = sc.layers[0]
+    sets, bit = [], 0
+    for i in range(L0.entry_count):
+        faces = list(range(1, 9)) if L0.entries[i].crystal.kind == abi.CRYSTAL_PRISM else PYR_FACES
+        terms = []
+        for _ in range(int(rng.integers(1, 4))):
+            terms.append((_term(rng, faces), "".join(c for c in "PBD" if rng.random() < 0.5), bit))
+            bit += 1
+        sets.append(scenes.color_set(terms))
+        L0.entries[i].color_id = len(sets)
+    classes = [scenes.color_class([int(b) for b in rng.choice(bit, size=int(rng.integers(1, min(bit, 3) + 1)), replace=False)], str(rng.choice(["any", "all"])))
+               for _ in range(int(rng.integers(1, 5)))]
+    return sets, classes
+
+
+def run_color_case(seed, n=3 << 20):
+    sc, rd, wl, filters, clock = make_case(seed)
+    sets, classes = make_color_tables(seed, sc)
+    hb = hip_backend(seed=seed, geom_clock=clock)
+    ob = OracleBackend(seed=seed, threads=THREADS, acc64=1, geom_clock=clock)
+    for b in (hb, ob):
+        b.set_filters(filters)
+        b.set_color(sets, classes)
+    sh = run_session(hb, sc, rd, wl, n)
+    route = hb.last_route()
+    so = run_session(ob, sc, rd, wl, n)
+    ih, lh = hb.ReadbackXyzAccum()
+    io, lo = ob.ReadbackXyzAccum()
+    lanes_h, lanes_o = hb.ReadbackClassLanes(), ob.ReadbackClassLanes()
+    hb.close()
+    ob.close()
+    L0 = sc.layers[0]
+    fixed = all(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
+                for i in range(L0.entry_count))
+    return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, fixed_axes=fixed,
+                lanes=(lanes_h.sum(axis=(1, 2), dtype=np.float64), lanes_o.sum(axis=(1, 2), dtype=np.float64)),
+                lane_l2=[rel_l2(block_mean(lanes_h[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) if lanes_o[k].sum() > 0 else 0.0 for k in range(len(classes))])
+
+
+def check_color(seed, r):
+    assert r["mode_mask"] & abi.MODE_COLOR and not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC | abi.MODE_FILTER)), (seed, r)   # every dispatch carries masks
+    loose = 10.0 if r["fixed_axes"] else 1.0
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 * loose, abs=20), (seed, r)
+    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
+    top = float(max(r["lanes"][1].max(), 1.0))
+    # The lanes are summed with global fp32 atomics (DESIGN 3.5b) against the oracle's doubles here: 1.5e-3 of a lane's sum on the hand-written
+    # scenes; seed 5103 (a one-entry illuminant pool: 50 units of weight per exit, 3 Mi rays on 512x256, 87 % of the light in one class and
+    # most of that on the sun's pixels, whose sums pass 1e7) reads 3.1e-3 low — the image itself, summed hierarchically, is off by 2.5e-7
+    for k in range(len(r["lanes"][1])):
+        assert r["lanes"][0][k] == pytest.approx(r["lanes"][1][k], rel=5e-3 * loose, abs=1e-4 * top + 1e-3), (seed, k, r)
+        assert r["lane_l2"][k] <= 1e-2 * loose, (seed, k, r)
+
+
+def _color_seeds():
+    spec = os.environ.get("FUZZ_COLOR_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(5000, 5012))
+
+
+@pytest.mark.parametrize("seed", _color_seeds())
+def test_random_scene_with_raypath_colour_on_the_production_kernels(seed):
+    check_color(seed, run_color_case(seed))
