@@ -37,7 +37,19 @@ for seed in [int(a) for a in sys.argv[1:]]:
             np.round(np.percentile(dw[bad], [50, 90, 99, 100]), 6), np.round(np.percentile(dd[bad], [50, 99, 100]), 7), np.median(b["weight"][bad])))
     bad_roots = np.unique(np.concatenate([only_h >> 8, only_o >> 8, a["root"][bad].astype(np.int64)]))
     print("  rays with any difference: %d of %d (%.3f %%)" % (len(bad_roots), 60000, 100.0 * len(bad_roots) / 60000))
-    for r in bad_roots[:4]:
+    # which crystal entry the differing rays belong to (rays are dealt out to the entries in order, PartitionCrystalRayNum)
+    import ctypes as C
+    from ice_halo_sim_amd import backend
+    from tests._libs import fptr
+    props = np.array([L.entries[i].proportion for i in range(L.entry_count)], np.float32)
+    carry = np.zeros(L.entry_count); cnt = (C.c_uint64 * L.entry_count)()
+    backend.load_library().halo_host_partition(fptr(props), L.entry_count, 60000, carry.ctypes.data_as(C.POINTER(C.c_double)), cnt)
+    edges = np.concatenate([[0], np.cumsum(list(cnt))])
+    print("  entry ranges", list(edges), "differing rays per entry", [int(((bad_roots >= edges[i]) & (bad_roots < edges[i + 1])).sum()) for i in range(L.entry_count)],
+          "| only-hip roots per entry", [int((((only_h >> 8) >= edges[i]) & ((only_h >> 8) < edges[i + 1])).sum()) for i in range(L.entry_count)],
+          "| only-oracle", [int((((only_o >> 8) >= edges[i]) & ((only_o >> 8) < edges[i + 1])).sum()) for i in range(L.entry_count)])
+    show = list(bad_roots[:2]) + list(np.unique(only_h >> 8)[:2]) + list(np.unique(only_o >> 8)[:2])
+    for r in show:
         print("   root", r)
         for tag, e in (("hip", eh), ("ora", eo)):
             m = e[e["root"] == r]
