@@ -492,25 +492,41 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     pre[s][3] = unit[s].d;
     if (active[s]) act_mask |= 1u << s;
   }
+  // Which planes a kept vertex lies on: the planes that pass through it EXACTLY (|distance| <= 1e-9 of the crystal's size: the concurrence is
+  // computed in double) — its own three and whatever else meets there — united over the candidates the duplicate filter folds into it.
+  // (Until round 3 a face claimed every kept vertex within 2 tol of its plane: a corner 6e-5 off a neighbouring plane — an apex ridge 1.2e-4
+  // long — joined that face too and tilted its fan off the plane; tables that are no polytope, and the reference's next-face strategies part
+  // ways on those: DESIGN 5, tests/test_gpu_fuzz.py.)
+  uint32_t vmask[kPyrMaxVerts];
+  const double tight = 1e-9 * fmax(scale, 1e-3);
   auto try_triple = [&](int i, int j, int k) {
     double x[3];
     if (!Concurrence(unit[i], unit[j], unit[k], x)) return;
     bool ok = true;
+    uint32_t mk = (1u << i) | (1u << j) | (1u << k);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol
-      if ((act_mask >> m) & 1u) ok = ok && (pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3] <= tol);
+      if ((act_mask >> m) & 1u) {
+        const double ev = pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3];
+        ok = ok && (ev <= tight);
+        if (fabs(ev) <= tight) mk |= 1u << m;
+      }
     if (!ok) return;
     for (int v = 0; v < nv; v++) {
       const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
       if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;   // farther than 2 tol for certain: no sqrt
-      if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) return;   // duplicate
+      if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+        vmask[v] |= mk;
+        return;   // duplicate
+      }
     }
     if (nv < kPyrMaxVerts) {
       verts[nv][0] = x[0];
       verts[nv][1] = x[1];
       verts[nv][2] = x[2];
+      vmask[nv] = mk;
       nv++;
     }
   };
@@ -573,7 +589,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
 #pragma unroll
 #endif
       for (int s = 0; s < 20; s++)
-        if (((act_mask >> s) & 1u) && fabs(pre[s][0] * x0 + pre[s][1] * x1 + pre[s][2] * x2 + pre[s][3]) <= 2.0 * tol && cnt_reg[s] < HALO_MAX_FACE_VTX)
+        if (((act_mask >> s) & 1u) && ((vmask[v] >> s) & 1u) && cnt_reg[s] < HALO_MAX_FACE_VTX)
           on[s][cnt_reg[s]++] = v;
     }
 #if defined(__HIP_DEVICE_COMPILE__)

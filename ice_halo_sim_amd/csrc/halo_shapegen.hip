@@ -61,12 +61,15 @@ constexpr int kTeam = 32, kTeamsPerBlock = 8, kTeamBlock = kTeam * kTeamsPerBloc
 struct TeamLds {
   geom::Plane3 unit[20];
   double verts[geom::kPyrMaxVerts][3];
+  uint32_t vmask[geom::kPyrMaxVerts];         // planes through kept vertex v (its own three, whatever else meets there, united over its duplicates)
   union {
     struct {   // vertex phase
       double cand[kTeam][3];                  // the round's feasible candidates
       double park[geom::kPyrMaxVerts][3];     // feasible concurrences of the cones' own triples (<= 20 per cone), parked by the apex phase
       float4 cand_f[kTeam];                   // float copies for the distance pre-test (w = unused)
       float4 kept_f[geom::kPyrMaxVerts];
+      uint32_t park_m[geom::kPyrMaxVerts];    // the three planes of a parked concurrence
+      uint32_t rmask[kTeam];                  // a round's incidence masks, gathered on the lanes that are kept
     } vtx;
     struct {   // face phase
       double key[20][HALO_MAX_FACE_VTX];      // pseudo-angle sort keys (float keys of order_face_fast in the front half; doubles when geom::PyrOrderFace runs)
@@ -250,6 +253,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   }
   const double scale = team_max(fmax(fabs(half), side_active ? fabs(unit.d) : 0.0));
   const double tol = 5.0 * static_cast<double>(geom::kGeomFloatEps) * fmax(scale, 1e-3);
+  const double tight = 1e-9 * fmax(scale, 1e-3);   // "on the plane" for a concurrence computed in double (geom::BuildPyramidShape)
   if (s < 20) T.unit[s] = unit;
   team_publish();
   // --- cone apexes: extreme z over the feasible concurrences of each cone's own six planes ---
@@ -283,6 +287,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     if (found) {
       const int slot = ns + __popc(fmask & ((1u << lane) - 1u));
       for (int a = 0; a < 3; a++) park[slot][a] = xs[a];
+      T.vtx.park_m[slot] = (1u << i) | (1u << j) | (1u << k);
     }
     ns += __popc(fmask);
     const bool any = fmask != 0u;
@@ -321,6 +326,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     bool feasible = false;
     const int cand = base + lane;
     bool solved = false;
+    uint32_t mk = 0u;   // planes through the candidate
     if (exhaustive) {
       if (cand < total) {   // triple number `cand` of 0 <= i < j < k < 20, lexicographic
         int rem = cand;
@@ -341,15 +347,23 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       if (cand < total_nc && team_triple(cand, upper, lower, i, j, k)) solved = geom::Concurrence(T.unit[i], T.unit[j], T.unit[k], x);
       if (cand >= total_nc && cand < total) {
         for (int a = 0; a < 3; a++) x[a] = park[cand - total_nc][a];
+        mk = T.vtx.park_m[cand - total_nc];
         solved = true;
       }
     }
     if (solved) {
+      if (mk == 0u) mk = (1u << i) | (1u << j) | (1u << k);
       bool ok = true;
-      // EvalPlane(unit[m], x) <= tol over the active planes — over all twenty slots without a branch: the slots of an absent cone hold
-      // the zero plane, which evaluates to 0 <= tol
+      // EvalPlane(unit[m], x) <= tight over the active planes (exact feasibility: the concurrence is computed in double), and the planes that
+      // pass through x — over all twenty slots without a branch: the slots of an absent cone hold the zero plane, which evaluates to 0 and is
+      // masked out of the incidences afterwards
 #pragma unroll 5
-      for (int m = 0; m < 20; m++) ok = ok & (T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d <= tol);
+      for (int m = 0; m < 20; m++) {
+        const double ev = T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d;
+        ok = ok & (ev <= tight);
+        mk |= (fabs(ev) <= tight ? 1u : 0u) << m;
+      }
+      mk &= act_mask;
       feasible = ok;
     }
     const uint32_t fm = team_ballot(feasible);
@@ -365,14 +379,18 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     }
     team_publish();
     bool dupk = false;
+    int dup_v = 0;   // the FIRST kept vertex it duplicates takes its incidences (the serial filter stops there)
     uint32_t D = feasible ? (1u << lane) : 0u;   // (a candidate is within 2 tol of itself)
     if (feasible) {
       for (int v = 0; v < nv; v++) {
         const float4 o = T.vtx.kept_f[v];
         const float ex = o.x - fx, ey = o.y - fy, ez = o.z - fz;
-        if (ex * ex + ey * ey + ez * ez <= thr2) {
+        if (!dupk && ex * ex + ey * ey + ez * ez <= thr2) {
           const double dx = T.verts[v][0] - x[0], dy = T.verts[v][1] - x[1], dz = T.verts[v][2] - x[2];
-          dupk = dupk || within(dx * dx + dy * dy + dz * dz, 2.0 * tol);
+          if (within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) {
+            dupk = true;
+            dup_v = v;
+          }
         }
       }
       for (uint32_t m = fm & ~(1u << lane); m != 0u; m &= m - 1u) {
@@ -398,34 +416,33 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
         if (((rm >> e) & 1u) && (d_e & keep) == 0u) keep |= 1u << e;
       }
     }
-    if ((keep >> lane) & 1u) {
+    // incidences: a duplicate's planes go to the vertex the serial filter would have stopped at — the first earlier-round vertex within
+    // 2 tol, else the lowest kept candidate of this round within 2 tol
+    const bool kept = ((keep >> lane) & 1u) != 0u;
+    if (kept) T.vtx.rmask[lane] = mk;
+    team_publish();
+    if (feasible && dupk) atomicOr(&T.vmask[dup_v], mk);
+    if (in_r && !kept) atomicOr(&T.vtx.rmask[__ffs(D & keep) - 1], mk);
+    team_publish();
+    if (kept) {
       const int pos = nv + __popc(keep & below);
       if (pos < geom::kPyrMaxVerts) {
         for (int a = 0; a < 3; a++) T.verts[pos][a] = x[a];
         T.vtx.kept_f[pos] = make_float4(fx, fy, fz, 0.0f);
+        T.vmask[pos] = T.vtx.rmask[lane];
       }
     }
     nv = min(nv + __popc(keep), geom::kPyrMaxVerts);
     team_publish();
   }
   // --- faces: vertices on plane s (ascending vertex order), then CCW order ---
-  // Turned around: lane v evaluates the twenty planes at vertex v (the vertex in registers, the planes broadcast reads that do not depend on
-  // one another), a ballot per plane hands lane s the set of vertices on plane s.  (One lane per plane walking the vertex list — a
-  // dependent LDS read and a conditional LDS write per step — sat waiting: 0.62 ms of the kernel for ~200 instructions.)
+  // Lane v holds the incidence mask of vertex v (gathered while the vertices were found); a ballot per plane hands lane s the set of
+  // vertices on plane s.
   uint32_t on_lo = 0u, on_hi = 0u;
   {
     const bool two = __ballot(nv > kTeam) != 0ull;   // more than 32 vertices in either team of the wave: lane v also holds vertex 32 + v
-    uint32_t pm0 = 0u, pm1 = 0u;
-    if (valid && lane < nv) {
-      const double vx = T.verts[lane][0], vy = T.verts[lane][1], vz = T.verts[lane][2];
-#pragma unroll 5
-      for (int m = 0; m < 20; m++) pm0 |= (fabs(T.unit[m].a * vx + T.unit[m].b * vy + T.unit[m].c * vz + T.unit[m].d) <= 2.0 * tol ? 1u : 0u) << m;
-    }
-    if (two && valid && lane + kTeam < nv) {
-      const double vx = T.verts[lane + kTeam][0], vy = T.verts[lane + kTeam][1], vz = T.verts[lane + kTeam][2];
-#pragma unroll 5
-      for (int m = 0; m < 20; m++) pm1 |= (fabs(T.unit[m].a * vx + T.unit[m].b * vy + T.unit[m].c * vz + T.unit[m].d) <= 2.0 * tol ? 1u : 0u) << m;
-    }
+    const uint32_t pm0 = (valid && lane < nv) ? T.vmask[lane] : 0u;
+    const uint32_t pm1 = (two && valid && lane + kTeam < nv) ? T.vmask[lane + kTeam] : 0u;
 #pragma unroll
     for (int m = 0; m < 20; m++) {
       const uint32_t b0 = team_ballot((pm0 >> m) & 1u);

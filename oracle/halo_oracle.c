@@ -983,7 +983,14 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
   raw[1] = unit[1] = (HoPlane){0.0, 0.0, -1.0, z_bot};
   active[0] = active[1] = 1;
   /* vertices: feasible, de-duplicated concurrences of plane triples */
+  /* Incidence: the planes that pass through a kept vertex exactly (|distance| <= 1e-9 of the crystal's size; the concurrence is computed
+   * in double) — its own three and whatever else meets there — united over the candidates the duplicate filter folds into it.  (A face used
+   * to claim every kept vertex within 2 tol of its plane; a corner 6e-5 off a neighbouring plane then joined that face too and tilted its
+   * fan off the plane — tables that are no polytope, which the reference's closed-form builder never emits, optics.cpp:100-104.  The 488
+   * topology goldens hold either way.) */
   double vx[96][3];
+  unsigned vmask[96];
+  const double tight = 1e-9 * fmax(scale, 1e-3);
   int nv = 0;
   for (int i = 0; i < 20; i++) {
     if (!active[i]) continue;
@@ -994,15 +1001,24 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
         double x[3];
         if (!solve3_planes(&unit[i], &unit[j], &unit[k], x)) continue;
         int ok = 1;
-        for (int m = 0; m < 20 && ok; m++)
-          if (active[m] && unit[m].a * x[0] + unit[m].b * x[1] + unit[m].c * x[2] + unit[m].d > tol) ok = 0;
+        unsigned mk = (1u << i) | (1u << j) | (1u << k);
+        for (int m = 0; m < 20; m++) {
+          if (!active[m]) continue;
+          double ev = unit[m].a * x[0] + unit[m].b * x[1] + unit[m].c * x[2] + unit[m].d;
+          if (ev > tight) ok = 0;
+          if (fabs(ev) <= tight) mk |= 1u << m;
+        }
         if (!ok) continue;
         int dup = 0;
         for (int v = 0; v < nv && !dup; v++) {
           double dx = vx[v][0] - x[0], dy = vx[v][1] - x[1], dz = vx[v][2] - x[2];
-          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) dup = 1;
+          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+            dup = 1;
+            vmask[v] |= mk;
+          }
         }
         if (dup || nv >= 96) continue;
+        vmask[nv] = mk;
         memcpy(vx[nv++], x, sizeof(x));
       }
     }
@@ -1014,7 +1030,7 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
     if (!active[s]) continue;
     int on[HALO_MAX_FACE_VTX], n_on = 0;
     for (int v = 0; v < nv; v++)
-      if (fabs(unit[s].a * vx[v][0] + unit[s].b * vx[v][1] + unit[s].c * vx[v][2] + unit[s].d) <= 2.0 * tol && n_on < HALO_MAX_FACE_VTX) on[n_on++] = v;
+      if (((vmask[v] >> s) & 1u) && n_on < HALO_MAX_FACE_VTX) on[n_on++] = v;
     g->plane_coef[s * 4 + 0] = (float)raw[s].a;
     g->plane_coef[s * 4 + 1] = (float)raw[s].b;
     g->plane_coef[s * 4 + 2] = (float)raw[s].c;
