@@ -1,7 +1,7 @@
 """Host pyramid builder (short candidate lists + the exhaustive second pass) against the oracle's exhaustive builder: topology disagreements
 (face / fan-triangle counts) over an ordinary and a deliberately degenerate sampler of pyramid parameters, and whether the oracle's own table
 is a polytope (fan triangles == 2 V - 4) where they disagree.  CPU only.  Round 3: 11 / 30000 ordinary and 2453 / 30000 degenerate
-disagreements before the second pass existed; 1 and 119 with it, in all of which the oracle's table is no polytope either."""
+disagreements with tolerance feasibility and tolerance face claims; 0 and 0 with exact feasibility and incidence masks on both sides."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
