@@ -359,7 +359,9 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
                             uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
-  if (planes > 1u) {
+  // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
+  // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
+  if (planes > 1u || tiles > 256u) {
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
     hipError_t e = hipGetLastError();

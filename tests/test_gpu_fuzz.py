@@ -203,11 +203,14 @@ def test_random_scene_traces_the_same_rays_as_the_oracle(seed):
 THREADS = max(8, min(os.cpu_count() or 8, 128))
 
 
-def run_production_case(seed, n=3 << 20):
+def run_production_case(seed, n=3 << 20, big=False):
     """Capture off: plain / kModeFilter kernels with the exit queue, hit log or binned routes, pool or one-shape geometry as the scene
     asks.  Same streams on both sides, so image, landed weight and exit count are compared like the single-layer production tests
     (tests/test_gpu_filter_production.py), the oracle with its double accumulator."""
     sc, rd, wl, filters, clock = make_case(seed)
+    if big:   # a production-size image, and sessions long enough for the per-entry-plane / binned / two-level routes of illuminant renders
+        rd.width, rd.height = [(1920, 1080), (2048, 1024), (4096, 2048)][seed % 3]
+        clock = 32 if clock == 8 else clock
     hb = hip_backend(seed=seed, geom_clock=clock)
     ob = OracleBackend(seed=seed, threads=THREADS, acc64=1, geom_clock=clock)
     for b in (hb, ob):
@@ -232,11 +235,29 @@ def check_production(seed, r):
     assert not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC)), (seed, r)      # max_hits <= 12: the production-shaped kernels
     loose = 10.0 if r["fixed_axes"] else 1.0        # (every ray the same way: see check())
     assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 * loose, abs=20), (seed, r)
-    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
-    assert r["l2"] <= 3e-3 * loose, (seed, r)
+    # (a heavily filtered scene lands a few thousand exits of 9 Mi rays: the two or three that differ between the sides weigh what an exit weighs)
+    per_exit = max(r["landed"][1], 1.0) / max(r["exits"][1], 1)
+    slack = 3.0 * per_exit * (abs(r["exits"][0] - r["exits"][1]) + 2)
+    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3 + slack, (seed, r)
+    assert r["l2"] <= 3e-3 * loose + 2.0 / np.sqrt(max(r["exits"][1], 1)), (seed, r)
     tot = float(r["sums"][1].sum())
     for ch in range(3):
-        assert r["sums"][0][ch] == pytest.approx(r["sums"][1][ch], rel=5e-4 * loose, abs=1e-5 * tot + 1e-6), (seed, ch, r)
+        assert r["sums"][0][ch] == pytest.approx(r["sums"][1][ch], rel=5e-4 * loose, abs=1e-5 * tot + 1e-6 + slack * tot / max(r["landed"][1], 1.0)), (seed, ch, r)
+
+
+def _big_seeds():
+    spec = os.environ.get("FUZZ_BIG_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(6000, 6005)) + [6011]   # 6011: a one-entry illuminant pool on 4096 x 2048 — 512 hit-log tiles on ONE plane (it faulted before the fix)
+
+
+@pytest.mark.parametrize("seed", _big_seeds())
+def test_random_scene_on_the_production_kernels_big_image(seed):
+    """The same at 9 Mi rays on 1920x1080 / 2048x1024 / 4096x2048: scalar-plane hit log, X/Y/Z log, one plane per pool entry with the binned
+    and two-level routes — whichever the session asks for."""
+    check_production(seed, run_production_case(seed, n=9 << 20, big=True))
 
 
 def _prod_seeds():
