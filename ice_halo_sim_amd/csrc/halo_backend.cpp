@@ -885,7 +885,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
         cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
         if (use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
-        uint64_t c2 = std::max<uint64_t>(2ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
+        // (8x the even share, within the 8 GB below: what runs over a tile list is added with fp32 atomics, and on a pixel that holds 4e5 the
+        // rounding of a near-constant addend is a bias, not noise — tools/route_fuzz.py seed 969: the sun's tile of a 1024 x 512 render took five
+        // even shares and its pixel read 5.6e-4 high with 2x)
+        uint64_t c2 = std::max<uint64_t>(8ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
         c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * log_tiles));
         if (b->hit_log_cap) {   // tests: run both overflow fallbacks
           cap = b->hit_log_cap;

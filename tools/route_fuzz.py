@@ -1,0 +1,51 @@
+"""Accumulation-route boundaries, HIP against HIP: random image size (64x48 .. 4096x2048), session length around the route thresholds (2 Mi,
+8 Mi rays), wavelength source (discrete, illuminant pools of 1 .. 255 entries), lens / visible range, deterministic or sampled crystals — the
+default routes (hit log, X/Y/Z log, per-entry planes, binned, two-level) against the same session with every hit added by a direct atomic
+(options hit_log=0, bin=0).  The image, landed weight and exit count must agree to float-accumulation accuracy.  Prints each case before it
+runs (a memory fault names its case).   python tools/route_fuzz.py [first_seed] [count]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ice_halo_sim_amd import abi, scenes
+from ice_halo_sim_amd.backend import HipTraceBackend
+from tests._oracle_backend import run_session
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+SIZES = [(64, 48), (333, 211), (512, 256), (1024, 512), (1920, 1080), (2048, 1024), (2048, 2048), (2896, 2896), (4096, 2048), (8192, 1024)]
+RAYS = [(2 << 20) - 1, 2 << 20, (2 << 20) + 77, 3 << 20, (8 << 20) - 1, 8 << 20, 9 << 20]
+worst = 0.0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    w, h = SIZES[rng.integers(len(SIZES))]
+    n = int(RAYS[rng.integers(len(RAYS))])
+    wl = scenes.wl_discrete(float(rng.uniform(400, 700))) if rng.random() < 0.35 else scenes.wl_illuminant(str(rng.choice(["D65", "A"])), int(rng.choice([1, 2, 3, 7, 31, 64, 255])))
+    lens = int(rng.integers(0, 11))
+    rd = scenes.render(lens, w, h, fov=float(rng.uniform(30, 110)) if lens == abi.LENS_LINEAR else 180.0, az=float(rng.uniform(0, 360)), el=float(rng.uniform(0, 90)),
+                       visible=int(rng.integers(0, 3)))
+    kind = int(rng.integers(3))
+    u = lambda m, s: {"type": "uniform", "mean": m, "std": s}
+    full = u(0.0, 360.0)
+    if kind == 0:
+        e = scenes.column_crystal_entry()
+    elif kind == 1:
+        e = scenes.entry(scenes.prism_crystal(u(1.0, 0.6), [u(1.0, 0.3)] * 6), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+    else:
+        e = scenes.entry(scenes.pyramid_crystal(u(0.3, 0.3), u(1.0, 0.5), 0.2, face_distance=[u(1.0, 0.2)] * 6), scenes.axis(zenith=u(90.0, 20.0), azimuth=full, roll=full), 1.0, 1)
+    entries = [e] if rng.random() < 0.6 else [e, scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 1.0}, roll=full), 0.7, 2)]
+    sc = scenes.scene([(0.0, entries)], max_hits=int(rng.choice([3, 7, 8])))
+    print("seed %d: %dx%d n=%d wl=(%d,%d) lens=%d vis=%d kind=%d entries=%d" % (seed, w, h, n, wl.illuminant, wl.pool_size, lens, rd.visible, kind, len(entries)), end=" ", flush=True)
+    res = []
+    for opts in ({}, {"hit_log": 0, "bin": 0}):
+        hb = HipTraceBackend(device=0, seed=seed, **opts)
+        st = run_session(hb, sc, rd, wl, n)
+        r = hb.last_route()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        res.append((st[0].exit_count, landed, img, r.accum_mask))
+    (xa, la, ia, ma), (xb, lb, ib, mb) = res
+    den = max(float(np.linalg.norm(ib.astype(np.float64))), 1e-30)
+    err = float(np.linalg.norm(ia.astype(np.float64) - ib)) / den if ib.any() else 0.0
+    worst = max(worst, err)
+    ok = abs(xa - xb) <= 2 and abs(la - lb) <= 2e-6 * max(lb, 1.0) and err <= 2e-4
+    print("routes %d vs %d: exits %d/%d landed rel %.1e image rel L2 %.1e %s" % (ma, mb, xa, xb, abs(la - lb) / max(lb, 1.0), err, "ok" if ok else "MISMATCH"), flush=True)
+print("worst image distance %.2e" % worst)
