@@ -11,6 +11,8 @@ from ice_halo_sim_amd.backend import HipTraceBackend
 from tests._oracle_backend import run_session
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+TWO_LAYERS = len(sys.argv) > 3 and sys.argv[3] == "ms"   # a second scattering layer (prob 0.5 / 1.0): continuation order differs run to run, so the
+                                                           # comparison is statistical there (landed 3 %, exits 1 %) — the point is the routes' memory safety
 SIZES = [(64, 48), (333, 211), (512, 256), (1024, 512), (1920, 1080), (2048, 1024), (2048, 2048), (2896, 2896), (4096, 2048), (8192, 1024)]
 RAYS = [(2 << 20) - 1, 2 << 20, (2 << 20) + 77, 3 << 20, (8 << 20) - 1, 8 << 20, 9 << 20]
 worst = 0.0
@@ -32,7 +34,11 @@ for seed in range(first, first + count):
     else:
         e = scenes.entry(scenes.pyramid_crystal(u(0.3, 0.3), u(1.0, 0.5), 0.2, face_distance=[u(1.0, 0.2)] * 6), scenes.axis(zenith=u(90.0, 20.0), azimuth=full, roll=full), 1.0, 1)
     entries = [e] if rng.random() < 0.6 else [e, scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 1.0}, roll=full), 0.7, 2)]
-    sc = scenes.scene([(0.0, entries)], max_hits=int(rng.choice([3, 7, 8])))
+    if TWO_LAYERS:
+        second = [scenes.entry(scenes.prism_crystal(1.5), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 3)]
+        sc = scenes.scene([(float(rng.choice([0.5, 1.0])), entries), (0.0, second)], max_hits=int(rng.choice([3, 7])))
+    else:
+        sc = scenes.scene([(0.0, entries)], max_hits=int(rng.choice([3, 7, 8])))
     print("seed %d: %dx%d n=%d wl=(%d,%d) lens=%d vis=%d kind=%d entries=%d" % (seed, w, h, n, wl.illuminant, wl.pool_size, lens, rd.visible, kind, len(entries)), end=" ", flush=True)
     res = []
     for opts in ({}, {"hit_log": 0, "bin": 0}):
@@ -41,11 +47,13 @@ for seed in range(first, first + count):
         r = hb.last_route()
         img, landed = hb.ReadbackXyzAccum()
         hb.close()
-        res.append((st[0].exit_count, landed, img, r.accum_mask))
+        res.append((sum(x.exit_count for x in st), landed, img, r.accum_mask))
     (xa, la, ia, ma), (xb, lb, ib, mb) = res
     den = max(float(np.linalg.norm(ib.astype(np.float64))), 1e-30)
     err = float(np.linalg.norm(ia.astype(np.float64) - ib)) / den if ib.any() else 0.0
     worst = max(worst, err)
     ok = abs(xa - xb) <= 2 and abs(la - lb) <= 2e-6 * max(lb, 1.0) and err <= 2e-4
+    if TWO_LAYERS:
+        ok = abs(xa - xb) <= 1e-2 * max(xb, 1) + 50 and abs(la - lb) <= 3e-2 * max(lb, 1.0) + 2.0
     print("routes %d vs %d: exits %d/%d landed rel %.1e image rel L2 %.1e %s" % (ma, mb, xa, xb, abs(la - lb) / max(lb, 1.0), err, "ok" if ok else "MISMATCH"), flush=True)
 print("worst image distance %.2e" % worst)
