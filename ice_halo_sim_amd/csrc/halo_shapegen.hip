@@ -43,19 +43,23 @@ __global__ void __launch_bounds__(kGenBlock, (sizeof(S) == sizeof(ShapeDev) ? HA
 //   scalars      lane q < 9 draws scalar q from the recipe's draw plan (geom::DrawShapeScalarOne); lane s takes its face distance by shuffle
 //   planes       lane s < 20 builds raw / unit plane s                                  (geom::PyrRawPlaneOne / PyrUnitPlane)
 //   cone apexes  lane t < 20 solves triple t of its cone, team max; the feasible ones are parked for the vertex phase (geom::Concurrence)
-//   vertices     the 60 basal / prism-pair triples in lexicographic order, then the parked cone survivors, 32 per round: one solve +
-//                feasibility scan per lane, then the serial duplicate filter evaluated in parallel — every feasible lane tests its
-//                candidate against the kept vertices and the round's other candidates (float pre-test, fp64 only for near pairs),
-//                the lowest of each duplicate group is kept, in lane order = list order (see the loop for why that IS the serial filter)
-//   faces        lane v evaluates the planes at vertex v, one ballot per plane hands lane s the vertices on plane s; CCW order by float
-//                pseudo-angle keys (order_face_fast: geom::PyrOrderFace's order without its divisions)
+//   vertices     the 60 basal / prism-pair triples in lexicographic order, then the parked cone survivors, 32 per round: one solve + one scan of
+//                the planes per lane — exact feasibility (no plane has the point outside by more than 1e-9 of the crystal's size) and the set
+//                of planes through it — then the serial duplicate filter evaluated in parallel: every feasible lane tests its candidate
+//                against the kept vertices and the round's other candidates (float pre-test, fp64 only for near pairs), the lowest of each
+//                duplicate group is kept, in lane order = list order (see the loop for why that IS the serial filter), and a duplicate's
+//                planes are OR-ed into the vertex it folds into (LDS)
+//   faces        lane v holds vertex v's incidence mask, one ballot per plane hands lane s the vertices on plane s; CCW order by float
+//                pseudo-angle keys (order_face_fast: geom::PyrOrderFace's order without its divisions; the serial ordering where keys are close)
+//   check        fan triangles = 2 V - 4 and >= 4 faces (Euler), else the exhaustive enumeration of all 1140 triples runs (second inlined copy)
 //   tables       lane s emits face row + fan triangles at offsets from a team prefix sum (geom::EmitFace), then pairs the
 //                opposite faces (geom::FinalizeSlabs' rule: the one slot that can hold the exact negative normal) with ballots
 // Every number is produced by the same expression on the same operands as in the serial builder, reductions are max / any
 // (order-free), and candidates are kept in the serial order, so the record is bit-identical to the host's
 // (tests/test_gpu_parity.py::test_device_crystal_generator_equals_host_builder).
-// Round 3: 4.28 -> 2.69 ms per 781 K crystals (measured per phase with early exits: draw plan + no scratch tables 0.96 -> 0.24 ms,
-// parallel duplicate filter and branch-free plane scan 1.30 -> 1.14 ms, face collection stays ~0.65 ms, slab pairing 0.31 -> ~0.05 ms).
+// Round 3: 4.28 -> 2.75 ms per 781 K crystals (measured per phase with early exits: draw plan + no scratch tables 0.96 -> 0.24 ms,
+// parallel duplicate filter and branch-free plane scan 1.30 -> 1.14 ms, slab pairing 0.31 -> ~0.05 ms; face collection ~0.65 ms until the
+// incidence masks replaced the per-vertex plane evaluation).
 constexpr int kTeam = 32, kTeamsPerBlock = 8, kTeamBlock = kTeam * kTeamsPerBlock;
 
 struct TeamLds {
