@@ -5,6 +5,7 @@
 //   halo_begin → (halo_trace_layer → halo_recombine)* → halo_trace_layer → halo_end ; halo_readback_xyz any time.
 // There is no CPU fallback in this library: every entry point that computes needs a gfx950 device and fails
 // with HALO_UNAVAILABLE otherwise.
+#include <cstdlib>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -885,10 +886,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         uint64_t cap = std::max<uint64_t>(4ull * per_wg, 4096ull);
         cap = std::min<uint64_t>(cap, (6ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
         if (use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) cap = std::min<uint64_t>(std::max<uint64_t>(8ull * per_wg, 4096ull), (8ull << 30) / (8ull * static_cast<uint64_t>(blocks)));
+        // (per-launch cost of the slack, measured: configs[1] split 234 / 238 / 241 us at 2x / 4x / 8x; configs[4]'s 512 X/Y/Z lists 554 / 574 / 635 us —
+        // so 8x for scalar planes, where a hot pixel meets near-constant addends, 4x for X/Y/Z, whose addends vary with the wavelength)
+        const uint64_t kListSlack = use_log_xyz ? 4ull : 8ull;
         // (8x the even share, within the 8 GB below: what runs over a tile list is added with fp32 atomics, and on a pixel that holds 4e5 the
         // rounding of a near-constant addend is a bias, not noise — tools/route_fuzz.py seed 969: the sun's tile of a 1024 x 512 render took five
         // even shares and its pixel read 5.6e-4 high with 2x)
-        uint64_t c2 = std::max<uint64_t>(8ull * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
+        uint64_t c2 = std::max<uint64_t>(kListSlack * ((use_log_xyz || b->render.visible == HALO_VISIBLE_FULL) ? 8ull : 4ull) * m / log_tiles, 1ull << 14);
         c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * log_tiles));
         if (b->hit_log_cap) {   // tests: run both overflow fallbacks
           cap = b->hit_log_cap;
