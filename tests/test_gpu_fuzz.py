@@ -486,3 +486,66 @@ def _color_seeds():
 @pytest.mark.parametrize("seed", _color_seeds())
 def test_random_scene_with_raypath_colour_on_the_production_kernels(seed):
     check_color(seed, run_color_case(seed))
+
+
+# ---- sequences of sessions on ONE backend: the accumulation planes, their layout and the routes change from session to session -------------
+def run_sequence_case(seed):
+    """Three to five sessions on one backend instance — wavelength source (discrete / illuminant pools of 1 .. 64 entries) and session length
+    (50 k .. 9 Mi rays: direct atomics, hit log, X/Y/Z log, per-entry planes, binned routes) drawn per session, the image read back (and so
+    zeroed) after some of them — against the oracle doing the same sequence.  What is compared is every readback."""
+    rng = np.random.default_rng(seed + 424242)
+    w, h = [(333, 211), (512, 256), (1920, 1080), (2048, 1024)][rng.integers(4)]
+    lens = int(rng.choice([abi.LENS_FISHEYE_EQUAL_AREA, abi.LENS_DUAL_FISHEYE_EQUAL_AREA, abi.LENS_RECTANGULAR, abi.LENS_LINEAR]))
+    rd = scenes.render(lens, w, h, fov=80.0 if lens == abi.LENS_LINEAR else 180.0, az=float(rng.uniform(0, 360)), el=float(rng.uniform(10, 80)), visible=int(rng.choice([abi.VISIBLE_UPPER, abi.VISIBLE_FULL])))
+    u = lambda m, s: {"type": "uniform", "mean": m, "std": s}
+    full = u(0.0, 360.0)
+    e = scenes.column_crystal_entry() if rng.random() < 0.5 else scenes.entry(scenes.prism_crystal(u(1.0, 0.6), [u(1.0, 0.3)] * 6), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.0, [e])], max_hits=7)
+    hb = hip_backend(seed=seed)
+    ob = OracleBackend(seed=seed, threads=THREADS, acc64=1)
+    out = []
+    n_sessions = int(rng.integers(3, 6))
+    n_min = 1 << 62   # the shortest session the next readback holds
+    for k in range(n_sessions):
+        wl = scenes.wl_discrete(float(rng.uniform(400, 700))) if rng.random() < 0.5 else scenes.wl_illuminant("D65", int(rng.choice([1, 3, 31, 64])))
+        n = int(rng.choice([50_000, 1_000_000, 2 << 20, 3 << 20, 9 << 20]))
+        n_min = min(n_min, n)
+        sh = run_session(hb, sc, rd, wl, n)
+        so = run_session(ob, sc, rd, wl, n)
+        if rng.random() < 0.5 or k == n_sessions - 1:
+            ih, lh = hb.ReadbackXyzAccum()
+            io, lo = ob.ReadbackXyzAccum()
+            io = np.asarray(io, np.float32)
+            bh, bo = block_mean(ih, 8).astype(np.float64), block_mean(io, 8).astype(np.float64)
+            out.append(dict(k=k, n=n, n_min=n_min, exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), l2=rel_l2(block_mean(ih, 8), block_mean(io, 8)) if io.sum() > 0 else 0.0,
+                            moved=float(np.abs(bh - bo).sum() / max(bo.sum(), 1e-300)), sums=(ih.sum(dtype=np.float64), io.sum(dtype=np.float64))))
+            n_min = 1 << 62
+    hb.close()
+    ob.close()
+    return out
+
+
+def check_sequence(seed, out):
+    for r in out:
+        assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4, abs=20), (seed, r)
+        assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
+        # An illuminant render of a few Mi rays on 2 M pixels is a few heavy exits (80 - 100 units each) per block, and one exit in ~4000
+        # lands in the neighbouring pixel or row between the two sides (a one-ulp difference of the projection is 1e-4 of a pixel on a
+        # 2048-wide linear lens; the same with direct atomics: tools/route_fuzz.py): percents of a per-pixel L2 distance there, whatever the
+        # route.  So: the share of the energy that sits in another 8x8 block is the bar, the block-mean L2 a loose second.
+        assert r["l2"] <= 3e-2, (seed, r)
+        assert r["moved"] <= 4e-3, (seed, r)
+        assert r["sums"][0] == pytest.approx(r["sums"][1], rel=5e-4), (seed, r)
+
+
+def _seq_seeds():
+    spec = os.environ.get("FUZZ_SEQ_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(7000, 7006))
+
+
+@pytest.mark.parametrize("seed", _seq_seeds())
+def test_random_sequence_of_sessions_on_one_backend(seed):
+    check_sequence(seed, run_sequence_case(seed))
