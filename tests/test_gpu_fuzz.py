@@ -36,9 +36,12 @@ def _face_distances(rng):
 
 
 def _crystal(rng):
-    # sync groups tie heights to heights and face distances to face distances (a height drawn as a face distance is a legal document, but
-    # its crystals sit in the degenerate regime where even the exhaustive vertex enumeration yields no polytope: tools/pyr_topology_scan.py)
+    # sync groups tie heights to heights and face distances to face distances; FUZZ_ANY_GROUPS=1 sweeps heights and distances in one group
+    # as well (a legal document with tiny or negative face distances: before the builder took exact incidences those crystals were no
+    # polytopes — seed 732 — now 599 of 600 such seeds sit inside the bars, the other at 0.993 matched)
     groups = ([int(g) for g in rng.choice([0, 0, 1], 3)] + [int(g) for g in rng.choice([0, 0, 0, 2, 3], 6)]) if rng.random() < 0.3 else None
+    if groups is not None and os.environ.get("FUZZ_ANY_GROUPS"):   # a sweep with heights and face distances in one group (tiny or negative distances)
+        groups = [int(g) for g in rng.choice([0, 0, 0, 1, 2], 9)]
     if rng.random() < 0.55:
         h = float(rng.choice([0.1, 0.3, 1.0, 1.3, 3.0])) if rng.random() < 0.6 else _dist(rng, rng.uniform(0.3, 2.0), [0.1, 0.5], ("uniform", "gauss"))
         return scenes.prism_crystal(h, _face_distances(rng), sync_group=groups), list(range(1, 9))
