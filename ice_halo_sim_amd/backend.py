@@ -79,6 +79,8 @@ def load_library():
         "halo_host_reduce_raypath": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]),
         "halo_host_filter_fast_check": (C.c_int, [C.POINTER(abi.HaloFilter), C.POINTER(abi.HaloAxis), C.POINTER(C.c_uint8), C.c_int32, C.POINTER(C.c_float), C.c_int32,
                                                   C.POINTER(C.c_int32)]),
+        "halo_host_color_fast_mask": (C.c_int, [C.POINTER(abi.HaloColorSet), C.POINTER(abi.HaloAxis), C.POINTER(C.c_uint8), C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                                C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export a declared symbol
@@ -93,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
     "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_shape_scalars", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
-    "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
+    "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_color_fast_mask", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
 ]
 
 

@@ -375,6 +375,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
     const uint64_t base = static_cast<uint64_t>(v) << 40;
     b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
+  } else if (k == "ray_base") {
+    // the session's first 64-bit ray index (SplitPcgRayBase, trace_backend.hpp:184: lo feeds the stream index, hi pcg_seed_with_high)
+    const uint64_t base = static_cast<uint64_t>(v);
+    b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
   } else return fail(b, HALO_FATAL, "unknown option: " + k);
   return HALO_OK;
 }
@@ -1395,6 +1399,15 @@ int halo_host_filter_fast_check(const HaloFilter* f, const HaloAxis* axis, const
   }
   if (!cache->fits) return HALO_FATAL;
   *pass = host::FastFilterCheck(cache->tables, path, static_cast<uint32_t>(n), dir, static_cast<uint32_t>(crystal_id)) ? 1 : 0;
+  return HALO_OK;
+}
+int halo_host_color_fast_mask(const HaloColorSet* colors, const HaloAxis* axis, const uint8_t* path, int32_t n, const float dir[3], int32_t crystal_id, uint64_t carried,
+                              uint64_t* mask) {
+  if (!colors || !axis || !mask || n < 0 || n > 16 || (n && !path) || !dir) return HALO_FATAL;
+  std::unique_ptr<FastTables> tables(new FastTables());
+  std::memset(tables.get(), 0, sizeof(FastTables));
+  if (!host::BuildFastTables(nullptr, colors, *axis, static_cast<uint32_t>(crystal_id), *tables)) return HALO_FATAL;
+  *mask = host::FastColorMask(*tables, carried, path, static_cast<uint32_t>(n), dir, static_cast<uint32_t>(crystal_id));
   return HALO_OK;
 }
 double halo_host_refractive_index(double wl) { return host::IceRefractiveIndex(wl); }

@@ -477,6 +477,38 @@ bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t L, const
   return F.action == 0u ? m : !m;
 }
 
+uint64_t FastColorMask(const FastTables& F, uint64_t carried, const uint8_t* path, uint32_t L, const float dir[3], uint32_t crystal_id) {
+  // the kernels' fast_color_bits (halo_trace.inl) on the host: every colour predicate that matches ORs its bit into the carried mask
+  uint64_t hi = 0, lo = 0;
+  for (uint32_t i = 0; i < L; i++) {
+    hi = (hi << 8) | (lo >> 56);
+    lo = (lo << 8) | path[i];
+  }
+  uint64_t mask = carried;
+  for (uint32_t k = 0; k < F.color_terms; k++) {
+    const FastTerm& raw = F.cterm[k];
+    const FastTermView t = ViewTerm(raw);
+    bool m = false;
+    if (t.type == HALO_FILTER_NONE) m = true;
+    else if (t.type == HALO_FILTER_RAYPATH) {
+      if (L == t.len)
+        for (uint32_t j = 0; j < t.orbit_n && !m; j++) m = lo == F.orbit_lo[t.orbit_off + j] && (L <= 8u || hi == F.orbit_hi[t.orbit_off + j]);
+    } else if (t.type == HALO_FILTER_ENTRY_EXIT) {
+      if (!(L == 0u || L < t.min_len || (t.max_len != 0u && L > t.max_len))) {
+        if (t.ee_off == 0xFFFFu) m = true;
+        else {
+          const uint32_t sh = 8u * (L - 1u);
+          const uint32_t first = static_cast<uint32_t>((sh < 64u ? lo >> sh : hi >> (sh - 64u)) & 0xFFull), last = static_cast<uint32_t>(lo & 0xFFull);
+          m = first < 32u && last < 32u && ((F.ee[t.ee_off][first & 31u] >> last) & 1u) != 0u;
+        }
+      }
+    } else if (t.type == HALO_FILTER_DIRECTION) m = raw.dir[0] * dir[0] + raw.dir[1] * dir[1] + raw.dir[2] * dir[2] > raw.radii_c;
+    else if (t.type == HALO_FILTER_CRYSTAL) m = crystal_id == raw.crystal_id;
+    if (m && t.bit < 64u) mask |= 1ull << t.bit;
+  }
+  return mask;
+}
+
 bool BuildEntryFast(const ShapeDev& s, EntryFastDev& out) {
   std::memset(&out, 0, sizeof(out));
   if (s.face_cnt != kEntryFastFaces || s.slab_cnt != 4 || s.single_cnt != 0 || s.tri_cnt < 8 || s.tri_cnt > kEntryFastTris) return false;

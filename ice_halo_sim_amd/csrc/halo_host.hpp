@@ -54,6 +54,8 @@ bool BuildFastTables(const HaloFilter* filter, const HaloColorSet* colors, const
 std::vector<std::array<uint64_t, 2>> RaypathMembers(const std::vector<uint8_t>& canon, uint8_t symmetry, int sigma_a, bool d_applicable);
 // The fast tables evaluated on the host, step for step like halo_trace.inl fast_filter (test hook).
 bool FastFilterCheck(const FastTables& F, const uint8_t* path, uint32_t len, const float dir[3], uint32_t crystal_id);
+// the colour pass of the production colour kernels (fast_color_bits) on the host: carried | bits of the matching predicates
+uint64_t FastColorMask(const FastTables& F, uint64_t carried, const uint8_t* path, uint32_t len, const float dir[3], uint32_t crystal_id);
 int ComputeSigmaA(float roll_center_deg);       // crystal.cpp:720-726
 bool IsDApplicable(const HaloAxis& axis);       // crystal.cpp:728-730
 

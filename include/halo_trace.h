@@ -252,7 +252,8 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out);
 int halo_destroy(halo_handle_t h);
 const char* halo_last_error(halo_handle_t h);
 /* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
- * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams),
+ * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams), "ray_base" (the 64-bit index of the next
+ * root ray — SplitPcgRayBase, trace_backend.hpp:184; counters run on from it, across 2^32 with the carry of pcg_advance_hi),
  * "chunk" (max rays per kernel launch, default 256 Mi), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that
  * plane, power of two, default 8), "async" (queue final-layer dispatches without a host sync, see halo_collect_stats),
@@ -426,6 +427,12 @@ int halo_host_reduce_raypath(const uint8_t* rp, int32_t n, int32_t symmetry, int
  * when the filter does not fit the fast form (the backend then runs the generic kernels).  A host-side test hook: the tests compare it with
  * the reduction-based predicate (halo_host_reduce_raypath) over every short face sequence. */
 int halo_host_filter_fast_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int32_t n, const float dir[3], int32_t crystal_id, int32_t* pass);
+/* The raypath-colour pass of the production colour kernels on the host — ApplyLayerColorBits, cuda_trace_backend.cu:498-527; CPU:
+ * the colour loop of CollectData, simulator.cpp:689-716 (FilterSpec::CheckSummandMask per predicate): every predicate of `colors`
+ * (with its OWN symmetry, evaluated for a crystal with orientation `axis`) that matches the exit ORs its bit into `carried`.
+ * Same member tables as halo_host_filter_fast_check (n <= 16).  A host-side test hook for the reference's component-gate vectors. */
+int halo_host_color_fast_mask(const HaloColorSet* colors, const HaloAxis* axis, const uint8_t* path, int32_t n, const float dir[3], int32_t crystal_id,
+                              uint64_t carried, uint64_t* mask);
 /* IceRefractiveIndex::Get — optics.cpp:180-197. */
 double halo_host_refractive_index(double wavelength_nm);
 /* GetIlluminantSpd(type, wavelength) — util/illuminant.cpp:113-134 (HALO_ILLUM_*; 0 outside the tabulated range). */

@@ -1303,6 +1303,21 @@ int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* pa
   return f->action == 0 ? m : !m;
 }
 
+/* The colour pass of the emit gate for one exit — simulator.cpp:689-716 (per ColorSpecGroup: CheckSummandMask, mapped bits OR'd into
+ * the carried mask), cuda_trace_backend.cu:498-527 ApplyLayerColorBits.  Each predicate carries its own symmetry. */
+uint64_t ho_color_mask(const HaloColorSet* cs, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id,
+                       uint64_t carried) {
+  int dap = ho_is_d_applicable(axis);
+  int sigma_a = dap ? ho_compute_sigma_a(axis->roll.center) : 0;
+  uint64_t m = carried;
+  for (int k = 0; k < cs->term_count; k++) {
+    const HaloColorTerm* ct = &cs->terms[k];
+    if (ct->bit >= 0 && ct->bit < 64 && filter_match_term(&ct->predicate, ct->symmetry, sigma_a, dap, path, len, dir_world, crystal_id))
+      m |= 1ull << ct->bit;
+  }
+  return m;
+}
+
 /* ======================================================================================== */
 /* whole path: the backend state machine of include/halo_trace.h on the CPU                  */
 /* ======================================================================================== */
@@ -1398,6 +1413,8 @@ int ho_set_option(HoBackend* b, const char* key, int64_t v) {
   else if (!strcmp(key, "rank")) {
     uint64_t base = (uint64_t)v << 40; /* disjoint 64-bit counter ranges per shard */
     b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
+  } else if (!strcmp(key, "ray_base")) { /* first 64-bit ray index of the session (SplitPcgRayBase trace_backend.hpp:184) */
+    b->gen_count = b->gate_count = b->transit_count = b->shape_count = (uint64_t)v;
   } else return HALO_FATAL;
   return HALO_OK;
 }
@@ -1652,15 +1669,7 @@ static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const floa
   if (c->filter && !ho_filter_check(c->filter, c->axis, path, path_len, exit_world, c->crystal_id)) return;
   /* raypath colour, non-destructive, after the physical filter (ApplyLayerColorBits cu:498-527) */
   uint64_t cmask = carried;
-  if (c->color) {
-    int dap = ho_is_d_applicable(c->axis);
-    int sigma_a = dap ? ho_compute_sigma_a(c->axis->roll.center) : 0;
-    for (int k = 0; k < c->color->term_count; k++) {
-      const HaloColorTerm* ct = &c->color->terms[k];
-      if (ct->bit >= 0 && ct->bit < 64 && filter_match_term(&ct->predicate, ct->symmetry, sigma_a, dap, path, path_len, exit_world, c->crystal_id))
-        cmask |= 1ull << ct->bit;
-    }
-  }
+  if (c->color) cmask = ho_color_mask(c->color, c->axis, path, path_len, exit_world, c->crystal_id, carried);
   int pass_prob = 0;
   if (c->prob > 0.0f) pass_prob = (c->prob >= 1.0f) ? 1 : (ho_pcg_uniform(gate) < c->prob); /* rng.GetUniform() < prob_ :719 */
   if (pass_prob) {
@@ -1879,28 +1888,30 @@ static float sync_draw(HoSync* y, int group, const HaloDist* d) {
   return v;
 }
 
-static void make_shape(const HoBackend* b, const HaloCrystal* cr, uint64_t shape_index, HaloGeomTables* out) {
+/* The nine shape scalars of crystal instance `shape_index` in slot order [h0, h1, h2, d0..d5] (prism: h0 and d0..d5), heights folded
+ * with fabs, face distances signed — SamplePrismShapeScalars / SamplePyramidShapeScalars (simulator.cpp:405-425) over the host PCG
+ * stream of this repo (the reference draws from mt19937).  Draw order = the contract of test_crystal_sync_group_sampling.cpp:81-165:
+ * heights first (upper, prism, lower), then d[0..5]; later members of a sync group reuse the group's first RAW draw. */
+void ho_shape_scalars(const HaloCrystal* cr, uint32_t seed, uint64_t shape_index, float out9[9]) {
   HoStream s;
   uint32_t lo = (uint32_t)(shape_index & 0xFFFFFFFFull), hi = (uint32_t)(shape_index >> 32);
-  s.seed = ho_pcg_seed_with_high(b->seed ^ NONCE_SHAPE_HOST, hi);
+  s.seed = ho_pcg_seed_with_high(seed ^ NONCE_SHAPE_HOST, hi);
   s.global_idx = lo;
   s.slot = 0;
   HoSync y;
   memset(&y, 0, sizeof(y));
   y.s = &s;
-  if (cr->kind == HALO_CRYSTAL_PRISM) {
-    float dist[6];
-    float h = fabsf(sync_draw(&y, cr->sync_group[0], &cr->height[0]));
-    for (int i = 0; i < 6; i++) dist[i] = sync_draw(&y, cr->sync_group[3 + i], &cr->face_dist[i]);
-    ho_prism_geometry(h, dist, out);
-  } else { /* SamplePyramidShapeScalars simulator.cpp:416-425 */
-    float dist[6];
-    float p1 = fabsf(sync_draw(&y, cr->sync_group[0], &cr->height[0]));
-    float p2 = fabsf(sync_draw(&y, cr->sync_group[1], &cr->height[1]));
-    float p3 = fabsf(sync_draw(&y, cr->sync_group[2], &cr->height[2]));
-    for (int i = 0; i < 6; i++) dist[i] = sync_draw(&y, cr->sync_group[3 + i], &cr->face_dist[i]);
-    ho_pyramid_geometry(cr->wedge_upper_deg, cr->wedge_lower_deg, p1, p2, p3, dist, out);
-  }
+  for (int i = 0; i < 9; i++) out9[i] = 0.0f;
+  int nh = cr->kind == HALO_CRYSTAL_PRISM ? 1 : 3;
+  for (int i = 0; i < nh; i++) out9[i] = fabsf(sync_draw(&y, cr->sync_group[i], &cr->height[i]));
+  for (int i = 0; i < 6; i++) out9[3 + i] = sync_draw(&y, cr->sync_group[3 + i], &cr->face_dist[i]);
+}
+
+static void make_shape(const HoBackend* b, const HaloCrystal* cr, uint64_t shape_index, HaloGeomTables* out) {
+  float sc[9];
+  ho_shape_scalars(cr, b->seed, shape_index, sc);
+  if (cr->kind == HALO_CRYSTAL_PRISM) ho_prism_geometry(sc[0], sc + 3, out);
+  else ho_pyramid_geometry(cr->wedge_upper_deg, cr->wedge_lower_deg, sc[0], sc[1], sc[2], sc + 3, out); /* simulator.cpp:416-425 */
 }
 
 int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloLayerStats* stats) {

@@ -111,6 +111,8 @@ void ho_reduce_raypath(const uint8_t* rp, int n, int symmetry, int sigma_a, int 
 int ho_compute_sigma_a(float roll_mean_deg);
 int ho_is_d_applicable(const HaloAxis* axis);
 int ho_filter_check(const HaloFilter* f, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id);
+uint64_t ho_color_mask(const HaloColorSet* cs, const HaloAxis* axis, const uint8_t* path, int len, const float dir_world[3], int crystal_id, uint64_t carried);
+void ho_shape_scalars(const HaloCrystal* cr, uint32_t seed, uint64_t shape_index, float out9[9]); /* simulator.cpp:405-425, :361-393 */
 int ho_set_filters(HoBackend* b, const HaloFilter* filters, int32_t count);
 int ho_set_color(HoBackend* b, const HaloColorSet* sets, int32_t n_sets, const HaloColorClass* classes, int32_t n_classes);
 int ho_readback_class_lanes(HoBackend* b, float* lanes, int width, int height, int class_count);

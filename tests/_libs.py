@@ -107,6 +107,9 @@ def oracle():
     L.ho_is_d_applicable.restype = C.c_int; L.ho_is_d_applicable.argtypes = [C.POINTER(abi.HaloAxis)]
     L.ho_filter_check.restype = C.c_int
     L.ho_filter_check.argtypes = [C.POINTER(abi.HaloFilter), C.POINTER(abi.HaloAxis), u8p, C.c_int, f32p, C.c_int]
+    L.ho_color_mask.restype = C.c_uint64
+    L.ho_color_mask.argtypes = [C.POINTER(abi.HaloColorSet), C.POINTER(abi.HaloAxis), u8p, C.c_int, f32p, C.c_int, C.c_uint64]
+    L.ho_shape_scalars.restype = None; L.ho_shape_scalars.argtypes = [C.POINTER(abi.HaloCrystal), C.c_uint32, C.c_uint64, f32p]
     L.ho_set_filters.restype = C.c_int; L.ho_set_filters.argtypes = [C.c_void_p, C.POINTER(abi.HaloFilter), C.c_int32]
     L.ho_set_color.restype = C.c_int; L.ho_set_color.argtypes = [C.c_void_p, C.POINTER(abi.HaloColorSet), C.c_int32, C.POINTER(abi.HaloColorClass), C.c_int32]
     L.ho_readback_class_lanes.restype = C.c_int; L.ho_readback_class_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]
