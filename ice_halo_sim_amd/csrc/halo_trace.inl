@@ -84,6 +84,36 @@ HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 HD float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// The Fresnel split's quotients and root (HALO_FRESNEL: 0 = hardware approximations, 1 = IEEE division / square root, 2 = the
+// approximations with one FMA refinement step — the correctly rounded quotient for operands in the normal range, which these are).
+// dd = (1 - rr^2) / cos^2 + rr^2 cancels near the critical angle: a 1-ulp reciprocal there moves the transmitted weight by 1e-3.
+#ifndef HALO_FRESNEL
+#define HALO_FRESNEL 0
+#endif
+HD float fresnel_div(float a, float b) {
+#if HALO_FRESNEL == 0
+  return a * fast_rcp(b);
+#elif HALO_FRESNEL == 1
+  return __fdiv_rn(a, b);
+#else
+  const float y = fast_rcp(b);
+  const float q = a * y;
+  return fmaf(fmaf(-b, q, a), y, q);
+#endif
+}
+HD float fresnel_sqrt(float x) {   // x >= 0
+#if HALO_FRESNEL == 0
+  return fast_sqrt(x);
+#elif HALO_FRESNEL == 1
+  return __fsqrt_rn(x);
+#else
+  const float xc = fmaxf(x, 1e-30f);   // rsq(0) is inf; sqrt(1e-30) is 1e-15, below half an ulp of everything it is added to here
+  const float y = fast_rsq(xc);
+  const float sq = xc * y;
+  return fmaf(fmaf(-sq, sq, xc), 0.5f * y, sq);
+#endif
+}
+
 // sin and cos together for |x| below a few turns (every angle on this path is): two-term Cody-Waite reduction by
 // pi/2 with FMAs, then the classic degree-7 / degree-8 minimax kernels on [-pi/4, pi/4].  ~1 ulp; replaces the
 // library sincosf whose general-argument reduction dominated root generation.
@@ -1659,12 +1689,16 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   };
   auto fresnel = [&](float cos_t, float rr, float rr2, float one_m_rr2, const float4& fn) {
     Split o;
+#if HALO_FRESNEL == 0
     const float dd = one_m_rr2 * fast_rcp(cos_t * cos_t) + rr2;
+#else
+    const float dd = add_rn(fresnel_div(one_m_rr2, cos_t * cos_t), rr2);   // quotient rounded, then the sum: the reference's order (optics.cpp:30)
+#endif
     o.tir = dd <= 0.0f;
-    const float sq = fast_sqrt(fmaxf(dd, 0.0f));
-    float Rs = (rr - sq) * fast_rcp(rr + sq);
+    const float sq = fresnel_sqrt(fmaxf(dd, 0.0f));
+    float Rs = fresnel_div(rr - sq, rr + sq);
     Rs *= Rs;
-    float Rp = (1.0f - rr * sq) * fast_rcp(1.0f + rr * sq);
+    float Rp = fresnel_div(1.0f - rr * sq, 1.0f + rr * sq);
     Rp *= Rp;
     o.w_refl = (Rs + Rp) * 0.5f * w;
     o.w_refr = w - o.w_refl;

@@ -14,6 +14,7 @@ from ice_halo_sim_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+ORACLE_FMA_SO = os.path.join(ROOT, "oracle", "liboracle_fma.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_shared.so")
 
 f32p = C.POINTER(C.c_float)
@@ -40,18 +41,20 @@ class HoProjResult(C.Structure):
     _fields_ = [("hits", HoPixelHit * 2), ("count", C.c_int32)]
 
 
-_oracle = None
+_oracle = {}
 
 
-def oracle():
-    global _oracle
-    if _oracle is not None:
-        return _oracle
+def oracle(fma=False):
+    """fma=True: the same source compiled with products contracted into FMAs (oracle/Makefile: liboracle_fma.so) — the second
+    legitimate rounding of the reference's expressions, the tests' yardstick for ill-conditioned exits"""
+    if fma in _oracle:
+        return _oracle[fma]
+    so = ORACLE_FMA_SO if fma else ORACLE_SO
     src = os.path.join(ROOT, "oracle", "halo_oracle.c")
     deps = [src, os.path.join(ROOT, "oracle", "halo_oracle.h"), os.path.join(ROOT, "include", "halo_trace.h")]
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
-    L = C.CDLL(ORACLE_SO)
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
+    L = C.CDLL(so)
     sp = C.POINTER(HoStream)
     L.ho_pcg_hash.restype = C.c_uint32; L.ho_pcg_hash.argtypes = [C.c_uint32]
     L.ho_u01_from_hash.restype = C.c_float; L.ho_u01_from_hash.argtypes = [C.c_uint32]
@@ -120,7 +123,7 @@ def oracle():
     L.ho_consumer_fold.restype = C.c_int; L.ho_consumer_fold.argtypes = [C.c_void_p]
     L.ho_consumer_snapshot.restype = C.c_int
     L.ho_consumer_snapshot.argtypes = [C.c_void_p, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]
-    _oracle = L
+    _oracle[fma] = L
     return L
 
 

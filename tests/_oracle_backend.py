@@ -10,8 +10,8 @@ from tests import _libs
 
 
 class OracleBackend:
-    def __init__(self, seed=42, **options):
-        self._L = _libs.oracle()
+    def __init__(self, seed=42, fma=False, **options):
+        self._L = _libs.oracle(fma=fma)   # fma: the contracted build (tests/_libs.py), the yardstick for ill-conditioned exits
         self._h = self._L.ho_create(int(seed) & 0xFFFFFFFF)
         self._render = None
         self._scene = None

@@ -15,7 +15,7 @@ import pytest
 
 from ice_halo_sim_amd import abi, scenes
 from tests._oracle_backend import OracleBackend, run_session
-from tests.test_gpu_parity import block_mean, hip_backend, match_exits, rel_l2
+from tests.test_gpu_parity import block_mean, hip_backend, match_exits, match_exits_conditioned, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -149,20 +149,25 @@ def run_case(seed, n=60_000):
     sc, rd, wl, filters, clock = make_case(seed)
     hb = hip_backend(seed=seed, capture_exits=1, geom_clock=clock)
     ob = OracleBackend(seed=seed, capture_exits=1, threads=8, geom_clock=clock)
-    for b in (hb, ob):
+    ob2 = OracleBackend(seed=seed, fma=True, capture_exits=1, threads=8, geom_clock=clock)   # the oracle's other rounding: which exits are ill-conditioned
+    for b in (hb, ob, ob2):
         b.set_filters(filters)
     sh = run_session(hb, sc, rd, wl, n)
     so = run_session(ob, sc, rd, wl, n)
-    eh, eo = hb.DrainExits(), ob.DrainExits()
+    run_session(ob2, sc, rd, wl, n)
+    eh, eo, eo2 = hb.DrainExits(), ob.DrainExits(), ob2.DrainExits()
     ih, lh = hb.ReadbackXyzAccum()
     io, lo = ob.ReadbackXyzAccum()
     hb.close()
     ob.close()
+    ob2.close()
     L0 = sc.layers[0]
     fixed = any(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
                 for i in range(L0.entry_count))   # an entry whose every ray meets the crystal the same way
     out = dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), n_exits=(len(eh), len(eo)), fixed_axes=fixed, degenerate=has_degenerate_tables(sc, seed))
     out["match"] = match_exits(eh, eo) if len(eo) and len(eh) else (1.0 if len(eh) == len(eo) else 0.0, 1.0, 1.0)
+    out["cond"] = match_exits_conditioned(eh, eo, eo2) if len(eo) and len(eh) else (1.0 if len(eh) == len(eo) else 0.0, 1.0, 1.0, 0)
+    out["oracle_pair"] = match_exits(eo2, eo)[0] if len(eo) and len(eo2) else 1.0
     # what the exits that do not pair up (or pair up with another weight) can move the landed weight by, at most
     n_un = int(round((1.0 - out["match"][0]) * (len(eh) + len(eo)))) + 1
     wmax = max(float(eh["weight"].max()) if len(eh) else 0.0, float(eo["weight"].max()) if len(eo) else 0.0)
@@ -174,20 +179,29 @@ def run_case(seed, n=60_000):
 
 
 def check(seed, r):
-    """The per-ray bars are those of the e2e documents.  Three things a random scene does that the documents do not, found by sweeping
-    3300 seeds (tools/diag_fuzz.py shows any seed in detail): (1) an entry with every axis FIXED — all its rays then meet the crystal the same way, and if
-    that way grazes a face (sun 0.35 degrees below a plate's basal plane: cos of the incidence angle passes through zero across the sun's
-    disc, the transmitted weight 1 - R is ill-conditioned there) or a critical angle, the weights of 1-3 % of the exits move by more
-    than the 2e-4 bar on every ray that goes that way (seed 11584: 9 % of a scene's exits, by 3e-4 .. 3e-3): 0.9 there (0.995 otherwise: 2500 more seeds had three scenes at 0.9955 - 0.996); (2) small sparse images at 60 k rays, where ONE exit crossing a pixel
-    border is 1 % of a block-mean distance: that bar is 5e-2 + 2 / sqrt(blocks that carry the image) here, the per-ray bars carry the comparison; (3) illuminant weights of
-    ~100 per exit: the landed weights may differ by what the unmatched exits weigh."""
+    """The per-ray bars are those of the e2e documents, applied to the exits the ORACLE itself is sure of.  What a random scene does that
+    the documents do not, found by sweeping 3300 seeds (tools/diag_fuzz.py shows any seed in detail): (1) an entry with every axis FIXED —
+    all its rays then meet the crystal the same way, and if that way grazes a face (sun 0.35 degrees below a plate's basal plane: cos of the
+    incidence angle passes through zero across the sun's disc, the transmitted weight 1 - R is ill-conditioned there) or a critical angle,
+    the weights of 1-9 % of the exits move by 3e-4 .. 3e-3 on every ray that goes that way.  Round 3 blamed the Fresnel split's hardware
+    reciprocal / square root and lowered the bar to 0.9 for such scenes; round 4 measured it (tools/fresnel_ab.py): IEEE division
+    and square root change nothing (seed 11584: 0.905 with, 0.910 without), because the ORACLE compiled with FMA contraction disagrees with
+    the oracle compiled without on the same exits (0.918 there; 0.945 / 0.951 / 0.976 on seeds 247 / 411 / 702) — the reference's own
+    result is not defined more finely than that, and a HIP build WITHOUT contraction pairs up on 99.9 % (at 14 % of the throughput).  So the
+    yardstick is that pair (match_exits_conditioned): 0.995 of the exits within the bars widened, per exit, by four times what the two
+    oracles differ by on it.
+    (2) small sparse images at 60 k rays, where ONE exit crossing a pixel border is 1 % of a block-mean distance: that bar is 5e-2 +
+    2 / sqrt(blocks that carry the image) here, the per-ray bars carry the comparison; (3) illuminant weights of ~100 per exit: the
+    landed weights may differ by what the unmatched exits weigh."""
     if r["degenerate"]:   # (see has_degenerate_tables: the two sides follow the reference's two next-face strategies)
         assert r["exits"][0] == pytest.approx(r["exits"][1], rel=6e-2, abs=20), (seed, r)
         assert r["match"][0] >= 0.85, (seed, r)
         return
     assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3, abs=20), (seed, r)
-    frac, pix, path = r["match"]
-    assert frac >= (0.9 if r["fixed_axes"] else 0.995) and pix >= 0.995 and path >= 0.998, (seed, r)
+    frac, pix, path, left_out = r["cond"]
+    assert frac >= 0.995 and pix >= 0.995 and path >= 0.998, (seed, r)
+    assert left_out <= 2e-3 * r["n_exits"][1] + 5, (seed, r)
+    assert r["match"][0] >= min(0.995, r["oracle_pair"] - 0.03), (seed, r)          # and never far below what the oracles reach between themselves
     assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3 + r["unmatched_weight"], (seed, r)
     assert r["l2"] <= 5e-2 + 2.0 / np.sqrt(max(r["n_eff"], 1.0)), (seed, r)
 
@@ -234,7 +248,31 @@ def run_production_case(seed, n=3 << 20, big=False):
     io = np.asarray(io, np.float32)
     return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, accum_mask=route.accum_mask, fixed_axes=fixed,
                 l2=rel_l2(block_mean(ih, 8), block_mean(io, 8)) if io.sum() > 0 else 0.0,
-                sums=(ih.sum(axis=(0, 1), dtype=np.float64), io.sum(axis=(0, 1), dtype=np.float64)))
+                sums=(ih.sum(axis=(0, 1), dtype=np.float64), io.sum(axis=(0, 1), dtype=np.float64)),
+                floor=oracle_pair_floor(seed, sc, rd, wl, filters, clock, n, so, io, lo) if fixed else None)
+
+
+def oracle_pair_floor(seed, sc, rd, wl, filters, clock, n, so, io, lo, sets=None, classes=None, lanes_o=None):
+    """How far the oracle is from ITSELF on this scene when its products are contracted into FMAs (liboracle_fma.so): the yardstick for
+    scenes whose every ray meets the crystal the same way (see check()).  Relative distances in exit count, landed weight, 8x8 block-mean
+    image, channel sums (and class lanes)."""
+    ob2 = OracleBackend(seed=seed, fma=True, threads=THREADS, acc64=1, geom_clock=clock)
+    ob2.set_filters(filters)
+    if sets is not None:
+        ob2.set_color(sets, classes)
+    s2 = run_session(ob2, sc, rd, wl, n)
+    i2, l2 = ob2.ReadbackXyzAccum()
+    lanes2 = ob2.ReadbackClassLanes() if sets is not None else None
+    ob2.close()
+    i2 = np.asarray(i2, np.float32)
+    f = dict(exits=abs(int(s2[0].exit_count) - int(so[0].exit_count)) / max(int(so[0].exit_count), 1), landed=abs(l2 - lo) / max(lo, 1.0),
+             l2=rel_l2(block_mean(i2, 8), block_mean(io, 8)) if io.sum() > 0 else 0.0,
+             sums=float(np.max(np.abs(i2.sum(axis=(0, 1), dtype=np.float64) - io.sum(axis=(0, 1), dtype=np.float64)) / max(float(io.sum(dtype=np.float64)), 1e-30))))
+    if lanes2 is not None:
+        a, b = lanes2.sum(axis=(1, 2), dtype=np.float64), lanes_o.sum(axis=(1, 2), dtype=np.float64)
+        f["lanes"] = float(np.max(np.abs(a - b) / np.maximum(b, 1.0)))
+        f["lane_l2"] = max([rel_l2(block_mean(lanes2[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) if lanes_o[k].sum() > 0 else 0.0 for k in range(len(lanes_o))] + [0.0])
+    return f
 
 
 def check_production(seed, r):
@@ -242,16 +280,17 @@ def check_production(seed, r):
         assert not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC)), (seed, r)      # max_hits <= 16: the production-shaped kernels
     else:
         assert not (r["mode_mask"] & abi.MODE_CAPTURE), (seed, r)                           # (a sweep with longer paths: filtered entries run the generic kernels)
-    loose = 10.0 if r["fixed_axes"] else 1.0        # (every ray the same way: see check())
-    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 * loose, abs=20), (seed, r)
+    # every ray the same way (see check()): the plain bars plus four times what the oracle's two roundings differ by on this scene
+    fl = r["floor"] or dict(exits=0.0, landed=0.0, l2=0.0, sums=0.0)
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 + 4.0 * fl["exits"], abs=20), (seed, r)
     # (a heavily filtered scene lands a few thousand exits of 9 Mi rays: the two or three that differ between the sides weigh what an exit weighs)
     per_exit = max(r["landed"][1], 1.0) / max(r["exits"][1], 1)
     slack = 3.0 * per_exit * (abs(r["exits"][0] - r["exits"][1]) + 2)
-    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3 + slack, (seed, r)
-    assert r["l2"] <= 3e-3 * loose + 4.0 / np.sqrt(max(r["exits"][1], 1)), (seed, r)   # (seed 6125: 3e5 exits of 9 Mi rays on 2 M pixels, 7.2e-3)
+    assert abs(r["landed"][0] - r["landed"][1]) <= (3e-4 + 4.0 * fl["landed"]) * max(r["landed"][1], 1.0) + 1e-3 + slack, (seed, r)
+    assert r["l2"] <= 3e-3 + 4.0 * fl["l2"] + 4.0 / np.sqrt(max(r["exits"][1], 1)), (seed, r)   # (seed 6125: 3e5 exits of 9 Mi rays on 2 M pixels, 7.2e-3)
     tot = float(r["sums"][1].sum())
     for ch in range(3):
-        assert r["sums"][0][ch] == pytest.approx(r["sums"][1][ch], rel=5e-4 * loose, abs=1e-5 * tot + 1e-6 + slack * tot / max(r["landed"][1], 1.0)), (seed, ch, r)
+        assert r["sums"][0][ch] == pytest.approx(r["sums"][1][ch], rel=5e-4, abs=(1e-5 + 4.0 * fl["sums"]) * tot + 1e-6 + slack * tot / max(r["landed"][1], 1.0)), (seed, ch, r)
 
 
 def _big_seeds():
@@ -320,6 +359,15 @@ def run_ms_case(seed, n=100_000):
     hb.close()
     ob.close()
     e0h, e0o = eh[eh["layer"] == 0], eo[eo["layer"] == 0]
+    # first-layer exits of the oracle's other rounding (liboracle_fma.so): which of them are ill-conditioned (see check())
+    o3 = OracleBackend(seed=seed, fma=True, capture_exits=1, threads=8, geom_clock=clock)
+    o3.set_filters(filters)
+    o3.BeginSession(sc, rd, wl, n)
+    o3.TraceLayer(n)
+    e0o2 = o3.DrainExits()
+    o3.EndSession()
+    o3.close()
+    e0o2 = e0o2[e0o2["layer"] == 0]
     # the oracle's own seed-to-seed scatter of the landed weight on this scene (two more seeds): the yardstick for the layers >= 1
     others = []
     for s2 in (seed + 1000, seed + 2000):
@@ -332,7 +380,8 @@ def run_ms_case(seed, n=100_000):
     fixed = any(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
                 for i in range(L0.entry_count))   # an entry whose every ray meets the crystal the same way
     return dict(layers=sc.layer_count, landed_other_seeds=others, fixed_axes=fixed, cont=[(a.continuation_count, b.continuation_count) for a, b in zip(sh, so)], exits=(len(eh), len(eo)),
-                first=match_exits(e0h, e0o) if len(e0h) and len(e0o) else (1.0 if len(e0h) == len(e0o) else 0.0, 1.0, 1.0), n_first=(len(e0h), len(e0o)), landed=(lh, lo))
+                first=match_exits(e0h, e0o) if len(e0h) and len(e0o) else (1.0 if len(e0h) == len(e0o) else 0.0, 1.0, 1.0), n_first=(len(e0h), len(e0o)), landed=(lh, lo),
+                first_cond=match_exits_conditioned(e0h, e0o, e0o2) if len(e0h) and len(e0o) else (1.0 if len(e0h) == len(e0o) else 0.0, 1.0, 1.0, 0))
 
 
 def check_ms(seed, r):
@@ -340,10 +389,10 @@ def check_ms(seed, r):
     the second layer on the continuation order differs (GPU append order vs the oracle's threads), so the rays are other draws of the same
     population: counts agree statistically — a few per cent at 100 k roots, against 1/sqrt(N) of the smallest count — and the landed weight
     within the oracle's own seed-to-seed scatter."""
-    frac, pix, path = r["first"]
-    # (0.99: seed 3201 has the sun 0.66 degrees above the horizon on crystals whose c axis is held horizontal — grazing incidence again, 0.55 %
-    # of the first layer's exits differ in weight by 3e-4 .. 1e-3)
-    assert frac >= (0.95 if r["fixed_axes"] else 0.99) and path >= 0.998, (seed, r)
+    # (seed 3201 has the sun 0.66 degrees above the horizon on crystals whose c axis is held horizontal — grazing incidence, 0.55 % of the
+    # first layer's exits differ in weight by 3e-4 .. 1e-3, between the oracle's two roundings as well: the conditioned match of check())
+    frac, pix, path, left_out = r["first_cond"]
+    assert frac >= 0.995 and path >= 0.998, (seed, r)
     c0h, c0o = r["cont"][0]
     assert c0h == pytest.approx(c0o, rel=1e-3, abs=20), (seed, r)
     for l in range(1, r["layers"] - 1):
@@ -460,22 +509,23 @@ def run_color_case(seed, n=3 << 20):
     fixed = any(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
                 for i in range(L0.entry_count))   # an entry whose every ray meets the crystal the same way
     return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, fixed_axes=fixed,
+                floor=oracle_pair_floor(seed, sc, rd, wl, filters, clock, n, so, np.asarray(io, np.float32), lo, sets, classes, lanes_o) if fixed else None,
                 lanes=(lanes_h.sum(axis=(1, 2), dtype=np.float64), lanes_o.sum(axis=(1, 2), dtype=np.float64)),
                 lane_l2=[rel_l2(block_mean(lanes_h[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) if lanes_o[k].sum() > 0 else 0.0 for k in range(len(classes))])
 
 
 def check_color(seed, r):
     assert r["mode_mask"] & abi.MODE_COLOR and not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC | abi.MODE_FILTER)), (seed, r)   # every dispatch carries masks
-    loose = 10.0 if r["fixed_axes"] else 1.0
-    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 * loose, abs=20), (seed, r)
-    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * loose * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
+    fl = r["floor"] or dict(exits=0.0, landed=0.0, lanes=0.0, lane_l2=0.0)   # every ray the same way: + four times the oracle pair's own distance (check())
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 + 4.0 * fl["exits"], abs=20), (seed, r)
+    assert abs(r["landed"][0] - r["landed"][1]) <= (3e-4 + 4.0 * fl["landed"]) * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
     top = float(max(r["lanes"][1].max(), 1.0))
     # The lanes are summed with global fp32 atomics against the oracle's doubles here: 1.5e-3 of a lane's sum on the hand-written
     # scenes; seed 5103 (a one-entry illuminant pool: 50 units of weight per exit, 3 Mi rays on 512x256, 87 % of the light in one class and
     # most of that on the sun's pixels, whose sums pass 1e7) reads 3.1e-3 low — the image itself, summed hierarchically, is off by 2.5e-7
     for k in range(len(r["lanes"][1])):
-        assert r["lanes"][0][k] == pytest.approx(r["lanes"][1][k], rel=5e-3 * loose, abs=1e-4 * top + 1e-3), (seed, k, r)
-        assert r["lane_l2"][k] <= 1e-2 * loose, (seed, k, r)
+        assert r["lanes"][0][k] == pytest.approx(r["lanes"][1][k], rel=5e-3 + 4.0 * fl["lanes"], abs=1e-4 * top + 1e-3), (seed, k, r)
+        assert r["lane_l2"][k] <= 1e-2 + 4.0 * fl["lane_l2"], (seed, k, r)
 
 
 def _color_seeds():

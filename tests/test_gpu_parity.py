@@ -52,6 +52,39 @@ def match_exits(eh, eo):
     return ok.sum() / max(n_union, 1), pix_same[ok].mean() if ok.any() else 0.0, same_path[ok].mean() if ok.any() else 0.0
 
 
+def match_exits_conditioned(eh, eo, eo2):
+    """match_exits with the oracle's OWN rounding sensitivity as the yardstick.  `eo2` are the exits of the same rays from the oracle
+    compiled with products contracted into FMAs (oracle/Makefile liboracle_fma.so): the second legitimate rounding of the reference's
+    expressions.  Where the two oracles disagree the exit is ill-conditioned — grazing incidence, a critical angle, a ray through an
+    edge: the transmitted weight 1 - R there amplifies a 1e-7 difference in cos(incidence) to 1e-3, whoever computes it (measured:
+    fixed-orientation scenes, where every ray meets the crystal the same way, have the two ORACLES pairing up on 92-98 % of their exits
+    only, and a HIP build without contraction pairs up with the uncontracted oracle on 99.9 %; tools/fresnel_ab.py).  So each
+    exit's bars are the plain ones (direction 2e-5, weight 2e-4) widened by four times what the two oracles differ by ON THAT EXIT, and
+    exits only one of the oracles emits are left out.  Returns (fraction within the bars, same pixel, same path, exits left out)."""
+    def keyed(e):
+        k = (e["layer"].astype(np.int64) << 48) | (e["root"].astype(np.int64) << 8) | e["seq"].astype(np.int64)
+        o = np.argsort(k)
+        return k[o], e[o]
+    kh, eh = keyed(eh)
+    ko, eo = keyed(eo)
+    k2, eo2 = keyed(eo2)
+    common, c1, c2 = np.intersect1d(ko, k2, return_indices=True)         # the exits both oracles emit
+    a, b = eo[c1], eo2[c2]
+    sd = np.abs(a["dir"] - b["dir"]).max(axis=1)
+    sw = np.abs(a["weight"] - b["weight"])
+    unsure = np.setxor1d(ko, k2)
+    wk, ch, cc = np.intersect1d(kh, common, return_indices=True)
+    x, y = eh[ch], a[cc]
+    dd = np.abs(x["dir"] - y["dir"]).max(axis=1)
+    dw = np.abs(x["weight"] - y["weight"])
+    ok = (dd <= 2e-5 + 4.0 * sd[cc]) & (dw <= 2e-4 * np.abs(y["weight"]) + 4.0 * sw[cc] + 1e-9)
+    n_union = len(np.union1d(np.setdiff1d(kh, unsure), common))
+    frac = ok.sum() / max(n_union, 1)
+    pix = (x["pixel"] == y["pixel"])[ok & (sd[cc] == 0.0)].mean() if (ok & (sd[cc] == 0.0)).any() else 1.0
+    path = ((x["path_len"] == y["path_len"]) & (x["path"] == y["path"]).all(axis=1))[ok].mean() if ok.any() else 0.0
+    return frac, pix, path, len(unsure)
+
+
 def run_both(scene, render, wl, n, seed=42, capture=True, shuffle=True, **opts):
     hb = hip_backend(seed=seed, capture_exits=int(capture), **opts)
     ob = OracleBackend(seed=seed, capture_exits=int(capture), threads=8, **{k: v for k, v in opts.items() if k == "geom_clock"})
