@@ -23,13 +23,14 @@
 
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono);
-hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream);
+hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, uint32_t frac_bits, hipStream_t stream);
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream);
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, hipStream_t stream);
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, hipStream_t stream);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
-                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream);
+                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
+                                hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -101,6 +102,7 @@ struct HaloBackend {
 
   // monotone ray counters: seeded once, never reset per session (cuda_trace_backend.cu:3724-3741)
   uint64_t gen_count = 0, gate_count = 0, transit_count = 0, shape_count = 0;
+  double sess_max_w = 1.0;     // largest initial ray weight of the open session (wavelength-pool spd weights)
 
   // session
   bool in_session = false;
@@ -455,6 +457,8 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->wl_pool_size = static_cast<uint32_t>(pool.size());
   if (pool.empty() || pool.size() > HALO_WL_POOL_MAX) return fail(b, HALO_FATAL, "wavelength pool size out of range");
   b->wl_pool_host = pool;  // travels to the device inside each dispatch slot
+  b->sess_max_w = 0.0;     // no ray of this session weighs more (continuations only lose weight): bounds the per-tile fixed-point sums
+  for (const WlEntryDev& e : pool) b->sess_max_w = std::max(b->sess_max_w, static_cast<double>(std::fabs(e.spd_weight)));
   // Accumulation planes of this session (kernels never touch the XYZ image; halo_fold_kernel closes the session):
   //  * discrete wavelength: ONE scalar plane, coefficient = CMF(lambda)            (1 atomic per hit)
   //  * illuminant, batch >= 8 Mi rays: one scalar plane per pool entry, coefficient = its CMF (1 atomic per hit, fold reads M planes)
@@ -519,6 +523,15 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->cont_in_n = 0;
   b->cont_out_slot = 0;
   return HALO_OK;
+}
+
+// Fractional bits of the per-tile fixed-point sums for a launch of `m` rays whose weights are at most `max_w`: the largest F <= 32 with
+// 4 * max_w * m * 2^F < 2^62 (see halo_kernels.hip FixQ for the factor 4).
+static uint32_t fix_frac_bits(double max_w, uint64_t m) {
+  const double bound = 4.0 * std::max(max_w, 1e-30) * static_cast<double>(std::max<uint64_t>(m, 1));
+  int e = 0;
+  (void)std::frexp(bound, &e);   // bound < 2^e
+  return static_cast<uint32_t>(std::min(32, std::max(0, 62 - e)));
 }
 
 static int fold_if_dirty(HaloBackend* b) {
@@ -632,6 +645,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
   }
 
+  if (rays && layer == 0)   // host rays bring their own weights (and hand them on to the layers behind)
+    for (uint64_t i = 0; i < n; i++) b->sess_max_w = std::max(b->sess_max_w, static_cast<double>(std::fabs(rays->w[i])));
   if (rays && layer == 0) {
     HIPCHK(b, b->host_f.reserve(n * 7));
     HIPCHK(b, b->host_u.reserve(n));
@@ -1002,17 +1017,20 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
+      // fixed-point scale of the per-tile sums (halo_kernels.hip FixQ): no slot of this launch can sum to more than 4 x max weight x rays
+      const uint32_t frac_bits = fix_frac_bits(b->sess_max_w, m);
       if (use_log) {
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
-                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, b->stream)
+                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
-                                                       b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, b->stream);
+                                                       b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
+                                                       b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {
         hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
-                                                         bin_tiles, fan_log2, b->stream)
-                                  : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, b->stream);
+                                                         bin_tiles, fan_log2, frac_bits, b->stream)
+                                  : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, frac_bits, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));

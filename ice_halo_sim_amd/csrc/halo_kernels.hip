@@ -5,26 +5,35 @@
 
 namespace halo {
 
-// Tile sums in 32.32 fixed point.  An fp64 LDS add is the slow kind here (tools/lds_atomic_bench.hip: ds_add_f64 1.5 T adds/s, ds_add_u64
+// Tile sums in 64-bit fixed point.  An fp64 LDS add is the slow kind here (tools/lds_atomic_bench.hip: ds_add_f64 1.5 T adds/s, ds_add_u64
 // 2.9 T), and these passes are LDS-bound (the index unit ~70 % busy, profiles/r03_bench4_pmc_lds.txt) — so a record's weight becomes a
-// 64-bit integer, weight x 2^32 truncated: resolution 2.3e-10 (the lightest exits that matter carry ~1e-7), range 2.1e9 per slot and launch
-// (a launch is at most 2^32 rays of weight <= 1, spread over the slots), and integer sums do not depend on the order of the adds.
-__device__ __forceinline__ long long fix32(float v) {   // v >= 0 (weights); exact below 2^31, saturating above
-  const float c = fminf(v, 2147483520.0f);
-  return static_cast<long long>(static_cast<double>(c) * 4294967296.0);
-}
-__device__ __forceinline__ float unfix32(long long a) { return static_cast<float>(static_cast<double>(a) * (1.0 / 4294967296.0)); }
+// 64-bit integer, weight x 2^F rounded to nearest, and integer sums do not depend on the order of the adds.  F comes with the launch
+// (halo_backend.cpp fix_frac_bits): the largest F <= 32 for which 4 x (largest ray weight of the session) x (rays of the launch) x 2^F
+// stays below 2^62 — no slot can sum to more than that bound (a ray's exits never outweigh the ray; x2 for the dual-fisheye overlap, x2
+// for the CMF rows of the X/Y/Z pass), so the unsigned sums cannot wrap.  F = 32 (resolution 2.3e-10) for every launch of unit-weight
+// rays up to 2^28; an illuminant session (spd weights ~100) of 2^26 rays runs F = 28.  (Round 3 had F fixed at 32 on the assumption
+// "weight <= 1" and a signed read-out: 4e9 of weight in one slot wrapped negative — ADVICE r3.)  A NaN or negative weight adds nothing.
+struct FixQ {
+  double to_fix, from_fix;
+  __device__ __forceinline__ explicit FixQ(uint32_t frac_bits)
+      : to_fix(__hiloint2double(static_cast<int>((1023u + frac_bits) << 20), 0)), from_fix(__hiloint2double(static_cast<int>((1023u - frac_bits) << 20), 0)) {}
+  __device__ __forceinline__ unsigned long long fix(float v) const {   // round to nearest; v <= the launch's bound by construction
+    return static_cast<unsigned long long>(static_cast<long long>(fma(static_cast<double>(fmaxf(v, 0.0f)), to_fix, 0.5)));
+  }
+  __device__ __forceinline__ float unfix(unsigned long long a) const { return static_cast<float>(static_cast<double>(a) * from_fix); }
+};
 
 // kBinSplit workgroups per image tile: each sums its share of the tile's hit list in a 64 KB LDS tile (8 independent
 // loads in flight per thread — the loop is load-latency-bound otherwise) and adds the non-zero slots to the plane.
 constexpr int kBinBlock = 1024;
 constexpr uint32_t kBinSplit = 2u;
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
-                                                                         const uint32_t* __restrict__ cnt, uint32_t tiles_log2) {
+                                                                         const uint32_t* __restrict__ cnt, uint32_t tiles_log2, uint32_t frac_bits) {
+  const FixQ fq(frac_bits);
   // fp64 sums, and not for precision: on gfx950 ds_add_f32 retires ~0.3 lanes per clock per CU (200 G adds/s chip-wide) while
   // ds_add_f64 runs at 1500 G/s and ds_add_u32 at 4600 G/s (tools/lds_atomic_bench.hip) — the fp32 LDS atomic is the slow one,
   // and this pass is one LDS add per hit.  128 KB of the CU's 160 KB: one workgroup of 16 waves per CU.
-  __shared__ unsigned long long acc[1u << kBinTileLog2];   // 32.32 fixed point (fix32)
+  __shared__ unsigned long long acc[1u << kBinTileLog2];   // fixed point (FixQ)
   const uint32_t tile = blockIdx.x / kBinSplit, part = blockIdx.x % kBinSplit;
   const uint32_t n = min(cnt[tile * kBinCntStride], cap);
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n) * part / kBinSplit);
@@ -40,21 +49,21 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_kernel(float* _
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x >> tiles_log2], static_cast<unsigned long long>(fix32(__uint_as_float(h[u].y))));
+    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x >> tiles_log2], fq.fix(__uint_as_float(h[u].y)));
   }
   for (; i < hi; i += kBinBlock) {
     const uint2 h = src[i];
-    atomicAdd(&acc[h.x >> tiles_log2], static_cast<unsigned long long>(fix32(__uint_as_float(h.y))));
+    atomicAdd(&acc[h.x >> tiles_log2], fq.fix(__uint_as_float(h.y)));
   }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < (1u << kBinTileLog2); j += kBinBlock) {
-    const float v = unfix32(static_cast<long long>(acc[j]));
+    const float v = fq.unfix(acc[j]);
     if (v != 0.0f) atomic_add_f32(plane + ((static_cast<size_t>(j) << tiles_log2) | tile), v);
   }
 }
 
-hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, hipStream_t stream) {
-  hipLaunchKernelGGL(halo_bin_accumulate_kernel, dim3(tiles * kBinSplit), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list), cap, cnt, static_cast<uint32_t>(__builtin_ctz(tiles)));
+hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, uint32_t frac_bits, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_bin_accumulate_kernel, dim3(tiles * kBinSplit), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list), cap, cnt, static_cast<uint32_t>(__builtin_ctz(tiles)), frac_bits);
   return hipGetLastError();
 }
 
@@ -222,8 +231,9 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
 // coalesced float4 read-modify-writes — the workgroup is the only writer of those slots while this kernel runs (direct
 // atomics of the trace / split kernels are ordered before it on the stream).
 __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(float* __restrict__ plane, const uint2* __restrict__ list, uint32_t cap,
-                                                                               const uint32_t* __restrict__ cnt, uint32_t tile_log2) {
-  __shared__ __attribute__((aligned(16))) unsigned long long acc[1u << kBinTileLog2];   // 32.32 fixed point (fix32); tile_log2 <= kBinTileLog2
+                                                                               const uint32_t* __restrict__ cnt, uint32_t tile_log2, uint32_t frac_bits) {
+  __shared__ __attribute__((aligned(16))) unsigned long long acc[1u << kBinTileLog2];   // fixed point (FixQ); tile_log2 <= kBinTileLog2
+  const FixQ fq(frac_bits);
   const uint32_t tile = blockIdx.x;
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
   if (n == 0u) return;
@@ -238,17 +248,16 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x & mask], static_cast<unsigned long long>(fix32(__uint_as_float(h[u].y))));
+    for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x & mask], fq.fix(__uint_as_float(h[u].y)));
   }
   for (; i < n; i += kBinBlock) {
     const uint2 h = src[i];
-    atomicAdd(&acc[h.x & mask], static_cast<unsigned long long>(fix32(__uint_as_float(h.y))));
+    atomicAdd(&acc[h.x & mask], fq.fix(__uint_as_float(h.y)));
   }
   __syncthreads();
   float4* dst = reinterpret_cast<float4*>(plane + (static_cast<size_t>(tile) << tile_log2));
   for (uint32_t j = threadIdx.x; j < slots / 4u; j += kBinBlock) {
-    const float4 v = make_float4(unfix32(static_cast<long long>(acc[4u * j])), unfix32(static_cast<long long>(acc[4u * j + 1u])),
-                                 unfix32(static_cast<long long>(acc[4u * j + 2u])), unfix32(static_cast<long long>(acc[4u * j + 3u])));
+    const float4 v = make_float4(fq.unfix(acc[4u * j]), fq.unfix(acc[4u * j + 1u]), fq.unfix(acc[4u * j + 2u]), fq.unfix(acc[4u * j + 3u]));
     if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
       float4 q = dst[j];
       q.x += v.x;
@@ -272,9 +281,10 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 template <uint32_t CH>
 __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* __restrict__ planes, uint32_t plane_stride, const uint2* __restrict__ list, uint32_t cap,
                                                                         const uint32_t* __restrict__ cnt, const WlEntryDev* __restrict__ pool, uint32_t pool_size,
-                                                                        uint32_t tiles_log2, uint32_t s_log2) {
+                                                                        uint32_t tiles_log2, uint32_t s_log2, uint32_t frac_bits) {
   constexpr uint32_t kTileLog2 = CH == 3u ? 12u : 14u;
-  __shared__ __attribute__((aligned(16))) unsigned long long acc[CH][1u << kTileLog2];   // 32.32 fixed point (fix32)
+  __shared__ __attribute__((aligned(16))) unsigned long long acc[CH][1u << kTileLog2];   // fixed point (FixQ)
+  const FixQ fq(frac_bits);
   __shared__ __attribute__((aligned(16))) float s_cmf[CH == 3u ? HALO_WL_POOL_MAX + 3 : 1][4];   // rows of 16 bytes: one LDS read per record
   const uint32_t tile = blockIdx.x;   // plane << tiles_log2 | tile of that plane (CH = 1: the scalar planes of a per-entry-plane session lie back to back)
   const uint32_t n = min(cnt[static_cast<size_t>(tile) * kBinCntStride], cap);
@@ -303,11 +313,11 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
     if constexpr (CH == 3u) {
       const uint32_t code = h.x >> kLogWlShift;
       const float4 c4 = *reinterpret_cast<const float4*>(s_cmf[code]);
-      if (c4.x != 0.0f) atomicAdd(&acc[0][s], static_cast<unsigned long long>(fix32(c4.x * w)));
-      if (c4.y != 0.0f) atomicAdd(&acc[1][s], static_cast<unsigned long long>(fix32(c4.y * w)));
-      if (c4.z != 0.0f) atomicAdd(&acc[2][s], static_cast<unsigned long long>(fix32(c4.z * w)));
+      if (c4.x != 0.0f) atomicAdd(&acc[0][s], fq.fix(c4.x * w));
+      if (c4.y != 0.0f) atomicAdd(&acc[1][s], fq.fix(c4.y * w));
+      if (c4.z != 0.0f) atomicAdd(&acc[2][s], fq.fix(c4.z * w));
     } else {
-      atomicAdd(&acc[0][s], static_cast<unsigned long long>(fix32(w)));
+      atomicAdd(&acc[0][s], fq.fix(w));
     }
   };
   // Where the time goes (configs[4], 137 M records, 1.00 ms): without the adds the pass takes 0.27 ms, without the write-out 0.94 — the
@@ -332,9 +342,9 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 #pragma unroll
       for (uint32_t u = 0; u < kU; ++u) {
         const float w = __uint_as_float(h[u].y);
-        if (c4[u].x != 0.0f) atomicAdd(&acc[0][sl[u]], static_cast<unsigned long long>(fix32(c4[u].x * w)));
-        if (c4[u].y != 0.0f) atomicAdd(&acc[1][sl[u]], static_cast<unsigned long long>(fix32(c4[u].y * w)));
-        if (c4[u].z != 0.0f) atomicAdd(&acc[2][sl[u]], static_cast<unsigned long long>(fix32(c4[u].z * w)));
+        if (c4[u].x != 0.0f) atomicAdd(&acc[0][sl[u]], fq.fix(c4[u].x * w));
+        if (c4[u].y != 0.0f) atomicAdd(&acc[1][sl[u]], fq.fix(c4[u].y * w));
+        if (c4[u].z != 0.0f) atomicAdd(&acc[2][sl[u]], fq.fix(c4[u].z * w));
       }
     } else {
 #pragma unroll
@@ -346,7 +356,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   for (uint32_t c = 0; c < CH; ++c) {
     float* dst = planes + static_cast<size_t>(c) * plane_stride + (static_cast<size_t>(plane_of_tile) << (s_log2 + 10u));
     for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) {
-      const float v = unfix32(static_cast<long long>(acc[c][j]));
+      const float v = fq.unfix(acc[c][j]);
       if (v != 0.0f) dst[map.slot_of(tile_in, j)] += v;
     }
   }
@@ -357,7 +367,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 // ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 // `planes` > 1: the scalar planes of a per-entry-plane illuminant session (back to back), `tiles` interleaved tiles EACH, planes x tiles <= 512.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, hipStream_t stream) {
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
   // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
   // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
@@ -367,7 +377,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles * planes), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
-                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2);
+                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2, frac_bits);
     return hipGetLastError();
   }
   if (interleaved)
@@ -380,65 +390,93 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
   if (e != hipSuccess) return e;
   if (interleaved)
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
-                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2);
-  else hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2, tile_log2);
+                       static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2, frac_bits);
+  else hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2, tile_log2, frac_bits);
   return hipGetLastError();
 }
 
 // the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of <= 4 Ki slots of one plane
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
-                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, hipStream_t stream) {
+                                uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
+                                hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
   hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, true, true>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((halo_log_accumulate_kernel<3u>), dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
-                     pool, pool_size, tiles_log2, s_log2);
+                     pool, pool_size, tiles_log2, s_log2, frac_bits);
   return hipGetLastError();
 }
 
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, hipStream_t stream) {
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, hipStream_t stream) {
   hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u, false, false>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
                      static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
-                     static_cast<uint32_t>(kBinTileLog2));
+                     static_cast<uint32_t>(kBinTileLog2), frac_bits);
   return hipGetLastError();
 }
 
 // xyz[pix] += sum over planes of coef[plane] * (sum over copies of plane[MonoSlot(pix)]); the slots are zeroed — closes a
 // session.  Planes: 1 (discrete wavelength, coef = CMF), 3 (X, Y, Z; unit coefs) or one per wavelength-pool entry
-// (coef = that entry's CMF), at most kFoldGroup per launch.  Tiled transpose through LDS: a block reads a 64-row x
+// (coef = that entry's CMF), at most kFoldGroup per launch.  Tiled transpose through LDS: a block reads a R-row x
 // 64-column tile of every plane copy along the columns (coalesced), then walks it along the rows, where consecutive
 // rows are consecutive pixels (coalesced xyz RMW).
+// Round 4.  The first form (R = 64 only) ran 436 us on the reference's own benchmark scene (512 x 256, 64 planes): 32 workgroups on
+// a 256-CU part, and per thread 16 rows x 64 planes of load -> compare -> store-zero round trips in sequence (the zeroing store may
+// alias the next load as far as the compiler knows, so nothing overlapped).  Now (1) the tile height R is 64, 16 or 4 rows, whichever
+// gives the launch >= 512 workgroups (the write runs stay >= 48 bytes, and an image that small is cache-resident anyway), and (2) a
+// thread requests kFoldBatch plane values before it looks at any of them or zeroes anything.
 constexpr uint32_t kFoldTile = 64u;
+constexpr uint32_t kFoldBatch = 8u;
+template <uint32_t R>
 __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ planes, uint32_t n_pix,
                                                             uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef coef) {
-  __shared__ float tile[3][kFoldTile][kFoldTile + 1];
+  __shared__ float tile[3][R][kFoldTile + 1];
   const uint32_t tiles_c = (1u << s_log2) / kFoldTile;  // columns per row / tile width (s_log2 >= 6)
-  const uint32_t row0 = (blockIdx.x / tiles_c) * kFoldTile, col0 = (blockIdx.x % tiles_c) * kFoldTile;
+  const uint32_t row0 = (blockIdx.x / tiles_c) * R, col0 = (blockIdx.x % tiles_c) * kFoldTile;
   const size_t plane = static_cast<size_t>(kMonoRows) << s_log2;
   const uint32_t lo = threadIdx.x & (kFoldTile - 1u), hi = threadIdx.x / kFoldTile;  // hi in [0, 4)
-  for (uint32_t r = hi; r < kFoldTile; r += kBlock / kFoldTile) {
+  for (uint32_t r = hi; r < R; r += kBlock / kFoldTile) {
     float* q = planes + (static_cast<size_t>(row0 + r) << s_log2) + col0 + lo;
     float x = 0.0f, y = 0.0f, z = 0.0f;
-    for (uint32_t pl = 0; pl < n_planes; ++pl) {
-      float v = 0.0f;
-      for (uint32_t c = 0; c < copies; ++c) {
-        float* a = q + (static_cast<size_t>(pl) * copies + c) * plane;
-        const float t = *a;
-        if (t != 0.0f) {
-          *a = 0.0f;
-          v += t;
+    if (copies == 1u) {   // per-entry planes, or a session whose launches all went through the hit log: batches of planes
+      for (uint32_t p0 = 0; p0 < n_planes; p0 += kFoldBatch) {
+        float t[kFoldBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kFoldBatch; ++u) t[u] = p0 + u < n_planes ? q[static_cast<size_t>(p0 + u) * plane] : 0.0f;
+#pragma unroll
+        for (uint32_t u = 0; u < kFoldBatch; ++u) {
+          if (t[u] == 0.0f) continue;
+          q[static_cast<size_t>(p0 + u) * plane] = 0.0f;
+          x += coef.c[p0 + u][0] * t[u];
+          y += coef.c[p0 + u][1] * t[u];
+          z += coef.c[p0 + u][2] * t[u];
         }
       }
-      x += coef.c[pl][0] * v;
-      y += coef.c[pl][1] * v;
-      z += coef.c[pl][2] * v;
+    } else {              // privatised copies of few planes: batches of copies, the plane's coefficient applied to their sum
+      for (uint32_t pl = 0; pl < n_planes; ++pl) {
+        float v = 0.0f;
+        float* qp = q + static_cast<size_t>(pl) * copies * plane;
+        for (uint32_t c0 = 0; c0 < copies; c0 += kFoldBatch) {
+          float t[kFoldBatch];
+#pragma unroll
+          for (uint32_t u = 0; u < kFoldBatch; ++u) t[u] = c0 + u < copies ? qp[static_cast<size_t>(c0 + u) * plane] : 0.0f;
+#pragma unroll
+          for (uint32_t u = 0; u < kFoldBatch; ++u) {
+            if (t[u] == 0.0f) continue;
+            qp[static_cast<size_t>(c0 + u) * plane] = 0.0f;
+            v += t[u];
+          }
+        }
+        x += coef.c[pl][0] * v;
+        y += coef.c[pl][1] * v;
+        z += coef.c[pl][2] * v;
+      }
     }
     tile[0][r][lo] = x;
     tile[1][r][lo] = y;
@@ -446,11 +484,12 @@ __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ x
   }
   __syncthreads();
   const uint32_t s_mask = (1u << s_log2) - 1u;
-  for (uint32_t c = hi; c < kFoldTile; c += kBlock / kFoldTile) {
-    const float x = tile[0][lo][c], y = tile[1][lo][c], z = tile[2][lo][c];
+  const uint32_t wr = threadIdx.x % R;   // row of the tile = consecutive pixels
+  for (uint32_t c = threadIdx.x / R; c < kFoldTile; c += kBlock / R) {
+    const float x = tile[0][wr][c], y = tile[1][wr][c], z = tile[2][wr][c];
     if (x == 0.0f && y == 0.0f && z == 0.0f) continue;
     const uint32_t a = ((col0 + c) * kMonoMulInv) & s_mask;   // column hash inverted
-    const uint32_t pix = a * kMonoRows + row0 + lo;
+    const uint32_t pix = a * kMonoRows + row0 + wr;
     if (pix < n_pix) {
       xyz[3u * pix + 0u] += x;
       xyz[3u * pix + 1u] += y;
@@ -562,8 +601,13 @@ hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rg
 // `planes` points at the first plane of this group; coef holds n_planes (<= kFoldGroup) coefficient triples
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
                        hipStream_t stream) {
-  const uint32_t blocks = (kMonoRows / kFoldTile) * ((1u << s_log2) / kFoldTile);
-  hipLaunchKernelGGL(halo_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+  const uint32_t tiles_c = (1u << s_log2) / kFoldTile;
+  if (tiles_c * (kMonoRows / 64u) >= 512u)
+    hipLaunchKernelGGL(halo_fold_kernel<64u>, dim3(tiles_c * (kMonoRows / 64u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+  else if (tiles_c * (kMonoRows / 16u) >= 512u)
+    hipLaunchKernelGGL(halo_fold_kernel<16u>, dim3(tiles_c * (kMonoRows / 16u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+  else
+    hipLaunchKernelGGL(halo_fold_kernel<4u>, dim3(tiles_c * (kMonoRows / 4u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
   return hipGetLastError();
 }
 

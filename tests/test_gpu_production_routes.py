@@ -336,6 +336,48 @@ def test_hit_log_route_equals_the_direct_route():
     assert rel_l2(small, want) <= 1e-3
 
 
+@pytest.mark.parametrize("case", ["discrete_weight_1000", "one_entry_d65_pool"])
+def test_per_tile_sums_hold_heavy_hot_pixels(case):
+    """The per-tile passes of the hit log sum in 64-bit fixed point whose scale comes with the launch (halo_kernels.hip FixQ,
+    halo_backend.cpp fix_frac_bits).  Round 3 had the scale fixed at 2^32 on the assumption "weight <= 1": a slot that collects more
+    than 2^31 of weight in one launch wrapped to a large negative pixel.  The scene that does it: rays of weight ~100-1000
+    (a user weight, or the one entry of an illuminant pool), a point sun on a plate held still — every ray goes the same way, a handful
+    of pixels take everything: 24 Mi rays of weight 1000 (192 Mi of D65's one-entry pool) put > 3e9 on the brightest.  Checked against what does not depend on the route: no negative
+    pixel, the image's Y sum = landed weight (fp64 tally) x cmf_y, and the direct-atomic route's image on everything but the hot pixels
+    (fp32 atomics lose the light addends there: 2.4e-7 x 4e9 is a thousand per add)."""
+    plate = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(), 1.0, 1)     # every axis fixed: c axis vertical
+    sc = scenes.scene([(0.0, [plate])], max_hits=5, sun_altitude=35.0, sun_diameter=0.0)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 512, 256, visible=abi.VISIBLE_FULL)
+    wl = scenes.wl_discrete(550.0, weight=1000.0) if case == "discrete_weight_1000" else scenes.wl_illuminant("D65", 1)
+    n = (24 << 20) if case == "discrete_weight_1000" else (192 << 20)
+    out = {}
+    for name, opts in (("log", {}), ("direct", {"hit_log": 0})):
+        hb = hip_backend(seed=3, **opts)
+        run_session(hb, sc, rd, wl, n)
+        route = hb.last_route()
+        assert bool(route.accum_mask & (abi.ACCUM_LOG | abi.ACCUM_LOG_XYZ)) == (name == "log"), (name, route.accum_mask)
+        out[name] = hb.ReadbackXyzAccum()
+        hb.close()
+    img, landed = out["log"]
+    ref, landed_ref = out["direct"]
+    assert landed == pytest.approx(landed_ref, rel=1e-6) and landed > 50.0 * n      # (per-thread float partial sums in two different instantiations)
+    assert img.min() >= 0.0 and np.isfinite(img).all()
+    assert img.max() > 2.0 ** 31                                      # the case the fixed 32.32 scale could not hold
+    import ctypes as C
+    from ice_halo_sim_amd import backend as _be
+    pool = np.zeros((4, 5), np.float32)
+    k = _be.load_library().halo_host_wl_pool(C.byref(wl), pool.ctypes.data_as(C.POINTER(C.c_float)), 4)
+    assert k == 1
+    print(case, "landed", landed, "max pixel", img.max(), "sums", img.sum(axis=(0, 1), dtype=np.float64), "direct sums", ref.sum(axis=(0, 1), dtype=np.float64), "cmf", pool[0])
+    # image = landed weight x CMF, channel by channel.  (1e-4, measured 2e-5: this scene's hits on a pixel all carry the SAME weight, and a
+    # constant addend rounds the same way on every fp32 add of the workgroup's LDS pixel cache until the sum changes its exponent — a bias,
+    # where addends that vary give noise; the wrap this test is about was a factor, not a fraction)
+    for ch in range(3):
+        assert float(img[..., ch].sum(dtype=np.float64)) == pytest.approx(landed * float(pool[0, 2 + ch]), rel=1e-4), ch
+    cold = ref < 1e-3 * ref.max()
+    assert cold.mean() > 0.99 and np.abs(img - ref)[cold].max() <= 1e-4 * max(float(ref[cold].max()), 1.0)
+
+
 @pytest.mark.parametrize("lens", list(range(11)))
 @pytest.mark.parametrize("visible", [abi.VISIBLE_UPPER, abi.VISIBLE_LOWER, abi.VISIBLE_FULL])
 @pytest.mark.parametrize("spectrum", ["discrete", "d65"])
