@@ -377,6 +377,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
     const uint64_t base = static_cast<uint64_t>(v) << 40;
     b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
+  } else if (k == "seed") {
+    // re-seed between sessions (the reference's backends take their seed from the first non-zero SessionSpec::seed, cpu_trace_backend.cpp:252)
+    if (b->in_session) return fail(b, HALO_FATAL, "seed cannot change inside a session");
+    b->seed = static_cast<uint32_t>(v) ? static_cast<uint32_t>(v) : 1u;
   } else if (k == "ray_base") {
     // the session's first 64-bit ray index (SplitPcgRayBase, trace_backend.hpp:184: lo feeds the stream index, hi pcg_seed_with_high)
     const uint64_t base = static_cast<uint64_t>(v);
@@ -464,7 +468,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   //  * illuminant, batch >= 8 Mi rays: one scalar plane per pool entry, coefficient = its CMF (1 atomic per hit, fold reads M planes)
   //  * illuminant, small batch or "mono" = 0: X, Y, Z planes, unit coefficients        (3 atomics per hit, cheap fold)
   const size_t npix = static_cast<size_t>(render->width) * render->height;
-  if (npix > (1u << 23)) return fail(b, HALO_FATAL, "more than 2^23 pixels");
+  if (npix > (1u << 23)) return fail(b, HALO_UNAVAILABLE, "more than 2^23 pixels");   // recoverable: the caller falls back (INTEGRATION.md limits table)
   const bool discrete = wl->illuminant < 0;
   //  * illuminant, batch >= 2 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
   //    the per-tile pass applies the CMF (halo_log_accumulate_kernel<3>): no plane per entry, no two-level split, a 3-plane fold

@@ -252,7 +252,8 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out);
 int halo_destroy(halo_handle_t h);
 const char* halo_last_error(halo_handle_t h);
 /* Options: "capture_exits" (0/1), "geom_clock" (rays per sampled shape, default 32 — simulator.hpp:144),
- * "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams), "ray_base" (the 64-bit index of the next
+ * "seed" (re-seed the engine between sessions: the reference's backends are seeded by the first non-zero SessionSpec::seed,
+ * cpu_trace_backend.cpp:248-257), "rank"/"world" (shard id mixed into the ray counters so ranks draw disjoint streams), "ray_base" (the 64-bit index of the next
  * root ray — SplitPcgRayBase, trace_backend.hpp:184; counters run on from it, across 2^32 with the carry of pcg_advance_hi),
  * "chunk" (max rays per kernel launch, default 256 Mi), "aggregate" (0 plain atomics, 1 LDS pixel cache [default], 2 diagnostic no-accumulate),
  * "mono" (one-channel accumulation for discrete-wavelength sessions, default 1), "mono_copies" (privatised copies of that

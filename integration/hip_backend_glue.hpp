@@ -20,6 +20,7 @@
 #include <map>
 #include <memory>
 #include <random>
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <variant>
@@ -249,12 +250,23 @@ class HipBackendGlue final : public TraceBackend {
   // process; a multi-GPU launcher passes its local rank).  Throws BackendUnavailableError without a gfx950 device.
   explicit HipBackendGlue(uint32_t seed = 0u, int device = 0) : device_(device), pinned_seed_(seed) {
     if (halo_device_count() <= device) throw BackendUnavailableError("no gfx950 device for the HIP trace backend");
-    if (seed != 0u) Create(seed);
+    if (seed != 0u) {
+      Create(seed);
+      seeded_ = true;
+    }
   }
 
   // --- TraceBackend::BeginSession (trace_backend.hpp:374-378) ----------------------------------------------------------
   void BeginSession(const SessionSpec& spec) override {
-    if (!be_) Create(spec.seed != 0u ? spec.seed : static_cast<uint32_t>(std::random_device{}()) | 1u);   // seeded once per instance
+    // Seeded ONCE per backend lifetime by the first NON-ZERO SessionSpec::seed (cpu_trace_backend.cpp:248-257: `spec.seed != 0 &&
+    // !seeded_`): sessions with seed 0 run on a non-deterministic seed and leave the engine unseeded, so a later fixed seed still applies.
+    if (!be_) {
+      Create(spec.seed != 0u ? spec.seed : (static_cast<uint32_t>(std::random_device{}()) | 1u));
+      seeded_ = spec.seed != 0u;
+    } else if (!seeded_ && spec.seed != 0u) {
+      Guard([&] { be_->SetOption("seed", static_cast<int64_t>(spec.seed)); });   // halo_set_option "seed": between sessions only
+      seeded_ = true;
+    }
     hip_glue::SceneTables t = hip_glue::ToHalo(*spec.scene, spec.raypath_color.get());       // SessionSpec::raypath_color
     if (!t.representable) throw BackendUnavailableError("scene exceeds the HIP backend's table caps (layers/entries/filter or colour terms)");
     const HaloRender rd = hip_glue::ToHalo(*spec.render);
@@ -281,6 +293,7 @@ class HipBackendGlue final : public TraceBackend {
   // reserved external-ingest path, :230-239) they are forwarded as crystal-local golden rays.  Device mode: consumes the
   // continuation of the preceding Recombine (it never left the backend).
   LayerHandlePtr TraceLayer(const RootRaySource& roots) override {
+    Need("TraceLayer");
     halo::LayerHandle lh;
     Guard([&] {
       if (roots.is_device) {
@@ -299,6 +312,7 @@ class HipBackendGlue final : public TraceBackend {
 
   // --- Recombine (trace_backend.hpp:391-395): pools swap roles inside the backend; the shuffle is applied by the next layer --
   RootRaySource Recombine(LayerHandlePtr h, const RecombineSpec& spec) override {
+    Need("Recombine");
     size_t n = 0;
     Guard([&] { n = be_->Recombine(static_cast<Handle&>(*h).lh, spec.shuffle); });
     return RootRaySource::FromDevice(DeviceRayBatch{ nullptr, n });
@@ -315,16 +329,24 @@ class HipBackendGlue final : public TraceBackend {
 
   // --- ReadbackXyzAccum (trace_backend.hpp:461-469): sync, ADD landed weight, copy W*H*3 floats, zero the device image -------
   void ReadbackXyzAccum(XyzImageData& xyz, float& landed_weight) override {
+    if (!be_) return;   // no session yet: nothing accumulated, nothing to add (the engine is created by the first BeginSession)
     halo::XyzImageData x{ xyz.data, xyz.width, xyz.height };
     Guard([&] { be_->ReadbackXyzAccum(x, landed_weight); });
   }
 
   // --- ReadbackClassLanes (trace_backend.hpp:471-493): lane c at lane_data[c*W*H + py*W + px]; zeroes the device lanes -------
   void ReadbackClassLanes(std::vector<float>& lane_data, size_t& class_count) override {
+    if (!be_) {
+      lane_data.clear();
+      class_count = 0;
+      return;
+    }
     Guard([&] { be_->ReadbackClassLanes(lane_data, class_count); });   // class_count == 0: lane_data stays empty (zero-cost default)
   }
 
-  void EndSession() override { Guard([&] { be_->EndSession(); }); }
+  void EndSession() override {
+    if (be_) Guard([&] { be_->EndSession(); });
+  }
 
   // --- IsCompatible (trace_backend.hpp:511-519, called at simulator.cpp:946): every lens / visible range is supported; what
   // the backend refuses is an image beyond 2^23 pixels (the LDS pixel-cache key width) ---------------------------------------
@@ -361,6 +383,9 @@ class HipBackendGlue final : public TraceBackend {
       throw BackendUnavailableError(e.what());
     }
   }
+  void Need(const char* what) const {   // a call that only makes sense inside a session, before any BeginSession created the engine
+    if (!be_) throw BackendUnavailableError(std::string(what) + " before BeginSession");
+  }
   void Create(uint32_t seed) {
     try {
       be_ = std::make_unique<halo::HipTraceBackend>(device_, seed);
@@ -369,7 +394,8 @@ class HipBackendGlue final : public TraceBackend {
     }
   }
   int device_ = 0;
-  uint32_t pinned_seed_ = 0u;
+  uint32_t pinned_seed_ = 0u;   // constructor seed (tests): the engine exists and is seeded from the start
+  bool seeded_ = false;          // a non-zero seed has been applied (constructor or a SessionSpec)
   std::unique_ptr<halo::HipTraceBackend> be_;
 };
 
