@@ -328,6 +328,8 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
             dist.barrier()
         torch.cuda.synchronize()
 
+    reduce_events = []                                       # (start, end) torch events around each step's collective, read after the timed region
+
     def step():
         for wl in wls:
             sts = tracer.trace_session_layers(wl, n)        # this rank's shard of the batch
@@ -336,7 +338,14 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                 first_layer["launches"] += st.launches
                 first_layer["hits"] += st.pixel_hits
                 first_layer["cont"] += st.continuation_count
-        tracer.reduce_to_root()                              # one RCCL sum-reduce at the drain point
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tracer.reduce_to_root()                          # one RCCL sum-reduce at the drain point
+            e1.record()
+            reduce_events.append((e0, e1))
+        else:
+            tracer.reduce_to_root()
 
     for _ in range(warmup):
         step()
@@ -344,6 +353,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
     tracer.backend.collect_stats()                            # drop the warm-up tallies
     for k in first_layer:
         first_layer[k] = 0
+    reduce_events.clear()
     times = []
     for _ in range(max(repeats, 1)):
         barrier()
@@ -369,6 +379,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
     assert int(st.root_count) == rays_per_rank + first_layer["cont"], (int(st.root_count), rays_per_rank, first_layer["cont"])
 
     img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
+    multi = certify_multi_gpu(ctx, tracer, wls[0], min(n, 4_000_000), reduce_events, dist_backend=ctx.get("dist_backend", "nccl")) if world > 1 else None
     tracer.backend.close()
     del tracer
     torch.cuda.empty_cache()
@@ -430,8 +441,69 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                                 "continuations_per_root": first_layer["cont"] / max(rays_per_rank, 1),
                                 "first_layer_kernel_ms_per_launch": first_layer["ms"] / max(first_layer["launches"], 1),
                                 "last_layer_kernel_ms_per_launch": avg_launch_s * 1e3}
+    if multi is not None:
+        out["multi_gpu"] = multi
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline(wk)
+    return out
+
+
+def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
+    """What makes an N > 1 line prove itself (every rank calls this; rank 0 gets the object): how many ranks the process group saw and on
+    which devices, what the drain-point collective cost (torch events around every timed step's reduce, per rank), and a check pass —
+    each rank traces `n_check` more roots, the ranks' OWN images (before the reduce) must differ from one another (disjoint ray-counter
+    ranges: a replica would be bit-identical) while their energies agree to 1 %, and the image the collective leaves on rank 0 must
+    be their sum."""
+    import numpy as np
+    torch, dist = ctx["torch"], ctx["dist"]
+    world, rank, local_rank = ctx["world"], ctx["rank"], ctx["local_rank"]
+    torch.cuda.synchronize()
+    reduce_ms = [a.elapsed_time(b) for a, b in reduce_events]
+    prop = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "name": prop.name,
+          "uuid": str(getattr(prop, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0)),
+          "hostname": os.uname().nodename, "pid": os.getpid(),
+          "reduce_ms_mean": (sum(reduce_ms) / len(reduce_ms)) if reduce_ms else None, "reduce_ms_max": max(reduce_ms) if reduce_ms else None, "reduces_timed": len(reduce_ms)}
+    # the check pass: this rank's own image first ...
+    tracer.zero()
+    tracer.trace_session(wl, n_check)
+    torch.cuda.synchronize()
+    w, h = tracer.render.width, tracer.render.height
+    own = tracer.acc[: w * h * 3].double()
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    probe = torch.rand(4096, generator=gen, dtype=torch.float64).to(own.device)      # a fixed random functional: two different images do not share it
+    idx = torch.randint(0, w * h * 3, (4096,), generator=gen).to(own.device)
+    me["check_sum_y"] = float(own[1::3].sum().item())
+    me["check_signature"] = float((own[idx] * probe).sum().item())
+    me["check_landed"] = float(tracer.backend.take_landed())
+    # ... then the collective, and what it leaves on the root
+    tracer.reduce_to_root()
+    torch.cuda.synchronize()
+    reduced_y = float(tracer.acc[: w * h * 3].double()[1::3].sum().item())
+    nonroot_drained = bool(rank == 0 or not tracer.acc.any().item())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, dict(me, nonroot_drained=nonroot_drained))
+    tracer.zero()
+    if rank != 0:
+        return None
+    ys = np.array([g["check_sum_y"] for g in gathered])
+    sigs = [g["check_signature"] for g in gathered]
+    distinct = len(set(sigs)) == world
+    agree = bool(np.all(np.abs(ys / ys.mean() - 1.0) <= 0.01))
+    summed = bool(abs(reduced_y - ys.sum()) <= 1e-5 * ys.sum())
+    devices = sorted({(g["hostname"], g["uuid"] or g["pci"], g["device_index"]) for g in gathered})
+    out = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "dist_backend_requested": dist_backend,
+           "distinct_devices": len(devices), "ranks": gathered,
+           "reduce_ms_mean_over_ranks": float(np.mean([g["reduce_ms_mean"] for g in gathered if g["reduce_ms_mean"] is not None])) if any(g["reduce_ms_mean"] is not None for g in gathered) else None,
+           "reduce_floats": w * h * 3 + 4,
+           "check": {"rays_per_rank": n_check, "rank_images_differ": distinct, "rank_energies_within_1pct": agree, "reduced_image_is_the_sum": summed,
+                     "nonroot_ranks_drained": all(g["nonroot_drained"] for g in gathered),
+                     "sum_y_per_rank": ys.tolist(), "sum_y_reduced_on_root": reduced_y},
+           "note": "ranks_seen / devices come from the process group and the runtime, not from --gpus; reduce_ms brackets the stream-ordered collective with events "
+                   "(it includes waiting for the slowest rank's trace: ranks arrive at the collective when their own kernels finish)"}
+    assert distinct and agree and summed and out["check"]["nonroot_ranks_drained"], out["check"]
+    if dist_backend == "nccl":
+        assert len(devices) == world, ("ranks share a device under RCCL", devices)
     return out
 
 
@@ -476,7 +548,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=dist_backend)
-    ctx = {"torch": torch, "dist": dist, "world": world, "rank": rank, "local_rank": local_rank}
+    ctx = {"torch": torch, "dist": dist, "world": world, "rank": rank, "local_rank": local_rank, "dist_backend": dist_backend}
 
     out = measure(args.config, args, ctx, args.steps, args.warmup, args.repeats, with_cpu=not args.no_cpu_baseline)
     if args.config == "1" and world == 1 and not args.no_others and not args.rays_per_wl:

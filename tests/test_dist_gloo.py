@@ -82,3 +82,83 @@ def test_world2_gloo_reduce_matches_sum_of_shards(tmp_path):
     # the two shards are different rays (disjoint counter ranges), not replicas
     assert not np.allclose(i0, i1)
     assert l0 != l1
+
+
+# ---- world 8: the two BASELINE readings of "rays sharded across 8" (configs[3]: 400 M rays single-scatter column, configs[4]: 200 M rays of
+# the stochastic-geometry scene with a D65 pool), scaled down 10^4-fold, as ONE strong-scaling job each ---------------------------------------
+W8 = 8
+
+
+def _job(kind):
+    from ice_halo_sim_amd import abi
+    if kind == "configs3":       # BASELINE configs[3]: single-scatter hex column, 400 M rays over 8 GPUs
+        return scenes.config2_scene(), scenes.config2_render(W, H), scenes.wl_discrete(550.0), 40_000
+    # BASELINE configs[4]: examples/bench_config_stoch.json's shape, 200 M rays over 8 GPUs
+    sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+    return sc, scenes.render(abi.LENS_RECTANGULAR, W, H, el=0.0, visible=abi.VISIBLE_FULL), scenes.wl_illuminant("D65", 31), 20_000
+
+
+def _trace_job_shard(kind, rank, world):
+    from tests._oracle_backend import OracleBackend, run_session
+    sc, rd, wl, total = _job(kind)
+    start, count = shard_range(total, rank, world)
+    ob = OracleBackend(seed=42, rank=rank, threads=1)
+    st = run_session(ob, sc, rd, wl, count)
+    img, landed = ob.ReadbackXyzAccum()
+    ob.close()
+    return img, landed, int(st[0].root_count), (start, count)
+
+
+def _worker8(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from ice_halo_sim_amd.dist import reduce_image, reduce_scalar
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == world
+    for kind in ("configs3", "configs4"):
+        img, landed, roots, span = _trace_job_shard(kind, rank, world)
+        acc = torch.zeros(W * H * 3 + 4, dtype=torch.float32)
+        acc[: W * H * 3] = torch.from_numpy(img.ravel())
+        own_y = float(img[..., 1].sum(dtype=np.float64))
+        acc = reduce_image(acc)                       # the drain-point collective
+        total_landed = reduce_scalar(landed, acc.device)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "roots": roots, "span": span, "sum_y": own_y, "landed": landed})
+        np.save(os.path.join(out_dir, "%s_acc%d.npy" % (kind, rank)), acc.numpy())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "%s_meta.npy" % kind), np.array([total_landed] + [g["sum_y"] for g in per_rank] + [g["landed"] for g in per_rank] + [g["roots"] for g in per_rank]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_gloo_strong_scaling_jobs(tmp_path):
+    """Eight ranks (gloo, CPU; the oracle as each rank's tracer) run configs[3]'s and configs[4]'s "N rays sharded across 8" as one job each:
+    shard_range cuts the job's roots into eight contiguous spans, rank r traces its span on the counter range r << 40, ONE reduce sums
+    the images on rank 0 and drains the others.  The reduced image is the sum of the eight shards, the shards are eight DIFFERENT sets of
+    rays of equal brightness, and the job's landed weight is that of the same job on one rank up to Monte-Carlo scatter."""
+    import torch.multiprocessing as mp
+    from tests._oracle_backend import OracleBackend, run_session
+    port = _free_port()
+    mp.spawn(_worker8, args=(W8, port, str(tmp_path)), nprocs=W8, join=True)
+    for kind in ("configs3", "configs4"):
+        sc, rd, wl, total = _job(kind)
+        meta = np.load(tmp_path / ("%s_meta.npy" % kind))
+        total_landed, ys, landeds, roots = meta[0], meta[1:1 + W8], meta[1 + W8:1 + 2 * W8], meta[1 + 2 * W8:]
+        assert roots.sum() == total and roots.max() - roots.min() <= 1          # the job's rays, dealt out evenly
+        accs = [np.load(tmp_path / ("%s_acc%d.npy" % (kind, r))) for r in range(W8)]
+        assert all(not a.any() for a in accs[1:])                                # non-root ranks are drained
+        shards = [_trace_job_shard(kind, r, W8) for r in range(W8)]             # the same shards again, in this process
+        want = sum(s[0].astype(np.float64) for s in shards)
+        assert np.allclose(accs[0][: W * H * 3], want.ravel(), rtol=2e-6, atol=1e-6 * want.max())
+        assert total_landed == pytest.approx(sum(s[1] for s in shards), rel=1e-12)
+        assert np.allclose(ys, [s[0][..., 1].sum(dtype=np.float64) for s in shards], rtol=1e-9)
+        assert len({round(float(y), 6) for y in ys}) == W8                       # eight different images ...
+        assert np.all(np.abs(landeds / landeds.mean() - 1.0) <= 0.05)            # ... of the same brightness (a few thousand rays each)
+        # the whole job on ONE rank: other rays (counter range 0 only), the same statistics
+        ob = OracleBackend(seed=42, threads=4)
+        run_session(ob, sc, rd, wl, total)
+        _, landed1 = ob.ReadbackXyzAccum()
+        ob.close()
+        assert total_landed == pytest.approx(landed1, rel=0.02)
