@@ -214,6 +214,35 @@ def _pmc_mean(name, key, kernel="halo_trace_kernel"):
 GROUP_KERNELS = ("halo_trace_kernel", "halo_split_kernel", "halo_bin_accumulate_range_kernel", "halo_bin_accumulate_kernel", "halo_log_accumulate_kernel")
 
 
+def shape_record_bytes(crystal, prism_records, samples=256):
+    """Bytes of a sampled-crystal record that the path NEEDS, from the face / fan-triangle counts of `samples` instances built on the host
+    (the same builder the device generator runs): the generator writes the rows a record uses — header 16 B, 16 B per face, 32 B per
+    opposite-face slab, 36 + 16 B per fan triangle (corners; normal + area), the face / triangle index bytes — and the trace reads, per
+    32 rays that share the crystal, all of that EXCEPT the corner rows, of which it needs one 36-byte row per ray (the entry pick's one
+    triangle; never more than all of them).  Round 3 charged the record's full sizeof (1360 / 4112 B) twice."""
+    import ctypes as C
+    import numpy as np
+    from ice_halo_sim_amd import abi, backend
+    L = backend.load_library()
+    faces, tris = [], []
+    for idx in range(samples):
+        sc9 = np.zeros(9, np.float32)
+        L.halo_host_shape_scalars(C.byref(crystal), 42, idx, 0, sc9.ctypes.data_as(C.POINTER(C.c_float)))
+        d = sc9[3:9].copy()
+        g = abi.HaloGeomTables()
+        if crystal.kind == abi.CRYSTAL_PRISM:
+            L.halo_host_prism_geometry(abs(float(sc9[0])), d.ctypes.data_as(C.POINTER(C.c_float)), C.byref(g))
+        else:
+            L.halo_host_pyramid_geometry(crystal.wedge_upper_deg, crystal.wedge_lower_deg, abs(float(sc9[0])), abs(float(sc9[1])), abs(float(sc9[2])),
+                                         d.ctypes.data_as(C.POINTER(C.c_float)), C.byref(g))
+        faces.append(g.face_cnt)
+        tris.append(g.tri_cnt)
+    f, t = float(np.mean(faces)), float(np.mean(tris))
+    rows = 16.0 + 16.0 * f + 32.0 * (f / 2.0) + 16.0 * t + t + 2.0 * f      # header, faces, slabs (<= faces / 2), triangle normal + area rows, index bytes
+    return {"mean_faces": f, "mean_fan_triangles": t, "sizeof_record": 1360 if prism_records else 4112,
+            "written_by_generator": rows + 36.0 * t, "read_by_trace_per_32_rays": rows + 36.0 * min(32.0, t)}
+
+
 def pmc_traffic_per_launch(cfg):
     """HBM-side bytes per launch GROUP — the trace kernel plus the accumulation passes that follow it on the stream (split,
     per-tile sums), which is also what the HIP events around a launch time — from the committed rocprofv3 PMC passes of this
@@ -397,9 +426,10 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
     alg = dom_hits * 24.0
     if layers > 1:
         alg += dom_rays * 40.0
-    shape_rec = {"4": 1360.0, "4p": 4112.0}.get(cfg)
-    if shape_rec:
-        alg += dom_rays / 32.0 * shape_rec * 2.0
+    shape_bytes = None
+    if cfg in ("4", "4p"):
+        shape_bytes = shape_record_bytes(sc.layers[0].entries[0].crystal, prism_records=(cfg == "4"))
+        alg += dom_rays / 32.0 * (shape_bytes["written_by_generator"] + shape_bytes["read_by_trace_per_32_rays"])
     alg_per_launch = alg / max(dom_launches, 1)
     achieved = alg_per_launch / max(avg_launch_s, 1e-12) / 1e9
     total_rays_step = rays_per_rank_step * world
@@ -431,10 +461,13 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                      "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % (PROFILE_ROUND, cfg),
                      "kernel": wk["kernel"], "launches": dom_launches,
                      "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
+                     "shape_record_bytes": shape_bytes,
                      "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
                      "valu": pmc_valu(cfg, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
                      "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
     }
+    if out["roofline"]["traffic"]:
+        out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / alg_per_launch
     if layers > 1:
         traced = rays_per_rank + first_layer["cont"]
         out["multi_scatter"] = {"root_rays_per_s": out["value"], "traced_rays_per_s": traced / (reps * steps) * world / (dt / steps),
