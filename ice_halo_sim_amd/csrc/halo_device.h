@@ -49,6 +49,19 @@ struct ShapeDev {
 };
 static_assert(sizeof(ShapeDev) % 16 == 0, "ShapeDev rows are read as float4");
 
+// What the kernels of ONE REGULAR hexagonal prism read of the dispatch's shape: the header, the face rows (normal + plane constant of the
+// Fresnel split) and the four slab rows (the entry pick's dot products).  Everything else they take from EntryFastDev or have as literals,
+// so their workgroups stage this 464-byte prefix of ShapeDev instead of its 4.1 KB — with that (and a byte per queued exit's pool entry) the
+// kernel's LDS is 31 KB and five workgroups fit a CU where four did.
+struct ShapeHead {
+  int32_t face_cnt;
+  int32_t tri_cnt;
+  int32_t slab_cnt, single_cnt;
+  float face[kMaxFaces][4];
+  float slab[4][8];
+};
+static_assert(sizeof(ShapeHead) % 16 == 0, "ShapeHead rows are read as float4");
+
 // A hexagonal prism never has more than 8 faces, 4 opposite-face slabs and 20 fan triangles: stochastic prism pools and
 // their LDS copies use this third-size record (same member names, so geometry and trace code are generic over the two).
 struct ShapePrism {

@@ -175,13 +175,13 @@ HD float gaussian(Stream& s) {  // Box-Muller, pcg_shared.h:277-281
 
 HD float get_dist(Stream& s, uint32_t dtype, float mean, float spread) {  // pcg_shared.h:290-308
   if (dtype == HALO_DIST_NONE) return mean;
-  if (dtype == HALO_DIST_UNIFORM) return (uniform(s) - 0.5f) * spread + mean;
-  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return gaussian(s) * spread + mean;
-  if (dtype == HALO_DIST_ZIGZAG) return fabsf(spread * sinf(uniform(s) * 2.0f * kPiF) + mean);
+  if (dtype == HALO_DIST_UNIFORM) return fmaf(uniform(s) - 0.5f, spread, mean);
+  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return fmaf(gaussian(s), spread, mean);
+  if (dtype == HALO_DIST_ZIGZAG) return fabsf(fmaf(spread, sinf(uniform(s) * 2.0f * kPiF), mean));
   float u = uniform(s);
   float sgn = (u < 0.5f) ? -1.0f : 1.0f;
   float arg = fmaxf(1.0f - 2.0f * fabsf(u - 0.5f), 1e-30f);
-  return mean - spread * sgn * logf(arg);
+  return fmaf(-(spread * sgn), logf(arg), mean);
 }
 
 // 4-round balanced Feistel + cycle walk on [0, n)  (pcg_shared.h:550-603)
@@ -240,7 +240,7 @@ HD float invert_lat_lut(float xi, const float* lut) {
   float c0 = cdf[lo], c1 = cdf[lo + 1u];
   float denom = c1 - c0;
   float w = denom > 0.0f ? (xi - c0) * fast_rcp(denom) : 0.0f;
-  return th[lo] + w * (th[lo + 1u] - th[lo]);
+  return fmaf(w, th[lo + 1u] - th[lo], th[lo]);
 }
 
 HD uint32_t lat_lut_bin(float theta, const float* lut) {
@@ -299,11 +299,14 @@ HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
   float t00 = c2 * c1, t01 = c2 * (-s1), t02 = s2 * k1;
   float t10 = k2 * s1, t11 = k2 * c1;  // t12 = 0
   float t20 = (-s2) * c1, t21 = (-s2) * (-s1), t22 = c2 * k1;
-  R[0] = c3 * t00 + (-s3) * t10;
-  R[1] = c3 * t01 + (-s3) * t11;
+  // (every sum of products on the ray's way is written as the fma chain it is evaluated as: which of a*b + c*d's two products gets fused is
+  // otherwise the backend's choice, and it follows the code AROUND the expression — instantiations of one kernel then trace rays that differ
+  // in the last bit, and one in a few million of them takes the other side of a decision; see dot3_fma)
+  R[0] = fmaf(-s3, t10, c3 * t00);
+  R[1] = fmaf(-s3, t11, c3 * t01);
   R[2] = c3 * t02;
-  R[3] = s3 * t00 + c3 * t10;
-  R[4] = s3 * t01 + c3 * t11;
+  R[3] = fmaf(c3, t10, s3 * t00);
+  R[4] = fmaf(c3, t11, s3 * t01);
   R[5] = s3 * t02;
   R[6] = k3 * t20;
   R[7] = k3 * t21;
@@ -311,9 +314,9 @@ HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
 }
 
 HD void apply_inverse(const float* R, float x, float y, float z, float* o) {  // o = R^T v
-  o[0] = R[0] * x + R[3] * y + R[6] * z;
-  o[1] = R[1] * x + R[4] * y + R[7] * z;
-  o[2] = R[2] * x + R[5] * y + R[8] * z;
+  o[0] = fmaf(R[6], z, fmaf(R[3], y, R[0] * x));
+  o[1] = fmaf(R[7], z, fmaf(R[4], y, R[1] * x));
+  o[2] = fmaf(R[8], z, fmaf(R[5], y, R[2] * x));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,12 +466,19 @@ HD void atomic_add_f32(float* addr, float v) {
 //    ds_add_f32 for the rest of the kernel and is flushed once; pixels that lose the claim go straight to HBM.
 //    Frequent pixels claim early with overwhelming probability, which is all the cache is for.
 typedef float float2v __attribute__((ext_vector_type(2)));
+HD float2v pk_dot(float2v X, float2v Y, float2v Z, float gx, float gy, float gz) {   // (n.d, n.p) of one plane: explicit packed fma chain (see dot3_fma)
+  const float2v vx = {gx, gx}, vy = {gy, gy}, vz = {gz, gz};
+  return __builtin_elementwise_fma(Z, vz, __builtin_elementwise_fma(Y, vy, X * vx));
+}
 
 // SMALLC: binned kernels of shape-pool dispatches halve the one-channel cache (their LDS also holds the pool slots and the
 // hit buffer; misses are cheap there) to stay at 4 workgroups per CU
+#ifndef HALO_CACHE_LOG2
+#define HALO_CACHE_LOG2 11
+#endif
 template <bool MONO, bool SMALLC>
 struct CacheGeom {  // 2048 one-channel slots (16 KB; 1024 with SMALLC) or 1024 three-channel slots (16 KB)
-  static constexpr int kLog2 = (MONO && !SMALLC) ? 11 : 10;
+  static constexpr int kLog2 = (MONO && !SMALLC) ? HALO_CACHE_LOG2 : 10;
   static constexpr int kN = 1 << kLog2;
 };
 
@@ -514,7 +524,7 @@ struct HitSlot<false> {
 constexpr uint32_t kExitQ = 128u;   // < 64 left after a drain + <= 64 pushed by one interaction
 struct ExitQueue {
   float x[kExitQ], y[kExitQ], z[kExitQ], w[kExitQ];
-  uint32_t wl[kExitQ];
+  uint8_t wl[kExitQ];   // wavelength-pool entry (HALO_WL_POOL_MAX = 255)
   uint32_t n;
 };
 struct ExitQueueMask {   // raypath colour (kModeColor): the exit's component mask rides along
@@ -1149,6 +1159,8 @@ struct PoolSlotType<kGeomPoolPrism> {
 static_assert(offsetof(ShapeSlot48, tri_na) % 16 == 0 && offsetof(ShapeSlot48, slab) % 16 == 0 &&
               offsetof(ShapeSlot48, tri_face) % 4 == 0 && offsetof(ShapeSlot48, face_number) % 4 == 0 && offsetof(ShapeSlot48, single) % 4 == 0,
               "rows are copied as float4 / dwords");
+static_assert(offsetof(ShapeHead, face) == offsetof(ShapeDev, face) && offsetof(ShapeHead, slab) == offsetof(ShapeDev, slab) && offsetof(ShapeHead, tri_cnt) == offsetof(ShapeDev, tri_cnt),
+              "ShapeHead is a prefix of ShapeDev");
 template <bool ON, typename SlotT, int N = kBlock / 32>
 struct PoolSlots {
   SlotT s[N];
@@ -1229,15 +1241,38 @@ HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens =
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT || t == HALO_LENS_FISHEYE_STEREOGRAPHIC ||
       t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
     if ((vr == HALO_VISIBLE_UPPER && wz > 0.0f) || (vr == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
-    return p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz) > -1e-6f;
+    return fmaf(p.rot[8], -wz, fmaf(p.rot[5], -wy, p.rot[2] * (-wx))) > -1e-6f;
   }
   return true;
+}
+
+// The dispatch record again, from where it lies.  DispatchParams is the kernel's one argument: it sits in the kernarg segment (constant
+// memory, scalar loads).  The compiler loads every field a kernel uses ONCE, at the top, and keeps it in an SGPR for the whole kernel — 200
+// live scalars against 102 registers: the headline instantiation spilled 104 of them to VGPR lanes and read them back with v_readlane
+// (a VALU slot each, plus s_nop hazards) 77 times per wave-ray.  A region that re-reads the record through an OPAQUE pointer to the
+// same memory (the empty asm hides where it points, so the loads can neither be hoisted nor merged with the kernel's) gets its
+// fields by s_load where it needs them, and the registers are free everywhere else.
+#ifndef HALO_RELOAD
+#define HALO_RELOAD 3      // bit 0: the exit queue's drain, bit 1: root generation
+#endif
+HD DispatchParams reload_params() {
+  const DispatchParams __attribute__((address_space(4)))* pc =
+      (const DispatchParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(pc));
+  DispatchParams L;
+  __builtin_memcpy(&L, pc, sizeof(DispatchParams));   // scalarised: only the fields the region uses are loaded
+  return L;
 }
 
 // Pop exits off the wave's queue, one per active lane and round, until fewer than 64 are left (`all`: until it is empty).
 // Called where every lane that took part in the pushes is active (their counts agree).
 template <int MODE, bool MONO, bool SMALLC>
-HD void drain_exits(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, RaySums& sums, bool all, Probe& pr) {
+HD void drain_exits(const DispatchParams& P_kernel, const AccCtx<MONO, SMALLC>& cache, RaySums& sums, bool all, Probe& pr) {
+#if HALO_RELOAD & 1
+  const DispatchParams P = reload_params();
+#else
+  const DispatchParams& P = P_kernel;
+#endif
   ExitQueue& Q = *cache.q;
   const uint64_t m = __ballot(1);
   const uint32_t k = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
@@ -1272,9 +1307,9 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   const bool queued = ModeTraits<MODE>::kFast && cache.q != nullptr;
   if (!queued && !live) return;
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
-  float wx = R[0] * lx + R[1] * ly + R[2] * lz;
-  float wy = R[3] * lx + R[4] * ly + R[5] * lz;
-  float wz = R[6] * lx + R[7] * ly + R[8] * lz;
+  float wx = fmaf(R[2], lz, fmaf(R[1], ly, R[0] * lx));
+  float wy = fmaf(R[5], lz, fmaf(R[4], ly, R[3] * lx));
+  float wz = fmaf(R[8], lz, fmaf(R[7], ly, R[6] * lx));
   // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
   if (ModeTraits<MODE>::kTables && filter != nullptr) {
     if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
@@ -1337,7 +1372,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
       Q.y[i] = wy;
       Q.z[i] = wz;
       Q.w[i] = w;
-      Q.wl[i] = wl_idx;
+      Q.wl[i] = static_cast<uint8_t>(wl_idx);
       if constexpr (MODE == kModeColor) {
         cache.qm->lo[i] = static_cast<uint32_t>(cmask);
         cache.qm->hi[i] = static_cast<uint32_t>(cmask >> 32);
@@ -1372,6 +1407,13 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   }
 }
 
+// The arithmetic of the entry picks is written out (explicit fma chains, products that feed a running sum rounded on their own): the three
+// variants below must pick the same triangle for the same uniform whatever else the instantiation around them compiles, and left to the
+// backend the choice between fma(a, b, c * d) and fma(c, d, a * b) follows the surrounding code (round 4: once the regular-prism kernels
+// stopped compiling the other two variants, one ray in 3 million entered through the neighbouring triangle).
+HD float dot3_fma(const float* d, float x, float y, float z) { return fmaf(d[2], z, fmaf(d[1], y, d[0] * x)); }
+HD float tri_point(float u, float v, float a, float b, float c) { return fmaf(u, b - a, fmaf(v, c - a, a)); }
+
 // Projected-area categorical entry pick + uniform point (InitRay_p_fid simulator.cpp:133-192 in its device form
 // gen_root_kernel cu:1556-1597).  Two passes over the fan table instead of a 64-float private array.
 template <typename ShapePtr>
@@ -1384,8 +1426,8 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
   float total = 0.0f;
   for (int t = 0; t < tri_cnt; ++t) {
     const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
-    float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
-    total += fmaxf(-dot * na.w, 0.0f);
+    const float dot = dot3_fma(d, na.x, na.y, na.z);
+    total += fmaxf(mul_rn(-dot, na.w), 0.0f);
   }
   int tri = 0;
   if (total > 0.0f) {
@@ -1394,8 +1436,8 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
     tri = tri_cnt - 1;
     for (int t = 0; t < tri_cnt; ++t) {
       const float4 na = *reinterpret_cast<const float4*>(sh->tri_na[t]);
-      float dot = d[0] * na.x + d[1] * na.y + d[2] * na.z;
-      cum += fmaxf(-dot * na.w, 0.0f);
+      const float dot = dot3_fma(d, na.x, na.y, na.z);
+      cum += fmaxf(mul_rn(-dot, na.w), 0.0f);
       if (cum > target) {
         tri = t;
         break;
@@ -1412,7 +1454,7 @@ HD int sample_entry(Stream& s, ShapePtr sh, int tri_cnt, const float* d, float* 
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     float a = vt[k], b = vt[3 + k], c = vt[6 + k];
-    p[k] = u * (b - a) + v * (c - a) + a;
+    p[k] = tri_point(u, v, a, b, c);
   }
   return static_cast<int>(sh->tri_face[tri]);
 }
@@ -1432,7 +1474,7 @@ HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int fac
   float total = 0.0f;
   for (int f = 0; f < face_cnt; ++f) {
     const float4 pl = *reinterpret_cast<const float4*>(sh->face[f]);
-    total += fmaxf(-(d[0] * pl.x + d[1] * pl.y + d[2] * pl.z), 0.0f) * fi.area[f];
+    total += mul_rn(fmaxf(-dot3_fma(d, pl.x, pl.y, pl.z), 0.0f), fi.area[f]);
   }
   int tri = 0;
   if (total > 0.0f) {
@@ -1441,8 +1483,8 @@ HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int fac
     tri = tri_cnt - 1;
     for (int f = 0; f < face_cnt; ++f) {
       const float4 pl = *reinterpret_cast<const float4*>(sh->face[f]);
-      const float c = fmaxf(-(d[0] * pl.x + d[1] * pl.y + d[2] * pl.z), 0.0f);
-      const float w = c * fi.area[f];
+      const float c = fmaxf(-dot3_fma(d, pl.x, pl.y, pl.z), 0.0f);
+      const float w = mul_rn(c, fi.area[f]);
       if (cum + w > target) {   // c > 0 here
         const float r = (target - cum) * fast_rcp(c);
         const int t0 = fi.tri0[f], tn = fi.tric[f];
@@ -1470,7 +1512,7 @@ HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int fac
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     float a = vt[k], b = vt[3 + k], c = vt[6 + k];
-    p[k] = u * (b - a) + v * (c - a) + a;
+    p[k] = tri_point(u, v, a, b, c);
   }
   return static_cast<int>(sh->tri_face[tri]);
 }
@@ -1486,7 +1528,7 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const float4 g = *reinterpret_cast<const float4*>(sh->slab[k]);
-    dn[k] = d[0] * g.x + d[1] * g.y + d[2] * g.z;
+    dn[k] = dot3_fma(d, g.x, g.y, g.z);
     const float2v a = *reinterpret_cast<const float2v*>(ef.slab_area[k]);
     ap[k] = a.x;
     am[k] = a.y;
@@ -1494,13 +1536,13 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
   // candidate k: 0 = basal slab (face 0 or 1), 1..3 = sides 2..4 (lit when d.n < 0), 4..6 = their opposites 5..7
   float wgt[7], cs[7];
   cs[0] = fabsf(dn[0]);
-  wgt[0] = cs[0] * (dn[0] < 0.0f ? ap[0] : am[0]);
+  wgt[0] = mul_rn(cs[0], dn[0] < 0.0f ? ap[0] : am[0]);
 #pragma unroll
   for (int k = 1; k < 4; k++) {
     cs[k] = fmaxf(-dn[k], 0.0f);
-    wgt[k] = cs[k] * ap[k];
+    wgt[k] = mul_rn(cs[k], ap[k]);
     cs[3 + k] = fmaxf(dn[k], 0.0f);
-    wgt[3 + k] = cs[3 + k] * am[k];
+    wgt[3 + k] = mul_rn(cs[3 + k], am[k]);
   }
   float total = wgt[0];
 #pragma unroll
@@ -1548,9 +1590,9 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
   }
   const float4* vt = reinterpret_cast<const float4*>(ef.tri_v[tri]);
   const float4 q0 = vt[0], q1 = vt[1], q2 = vt[2];   // a = q0.xyz, b = (q0.w, q1.x, q1.y), c = (q1.z, q1.w, q2.x)
-  p[0] = u * (q0.w - q0.x) + v * (q1.z - q0.x) + q0.x;
-  p[1] = u * (q1.x - q0.y) + v * (q1.w - q0.y) + q0.y;
-  p[2] = u * (q1.y - q0.z) + v * (q2.x - q0.z) + q0.z;
+  p[0] = tri_point(u, v, q0.x, q0.w, q1.z);
+  p[1] = tri_point(u, v, q0.y, q1.x, q1.w);
+  p[2] = tri_point(u, v, q0.z, q1.y, q2.x);
   return face;
 }
 
@@ -1567,26 +1609,31 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   int face;
   uint32_t wl_idx = 0u;
   const int face_cnt = sh->face_cnt;
-  Stream gate = make_stream(P.gate_seed, P.gate_lo, P.gate_hi, tid);
+#if HALO_RELOAD & 2
+  const DispatchParams G = reload_params();   // root generation reads its share of the dispatch record here, once per pass (see reload_params)
+#else
+  const DispatchParams& G = P;
+#endif
+  Stream gate = make_stream(G.gate_seed, G.gate_lo, G.gate_hi, tid);
 
-  if (P.source == kSrcGen) {
-    Stream s = make_stream(P.gen_seed, P.gen_lo, P.gen_hi, tid);
+  if (G.source == kSrcGen) {
+    Stream s = make_stream(G.gen_seed, G.gen_lo, G.gen_hi, tid);
     // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
     Stream wls = s;
     wls.seed ^= kNonceWl;
-    if (P.wl_pool_size > 1u) {  // a one-entry pool needs no draw: floor(u * 1) is 0 for every u in [0, 1) (own stream, nothing to keep aligned)
-      wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(P.wl_pool_size));
-      if (wl_idx >= P.wl_pool_size) wl_idx = P.wl_pool_size - 1u;
+    if (G.wl_pool_size > 1u) {  // a one-entry pool needs no draw: floor(u * 1) is 0 for every u in [0, 1) (own stream, nothing to keep aligned)
+      wl_idx = static_cast<uint32_t>(uniform(wls) * static_cast<float>(G.wl_pool_size));
+      if (wl_idx >= G.wl_pool_size) wl_idx = G.wl_pool_size - 1u;
     }
     float lon, lat, roll;
     PROBE_MARK(pr, kPhStream);
-    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    sample_lat_lon_roll(s, G, T.lut, lon, lat, roll);
     PROBE_MARK(pr, kPhOrient);
     build_crystal_rotation(lon, lat, roll, R);
     PROBE_MARK(pr, kPhRotation);
     // sun cone (sample_sph_cap pcg_shared.h:514-529; trig of the fixed sun angles is host-evaluated)
     float u = uniform(s);
-    float x = add_rn(u, mul_rn(1.0f - u, P.c_cap));  // separately rounded: see the note on r below
+    float x = add_rn(u, mul_rn(1.0f - u, G.c_cap));  // separately rounded: see the note on r below
     // x is within 1e-5 of 1: `1 - x*x` cancels catastrophically, so keep the product separately rounded like the
     // reference's host evaluation (a contracted fma here moves r by up to ~2e-4 for rays near the cone axis)
     float r = fast_sqrt(fmaxf(add_rn(1.0f, -mul_rn(x, x)), 0.0f));
@@ -1594,18 +1641,19 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float sp, cp;
     sincos_small(phi, &sp, &cp);
     float y = cp * r, z = sp * r;
-    float dwx = P.c_lon * P.c_lat * x - P.s_lon * y - P.c_lon * P.s_lat * z;
-    float dwy = P.s_lon * P.c_lat * x + P.c_lon * y - P.s_lon * P.s_lat * z;
-    float dwz = P.s_lat * x + P.c_lat * z;
+    float dwx = fmaf(-(G.c_lon * G.s_lat), z, fmaf(-G.s_lon, y, (G.c_lon * G.c_lat) * x));
+    float dwy = fmaf(-(G.s_lon * G.s_lat), z, fmaf(G.c_lon, y, (G.s_lon * G.c_lat) * x));
+    float dwz = fmaf(G.c_lat, z, G.s_lat * x);
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
-    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
+    if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
+    else if (G.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
-    w = (P.wl_pool_size == 1u) ? wl0.e.spd_weight : P.wl_pool[wl_idx].spd_weight;
+    w = (G.wl_pool_size == 1u) ? wl0.e.spd_weight : G.wl_pool[wl_idx].spd_weight;
     PROBE_MARK(pr, kPhEntry);
-  } else if (P.source == kSrcTransit) {
-    Stream s = make_stream(P.transit_seed, P.transit_lo, P.transit_hi, tid);
-    const uint32_t pos = P.ci_start + tid;
+  } else if (G.source == kSrcTransit) {
+    Stream s = make_stream(G.transit_seed, G.transit_lo, G.transit_hi, tid);
+    const uint32_t pos = G.ci_start + tid;
     // Recombine's shuffle, applied as a gather at read time.  The reference permutes single rays (shuffle_cont_kernel
     // cu:1633-1657, out[tid] = in[feistel(tid)]); a per-ray random gather costs five scattered 4-byte reads per ray (one
     // 64 B sector each: 76 GB for 237 M rays).  Here the same Feistel bijection permutes CHUNKS of 2^shuffle_chunk_log2
@@ -1614,32 +1662,33 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     // position ranges assigned to crystal entries, the K-shape clock — sees correlated neighbours.  The tail past the last
     // full chunk keeps its place.  Option "shuffle_chunk" = 1 gives the reference's per-ray permutation (A/B in the tests).
     uint32_t logical = pos;
-    if (P.shuffle) {
-      const uint32_t cl = P.shuffle_chunk_log2;
-      const uint32_t chunks = P.cont_in_n >> cl;
-      if (pos < (chunks << cl)) logical = (feistel_bijection(pos >> cl, chunks, P.shuffle_seed) << cl) + (pos & ((1u << cl) - 1u));
+    if (G.shuffle) {
+      const uint32_t cl = G.shuffle_chunk_log2;
+      const uint32_t chunks = G.cont_in_n >> cl;
+      if (pos < (chunks << cl)) logical = (feistel_bijection(pos >> cl, chunks, G.shuffle_seed) << cl) + (pos & ((1u << cl) - 1u));
     }
     uint32_t sh_i = 0u;  // largest shard with seg[shard] <= logical (empty shards repeat their neighbour's start)
 #pragma unroll
     for (uint32_t step = kContShards / 2; step >= 1u; step >>= 1)
       if (T.seg[sh_i + step] <= logical) sh_i += step;
-    const uint32_t src = sh_i * P.cont_in_region + (logical - T.seg[sh_i]);
-    const uint32_t st = P.cont_in_stride;
-    float dwx = P.cont_in[src], dwy = P.cont_in[st + src], dwz = P.cont_in[2u * st + src];
-    w = P.cont_in[3u * st + src];
-    wl_idx = reinterpret_cast<const uint32_t*>(P.cont_in)[4u * st + src];
+    const uint32_t src = sh_i * G.cont_in_region + (logical - T.seg[sh_i]);
+    const uint32_t st = G.cont_in_stride;
+    float dwx = G.cont_in[src], dwy = G.cont_in[st + src], dwz = G.cont_in[2u * st + src];
+    w = G.cont_in[3u * st + src];
+    wl_idx = reinterpret_cast<const uint32_t*>(G.cont_in)[4u * st + src];
     if (MODE == kModeColor || (ModeTraits<MODE>::kTables && color != nullptr))
-      carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[5u * st + src]) |
-                (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(P.cont_in)[6u * st + src]) << 32);
+      carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(G.cont_in)[5u * st + src]) |
+                (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(G.cont_in)[6u * st + src]) << 32);
     float lon, lat, roll;
     PROBE_MARK(pr, kPhStream);
-    sample_lat_lon_roll(s, P, T.lut, lon, lat, roll);
+    sample_lat_lon_roll(s, G, T.lut, lon, lat, roll);
     PROBE_MARK(pr, kPhOrient);
     build_crystal_rotation(lon, lat, roll, R);
     PROBE_MARK(pr, kPhRotation);
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
-    if (P.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
+    if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
+    else if (G.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     PROBE_MARK(pr, kPhEntry);
   } else {  // kSrcHost: crystal-local golden rays, identity rotation (cpu_trace_backend.cpp:121-144)
@@ -1647,11 +1696,11 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      d[k] = P.host_d[static_cast<size_t>(tid) * 3 + k];
-      p[k] = P.host_p[static_cast<size_t>(tid) * 3 + k];
+      d[k] = G.host_d[static_cast<size_t>(tid) * 3 + k];
+      p[k] = G.host_p[static_cast<size_t>(tid) * 3 + k];
     }
-    w = P.host_w[tid];
-    face = static_cast<int>(P.host_tf[tid]);
+    w = G.host_w[tid];
+    face = static_cast<int>(G.host_tf[tid]);
   }
   if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
 
@@ -1669,8 +1718,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 
   uint8_t path[ModeTraits<MODE>::kTables ? kFilterPathCap : 1];
   PathView pv = {path, 0u, {0ull, 0ull}};
-  if (MODE != kModePlain) {
-    pv.reg.lo = (HEX && ModeTraits<MODE>::kFastPath) ? static_cast<uint32_t>(face) + 1u : sh->face_number[face];
+  if constexpr (MODE != kModePlain) {
+    if constexpr (HEX) pv.reg.lo = static_cast<uint32_t>(face) + 1u;   // regular prism: face numbers 1..8 in face order (BuildEntryFast checks)
+    else pv.reg.lo = sh->face_number[face];
     pv.len = 1u;
   }
 
@@ -1690,7 +1740,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   auto fresnel = [&](float cos_t, float rr, float rr2, float one_m_rr2, const float4& fn) {
     Split o;
 #if HALO_FRESNEL == 0
-    const float dd = one_m_rr2 * fast_rcp(cos_t * cos_t) + rr2;
+    const float dd = fmaf(one_m_rr2, fast_rcp(cos_t * cos_t), rr2);
 #else
     const float dd = add_rn(fresnel_div(one_m_rr2, cos_t * cos_t), rr2);   // quotient rounded, then the sum: the reference's order (optics.cpp:30)
 #endif
@@ -1698,21 +1748,21 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const float sq = fresnel_sqrt(fmaxf(dd, 0.0f));
     float Rs = fresnel_div(rr - sq, rr + sq);
     Rs *= Rs;
-    float Rp = fresnel_div(1.0f - rr * sq, 1.0f + rr * sq);
+    float Rp = fresnel_div(fmaf(-rr, sq, 1.0f), fmaf(rr, sq, 1.0f));
     Rp *= Rp;
-    o.w_refl = (Rs + Rp) * 0.5f * w;
+    o.w_refl = ((Rs + Rp) * 0.5f) * w;
     o.w_refr = w - o.w_refl;
     const float k_refl = 2.0f * cos_t;
     const float k_refr = (rr - sq) * cos_t;
-    o.rl[0] = d[0] - k_refl * fn.x, o.rl[1] = d[1] - k_refl * fn.y, o.rl[2] = d[2] - k_refl * fn.z;
-    o.rf[0] = rr * d[0] - k_refr * fn.x, o.rf[1] = rr * d[1] - k_refr * fn.y, o.rf[2] = rr * d[2] - k_refr * fn.z;
+    o.rl[0] = fmaf(-k_refl, fn.x, d[0]), o.rl[1] = fmaf(-k_refl, fn.y, d[1]), o.rl[2] = fmaf(-k_refl, fn.z, d[2]);
+    o.rf[0] = fmaf(-k_refr, fn.x, rr * d[0]), o.rf[1] = fmaf(-k_refr, fn.y, rr * d[1]), o.rf[2] = fmaf(-k_refr, fn.z, rr * d[2]);
     return o;
   };
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
-    const float cos_t = d[0] * fn.x + d[1] * fn.y + d[2] * fn.z;
+    const float cos_t = dot3_fma(d, fn.x, fn.y, fn.z);
     // On a convex body exactly one child stays inside: the refracted one when entering (cos < 0), the reflected one otherwise; the other
     // child leaves through `face` and is the outgoing candidate.  A ray ENTERS at most once, at its first interaction: every later face
     // was picked by the search below with n.d > eps, i.e. it is hit from inside.  So only the first turn of the loop (a wave-uniform
@@ -1776,7 +1826,8 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       const float db = hex_d_basal, ds = hex_d_side;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? (X * 0.5f + Y * kS60) : (X * -0.5f + Y * kS60);
+        const float2v s60 = {kS60, kS60};
+        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? __builtin_elementwise_fma(Y, s60, X * 0.5f) : __builtin_elementwise_fma(Y, s60, X * -0.5f);
         const float dk = (k == 0) ? db : ds;
         const bool pos = r.x > 0.0f;
         const float den = fabsf(r.x);
@@ -1793,7 +1844,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       // opposite faces +n / -n: den(-n) = -den(+n) and n.p flips sign, so only the face the ray travels towards can be ahead
       const float4 g = *reinterpret_cast<const float4*>(sh->slab[k]);
       const float4 e = *reinterpret_cast<const float4*>(sh->slab[k] + 4);
-      const float2v r = X * g.x + Y * g.y + Z * g.z;
+      const float2v r = pk_dot(X, Y, Z, g.x, g.y, g.z);
       const bool pos = r.x > 0.0f;
       const float den = fabsf(r.x);
       const float num = pos ? -(r.y + g.w) : (r.y - e.x);
@@ -1808,7 +1859,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     for (int k = 0; k < single_cnt; ++k) {
       const int fi = sh->single[k];
       const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
-      const float2v r = X * g.x + Y * g.y + Z * g.z;
+      const float2v r = pk_dot(X, Y, Z, g.x, g.y, g.z);
       const float den = r.x;
       const float num = -(r.y + g.w);
       const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
@@ -1831,15 +1882,17 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       done = done || stray;
     }
     if (!done) {
-      p[0] += t_best * d[0];
-      p[1] += t_best * d[1];
-      p[2] += t_best * d[2];
+      p[0] = fmaf(t_best, d[0], p[0]);
+      p[1] = fmaf(t_best, d[1], p[1]);
+      p[2] = fmaf(t_best, d[2], p[2]);
       face = hit;
       if constexpr (ModeTraits<MODE>::kFastPath) {   // (max_hits <= 16: the register holds every path; its length is the loop counter)
-        const uint32_t fn = HEX ? static_cast<uint32_t>(face) + 1u : sh->face_number[face];   // regular prism: numbers 1..8 in face order (BuildEntryFast checks)
+        uint32_t fn;
+        if constexpr (HEX) fn = static_cast<uint32_t>(face) + 1u;   // regular prism: numbers 1..8 in face order (BuildEntryFast checks)
+        else fn = sh->face_number[face];
         pv.reg = pk_shl8(pv.reg);
         pv.reg.lo |= fn;
-      } else if (MODE != kModePlain) {
+      } else if constexpr (MODE != kModePlain && !HEX) {
         const uint8_t fn = sh->face_number[face];
         if (pv.len < 16u) {
           pv.reg = pk_shl8(pv.reg);
@@ -1910,6 +1963,9 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 5
 #endif
+#ifndef HALO_LOG_WAVES
+#define HALO_LOG_WAVES 5   // the one-regular-prism scalar-plane kernels (exit queue + hit log): 91 VGPRs since the dispatch record is re-read per region (reload_params), 31 KB of LDS since ShapeHead
+#endif
 #ifndef HALO_MIN_WAVES_FILTER
 #define HALO_MIN_WAVES_FILTER 3
 #endif
@@ -1917,7 +1973,7 @@ HD float wave_sum(float v) {
 // types (uniform branches, and the SGPRs their parameters hold), the visibility tests and the gate stream fold away: configs[1]
 // 2.96 -> 2.73 (lens) -> 2.60 ms per launch.  Done for the last-layer one-shape scalar kernels and the lenses of the shipped examples.
 template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1, int VIS = -1, bool NOGATE = false>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
-__global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? 4 : (MODE == kModePlain ? HALO_MIN_WAVES : 4)) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? ((MODE == kModePlain && GEOM == kGeomOneHex && MONO) ? HALO_LOG_WAVES : 4) : (MODE == kModePlain ? HALO_MIN_WAVES : 4)) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || ModeTraits<MODE>::kFast, "the hit log is a production-mode route");
   static_assert(!NONE || (ModeTraits<MODE>::kFast && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
@@ -1973,7 +2029,9 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
-  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, ShapeDev, 1> s_shape;  // deterministic: the dispatch's one shape
+  constexpr bool HEXK = GEOM == kGeomOneHex;
+  typedef typename std::conditional<HEXK, ShapeHead, ShapeDev>::type OneShape;   // a regular prism's kernels stage the 464-byte prefix they read (halo_device.h ShapeHead)
+  __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, OneShape, 1> s_shape;  // deterministic: the dispatch's one shape
   __shared__ __attribute__((aligned(16))) ColorSlot<ModeTraits<MODE>::kTables> s_color;
   const ColorDev* color = nullptr;
   if (ModeTraits<MODE>::kTables && P.color != nullptr) {
@@ -2007,7 +2065,9 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
   if constexpr (!POOL) {
     const float4* src = reinterpret_cast<const float4*>(P.shapes);
     float4* dst = reinterpret_cast<float4*>(&s_shape.s[0]);
-    for (uint32_t i = threadIdx.x; i < sizeof(ShapeDev) / 16u; i += kBlock) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(OneShape) / 16u; i += kBlock) dst[i] = src[i];
+  }
+  if constexpr (!POOL && !HEXK) {   // (a regular prism's entry pick goes by EntryFastDev alone: no per-face view needed)
     __syncthreads();
     // per-face view of the fan table (FaceIndex): thread f sums face f's triangles; the grouping is verified, not assumed
     const ShapeDev& S0 = s_shape.s[0];
@@ -2084,7 +2144,7 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
           const PoolRec* sh = reinterpret_cast<const PoolRec*>(P.shapes) + (tid / P.geom_clock);
           trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, wl0, tid, sums, pr);
         } else {
-          const ShapeDev* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
+          const OneShape* sh = &s_shape.s[0];  // LDS: ds_read_b128 broadcasts
           trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, sh, wl0, tid, sums, pr);
         }
       }
