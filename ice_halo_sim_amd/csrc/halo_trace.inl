@@ -1964,16 +1964,30 @@ HD float wave_sum(float v) {
 #define HALO_MIN_WAVES 5
 #endif
 #ifndef HALO_LOG_WAVES
-#define HALO_LOG_WAVES 5   // the one-regular-prism scalar-plane kernels (exit queue + hit log): 91 VGPRs since the dispatch record is re-read per region (reload_params), 31 KB of LDS since ShapeHead
+#define HALO_LOG_WAVES 6   // the LOGGING plain scalar-plane kernels of one regular prism (see min_waves)
 #endif
 #ifndef HALO_MIN_WAVES_FILTER
 #define HALO_MIN_WAVES_FILTER 3
 #endif
+// The plain scalar-plane kernels of one REGULAR prism: 81 VGPRs and 31 KB of LDS run five waves per SIMD (round 4: +7 % over four); the
+// logging ones of them halve the pixel cache (a miss is an 8-byte log record there, not a memory-side atomic: 1024 slots measure the same
+// as 2048 at four and five waves) for 26 KB and SIX waves: configs[1] 20.24 -> 19.60 ms per step.
+template <int MODE, int GEOM, bool MONO, int ACC>
+constexpr bool small_cache_hex() { return MODE == kModePlain && GEOM == kGeomOneHex && MONO && (ACC == kAccLog || ACC == kAccLogFinal); }
+template <int MODE, int GEOM, bool MONO, int ACC>
+constexpr int min_waves() {
+  if (!ModeTraits<MODE>::kFast) return HALO_MIN_WAVES_FILTER;
+  if ((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) {
+    if (small_cache_hex<MODE, GEOM, MONO, ACC>()) return HALO_LOG_WAVES;
+    return (MODE == kModePlain && GEOM == kGeomOneHex && MONO) ? 5 : 4;
+  }
+  return MODE == kModePlain ? HALO_MIN_WAVES : 4;
+}
 // LENS / VIS >= 0, NOGATE: instantiated for that lens, that visible range and prob <= 0 — the projection's dispatch over 11 lens
 // types (uniform branches, and the SGPRs their parameters hold), the visibility tests and the gate stream fold away: configs[1]
 // 2.96 -> 2.73 (lens) -> 2.60 ms per launch.  Done for the last-layer one-shape scalar kernels and the lenses of the shipped examples.
 template <int MODE, int GEOM, bool MONO, int ACC, int LENS = -1, int VIS = -1, bool NOGATE = false>   // ACC: kAccDirect, kAccBin (staged + binned hit lists), kAccLog (per-workgroup hit log), ...
-__global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) ? ((MODE == kModePlain && GEOM == kGeomOneHex && MONO) ? HALO_LOG_WAVES : 4) : (MODE == kModePlain ? HALO_MIN_WAVES : 4)) : HALO_MIN_WAVES_FILTER)) halo_trace_kernel(const DispatchParams P) {
+__global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) halo_trace_kernel(const DispatchParams P) {
   constexpr bool BIN = ACC == kAccBin, LOG = ACC == kAccLog || ACC == kAccLogFinal, NONE = ACC == kAccNone, LAST = ACC == kAccLogFinal;
   static_assert(!LOG || ModeTraits<MODE>::kFast, "the hit log is a production-mode route");
   static_assert(!NONE || (ModeTraits<MODE>::kFast && MONO), "kAccNone: production mode; nothing accumulates, so one (scalar) flavour serves every session");
@@ -1985,7 +1999,7 @@ __global__ void __launch_bounds__(kBlock, (ModeTraits<MODE>::kFast ? (((ACC != k
   probe_start(pr);
   const uint64_t t_begin = pr.t0;
 #endif
-  constexpr bool SMALLC = BIN && GEOM != kGeomOne && GEOM != kGeomOneHex;
+  constexpr bool SMALLC = (BIN && GEOM != kGeomOne && GEOM != kGeomOneHex) || small_cache_hex<MODE, GEOM, MONO, ACC>();
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
   constexpr bool QUEUE = ModeTraits<MODE>::kFast && ACC != kAccBin && ACC != kAccNone && (GEOM == kGeomOne || GEOM == kGeomOneHex);
