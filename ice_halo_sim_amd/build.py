@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
             elif os.environ.get("HALO_FP_CONTRACT"):  # experiment knob: off | on | fast
                 cmd.append("-ffp-contract=" + os.environ["HALO_FP_CONTRACT"])
         else:  # host tables must round like the reference's host build: no FMA contraction
-            cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common
+            cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common + os.environ.get("HALO_DEFS", "").split()
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if src.endswith(".hip") and r.returncode == 0:

@@ -21,6 +21,9 @@
 #include "halo_device.h"
 #include "halo_host.hpp"
 
+#ifndef HALO_XYZ_LOG_MIN_PIX
+#define HALO_XYZ_LOG_MIN_PIX (1u << 19)   // illuminant sessions on images ABOVE this many pixels take the X/Y/Z hit log (below: one scalar plane per pool entry)
+#endif
 namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, uint32_t frac_bits, hipStream_t stream);
@@ -480,7 +483,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   // takes <= 4 Ki-slot tiles x 512, scalar planes 16 Ki-slot tiles x 256.  A session the log cannot serve keeps the routes it had before
   // (one plane per pool entry + binned lists; privatised copies for the direct atomics).
   const bool log_xyz_fits = s_log2 <= 11u, log_mono_fits = s_log2 <= 12u;
-  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > (1u << 19) && log_xyz_fits;
+  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > HALO_XYZ_LOG_MIN_PIX && log_xyz_fits;
   b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);

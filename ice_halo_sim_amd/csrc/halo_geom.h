@@ -541,6 +541,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
   int on[20][HALO_MAX_FACE_VTX];
   int on_n[20];
   int present = 0;
+  bool polytope = false;
   for (int pass = 0; pass < 2; pass++) {
   nv = 0;
   if (pass == 0) {
@@ -609,9 +610,14 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
   }
   int tris = 0;
   for (int s = 0; s < 20; s++) tris += on_n[s] > 0 ? on_n[s] - 2 : 0;
-  if (tris == 2 * nv - 4 && present >= 4) break;   // a polytope: the short lists found it
+  polytope = tris == 2 * nv - 4 && present >= 4;
+  if (polytope) break;   // a polytope: the short lists found it
   }
-  if (present < 4) return false;
+  // A table that fails Euler's count even after the exhaustive enumeration (2 of 10^4 deliberately degenerate draws: a concurrence whose
+  // determinant sits just above the 1e-9 gate) is REFUSED: the empty crystal, whose rays carry no weight — what the reference does with a
+  // sample its builder rejects (MakeCrystal, simulator.cpp:448; crystal.cpp:77-79) — rather than a body the next-face search can leave
+  // through a gap.  Host, device team kernel and oracle refuse the same samples.
+  if (!polytope) return false;
   ShapeCursor cur;
   float fn_rows[kMaxFaces][4];
   cur.fn = fn_rows;

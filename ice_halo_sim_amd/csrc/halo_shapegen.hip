@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     team_publish();   // (the face phase's LDS is the vertex phase's staging area)
     build(true);
   }
-  if (__popc(present) < 4) valid = false;
+  if (!(tri_total == 2 * nv - 4 && __popc(present) >= 4)) valid = false;   // still no polytope: refused, the empty crystal (geom::BuildPyramidShape)
   // --- tables ---
   if (!valid) {
     if (live && lane == 0) out.face_cnt = out.tri_cnt = out.slab_cnt = out.single_cnt = 0;

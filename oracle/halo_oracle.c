@@ -1074,8 +1074,14 @@ int ho_pyramid_face_mask(float wedge_u, float wedge_l, float h1, float h2, float
 
 void ho_pyramid_geometry(float wedge_u, float wedge_l, float h1, float h2, float h3, const float dist[6], HaloGeomTables* out) {
   HoCfGeom g;
-  int present = ho_pyramid_topology(wedge_u, wedge_l, h1, h2, h3, dist, &g, NULL);
-  if (present < 4) { /* IsValidClosedFormPyramid crystal.cpp:93-101 */
+  int nv = 0;
+  int present = ho_pyramid_topology(wedge_u, wedge_l, h1, h2, h3, dist, &g, &nv);
+  int tris = 0;
+  for (int s = 0; s < 20; s++) if (g.face_present[s]) tris += g.face_vtx_cnt[s] - 2;
+  /* IsValidClosedFormPyramid crystal.cpp:93-101; and a vertex / face table that fails Euler's count (fan triangles != 2 V - 4: an
+   * ill-conditioned concurrence, 2 of 10^4 deliberately degenerate draws) is a rejected sample like the reference's MakeCrystal rejects
+   * (simulator.cpp:448): the empty crystal */
+  if (present < 4 || tris != 2 * nv - 4) {
     memset(out, 0, sizeof(*out));
     return;
   }

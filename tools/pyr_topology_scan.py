@@ -48,3 +48,18 @@ def detail(sampler, n, seed):
     return ok_o, bad_o
 print("degenerate sampler, remaining: oracle table a polytope in %d, not in %d" % detail(degenerate, 30000, 3))
 print("ordinary sampler, remaining:   oracle table a polytope in %d, not in %d" % detail(ordinary, 30000, 4))
+# round 4: a table that is no polytope after the exhaustive pass is REFUSED (the empty crystal) on host, device and oracle alike: how many
+def refused(sampler, n, seed):
+    rng = np.random.default_rng(seed); e_h = e_o = valid = 0
+    for t in range(n):
+        wu, wl, h1, h2, h3, d = sampler(rng)
+        a, b = abi.HaloGeomTables(), abi.HaloGeomTables()
+        L.halo_host_pyramid_geometry(wu, wl, h1, h2, h3, fptr(d), C.byref(a))
+        O.ho_pyramid_geometry(wu, wl, h1, h2, h3, fptr(d), C.byref(b))
+        e_h += a.face_cnt == 0; e_o += b.face_cnt == 0
+        if a.face_cnt:
+            valid += 1
+            assert a.tri_cnt >= 4
+    return e_h, e_o, valid
+print("degenerate sampler: empty crystals host %d / oracle %d of 10000 (invalid parameters and refused tables); %d polytopes" % refused(degenerate, 10000, 5))
+print("ordinary sampler:   empty crystals host %d / oracle %d of 10000; %d polytopes" % refused(ordinary, 10000, 6))
