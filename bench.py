@@ -55,7 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r03"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
+PROFILE_ROUND = "r04"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
 
 # The reference's legacy CPU path measured by the survey in the build container (compiled with shims, 6 worker
 # threads, config_example-shaped scene): the only number that relates the oracle ("port") to the real reference.
@@ -211,6 +211,24 @@ def _pmc_mean(name, key, kernel="halo_trace_kernel"):
     return val
 
 
+def _pmc_kernel_us(name, key, kernel="halo_trace_kernel"):
+    """average duration (us) of the kernel whose counter row _pmc_mean(name, key) reads, from the kernel table of the same summary"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    full, rows = None, {}
+    for line in open(path):
+        if kernel in line and (" " + key + " ") in line:
+            full = line.split(" " + key + " ")[0].strip()
+        elif not line.startswith(" ") and len(line.split()) >= 6:
+            f = line.rsplit(None, 6)
+            try:
+                rows[f[0].strip()] = float(f[3])
+            except ValueError:
+                pass
+    return rows.get(full) if full else None
+
+
 GROUP_KERNELS = ("halo_trace_kernel", "halo_split_kernel", "halo_bin_accumulate_range_kernel", "halo_bin_accumulate_kernel", "halo_log_accumulate_kernel")
 
 
@@ -310,7 +328,14 @@ def pmc_valu(cfg, rays_per_launch):
             0.19 * c("v_xor_b32", 3.1) + 0.10 * c("v_readlane_b32", 4.56)
         classified = sum(counts.values())
         cycles = sum(counts[k] * price[k] for k in keys) + max(total - classified, 0.0) * other
-        out["issue_frac"] = cycles / (32.0 * busy)
+        # In TIME, not in counted cycles: the micro-benchmark's "cycles" are its elapsed time x 2.4 GHz, and the part clocks lower under this
+        # kernel (SQ_BUSY_CYCLES / duration = 2.1 GHz in the round-4 passes) — so the priced instruction stream is compared with the kernel's
+        # own duration in the pass that counted it.  issue_frac_cycles keeps round 3's cycle-domain figure for comparison (it reads ~12 % high).
+        dur_us = _pmc_kernel_us(cls, "SQ_INSTS_VALU")
+        out["issue_frac_cycles"] = cycles / (32.0 * busy)
+        out["issue_frac"] = (cycles / 2.4e9 / 32.0) / (dur_us * 1e-6) if dur_us else out["issue_frac_cycles"]
+        out["kernel_us_in_counter_pass"] = dur_us
+        out["busy_cycles_per_us"] = busy / _pmc_kernel_us(cyc, "SQ_BUSY_CYCLES") if _pmc_kernel_us(cyc, "SQ_BUSY_CYCLES") else None
         out["census"] = {k: counts[k] / total for k in keys}
         out["census"]["other (moves, selects, compares, logic, lane moves)"] = max(total - classified, 0.0) / total
         out["cost_cycles_per_wave64_instruction"] = dict(price, other=other)

@@ -1963,6 +1963,9 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 5
 #endif
+#ifndef HALO_POOL_WAVES
+#define HALO_POOL_WAVES 4   // the logging shape-pool kernels
+#endif
 #ifndef HALO_LOG_WAVES
 #define HALO_LOG_WAVES 6   // the LOGGING plain scalar-plane kernels of one regular prism (see min_waves)
 #endif
@@ -1979,6 +1982,7 @@ constexpr int min_waves() {
   if (!ModeTraits<MODE>::kFast) return HALO_MIN_WAVES_FILTER;
   if ((ACC != kAccDirect && ACC != kAccNone) || ((GEOM == kGeomOne || GEOM == kGeomOneHex) && ACC != kAccNone)) {
     if (small_cache_hex<MODE, GEOM, MONO, ACC>()) return HALO_LOG_WAVES;
+    if (MODE == kModePlain && (GEOM == kGeomPoolPrism || GEOM == kGeomPool) && (ACC == kAccLog || ACC == kAccLogFinal)) return HALO_POOL_WAVES;
     return (MODE == kModePlain && GEOM == kGeomOneHex && MONO) ? 5 : 4;
   }
   return MODE == kModePlain ? HALO_MIN_WAVES : 4;
