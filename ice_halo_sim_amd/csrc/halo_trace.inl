@@ -1963,6 +1963,9 @@ HD float wave_sum(float v) {
 #ifndef HALO_MIN_WAVES
 #define HALO_MIN_WAVES 5
 #endif
+#ifndef HALO_FILTER_SIX
+#define HALO_FILTER_SIX 1   // the logging filter kernels of one regular prism take the small cache and six waves too (round 4: +8 .. +14 %)
+#endif
 #ifndef HALO_POOL_WAVES
 #define HALO_POOL_WAVES 4   // the logging shape-pool kernels
 #endif
@@ -1976,7 +1979,7 @@ HD float wave_sum(float v) {
 // logging ones of them halve the pixel cache (a miss is an 8-byte log record there, not a memory-side atomic: 1024 slots measure the same
 // as 2048 at four and five waves) for 26 KB and SIX waves: configs[1] 20.24 -> 19.60 ms per step.
 template <int MODE, int GEOM, bool MONO, int ACC>
-constexpr bool small_cache_hex() { return MODE == kModePlain && GEOM == kGeomOneHex && MONO && (ACC == kAccLog || ACC == kAccLogFinal); }
+constexpr bool small_cache_hex() { return (MODE == kModePlain || (HALO_FILTER_SIX && MODE == kModeFilter)) && GEOM == kGeomOneHex && MONO && (ACC == kAccLog || ACC == kAccLogFinal); }
 template <int MODE, int GEOM, bool MONO, int ACC>
 constexpr int min_waves() {
   if (!ModeTraits<MODE>::kFast) return HALO_MIN_WAVES_FILTER;

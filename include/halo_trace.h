@@ -409,7 +409,7 @@ int halo_host_shape_scalars(const HaloCrystal* crystal, uint32_t seed, uint64_t 
 /* Sample crystal instances [first_index, first_index + n) of `crystal` from the backend's shape-scalar stream
  * (MakeCrystal simulator.cpp:448 + SyncGroupSampler :361-393 + closed-form geometry) into `out[n]`:
  * on_device = 1 runs the device generator of the general (4.1 KB) records, 2 — prisms only — the generator of the prism pools' 1360-byte
- * records (one team of 16 lanes per crystal: what a stochastic-prism trace really runs), 0 the host builder.
+ * records (one team of 8 lanes per crystal: what a stochastic-prism trace really runs), 0 the host builder.
  * All of them are the same geometry (csrc/halo_geom.h); the tables are bit-equal whenever the draws involve no libm call
  * (fixed / uniform distributions) and equal to float rounding otherwise.  Parity-test hook. */
 int halo_generate_shapes(halo_handle_t h, const HaloCrystal* crystal, uint64_t first_index, uint32_t n, int on_device,
