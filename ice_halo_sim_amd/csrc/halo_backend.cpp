@@ -28,16 +28,16 @@ namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, uint32_t frac_bits, hipStream_t stream);
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, hipStream_t stream);
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, hipStream_t stream);
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                hipStream_t stream);
+                                double* ovf, uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
-                       hipStream_t stream);
+                       double* ovf, const uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
@@ -125,11 +125,13 @@ struct HaloBackend {
   std::vector<HaloFilter> filters;  // table referenced by HaloEntry::filter_id
   std::vector<HaloColorSet> color_sets;      // table referenced by HaloEntry::color_id
   std::vector<HaloColorClass> color_classes; // raypath-colour classes (Y lanes)
-  DevBuf<float> lanes;                       // class_count x W x H
+  DevBuf<double> lanes;                      // class_count x W x H, accumulated in fp64 (handed out as float)
   int lanes_w = 0, lanes_h = 0;
   DevBuf<FilterDev> filter_dev;
   std::unique_ptr<FastTables> fast_scratch;  // host staging of a dispatch's fast filter tables (20 KB: not on the stack)
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
+  DevBuf<double> ovf;          // fp64 twin of the planes (same offsets; only copy 0 is ever written): where full log regions / tile lists overflow to
+  DevBuf<uint32_t> ovf_flag;   // one word: something was written to the twin since the last fold
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
   bool xyz_log = false;        // illuminant session on X, Y, Z planes whose big production launches go through the hit log
@@ -304,6 +306,8 @@ int halo_destroy(halo_handle_t b) {
   b->acc_own.release();
   b->sums.release();
   b->mono.release();
+  b->ovf.release();
+  b->ovf_flag.release();
   b->filter_dev.release();
   b->cons_sum.release();
   b->cons_comp.release();
@@ -510,12 +514,21 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
     }
     b->mono_s_log2 = s_log2;  // planes are all-zero between sessions, so the layout may change freely
+    // the twin: as many doubles as the planes have floats (16.8 MB at configs[1]; a 64-plane session on 2048x1024 takes 1 GB), kept all-zero
+    // between sessions like the planes; sessions whose planes pass 512 Mi floats go without (their overflow stays on the fp32 plane)
+    if (b->ovf.cap < b->mono.cap && b->mono.cap <= (512ull << 20) && b->ovf.reserve(b->mono.cap) == hipSuccess) {
+      HIPCHK(b, hipMemsetAsync(b->ovf.ptr, 0, b->ovf.cap * sizeof(double), b->stream));
+      if (!b->ovf_flag.ptr) {
+        HIPCHK(b, b->ovf_flag.reserve(1));
+        HIPCHK(b, hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream));
+      }
+    }
   }
   if (!b->color_classes.empty()) {  // Y lanes persist like the accumulator, until halo_readback_class_lanes
     const size_t need = b->color_classes.size() * npix;
     if (b->lanes.cap < need || b->lanes_w != render->width || b->lanes_h != render->height) {
       HIPCHK(b, b->lanes.reserve(need));
-      HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(float), b->stream));
+      HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(double), b->stream));
       b->lanes_w = render->width;
       b->lanes_h = render->height;
     }
@@ -551,9 +564,12 @@ static int fold_if_dirty(HaloBackend* b) {
     FoldCoef coef{};
     for (uint32_t m = 0; m < n; m++)
       for (int a = 0; a < 3; a++) coef.c[m][a] = b->plane_coef[first + m][static_cast<size_t>(a)];
-    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, b->stream);
+    const bool twin = b->ovf.ptr != nullptr && b->ovf.cap >= b->mono.cap && b->ovf_flag.ptr != nullptr;
+    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? b->ovf.ptr + first * plane : nullptr,
+                               b->ovf_flag.ptr, b->stream);
     if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   }
+  if (b->ovf_flag.ptr) HIPCHK(b, hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream));   // every group has seen it; the fold zeroed what it took
   b->mono_dirty = false;
   return HALO_OK;
 }
@@ -716,6 +732,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.counters = b->counters.ptr;
     P.mono = b->mono.ptr;
     P.mono_s_log2 = b->mono_s_log2;
+    P.ovf = (b->ovf.ptr != nullptr && b->ovf.cap >= b->mono.cap && b->ovf_flag.ptr != nullptr) ? b->ovf.ptr : nullptr;
+    P.ovf_flag = b->ovf_flag.ptr;
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.bin_list = nullptr;
@@ -1028,15 +1046,15 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint32_t frac_bits = fix_frac_bits(b->sess_max_w, m);
       if (use_log) {
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
-                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, b->stream)
+                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
                                                        b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
-                                                       b->stream);
+                                                       P.ovf, P.ovf_flag, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {
         hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
-                                                         bin_tiles, fan_log2, frac_bits, b->stream)
+                                                         bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, b->stream)
                                   : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, frac_bits, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
@@ -1150,9 +1168,11 @@ int halo_readback_class_lanes(halo_handle_t b, float* lanes, int width, int heig
     return fail(b, HALO_FATAL, "class lanes: size does not match the session (classes x width x height)");
   HIPCHK(b, hipSetDevice(b->device));
   const size_t n = static_cast<size_t>(class_count) * width * height;
-  HIPCHK(b, hipMemcpyAsync(lanes, b->lanes.ptr, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, n * sizeof(float), b->stream));
+  std::vector<double> wide(n);   // the lanes are summed in fp64 on the device (hot pixels), the seam hands out floats (trace_backend.hpp:471-493)
+  HIPCHK(b, hipMemcpyAsync(wide.data(), b->lanes.ptr, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, n * sizeof(double), b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));
+  for (size_t i = 0; i < n; i++) lanes[i] = static_cast<float>(wide[i]);
   return HALO_OK;
 }
 

@@ -288,6 +288,10 @@ struct DispatchParams {
                                // mono_copy_mask+1 copies of kMonoRows << mono_s_log2 floats, pixel p at MonoSlot(p)
   uint32_t mono_s_log2;
   uint32_t mono_copy_mask;
+  double* ovf;                 // fp64 twin of the planes' copy 0 (nullptr = none): what a full hit-log region or a full tile list cannot hold is added
+                               // HERE, not to the fp32 plane — a hot pixel's overflow is thousands of near-equal addends onto one large float, which
+                               // fp32 atomics round the same way every time (5.6e-4 high, round 3); the closing fold takes the twin in when ovf_flag says so
+  uint32_t* ovf_flag;          // set to 1 by whoever writes the twin
   HitRec* bin_list;             // binned accumulation (nullptr = off): bin_tiles lists of bin_cap {slot, weight} records
   uint32_t bin_cap;
   uint32_t bin_tiles;
@@ -309,7 +313,7 @@ struct DispatchParams {
   const FilterDev* filter;     // nullptr = pass-all
   const ColorDev* color;       // nullptr = no raypath colour: no masks carried, no lanes
   const FastTables* fast;      // kFilter / kColor kernels: the filter and the colour predicates in their fast form (else nullptr)
-  float* lanes;                // class_cnt x lane_stride Y lanes
+  double* lanes;               // class_cnt x lane_stride Y lanes, fp64: a hot pixel's lane passes 1e7 and fp32 atomics round a near-constant addend the same way every time (3e-3 low, round 3)
   uint32_t lane_stride;        // W*H
 };
 

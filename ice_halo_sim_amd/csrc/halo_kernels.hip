@@ -117,11 +117,21 @@ constexpr uint32_t kSplitParts = 8u;
 // Tile of a record: ((slot & slot_mask) >> tile_log2) & (fan - 1) — contiguous 16 Ki-slot tiles of the plane array (tile_log2 14),
 // or, X/Y/Z hit log, interleaved tiles of one plane (tile_log2 0, mix_log2 = log2 of the plane's columns; the wavelength-pool
 // entry above the slot is cut off by slot_mask).  kSplitFanMax = destination tiles per source list.
-struct SplitXyz {              // X/Y/Z hit log only: what a record that finds its tile list full is added to
-  const WlEntryDev* pool;      // nullptr = scalar planes: plane[slot] += w
+struct SplitXyz {              // what a record that finds its tile list full is added to
+  const WlEntryDev* pool;      // X/Y/Z hit log; nullptr = scalar planes: plane[slot] += w
   uint32_t pool_size;          // CMF codes: pool entries, then pool_size + c = "the weight is channel c already"
   uint32_t plane_stride;
+  double* ovf;                 // the planes' fp64 twin (DispatchParams::ovf); nullptr = the fp32 plane itself
+  uint32_t* ovf_flag;
 };
+__device__ __forceinline__ void split_overflow(float* plane, const SplitXyz& x, size_t off, float v) {
+  if (x.ovf != nullptr) {
+    atomicAdd(x.ovf + off, static_cast<double>(v));
+    *x.ovf_flag = 1u;
+  } else {
+    atomic_add_f32(plane + off, v);
+  }
+}
 template <uint32_t kSplitBlock, uint32_t kSplitPer, uint32_t kSplitFanMax, bool kXyz, bool kMix>
 __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restrict__ plane, const uint2* __restrict__ list1, uint32_t cap1,
                                                                  const uint32_t* __restrict__ cnt1, uint32_t cnt1_stride, uint32_t parts,
@@ -216,11 +226,11 @@ __global__ void __launch_bounds__(kSplitBlock) halo_split_kernel(float* __restri
         } else {
           for (uint32_t k = 0; k < 3u; ++k) c[k] = code == xyz.pool_size + k ? 1.0f : 0.0f;
         }
-        float* at = plane + (r.x & slot_mask);
+        const size_t at = r.x & slot_mask;
         for (uint32_t k = 0; k < 3u; ++k)
-          if (c[k] != 0.0f) atomic_add_f32(at + k * xyz.plane_stride, c[k] * __uint_as_float(r.y));
+          if (c[k] != 0.0f) split_overflow(plane, xyz, at + static_cast<size_t>(k) * xyz.plane_stride, c[k] * __uint_as_float(r.y));
       } else {
-        atomic_add_f32(plane + r.x, __uint_as_float(r.y));
+        split_overflow(plane, xyz, r.x, __uint_as_float(r.y));
       }
     }
     __syncthreads();
@@ -367,13 +377,13 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 // ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 // `planes` > 1: the scalar planes of a per-entry-plane illuminant session (back to back), `tiles` interleaved tiles EACH, planes x tiles <= 512.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, hipStream_t stream) {
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
   // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
   // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
   if (planes > 1u || tiles > 256u) {
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles * planes), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -382,10 +392,10 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
   }
   if (interleaved)
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
   else
     hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, false>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (interleaved)
@@ -398,10 +408,10 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
 // the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of <= 4 Ki slots of one plane
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                hipStream_t stream) {
+                                double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
   hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, true, true>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
-                     reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride});
+                     reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride, ovf, ovf_flag});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((halo_log_accumulate_kernel<3u>), dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -410,10 +420,10 @@ hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitR
 }
 
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, hipStream_t stream) {
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
   hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u, false, false>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
-                     static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u});
+                     static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -435,8 +445,12 @@ constexpr uint32_t kFoldTile = 64u;
 constexpr uint32_t kFoldBatch = 8u;
 template <uint32_t R>
 __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ xyz, float* __restrict__ planes, uint32_t n_pix,
-                                                            uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef coef) {
+                                                            uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef coef,
+                                                            double* __restrict__ ovf, const uint32_t* __restrict__ ovf_flag) {
   __shared__ float tile[3][R][kFoldTile + 1];
+  // the planes' fp64 twin (copy 0: what log regions and tile lists could not hold, DispatchParams::ovf) comes in only when something was written
+  // to it — one uniform load — and `ovf` already points at this group's first plane
+  const bool take_ovf = ovf != nullptr && *ovf_flag != 0u;
   const uint32_t tiles_c = (1u << s_log2) / kFoldTile;  // columns per row / tile width (s_log2 >= 6)
   const uint32_t row0 = (blockIdx.x / tiles_c) * R, col0 = (blockIdx.x % tiles_c) * kFoldTile;
   const size_t plane = static_cast<size_t>(kMonoRows) << s_log2;
@@ -449,6 +463,19 @@ __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ x
         float t[kFoldBatch];
 #pragma unroll
         for (uint32_t u = 0; u < kFoldBatch; ++u) t[u] = p0 + u < n_planes ? q[static_cast<size_t>(p0 + u) * plane] : 0.0f;
+        if (take_ovf) {
+          double* qo = ovf + (q - planes);
+#pragma unroll
+          for (uint32_t u = 0; u < kFoldBatch; ++u) {
+            if (p0 + u >= n_planes) continue;
+            const double o = qo[static_cast<size_t>(p0 + u) * plane];
+            if (o != 0.0) {
+              qo[static_cast<size_t>(p0 + u) * plane] = 0.0;
+              const float sum = static_cast<float>(static_cast<double>(t[u]) + o);
+              t[u] = sum;
+            }
+          }
+        }
 #pragma unroll
         for (uint32_t u = 0; u < kFoldBatch; ++u) {
           if (t[u] == 0.0f) continue;
@@ -471,6 +498,14 @@ __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ x
             if (t[u] == 0.0f) continue;
             qp[static_cast<size_t>(c0 + u) * plane] = 0.0f;
             v += t[u];
+          }
+        }
+        if (take_ovf) {   // the twin shadows copy 0
+          double* qo = ovf + (qp - planes);
+          const double o = *qo;
+          if (o != 0.0) {
+            *qo = 0.0;
+            v = static_cast<float>(static_cast<double>(v) + o);
           }
         }
         x += coef.c[pl][0] * v;
@@ -600,14 +635,14 @@ hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rg
 
 // `planes` points at the first plane of this group; coef holds n_planes (<= kFoldGroup) coefficient triples
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
-                       hipStream_t stream) {
+                       double* ovf, const uint32_t* ovf_flag, hipStream_t stream) {
   const uint32_t tiles_c = (1u << s_log2) / kFoldTile;
   if (tiles_c * (kMonoRows / 64u) >= 512u)
-    hipLaunchKernelGGL(halo_fold_kernel<64u>, dim3(tiles_c * (kMonoRows / 64u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+    hipLaunchKernelGGL(halo_fold_kernel<64u>, dim3(tiles_c * (kMonoRows / 64u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef, ovf, ovf_flag);
   else if (tiles_c * (kMonoRows / 16u) >= 512u)
-    hipLaunchKernelGGL(halo_fold_kernel<16u>, dim3(tiles_c * (kMonoRows / 16u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+    hipLaunchKernelGGL(halo_fold_kernel<16u>, dim3(tiles_c * (kMonoRows / 16u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef, ovf, ovf_flag);
   else
-    hipLaunchKernelGGL(halo_fold_kernel<4u>, dim3(tiles_c * (kMonoRows / 4u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef);
+    hipLaunchKernelGGL(halo_fold_kernel<4u>, dim3(tiles_c * (kMonoRows / 4u)), dim3(kBlock), 0, stream, xyz, planes, n_pix, s_log2, copies, n_planes, coef, ovf, ovf_flag);
   return hipGetLastError();
 }
 

@@ -582,6 +582,16 @@ HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
   return true;
 }
 
+// Where a record goes that found its log region or its tile list full: the planes' fp64 twin when the dispatch has one, else the fp32 plane.
+HD void overflow_add(const DispatchParams& P, size_t off, float v) {
+  if (P.ovf != nullptr) {
+    atomicAdd(P.ovf + off, static_cast<double>(v));
+    *P.ovf_flag = 1u;
+  } else {
+    atomic_add_f32(P.mono + off, v);
+  }
+}
+
 // Hit log.  Global fp32 atomics execute memory-side on this part, 21 G/s whatever the footprint or the lanes per instruction
 // (tools/atomic_rate_bench.hip) — a floor of 2.8 ms under configs[1]'s 58 M cache misses, next to a 2.4 ms trace — while a wave
 // appending 8-byte records to a private run of HBM sustains > 200 G records/s.  So a logging kernel ADDS nothing: a hit that
@@ -607,12 +617,12 @@ HD void log_hit(const DispatchParams& P, uint32_t* log_n, uint32_t slot, float w
     } else {
       cx = code == P.wl_pool_size ? 1.0f : 0.0f, cy = code == P.wl_pool_size + 1u ? 1.0f : 0.0f, cz = code == P.wl_pool_size + 2u ? 1.0f : 0.0f;
     }
-    float* at = P.mono + (slot & ((1u << kLogWlShift) - 1u));
-    if (cx != 0.0f) atomic_add_f32(at, cx * w);
-    if (cy != 0.0f) atomic_add_f32(at + P.log_plane_stride, cy * w);
-    if (cz != 0.0f) atomic_add_f32(at + 2u * P.log_plane_stride, cz * w);
+    const size_t at = slot & ((1u << kLogWlShift) - 1u);
+    if (cx != 0.0f) overflow_add(P, at, cx * w);
+    if (cy != 0.0f) overflow_add(P, at + P.log_plane_stride, cy * w);
+    if (cz != 0.0f) overflow_add(P, at + 2u * static_cast<size_t>(P.log_plane_stride), cz * w);
   } else {
-    atomic_add_f32(P.mono + slot, w);   // copy 0
+    overflow_add(P, slot, w);   // copy 0
   }
 }
 
@@ -938,7 +948,7 @@ HD void fan_lanes(const DispatchParams& P, const ColorDev& c, uint64_t mask, uin
     if (bits == 0ull) continue;
     const uint64_t matched = mask & bits;
     const bool ok = c.class_all[k] ? (matched == bits) : (matched != 0ull);
-    if (ok) atomic_add_f32(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, y_val);
+    if (ok) atomicAdd(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, static_cast<double>(y_val));   // global_atomic_add_f64
   }
 }
 
@@ -1086,7 +1096,7 @@ HD void fan_lanes_fast(const DispatchParams& P, FastTablesC& F, uint64_t mask, u
     if (bits == 0ull) continue;
     const uint64_t matched = mask & bits;
     const bool ok = F.class_all[k] ? (matched == bits) : (matched != 0ull);
-    if (ok) atomic_add_f32(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, y_val);
+    if (ok) atomicAdd(P.lanes + static_cast<size_t>(k) * P.lane_stride + pix, static_cast<double>(y_val));   // global_atomic_add_f64
   }
 }
 
@@ -1931,7 +1941,7 @@ HD void bin_flush(const DispatchParams& P, HitBuffer& hb) {
     const uint32_t tile = (h.x >> P.bin_shift) & tmask;
     const uint32_t idx = atomicAdd(&hb.cur[tile], 1u);
     if (idx < P.bin_cap) reinterpret_cast<uint2*>(P.bin_list)[static_cast<size_t>(tile) * P.bin_cap + idx] = h;
-    else atomic_add_f32(P.mono + h.x, __uint_as_float(h.y));   // list full: direct (copy 0)
+    else overflow_add(P, h.x, __uint_as_float(h.y));   // list full (copy 0)
   }
   __syncthreads();
   if (threadIdx.x == 0) hb.n = 0u;
