@@ -344,6 +344,9 @@ const char* halo_last_error(halo_handle_t b) { return b ? b->error.c_str() : "nu
 int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (!b || !key) return HALO_FATAL;
   const std::string k(key);
+  // the session's plane layout (privatised copies, hit-log eligibility) was decided at halo_begin from these two: changing them with a session
+  // open would send direct atomics to a layout made for another route
+  if ((k == "capture_exits" || k == "filter_fast") && b->in_session) return fail(b, HALO_FATAL, k + " cannot change inside a session");
   if (k == "capture_exits") b->capture = v ? 1 : 0;
   else if (k == "geom_clock") b->geom_clock = static_cast<uint32_t>(v > 0 ? v : 32);
   else if (k == "chunk") {  // the kernels' grid-stride index is 32-bit: n_rays + one stride of workgroups must stay below 2^32
