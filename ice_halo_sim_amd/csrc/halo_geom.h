@@ -327,16 +327,24 @@ HALO_GEOM_HD bool BuildPrismShape(float h, const float dist[6], S& out) {
 struct Plane3 {
   double a, b, c, d;
 };
-HALO_GEOM_HD double EvalPlane(const Plane3& p, const double x[3]) { return p.a * x[0] + p.b * x[1] + p.c * x[2] + p.d; }
+// Round 4: plane evaluations and the 3 x 3 solve are explicit fma chains.  This file compiles with contraction OFF on host and device so
+// that both round alike; an explicit fma() is one IEEE operation on either side (v_fma_f64; vfmadd or libm's fma on the host), so the
+// tables stay bit-equal — and the device generator, whose time is the twenty-plane feasibility scan of ~100 candidate vertices in fp64,
+// issues three operations per plane where it issued six.
+HALO_GEOM_HD double EvalPlane4(double a, double b, double c, double d, double x0, double x1, double x2) { return fma(a, x0, fma(b, x1, fma(c, x2, d))); }
+HALO_GEOM_HD double EvalPlane(const Plane3& p, const double x[3]) { return EvalPlane4(p.a, p.b, p.c, p.d, x[0], x[1], x[2]); }
+HALO_GEOM_HD double Minor2(double a, double b, double c, double d) { return fma(a, b, -(c * d)); }   // a b - c d
 
 HALO_GEOM_HD bool Concurrence(const Plane3& p, const Plane3& q, const Plane3& r, double out[3]) {
-  const double det = p.a * (q.b * r.c - q.c * r.b) - p.b * (q.a * r.c - q.c * r.a) + p.c * (q.a * r.b - q.b * r.a);
+  const double m_bc = Minor2(q.b, r.c, q.c, r.b), m_ac = Minor2(q.a, r.c, q.c, r.a), m_ab = Minor2(q.a, r.b, q.b, r.a);
+  const double det = fma(p.a, m_bc, fma(-p.b, m_ac, p.c * m_ab));
   if (fabs(det) < 1e-9) return false;
   const double dx = -p.d, dy = -q.d, dz = -r.d;
   const double inv = 1.0 / det;   // one fp64 division per concurrence (a long sequence on the device), not three
-  out[0] = (dx * (q.b * r.c - q.c * r.b) - p.b * (dy * r.c - q.c * dz) + p.c * (dy * r.b - q.b * dz)) * inv;
-  out[1] = (p.a * (dy * r.c - q.c * dz) - dx * (q.a * r.c - q.c * r.a) + p.c * (q.a * dz - dy * r.a)) * inv;
-  out[2] = (p.a * (q.b * dz - dy * r.b) - p.b * (q.a * dz - dy * r.a) + dx * (q.a * r.b - q.b * r.a)) * inv;
+  const double n_yc = Minor2(dy, r.c, q.c, dz), n_yb = Minor2(dy, r.b, q.b, dz), n_az = Minor2(q.a, dz, dy, r.a), n_bz = Minor2(q.b, dz, dy, r.b);
+  out[0] = fma(dx, m_bc, fma(-p.b, n_yc, p.c * n_yb)) * inv;
+  out[1] = fma(p.a, n_yc, fma(-dx, m_ac, p.c * n_az)) * inv;
+  out[2] = fma(p.a, n_bz, fma(-p.b, n_az, dx * m_ab)) * inv;
   return true;
 }
 
@@ -509,7 +517,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
 #endif
     for (int m = 0; m < 20; m++)   // EvalPlane(unit[m], x) <= tol
       if ((act_mask >> m) & 1u) {
-        const double ev = pre[m][0] * x[0] + pre[m][1] * x[1] + pre[m][2] * x[2] + pre[m][3];
+        const double ev = EvalPlane4(pre[m][0], pre[m][1], pre[m][2], pre[m][3], x[0], x[1], x[2]);
         ok = ok && (ev <= tight);
         if (fabs(ev) <= tight) mk |= 1u << m;
       }

@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       // masked out of the incidences afterwards
 #pragma unroll 5
       for (int m = 0; m < 20; m++) {
-        const double ev = T.unit[m].a * x[0] + T.unit[m].b * x[1] + T.unit[m].c * x[2] + T.unit[m].d;
+        const double ev = geom::EvalPlane4(T.unit[m].a, T.unit[m].b, T.unit[m].c, T.unit[m].d, x[0], x[1], x[2]);
         ok = ok & (ev <= tight);
         mk |= (fabs(ev) <= tight ? 1u : 0u) << m;
       }
