@@ -478,7 +478,9 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   //  * illuminant, batch >= 8 Mi rays: one scalar plane per pool entry, coefficient = its CMF (1 atomic per hit, fold reads M planes)
   //  * illuminant, small batch or "mono" = 0: X, Y, Z planes, unit coefficients        (3 atomics per hit, cheap fold)
   const size_t npix = static_cast<size_t>(render->width) * render->height;
-  if (npix > (1u << 23)) return fail(b, HALO_UNAVAILABLE, "more than 2^23 pixels");   // recoverable: the caller falls back (INTEGRATION.md limits table)
+  // 2^25 pixels (an 8192x4096 panorama) is what the workgroup cache's 32-bit key names on its own; with a plane index beside the pixel the
+  // key keeps 23 bits for the pixel, so sessions above 2^23 pixels take the layouts without per-entry planes (below: mono_by_wl)
+  if (npix > (1u << 25)) return fail(b, HALO_UNAVAILABLE, "more than 2^25 pixels");   // recoverable: the caller falls back (INTEGRATION.md limits table)
   const bool discrete = wl->illuminant < 0;
   //  * illuminant, batch >= 2 Mi rays, hit log on (the default): X, Y, Z planes too, but the launches log {slot, pool entry, w} and
   //    the per-tile pass applies the CMF (halo_log_accumulate_kernel<3>): no plane per entry, no two-level split, a 3-plane fold
@@ -491,7 +493,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   // (one plane per pool entry + binned lists; privatised copies for the direct atomics).
   const bool log_xyz_fits = s_log2 <= 11u, log_mono_fits = s_log2 <= 12u;
   b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > HALO_XYZ_LOG_MIN_PIX && log_xyz_fits;
-  b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
+  b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && npix <= (1u << 23) && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
   b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
   b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
   // privatised copies spread the direct atomics of hot pixels; per-entry planes spread them already, and a session whose

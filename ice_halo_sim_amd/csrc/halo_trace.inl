@@ -2201,7 +2201,8 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
     for (int i = threadIdx.x; i < CacheGeom<MONO, SMALLC>::kN; i += kBlock) {
       const uint32_t key = T.cache.tag[i];
       if (key == 0u) continue;
-      const uint32_t pix = (key - 1u) & 0x7FFFFFu, pl = (key - 1u) >> 23;
+      // (a plane index rides above bit 23 only in sessions with a plane per pool entry, which stop at 2^23 pixels: halo_begin)
+      const uint32_t pl = (MONO && P.mono_by_wl) ? (key - 1u) >> 23 : 0u, pix = (MONO && P.mono_by_wl) ? ((key - 1u) & 0x7FFFFFu) : key - 1u;
       if (MONO) {
         const float v = T.cache.val[i];
         if (v == 0.0f) continue;

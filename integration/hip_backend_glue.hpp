@@ -349,10 +349,10 @@ class HipBackendGlue final : public TraceBackend {
   }
 
   // --- IsCompatible (trace_backend.hpp:511-519, called at simulator.cpp:946): every lens / visible range is supported; what
-  // the backend refuses is an image beyond 2^23 pixels (the LDS pixel-cache key width) ---------------------------------------
+  // the backend refuses is an image beyond 2^25 pixels (the LDS pixel-cache key width) ---------------------------------------
   bool IsCompatible(const RenderConfig& render) const override {
     return render.resolution_[0] > 0 && render.resolution_[1] > 0 &&
-           static_cast<uint64_t>(render.resolution_[0]) * static_cast<uint64_t>(render.resolution_[1]) <= (1ull << 23);
+           static_cast<uint64_t>(render.resolution_[0]) * static_cast<uint64_t>(render.resolution_[1]) <= (1ull << 25);
   }
 
   // --- WlPoolSize (trace_backend.hpp:521): > 0 = the backend samples the wavelength per ray from an M-entry pool in

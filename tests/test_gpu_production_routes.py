@@ -557,3 +557,35 @@ def test_unspecialised_lens_runs_the_generic_last_layer_kernel():
     assert r.spec_mask == abi.SPEC_LAST and r.generic_launches == 0 and r.accum_mask == abi.ACCUM_LOG, (r.spec_mask, r.generic_launches, r.accum_mask)
     img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 78, acc64=1)
     _check_single_layer(hip, (img_o, landed_o))
+
+
+@pytest.mark.parametrize("spectrum", ["discrete", "d65"])
+def test_panorama_of_two_to_the_25_pixels(spectrum):
+    """An 8192x4096 session — 2^25 pixels, what the workgroup cache's key names on its own (halo_begin; the reference has no cap,
+    render.cpp takes any resolution) — against the oracle on the same rays: landed weight rel 1e-4, 64x64 block means rel L2 <= 3e-3,
+    channel sums rel 2e-4; the pixels above 2^23 (the lower three quarters of the image) must carry their share.  One pixel more is
+    HALO_UNAVAILABLE, which the glue turns into the reference's own CPU path for that Run."""
+    from ice_halo_sim_amd.backend import BackendUnavailableError
+    sc = scenes.config2_scene()
+    rd = scenes.render(abi.LENS_RECTANGULAR, 8192, 4096, fov=360.0, el=0.0, visible=abi.VISIBLE_FULL)
+    wl = scenes.wl_discrete(550.0) if spectrum == "discrete" else scenes.wl_illuminant("D65", 64)
+    n = 8 << 20   # where an illuminant session on a smaller image would take a plane per pool entry
+    hb = hip_backend(seed=67)
+    st = run_session(hb, sc, rd, wl, n)
+    img, landed = hb.ReadbackXyzAccum()
+    hb.close()
+    oimg, olanded, ost = _oracle_image(sc, rd, wl, n, 67)
+    # (a few rays per 10^7 take the other side of a total-reflection threshold in fp32: DESIGN.md section 4)
+    assert st[0].exit_count == pytest.approx(ost[0].exit_count, rel=1e-5) and st[0].pixel_hits == pytest.approx(ost[0].pixel_hits, rel=1e-5)
+    assert landed == pytest.approx(olanded, rel=1e-4)
+    assert img.shape == oimg.shape == (4096, 8192, 3)
+    lower = img[1024:].astype(np.float64).sum()
+    assert lower > 0.05 * img.astype(np.float64).sum()
+    assert lower == pytest.approx(oimg[1024:].astype(np.float64).sum(), rel=2e-4)
+    assert rel_l2(block_mean(img, 64), block_mean(oimg, 64)) <= 3e-3
+    for c in range(3):
+        assert img[..., c].astype(np.float64).sum() == pytest.approx(oimg[..., c].astype(np.float64).sum(), rel=2e-4)
+    hb = hip_backend(seed=67)
+    with pytest.raises(BackendUnavailableError):
+        hb.BeginSession(sc, scenes.render(abi.LENS_RECTANGULAR, 8192, 4097, fov=360.0, el=0.0, visible=abi.VISIBLE_FULL), wl, n)
+    hb.close()
