@@ -129,10 +129,10 @@ HD void sincos_small(float x, float* sn, float* cs) {
   const bool swap = (q & 1) != 0;
   float so = swap ? cp : sp;
   float co = swap ? sp : cp;
-  so = (q & 2) ? -so : so;
-  co = ((q + 1) & 2) ? -co : co;
-  *sn = so;
-  *cs = co;
+  // quadrant signs as sign-bit flips (bit 1 of q and of q + 1 moved to bit 31): a shift and one three-input bit op each, no compare / select
+  const uint32_t uq = static_cast<uint32_t>(q);
+  *sn = __uint_as_float(__float_as_uint(so) ^ ((uq << 30) & 0x80000000u));
+  *cs = __uint_as_float(__float_as_uint(co) ^ (((uq + 1u) << 30) & 0x80000000u));
 }
 
 // ------------------------------------------------------------------------------------------------

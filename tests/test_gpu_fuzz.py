@@ -114,13 +114,16 @@ def make_case(seed):
 
 
 def has_degenerate_tables(sc, seed, samples=8):
-    """True when a pyramid entry's sampled instances give a vertex / face table that is no polytope (fan triangles != 2 V - 4).  Until the
-    builder took exact incidences (csrc/halo_geom.h) full apexes (height fraction 1) over face distances 0.5 % apart did that: a
-    corner within the tolerance of a plane it does not belong to joined that face and tilted its fan off the plane.  On such tables the
-    reference's two next-face strategies part ways (src/core/shared/traversal_shared.h:23-29: the CPU path's relaxed-threshold test lets a
-    child leaving a tilted face 're-hit' it, the CUDA path's explicit skip — and this library's rule that the outgoing child leaves — do
-    not), so the oracle (the CPU strategy) and HIP agree only loosely there.  None in 3500 seeds since the fix; the looser bars stay for
-    whatever table still escapes."""
+    """The fraction of a pyramid entry's sampled instances (the first `samples` of the session's shape stream) whose vertex / face table is no
+    polytope (fan triangles != 2 V - 4) or has a fan corner off its own face's plane by more than 1e-6 (ordinary tables: <= 1.2e-7, the
+    rounding of the corners to float).  Until the builder took exact incidences (csrc/halo_geom.h) full apexes (height fraction 1)
+    over face distances 0.5 % apart did the first: a corner within the tolerance of a plane it does not belong to joined that face and tilted
+    its fan off the plane.  The second is what the vertex merge leaves of a pyramid segment thinner than the merge tolerance (seed 20234: upper
+    segments of 5.6e-5 and 3.8e-5 of the crystal in 2 of its 937 instances — the ring's corners merge into the basal face's, 1.2e-5 above, and
+    the six lower faces' fans end 1.8e-5 .. 2.7e-5 off their planes).  On such tables the reference's two next-face strategies part ways
+    (src/core/shared/traversal_shared.h:23-29: the CPU path's relaxed-threshold test lets a child leaving a tilted face 're-hit' it — 58 % of
+    the outside reflections on seed 20234's two instances — the CUDA path's explicit skip, and this library's rule that the outgoing child
+    leaves, do not), so the oracle (the CPU strategy) and HIP agree only loosely on those instances' rays."""
     import ctypes as C
     from ice_halo_sim_amd import backend
     from tests import _libs
@@ -128,10 +131,12 @@ def has_degenerate_tables(sc, seed, samples=8):
     L, O = backend.load_library(), _libs.oracle()
     O.ho_pyramid_face_mask.restype = C.c_int
     L0 = sc.layers[0]
+    worst = 0.0
     for i in range(L0.entry_count):
         cr = L0.entries[i].crystal
         if cr.kind != abi.CRYSTAL_PYRAMID:
             continue
+        bad = 0
         for idx in range(samples):
             scal = np.zeros(9, np.float32)
             L.halo_host_shape_scalars(C.byref(cr), seed, idx, 0, fptr(scal))
@@ -140,9 +145,17 @@ def has_degenerate_tables(sc, seed, samples=8):
             args = (cr.wedge_upper_deg, cr.wedge_lower_deg, abs(float(scal[0])), abs(float(scal[1])), abs(float(scal[2])), fptr(d))
             O.ho_pyramid_face_mask(*args, C.byref(nv))
             O.ho_pyramid_geometry(*args, C.byref(g))
-            if g.face_cnt > 0 and g.tri_cnt != 2 * nv.value - 4:
-                return True
-    return False
+            fc, tc = g.face_cnt, g.tri_cnt
+            if fc == 0:
+                continue
+            fn = np.frombuffer(g.face_n, np.float32)[:fc * 3].reshape(fc, 3).astype(np.float64)
+            fd = np.frombuffer(g.face_d, np.float32)[:fc].astype(np.float64)
+            tv = np.frombuffer(g.tri_v, np.float32)[:tc * 9].reshape(tc, 3, 3).astype(np.float64)
+            tf = np.frombuffer(g.tri_face, np.int32)[:tc]
+            off = float(np.abs(np.einsum("tkc,tc->tk", tv, fn[tf]) + fd[tf][:, None]).max())
+            bad += int(tc != 2 * nv.value - 4 or off > 1e-6)
+        worst = max(worst, bad / float(samples))
+    return worst
 
 
 def run_case(seed, n=60_000):
@@ -164,7 +177,9 @@ def run_case(seed, n=60_000):
     L0 = sc.layers[0]
     fixed = any(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
                 for i in range(L0.entry_count))   # an entry whose every ray meets the crystal the same way
-    out = dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), n_exits=(len(eh), len(eo)), fixed_axes=fixed, degenerate=has_degenerate_tables(sc, seed))
+    # (every instance the session can draw: a layer's entries take consecutive runs of the shape stream, one instance per `clock` rays)
+    out = dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), n_exits=(len(eh), len(eo)), fixed_axes=fixed,
+               degenerate=has_degenerate_tables(sc, seed, samples=n // max(int(clock), 1) + L0.entry_count + 1))
     out["match"] = match_exits(eh, eo) if len(eo) and len(eh) else (1.0 if len(eh) == len(eo) else 0.0, 1.0, 1.0)
     out["cond"] = match_exits_conditioned(eh, eo, eo2) if len(eo) and len(eh) else (1.0 if len(eh) == len(eo) else 0.0, 1.0, 1.0, 0)
     out["oracle_pair"] = match_exits(eo2, eo)[0] if len(eo) and len(eo2) else 1.0
@@ -193,13 +208,14 @@ def check(seed, r):
     (2) small sparse images at 60 k rays, where ONE exit crossing a pixel border is 1 % of a block-mean distance: that bar is 5e-2 +
     2 / sqrt(blocks that carry the image) here, the per-ray bars carry the comparison; (3) illuminant weights of ~100 per exit: the
     landed weights may differ by what the unmatched exits weigh."""
-    if r["degenerate"]:   # (see has_degenerate_tables: the two sides follow the reference's two next-face strategies)
+    deg = float(r["degenerate"])   # the fraction of an entry's crystal instances on which the two sides follow the reference's two next-face strategies (has_degenerate_tables)
+    if deg > 0.02:
         assert r["exits"][0] == pytest.approx(r["exits"][1], rel=6e-2, abs=20), (seed, r)
         assert r["match"][0] >= 0.85, (seed, r)
         return
-    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3, abs=20), (seed, r)
+    assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3 + 2.0 * deg, abs=20), (seed, r)
     frac, pix, path, left_out = r["cond"]
-    assert frac >= 0.995 and pix >= 0.995 and path >= 0.998, (seed, r)
+    assert frac >= 0.995 - 2.0 * deg and pix >= 0.995 - 2.0 * deg and path >= 0.998 - 2.0 * deg, (seed, r)
     assert left_out <= 2e-3 * r["n_exits"][1] + 5, (seed, r)
     assert r["match"][0] >= min(0.995, r["oracle_pair"] - 0.03), (seed, r)          # and never far below what the oracles reach between themselves
     assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3 + r["unmatched_weight"], (seed, r)
@@ -211,7 +227,7 @@ def _seeds():
     if spec:
         a, b = spec.split(":")
         return list(range(int(a), int(b)))
-    return list(range(100, 148))
+    return list(range(100, 148)) + [20234]   # 20234: two instances with a segment thinner than the vertex merge (has_degenerate_tables)
 
 
 @pytest.mark.parametrize("seed", _seeds())
@@ -443,7 +459,11 @@ def run_ms_production_case(seed, n=1 << 21):
 
 
 def check_ms_production(seed, r):
-    assert not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC)) and (r["source_mask"] & 2), (seed, r)   # production kernels, transit source used
+    assert not (r["mode_mask"] & (abi.MODE_CAPTURE | abi.MODE_GENERIC)), (seed, r)   # production kernels
+    if all(c[0] == 0 for c in r["cont"][1:]):   # a first-layer filter nothing passes (six of the sixty scenes 20000..20059): the oracle continues no ray, nor may the device
+        assert r["cont"][0][0] == 0 and r["exits"][0] == r["exits"][1] and r["landed"][0] == pytest.approx(r["landed"][1], rel=1e-4, abs=1e-3), (seed, r)
+        return
+    assert r["source_mask"] & 2, (seed, r)   # transit source used
     assert r["cont"][0][0] == pytest.approx(r["cont"][1][0], rel=1e-3, abs=20), (seed, r)     # same seed, same first-layer rays
 
     def within(vals, rel, abs_floor):   # HIP (vals[0]) against the oracle's two seeds
@@ -461,7 +481,7 @@ def _ms_prod_seeds():
     if spec:
         a, b = spec.split(":")
         return list(range(int(a), int(b)))
-    return [4001, 4004]   # (5 - 15 s each; 4003 and 4005 take 30 s, nearly all of it the oracle; a three-layer prob-1 scene like seed 4000 takes it six minutes)
+    return [4001, 4004, 20003]   # 20003: a first-layer filter nothing passes (round-4 sweep); (5 - 15 s each; 4003 and 4005 take 30 s, nearly all of it the oracle; a three-layer prob-1 scene like seed 4000 takes it six minutes)
 
 
 @pytest.mark.parametrize("seed", _ms_prod_seeds())
@@ -508,10 +528,13 @@ def run_color_case(seed, n=3 << 20):
     L0 = sc.layers[0]
     fixed = any(L0.entries[i].axis.latitude.type == abi.DIST_NONE and L0.entries[i].axis.azimuth.type == abi.DIST_NONE and L0.entries[i].axis.roll.type == abi.DIST_NONE
                 for i in range(L0.entry_count))   # an entry whose every ray meets the crystal the same way
-    return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, fixed_axes=fixed,
+    return dict(exits=(sh[0].exit_count, so[0].exit_count), landed=(lh, lo), mode_mask=route.mode_mask, fixed_axes=fixed, y_image=float(np.asarray(io)[..., 1].sum(dtype=np.float64)),
                 floor=oracle_pair_floor(seed, sc, rd, wl, filters, clock, n, so, np.asarray(io, np.float32), lo, sets, classes, lanes_o) if fixed else None,
                 lanes=(lanes_h.sum(axis=(1, 2), dtype=np.float64), lanes_o.sum(axis=(1, 2), dtype=np.float64)),
-                lane_l2=[rel_l2(block_mean(lanes_h[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) if lanes_o[k].sum() > 0 else 0.0 for k in range(len(classes))])
+                lane_l2=[rel_l2(block_mean(lanes_h[k][..., None], 8), block_mean(lanes_o[k][..., None], 8)) if lanes_o[k].sum() > 0 else 0.0 for k in range(len(classes))],
+                # the same distances on the scale of the image's Y, of which a lane is a subset (check_color)
+                lane_l2_of_image=[float(np.linalg.norm(block_mean(lanes_h[k][..., None], 8).astype(np.float64) - block_mean(lanes_o[k][..., None], 8)) /
+                                        max(np.linalg.norm(block_mean(np.asarray(io)[..., 1:2], 8).astype(np.float64)), 1e-30)) for k in range(len(classes))])
 
 
 def check_color(seed, r):
@@ -519,13 +542,18 @@ def check_color(seed, r):
     fl = r["floor"] or dict(exits=0.0, landed=0.0, lanes=0.0, lane_l2=0.0)   # every ray the same way: + four times the oracle pair's own distance (check())
     assert r["exits"][0] == pytest.approx(r["exits"][1], rel=3e-4 + 4.0 * fl["exits"], abs=20), (seed, r)
     assert abs(r["landed"][0] - r["landed"][1]) <= (3e-4 + 4.0 * fl["landed"]) * max(r["landed"][1], 1.0) + 1e-3, (seed, r)
-    top = float(max(r["lanes"][1].max(), 1.0))
+    # A lane is a subset of the image's Y: the few rays per 10^6 that take the other side of an fp32 threshold (the exits bar above) may all
+    # belong to one rare class — seed 20030, fixed axes: 21 of 4.9 M exits differ, 1.9 units of Y, all of them in a class that holds 1125 of the
+    # image's 1.4e6 — so the absolute part of a lane's bar is 1e-5 of the IMAGE's Y (thirty times tighter than the image's own 3e-4), not of the lane
+    top = float(max(r["lanes"][1].max(), r.get("y_image", 0.0), 1.0))
     # The lanes are summed with global fp64 atomics since round 4 against the oracle's doubles here.  With fp32 atomics seed 5103
     # (a one-entry illuminant pool: 50 units of weight per exit, 3 Mi rays on 512x256, 87 % of the light in one class and most of that on the
     # sun's pixels, whose sums pass 1e7) read 3.1e-3 low and the bar was 5e-3; now 2.7e-7, and the bars are the image's
     for k in range(len(r["lanes"][1])):
         assert r["lanes"][0][k] == pytest.approx(r["lanes"][1][k], rel=3e-4 + 4.0 * fl["lanes"], abs=1e-5 * top + 1e-3), (seed, k, r)
-        assert r["lane_l2"][k] <= 3e-3 + 4.0 * fl["lane_l2"], (seed, k, r)
+        # (a rare class again: seed 20030's 21 exits land in two blocks of a lane that holds a thousandth of the image — 2.3 % of the lane's own
+        # norm, 4e-6 of the image's; a lane within 3e-4 of the IMAGE's norm, a tenth of the image's own bar, is as close as the image is)
+        assert r["lane_l2"][k] <= 3e-3 + 4.0 * fl["lane_l2"] or r["lane_l2_of_image"][k] <= 3e-4, (seed, k, r)
 
 
 def _color_seeds():
@@ -533,7 +561,7 @@ def _color_seeds():
     if spec:
         a, b = spec.split(":")
         return list(range(int(a), int(b)))
-    return list(range(5000, 5012))
+    return list(range(5000, 5012)) + [20030]   # 20030: the round-4 sweep's rare-class case (check_color)
 
 
 @pytest.mark.parametrize("seed", _color_seeds())
