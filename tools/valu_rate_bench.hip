@@ -105,6 +105,34 @@ __global__ void __launch_bounds__(256, 5) rate_kernel(uint32_t iters, uint32_t* 
 #define X(k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[k]) : "s"(sgu));
         REP8(X)
 #undef X
+      } else if (OP == 28) {
+#define X(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[k]) : "s"(sgu));
+        REP8(X)
+#undef X
+      } else if (OP == 29) {
+#define X(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[k]) : "v"(a[k]), "s"(sgu) : "vcc");
+        REP8(X)
+#undef X
+      } else if (OP == 30) {
+#define X(k) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f7fbe77" : "+v"(a[k]) : "v"(cf));
+        REP8(X)
+#undef X
+      } else if (OP == 31) {
+#define X(k) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(a[k]) : "s"(sgu));
+        REP8(X)
+#undef X
+      } else if (OP == 32) {
+#define X(k) asm volatile("v_xor_b32_e32 %0, 0x2c9277b5, %0" : "+v"(a[k]));
+        REP8(X)
+#undef X
+      } else if (OP == 33) {
+#define X(k) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[k]) : "s"(sgu));
+        REP8(X)
+#undef X
+      } else if (OP == 34) {
+#define X(k) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[k]) : "v"(cf));
+        REP8(X)
+#undef X
       } else if (OP == 25) {
 #define X(k) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(a[k]) : "v"(cf), "v"(c1) : "vcc");
         X(0) X(1) X(2) X(3)
@@ -214,5 +242,12 @@ int main() {
   run<23>("v_add_u32", 64, b);
   run<24>("v_fma_f32 with an SGPR operand", 64, b);
   run<26>("v_cvt_i32_f32", 64, b);
+  run<34>("v_mul_f32 (VOP2, VGPR operands)", 64, b);
+  run<33>("v_mul_f32 with an SGPR operand", 64, b);
+  run<30>("v_fmaak_f32 (32-bit literal)", 64, b);
+  run<28>("v_mul_lo_u32 with an SGPR operand", 64, b);
+  run<29>("v_mad_u64_u32 with an SGPR operand", 64, b);
+  run<31>("v_add_u32 with an SGPR operand", 64, b);
+  run<32>("v_xor_b32 with a 32-bit literal", 64, b);
   return 0;
 }
