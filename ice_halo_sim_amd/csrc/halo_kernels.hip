@@ -110,6 +110,17 @@ struct TileMap {
 // global atomic per tile and step reserves the run's place in the tile list; a tile list that overflows falls back to direct
 // atomics on the plane.
 constexpr uint32_t kSplitParts = 8u;
+#ifndef HALO_SPLIT_THREADS
+#define HALO_SPLIT_THREADS 1024
+#endif
+#ifndef HALO_SPLIT_PER
+#define HALO_SPLIT_PER 16
+#endif
+// the hit log's split: records per step = threads x per.  Round 4 tried the shapes that put two workgroups on a CU (the kernel waits 61 % of its
+// wave cycles, profiles/r04_ref_bench_light_single_ms_pmc_wait.txt): 512 x 16 and 1024 x 8 (8 Ki records, 70 KB) and 512 x 32 (16 Ki, eight waves)
+// are 3-4 %, 4-5 % and 1.5-3 % SLOWER on the whole step of bench_light_single_ms / configs[1] / ms_multi_crystal — the length of the runs a step
+// writes (32 records = 256 B per list at 512 lists) matters more than a second workgroup to hide the latencies behind
+constexpr uint32_t kLogSplitThreads = HALO_SPLIT_THREADS, kLogSplitPer = HALO_SPLIT_PER;
 // Step sizes (threads x records per thread).  The hit log has 128..256 destinations per step, and its stores only coalesce
 // when a step is large: 16384 records (a region is read in one or two steps; 128 KB of LDS, one workgroup per CU) runs
 // at 0.23 ms per 58 M records where 4096 takes 0.36 and 1024 takes 1.1.  The coarse lists of the two-level route have <= 32
@@ -382,7 +393,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
   // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
   // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
   if (planes > 1u || tiles > 256u) {
-    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+    hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 512u, false, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -391,10 +402,10 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
     return hipGetLastError();
   }
   if (interleaved)
-    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, true>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+    hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 256u, false, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
   else
-    hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 256u, false, false>), dim3(regions), dim3(1024u), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
+    hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 256u, false, false>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -410,7 +421,7 @@ hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitR
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
                                 double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
-  hipLaunchKernelGGL((halo_split_kernel<1024u, 16u, 512u, true, true>), dim3(regions), dim3(1024u), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
+  hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 512u, true, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride, ovf, ovf_flag});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
