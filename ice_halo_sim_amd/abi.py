@@ -128,6 +128,37 @@ class HaloDisplay(C.Structure):
     _fields_ = [("intensity_factor", C.c_float), ("ray_color", C.c_float * 3), ("background", C.c_float * 3)]
 
 
+COMPOSITE_DOMINANT, COMPOSITE_ADDITIVE, COMPOSITE_PAINTER = 0, 1, 2
+
+
+class HaloCompositeClass(C.Structure):
+    """Display half of a ColorClass (reference config/color_class_table.hpp:21-35)."""
+    _fields_ = [("color", C.c_float * 3), ("z_order", C.c_int32), ("visible", C.c_int32), ("solo", C.c_int32)]
+
+
+class HaloComposite(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("display_exposure_scale", C.c_float), ("intensity_factor", C.c_float), ("class_count", C.c_int32),
+                ("classes", HaloCompositeClass * COLOR_MAX_CLASSES)]
+
+
+def composite(classes, mode="painter", display_exposure_scale=1.0, intensity_factor=1.0):
+    """HaloComposite from [{"color": (r, g, b), "visible": True, "solo": False, "z_order": i}, ...] (z_order defaults to the list
+    position, like BuildColorClassTable) and a mode name or HALO_COMPOSITE_* value."""
+    names = {"dominant": COMPOSITE_DOMINANT, "additive": COMPOSITE_ADDITIVE, "painter": COMPOSITE_PAINTER}
+    spec = HaloComposite()
+    spec.mode = mode if isinstance(mode, int) else names.get(mode, COMPOSITE_PAINTER)   # ParseCompositeMode: unknown -> painter
+    spec.display_exposure_scale = float(display_exposure_scale)
+    spec.intensity_factor = float(intensity_factor)
+    spec.class_count = len(classes)
+    for i, c in enumerate(classes):
+        k = spec.classes[i]
+        k.color = (C.c_float * 3)(*[float(v) for v in c.get("color", (1.0, 1.0, 1.0))])
+        k.z_order = int(c.get("z_order", i))
+        k.visible = 1 if c.get("visible", True) else 0
+        k.solo = 1 if c.get("solo", False) else 0
+    return spec
+
+
 class ProjParams(C.Structure):
     """lm_proj::ProjParams — reference src/core/shared/projection_shared.h:106-118 (76 bytes)."""
     _fields_ = [("proj_type", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32), ("visible_range", C.c_int32),

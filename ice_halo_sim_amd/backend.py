@@ -66,6 +66,9 @@ def load_library():
         "halo_consumer_fold": (C.c_int, [H]),
         "halo_consumer_snapshot": (C.c_int, [H, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]),
         "halo_consumer_reset": (C.c_int, [H]),
+        "halo_consumer_composite": (C.c_int, [H, C.POINTER(abi.HaloComposite), f32p, C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_int32)]),
+        "halo_consumer_load_lanes": (C.c_int, [H, f32p, C.c_int, C.c_int, C.c_int, C.c_double]),
+        "halo_host_parse_composite_mode": (C.c_int, [C.c_char_p]),
         "halo_host_prism_geometry": (C.c_int, [C.c_float, f32p, C.POINTER(abi.HaloGeomTables)]),
         "halo_host_pyramid_geometry": (C.c_int, [C.c_float] * 5 + [f32p, C.POINTER(abi.HaloGeomTables)]),
         "halo_host_shape_scalars": (C.c_int, [C.POINTER(abi.HaloCrystal), C.c_uint32, C.c_uint64, C.c_int, f32p]),
@@ -93,7 +96,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_consumer_composite", "halo_consumer_load_lanes", "halo_host_parse_composite_mode", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_shape_scalars", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_color_fast_mask", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
 ]
@@ -209,6 +212,7 @@ class HipTraceBackend:
     def BeginSession(self, scene, render, wl, ray_num=0):
         self._render = render
         self._scene = scene
+        self._lanes_shape = None   # the session's lanes take the render's size
         self._check(self._L.halo_begin(self._h, C.byref(scene), C.byref(render), C.byref(wl), int(ray_num)))
 
     def TraceLayer(self, count=0, host_rays=None):
@@ -275,6 +279,27 @@ class HipTraceBackend:
 
     def ResetConsumer(self):
         self._check(self._L.halo_consumer_reset(self._h))
+
+    # --- display-side composite of the class lanes (reference src/server/component_compositor.cpp) ---
+    def LoadClassLanes(self, lanes, total_intensity=-1.0):
+        """Replace the device lanes with (class_count, H, W) float32 host values (lanes summed over ranks, a saved consumer);
+        total_intensity >= 0 replaces the consumer's total intensity too."""
+        lanes = np.ascontiguousarray(lanes, np.float32)
+        n, h, w = lanes.shape
+        self._check(self._L.halo_consumer_load_lanes(self._h, lanes.ctypes.data_as(C.POINTER(C.c_float)), w, h, n, float(total_intensity)))
+        self._lanes_shape = (n, h, w)
+
+    def CompositeColorClasses(self, classes, mode="painter", display_exposure_scale=1.0, intensity_factor=1.0, want_srgb=True):
+        """CompositeColorClassesLinear + LinearRgbToSrgbU8 on the device lanes (which stay).  Returns (produced, linear_rgb[H,W,3]
+        float32, srgb[H,W,3] uint8 | None, participating_p99_y)."""
+        n, h, w = getattr(self, "_lanes_shape", None) or (getattr(self, "_n_classes", 0), self._render.height, self._render.width)
+        spec = abi.composite(classes, mode, display_exposure_scale, intensity_factor)
+        lin = np.zeros((h, w, 3), np.float32)
+        srgb = np.zeros((h, w, 3), np.uint8) if want_srgb else None
+        p99, produced = C.c_float(-1.0), C.c_int32(0)
+        self._check(self._L.halo_consumer_composite(self._h, C.byref(spec), lin.ctypes.data_as(C.POINTER(C.c_float)),
+                                                    srgb.ctypes.data_as(C.POINTER(C.c_uint8)) if want_srgb else None, C.byref(p99), C.byref(produced)))
+        return bool(produced.value), lin, srgb, p99.value
 
 
 EXIT_DTYPE = np.dtype([("dir", np.float32, 3), ("weight", np.float32), ("root", np.uint32), ("seq", np.uint16),

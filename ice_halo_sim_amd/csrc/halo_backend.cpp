@@ -39,6 +39,10 @@ hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t 
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
                        double* ovf, const uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream);
+hipError_t launch_lane_hist(const double* lanes, uint32_t n_pix, const CompositeDev& cd, uint32_t shift, uint32_t bits, uint32_t prefix, uint32_t* hist, int blocks,
+                            hipStream_t stream);
+hipError_t launch_composite(const double* lanes, uint32_t n_pix, const CompositeDev& cd, float* rgb_out, uint8_t* srgb_out, int blocks, hipStream_t stream);
+hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
 }
@@ -141,6 +145,8 @@ struct HaloBackend {
   // consumer (RenderConsumer state, server/render.hpp): Neumaier running image + total landed intensity
   DevBuf<float> cons_sum, cons_comp, cons_xyz_out;
   DevBuf<uint8_t> cons_rgb;
+  DevBuf<float> comp_rgb, lanes_stage;   // halo_consumer_composite's linear image, halo_consumer_load_lanes' staging
+  DevBuf<uint32_t> comp_hist;            // radix-select histogram (2048 bins)
   int cons_w = 0, cons_h = 0;
   double total_intensity = 0.0;
   DevBuf<double> sums;         // [kSumLanded] persistent landed-weight tally
@@ -313,6 +319,9 @@ int halo_destroy(halo_handle_t b) {
   b->cons_comp.release();
   b->cons_xyz_out.release();
   b->cons_rgb.release();
+  b->comp_rgb.release();
+  b->lanes_stage.release();
+  b->comp_hist.release();
   b->counters.release();
   b->ring_dev.release();
   if (b->ring_host) (void)hipHostFree(b->ring_host);
@@ -1327,6 +1336,7 @@ int halo_consumer_reset(halo_handle_t b) {
     HIPCHK(b, hipMemsetAsync(b->cons_sum.ptr, 0, n * sizeof(float), b->stream));
     HIPCHK(b, hipMemsetAsync(b->cons_comp.ptr, 0, n * sizeof(float), b->stream));
   }
+  if (b->lanes.ptr) HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(double), b->stream));   // RenderConsumer::Reset clears the class lanes too (render.cpp:598-612)
   b->total_intensity = 0.0;
   return HALO_OK;
 }
@@ -1377,6 +1387,136 @@ int halo_consumer_snapshot(halo_handle_t b, const HaloDisplay* dsp, uint8_t* rgb
   HIPCHK(b, hipStreamSynchronize(b->stream));
   if (rgb_out && scale == 0.0f) std::memset(rgb_out, 0, n);  // PostSnapshot early-out (render.cpp:515-518)
   if (total_intensity) *total_intensity = b->total_intensity;
+  return HALO_OK;
+}
+
+// ---- display-side composite of the class lanes (server/component_compositor.cpp) -------------------------
+int halo_host_parse_composite_mode(const char* mode) {   // ParseCompositeMode, component_compositor.cpp:118-134
+  if (mode && std::strcmp(mode, "dominant") == 0) return HALO_COMPOSITE_DOMINANT;
+  if (mode && std::strcmp(mode, "additive") == 0) return HALO_COMPOSITE_ADDITIVE;
+  return HALO_COMPOSITE_PAINTER;
+}
+
+int halo_consumer_load_lanes(halo_handle_t b, const float* lanes, int width, int height, int class_count, double total_intensity) {
+  if (!b || !lanes) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "consumer_load_lanes inside a session");
+  if (width <= 0 || height <= 0 || class_count <= 0 || class_count != static_cast<int>(b->color_classes.size()))
+    return fail(b, HALO_FATAL, "consumer_load_lanes: class count must equal halo_set_color's, image must not be empty");
+  if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > (1ull << 25)) return fail(b, HALO_UNAVAILABLE, "more than 2^25 pixels");
+  HIPCHK(b, hipSetDevice(b->device));
+  const size_t n = static_cast<size_t>(class_count) * width * height;
+  HIPCHK(b, b->lanes.reserve(n));
+  b->lanes_w = width;
+  b->lanes_h = height;
+  HIPCHK(b, b->lanes_stage.reserve(n));
+  HIPCHK(b, hipMemcpyAsync(b->lanes_stage.ptr, lanes, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  hipError_t e = launch_lanes_load(b->lanes_stage.ptr, b->lanes.ptr, n, b->cu_count * 8, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_lanes_load_kernel launch");
+  HIPCHK(b, hipStreamSynchronize(b->stream));   // `lanes` is the caller's (pageable) memory
+  if (total_intensity >= 0.0) b->total_intensity = total_intensity;
+  return HALO_OK;
+}
+
+int halo_consumer_composite(halo_handle_t b, const HaloComposite* spec, float* linear_rgb_out, uint8_t* srgb_out, float* participating_p99_y, int32_t* produced) {
+  if (!b || !spec || !produced) return HALO_FATAL;
+  *produced = 0;
+  if (spec->mode < HALO_COMPOSITE_DOMINANT || spec->mode > HALO_COMPOSITE_PAINTER) return fail(b, HALO_FATAL, "consumer_composite: unknown mode");
+  uint64_t referenced = 0;   // ColorClassTable::referenced_mask_ = OR of the classes' member bits (color_class_table.hpp:38-43)
+  for (const HaloColorClass& c : b->color_classes) referenced |= c.bits;
+  if (referenced == 0) return HALO_OK;   // component_compositor.cpp:183-185: nothing is touched
+  if (spec->class_count != static_cast<int>(b->color_classes.size())) return fail(b, HALO_FATAL, "consumer_composite: class_count differs from halo_set_color's");
+  if (!b->lanes.ptr || b->lanes_w <= 0 || b->lanes_h <= 0) return fail(b, HALO_FATAL, "consumer_composite before any colour session (no lanes)");
+  HIPCHK(b, hipSetDevice(b->device));
+  const uint32_t npix = static_cast<uint32_t>(b->lanes_w) * static_cast<uint32_t>(b->lanes_h);
+  const size_t n3 = static_cast<size_t>(npix) * 3u;
+  // GatherActiveClasses (component_compositor.cpp:24-54): solo beats visible; stable sort by z_order; lane binding by class index
+  bool any_solo = false;
+  for (int c = 0; c < spec->class_count; c++) any_solo = any_solo || spec->classes[c].solo != 0;
+  std::vector<int> order(static_cast<size_t>(spec->class_count));
+  for (int c = 0; c < spec->class_count; c++) order[static_cast<size_t>(c)] = c;
+  std::stable_sort(order.begin(), order.end(), [spec](int x, int y) { return spec->classes[x].z_order < spec->classes[y].z_order; });
+  CompositeDev cd{};
+  cd.mode = static_cast<uint32_t>(spec->mode);
+  for (int c : order) {
+    const HaloCompositeClass& k = spec->classes[c];
+    if (!(any_solo ? k.solo != 0 : k.visible != 0)) continue;
+    cd.lane[cd.n_active] = static_cast<uint32_t>(c);
+    for (int j = 0; j < 3; j++) cd.color[cd.n_active][j] = k.color[j];
+    cd.n_active++;
+  }
+  auto deliver_black = [&]() -> int {   // "nothing visible -> all-black, still a valid composite" (:201-206)
+    if (linear_rgb_out) std::memset(linear_rgb_out, 0, n3 * sizeof(float));
+    if (srgb_out) std::memset(srgb_out, 0, n3);
+    if (participating_p99_y) *participating_p99_y = 0.0f;
+    *produced = 1;
+    return HALO_OK;
+  };
+  if (cd.n_active == 0) return deliver_black();
+  // ComputeParticipatingP99Y (:138-163) as a radix select: 11 + 11 + 10 bits of the float pattern, one histogram pass each
+  HIPCHK(b, b->comp_hist.reserve(2048));
+  std::vector<uint32_t> hist(2048);
+  const int blocks = b->cu_count * 8;
+  float p99 = 0.0f;
+  {
+    uint32_t prefix = 0u;
+    uint64_t rank = 0;   // 0-based rank wanted among the values that share `prefix`
+    const uint32_t shifts[3] = {21u, 10u, 0u}, widths[3] = {11u, 11u, 10u};
+    bool empty = false;
+    for (int pass = 0; pass < 3 && !empty; pass++) {
+      const uint32_t nb = 1u << widths[pass];
+      HIPCHK(b, hipMemsetAsync(b->comp_hist.ptr, 0, nb * sizeof(uint32_t), b->stream));
+      hipError_t e = launch_lane_hist(b->lanes.ptr, npix, cd, shifts[pass], widths[pass], prefix, b->comp_hist.ptr, blocks, b->stream);
+      if (e != hipSuccess) return hip_fail(b, e, "halo_lane_hist_kernel launch");
+      HIPCHK(b, hipMemcpyAsync(hist.data(), b->comp_hist.ptr, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+      HIPCHK(b, hipStreamSynchronize(b->stream));
+      if (pass == 0) {
+        uint64_t count = 0;
+        for (uint32_t i = 0; i < nb; i++) count += hist[i];
+        if (count == 0) {
+          empty = true;
+          break;
+        }
+        // idx = size * 0.99f in float, clamped (:156-159)
+        uint64_t idx = static_cast<uint64_t>(static_cast<float>(count) * 0.99f);
+        if (idx >= count) idx = count - 1;
+        rank = idx;
+      }
+      uint32_t bin = 0;
+      for (; bin < nb; bin++) {
+        if (rank < hist[bin]) break;
+        rank -= hist[bin];
+      }
+      if (bin >= nb) return fail(b, HALO_FATAL, "consumer_composite: lanes changed under the P99 select");
+      prefix = (prefix << widths[pass]) | bin;
+    }
+    if (!empty) std::memcpy(&p99, &prefix, sizeof(float));
+  }
+  // ParticipatingExposureScale (render.cpp:120-135), in float like the reference
+  const float snapshot_intensity = static_cast<float>(b->total_intensity);
+  float A = 0.0f;
+  if (p99 > 0.0f && snapshot_intensity > 0.0f) {
+    const float target_srgb = 135.0f / 255.0f;
+    const float target_linear = target_srgb <= 0.04045f ? target_srgb / 12.92f : std::pow((target_srgb + 0.055f) / 1.055f, 2.4f);
+    A = spec->intensity_factor * target_linear / p99;
+  }
+  if (participating_p99_y) *participating_p99_y = p99;
+  if (!(A > 0.0f)) {   // :209-214: P99 published, no composite; the linear buffer was already assigned zeros (:189)
+    if (linear_rgb_out) std::memset(linear_rgb_out, 0, n3 * sizeof(float));
+    return HALO_OK;
+  }
+  cd.a = A;
+  cd.s = A * spec->display_exposure_scale;
+  cd.display = spec->display_exposure_scale;
+  if (linear_rgb_out) HIPCHK(b, b->comp_rgb.reserve(n3));
+  if (srgb_out) HIPCHK(b, b->cons_rgb.reserve(n3));
+  if (linear_rgb_out || srgb_out) {
+    hipError_t e = launch_composite(b->lanes.ptr, npix, cd, linear_rgb_out ? b->comp_rgb.ptr : nullptr, srgb_out ? b->cons_rgb.ptr : nullptr, blocks, b->stream);
+    if (e != hipSuccess) return hip_fail(b, e, "halo_composite_kernel launch");
+    if (linear_rgb_out) HIPCHK(b, hipMemcpyAsync(linear_rgb_out, b->comp_rgb.ptr, n3 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (srgb_out) HIPCHK(b, hipMemcpyAsync(srgb_out, b->cons_rgb.ptr, n3, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(b, hipStreamSynchronize(b->stream));
+  }
+  *produced = 1;
   return HALO_OK;
 }
 
@@ -1490,6 +1630,7 @@ uint64_t halo_abi_sizeof(int which) {
     case 8: return sizeof(HaloColorClass);
     case 9: return sizeof(HaloFilter);
     case 10: return sizeof(HaloRouteInfo);
+    case 11: return sizeof(HaloComposite);
     default: return 0;
   }
 }

@@ -325,6 +325,17 @@ struct DispatchParams {
 // (consecutive rows = consecutive pixels).
 constexpr uint32_t kMonoRows = 1024u;
 constexpr uint32_t kFoldGroup = 64u;            // planes folded per halo_fold_kernel launch (coefficients ride in the kernel argument)
+// halo_consumer_composite: what the composite kernels read (server/component_compositor.cpp)
+struct CompositeDev {
+  uint32_t n_active;          // participating classes, in draw order (ascending z_order, stable)
+  uint32_t mode;              // HALO_COMPOSITE_*
+  float s;                    // A * display_exposure_scale (dominant / additive)
+  float a;                    // A, the self-anchor (painter's alpha)
+  float display;              // display_exposure_scale (painter's post-multiplier)
+  uint32_t lane[HALO_COLOR_MAX_CLASSES];   // lane index of active class k
+  float color[HALO_COLOR_MAX_CLASSES][3];
+};
+
 struct FoldCoef {
   float c[kFoldGroup][3];
 };

@@ -627,6 +627,102 @@ __global__ void __launch_bounds__(kBlock) halo_post_snapshot_kernel(const float*
   }
 }
 
+// ---- display-side composite of the raypath-colour class lanes (server/component_compositor.cpp) --------------------------------
+// The lanes are fp64 on the device and are handed out as floats (halo_readback_class_lanes); the composite reads them the same way.
+
+// One pass of the radix select behind ComputeParticipatingP99Y (component_compositor.cpp:138-163): a histogram of `bits` bits at `shift`
+// of the float bit patterns of the positive lane values whose higher bits equal `prefix` (positive floats order like their patterns).
+// shift + bits == 32 on the first pass (no prefix).
+__global__ void __launch_bounds__(kBlock) halo_lane_hist_kernel(const double* __restrict__ lanes, uint32_t n_pix, CompositeDev cd, uint32_t shift, uint32_t bits,
+                                                                 uint32_t prefix, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[2048];
+  const uint32_t nb = 1u << bits;
+  for (uint32_t i = threadIdx.x; i < nb; i += kBlock) h[i] = 0u;
+  __syncthreads();
+  const uint64_t total = static_cast<uint64_t>(n_pix) * cd.n_active;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+  const uint32_t hi = shift + bits;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const uint32_t k = static_cast<uint32_t>(i / n_pix), p = static_cast<uint32_t>(i - static_cast<uint64_t>(k) * n_pix);
+    const float v = static_cast<float>(lanes[static_cast<size_t>(cd.lane[k]) * n_pix + p]);
+    if (!(v > 0.0f)) continue;
+    const uint32_t u = __float_as_uint(v);
+    if (hi < 32u && (u >> hi) != prefix) continue;
+    atomicAdd(&h[(u >> shift) & (nb - 1u)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nb; i += kBlock)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// CompositeDominantPixel / CompositeAdditivePixel / CompositePainterPixel (component_compositor.cpp:56-114) + the painter's post-multiply and
+// clamp (:268-274) + LinearRgbToSrgbU8 (:292-300).  Every product and sum is rounded on its own (mul_rn / add_rn: the backend fuses plain a * b + c whatever the source says), like the
+// reference's host build.
+__global__ void __launch_bounds__(kBlock) halo_composite_kernel(const double* __restrict__ lanes, uint32_t n_pix, CompositeDev cd, float* __restrict__ rgb_out,
+                                                                 uint8_t* __restrict__ srgb_out) {
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pix; p += stride) {
+    float out[3] = {0.0f, 0.0f, 0.0f};
+    if (cd.mode == HALO_COMPOSITE_DOMINANT) {
+      int best = -1;
+      float best_ey = 0.0f;
+      for (uint32_t k = 0; k < cd.n_active; k++) {
+        const float ey = mul_rn(static_cast<float>(lanes[static_cast<size_t>(cd.lane[k]) * n_pix + p]), cd.s);
+        if (ey > best_ey) {
+          best_ey = ey;
+          best = static_cast<int>(k);
+        }
+      }
+      if (best >= 0)
+        for (int j = 0; j < 3; j++) out[j] = mul_rn(cd.color[best][j], best_ey);
+    } else if (cd.mode == HALO_COMPOSITE_ADDITIVE) {
+      for (uint32_t k = 0; k < cd.n_active; k++) {
+        const float ey = mul_rn(static_cast<float>(lanes[static_cast<size_t>(cd.lane[k]) * n_pix + p]), cd.s);
+        if (!(ey > 0.0f)) continue;
+        for (int j = 0; j < 3; j++) out[j] = add_rn(out[j], mul_rn(cd.color[k][j], ey));
+      }
+      for (int j = 0; j < 3; j++) out[j] = fminf(fmaxf(out[j], 0.0f), 1.0f);
+    } else {
+      float T = 1.0f;
+      for (uint32_t k = 0; k < cd.n_active && T > 0.0f; k++) {
+        const float alpha = fminf(mul_rn(static_cast<float>(lanes[static_cast<size_t>(cd.lane[k]) * n_pix + p]), cd.a), 1.0f);
+        if (!(alpha > 0.0f)) continue;
+        const float ta = mul_rn(T, alpha);
+        for (int j = 0; j < 3; j++) out[j] = add_rn(out[j], mul_rn(ta, cd.color[k][j]));
+        T = mul_rn(T, add_rn(1.0f, -alpha));
+      }
+      for (int j = 0; j < 3; j++) out[j] = fminf(fmaxf(mul_rn(out[j], cd.display), 0.0f), 1.0f);
+    }
+    if (rgb_out)
+      for (int j = 0; j < 3; j++) rgb_out[3u * p + j] = out[j];
+    if (srgb_out)
+      for (int j = 0; j < 3; j++) {
+        const float v = fminf(fmaxf(out[j], 0.0f), 1.0f);
+        const float g = (v < 0.0031308f) ? mul_rn(v, 12.92f) : add_rn(mul_rn(1.055f, powf(v, 1.0f / 2.4f)), -0.055f);   // LinearToSrgb color_space.cpp:47-52
+        srgb_out[3u * p + j] = static_cast<uint8_t>(mul_rn(g, 255.0f));
+      }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) halo_lanes_load_kernel(const float* __restrict__ src, double* __restrict__ lanes, uint64_t n) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) lanes[i] = static_cast<double>(src[i]);
+}
+
+hipError_t launch_lane_hist(const double* lanes, uint32_t n_pix, const CompositeDev& cd, uint32_t shift, uint32_t bits, uint32_t prefix, uint32_t* hist, int blocks,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(halo_lane_hist_kernel, dim3(blocks), dim3(kBlock), 0, stream, lanes, n_pix, cd, shift, bits, prefix, hist);
+  return hipGetLastError();
+}
+hipError_t launch_composite(const double* lanes, uint32_t n_pix, const CompositeDev& cd, float* rgb_out, uint8_t* srgb_out, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_composite_kernel, dim3(blocks), dim3(kBlock), 0, stream, lanes, n_pix, cd, rgb_out, srgb_out);
+  return hipGetLastError();
+}
+hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_lanes_load_kernel, dim3(blocks), dim3(kBlock), 0, stream, src, lanes, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_consumer_fold(float* acc, float* sum, float* comp, uint32_t n, int blocks, hipStream_t stream) {
   hipLaunchKernelGGL(halo_consumer_fold_kernel, dim3(blocks), dim3(kBlock), 0, stream, acc, sum, comp, n);
   return hipGetLastError();

@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 4   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
+#define HALO_ABI_VERSION 5   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
                                 halo_drain_exits, option "shuffle_chunk", exit records carry full 64-face paths; 4: HaloRouteInfo
-                                names the kernel mode (5 modes) and its specialisation, option "filter_fast" */
+                                names the kernel mode (5 modes) and its specialisation, option "filter_fast"; 5: halo_consumer_composite /
+                                halo_consumer_load_lanes (additive: nothing that existed changed) */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 
@@ -383,6 +384,40 @@ int halo_consumer_fold(halo_handle_t h);
 int halo_consumer_snapshot(halo_handle_t h, const HaloDisplay* display, uint8_t* rgb_out, float* xyz_out, double* total_intensity);
 int halo_consumer_reset(halo_handle_t h);
 
+/* --- display-side composite of the raypath-colour class lanes (server/component_compositor.cpp) ------------- */
+/* CompositeMode (component_compositor.hpp:21): how the per-class Y lanes become one colour per pixel. */
+enum { HALO_COMPOSITE_DOMINANT = 0, HALO_COMPOSITE_ADDITIVE = 1, HALO_COMPOSITE_PAINTER = 2 };
+/* The display half of a ColorClass (config/color_class_table.hpp:21-35): colour, visibility, solo, draw order.  Entry c belongs
+ * to lane c of halo_set_color's `classes`; z_order re-orders the DRAW, never the lane binding (component_compositor.cpp:34-37). */
+typedef struct HaloCompositeClass {
+  float color[3];
+  int32_t z_order;
+  int32_t visible; /* ColorClass::visible_ */
+  int32_t solo;    /* ColorClass::solo_: if any class is solo, only solo classes take part */
+} HaloCompositeClass;
+typedef struct HaloComposite {
+  int32_t mode;                 /* HALO_COMPOSITE_* */
+  float display_exposure_scale; /* GUI EV multiplier; 1 = none */
+  float intensity_factor;       /* RenderConfig::intensity_factor_ (ParticipatingExposureScale, render.cpp:120-135) */
+  int32_t class_count;          /* must equal the class count of halo_set_color */
+  HaloCompositeClass classes[HALO_COLOR_MAX_CLASSES];
+} HaloComposite;
+/* CompositeColorClassesLinear + LinearRgbToSrgbU8 (component_compositor.cpp:180-303) on the device lanes, which stay as they are
+ * (the consumer's lanes: they accumulate over sessions until halo_readback_class_lanes or halo_consumer_reset).  The participating
+ * P99 is the exact order statistic the reference takes with nth_element (index = float(count) * 0.99f of the positive lane values
+ * of the participating classes), found by a radix select over the float bit patterns; A = intensity_factor * target_linear / P99.
+ * *produced = 0 where the reference returns false: no class bit referenced (outputs untouched), or total intensity / P99 zero (P99
+ * written, the linear image zeroed as the reference's assign does, :189).  linear_rgb_out: W*H*3 floats, srgb_out: W*H*3 bytes (either
+ * may be NULL).  total intensity = what halo_consumer_fold has summed (or halo_consumer_load_lanes set). */
+int halo_consumer_composite(halo_handle_t h, const HaloComposite* spec, float* linear_rgb_out, uint8_t* srgb_out,
+                            float* participating_p99_y, int32_t* produced);
+/* Replace the device lanes with host values (class_count x W x H floats, lane c at lanes[c*W*H + py*W + px]): lanes summed over
+ * ranks on the host, or a saved consumer.  total_intensity >= 0 also replaces the consumer's total intensity.  Needs halo_set_color
+ * (the lane count is its class count); allocates the lanes when no session has yet. */
+int halo_consumer_load_lanes(halo_handle_t h, const float* lanes, int width, int height, int class_count, double total_intensity);
+/* ParseCompositeMode (component_compositor.cpp:118-134): "dominant" / "additive" / "painter"; anything else is painter. */
+int halo_host_parse_composite_mode(const char* mode);
+
 /* --- host-side pieces of the path, exported for parity tests (no GPU needed) ---------------- */
 /* Geometry tables the kernels consume (reference: Crystal::PopulateFromCfGeom crystal.cpp:304-347,
  * detail::BuildEntrySubTris simulator.cpp:90-129). */
@@ -443,7 +478,7 @@ float halo_host_illuminant_spd(int illuminant, float wavelength_nm);
  * entries are written), 0 on error. */
 int halo_host_wl_pool(const HaloWl* wl, float* entries5, int cap);
 int halo_abi_version(void);
-/* sizeof() of boundary structs as compiled (0 scene, 1 render, 2 wl, 3 exit record, 4 geom tables, 5 layer stats, 6 entry). */
+/* sizeof() of boundary structs as compiled (0 scene, 1 render, 2 wl, 3 exit record, 4 geom tables, 5 layer stats, 6 entry, 7 colour set, 8 colour class, 9 filter, 10 route info, 11 composite). */
 uint64_t halo_abi_sizeof(int which);
 
 #ifdef __cplusplus
@@ -478,5 +513,7 @@ HALO_STATIC_ASSERT(sizeof(HaloLayerStats) == 56, "HaloLayerStats");
 HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 40 + HALO_PATH_CAP, "HaloExitRecord");
 HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 40, "HaloRouteInfo");
 HALO_STATIC_ASSERT(sizeof(HaloDisplay) == 28, "HaloDisplay");
+HALO_STATIC_ASSERT(sizeof(HaloCompositeClass) == 24, "HaloCompositeClass");
+HALO_STATIC_ASSERT(sizeof(HaloComposite) == 16 + HALO_COLOR_MAX_CLASSES * 24, "HaloComposite");
 HALO_STATIC_ASSERT(sizeof(HaloGeomTables) == 4 + HALO_MAX_FACES * 20 + 4 + HALO_MAX_TRIS * (36 + 12 + 4 + 4), "HaloGeomTables");
 #endif /* HALO_TRACE_H_ */

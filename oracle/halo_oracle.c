@@ -2205,3 +2205,133 @@ int ho_consumer_snapshot(HoBackend* b, const HaloDisplay* dsp, uint8_t* rgb_out,
   }
   return HALO_OK;
 }
+
+/* ---- display-side composite of the class lanes ------------------------------------------------------------- */
+/* server/component_compositor.cpp, restated: GatherActiveClasses :24-54, the three per-pixel modes :56-114, ParseCompositeMode :118-134,
+ * ComputeParticipatingP99Y :138-163, CompositeColorClassesLinear :180-285, LinearRgbToSrgbU8 :292-300; RenderConsumer::
+ * ParticipatingExposureScale render.cpp:120-135. */
+float ho_participating_exposure_scale(float intensity_factor, float snapshot_intensity, float p99) {
+  if (p99 <= 0.0f || snapshot_intensity <= 0.0f) return 0.0f;
+  const float target_srgb = 135.0f / 255.0f;
+  const float target_linear = target_srgb <= 0.04045f ? target_srgb / 12.92f : powf((target_srgb + 0.055f) / 1.055f, 2.4f);
+  if (target_linear <= 0.0f) return 0.0f;
+  return intensity_factor * target_linear / p99;
+}
+int ho_parse_composite_mode(const char* mode) {
+  if (mode && strcmp(mode, "dominant") == 0) return HALO_COMPOSITE_DOMINANT;
+  if (mode && strcmp(mode, "additive") == 0) return HALO_COMPOSITE_ADDITIVE;
+  return HALO_COMPOSITE_PAINTER; /* "painter" and every unknown string */
+}
+static int cmp_float_asc(const void* a, const void* b) {
+  float x = *(const float*)a, y = *(const float*)b;
+  return (x > y) - (x < y);
+}
+int ho_composite(const float* lanes, int width, int height, int class_count, uint64_t referenced_mask, float total_intensity,
+                 const HaloComposite* spec, float* out_rgb, uint8_t* out_srgb, float* p99_out, int32_t* produced) {
+  if (!spec || !produced || class_count != spec->class_count || class_count > HALO_COLOR_MAX_CLASSES) return HALO_FATAL;
+  *produced = 0;
+  if (referenced_mask == 0) return HALO_OK;
+  size_t n = (size_t)width * (size_t)height;
+  if (out_rgb) memset(out_rgb, 0, n * 3 * sizeof(float));
+  if (n == 0) {
+    if (p99_out) *p99_out = 0.0f;
+    *produced = 1;
+    return HALO_OK;
+  }
+  /* active classes in draw order: stable by z_order (insertion sort keeps equal keys in list order) */
+  int order[HALO_COLOR_MAX_CLASSES], active[HALO_COLOR_MAX_CLASSES], na = 0, any_solo = 0;
+  for (int c = 0; c < class_count; c++) {
+    order[c] = c;
+    if (spec->classes[c].solo) any_solo = 1;
+  }
+  for (int i = 1; i < class_count; i++) {
+    int v = order[i], j = i - 1;
+    while (j >= 0 && spec->classes[order[j]].z_order > spec->classes[v].z_order) {
+      order[j + 1] = order[j];
+      j--;
+    }
+    order[j + 1] = v;
+  }
+  for (int i = 0; i < class_count; i++) {
+    const HaloCompositeClass* k = &spec->classes[order[i]];
+    if (any_solo ? k->solo : k->visible) active[na++] = order[i];
+  }
+  if (na == 0) {
+    if (out_srgb) memset(out_srgb, 0, n * 3);
+    if (p99_out) *p99_out = 0.0f;
+    *produced = 1;
+    return HALO_OK;
+  }
+  /* participating P99: the order statistic nth_element picks */
+  float p99 = 0.0f;
+  {
+    float* y = (float*)malloc((size_t)na * n * sizeof(float));
+    size_t m = 0;
+    for (int a = 0; a < na; a++)
+      for (size_t p = 0; p < n; p++) {
+        float v = lanes[(size_t)active[a] * n + p];
+        if (v > 0.0f) y[m++] = v;
+      }
+    if (m > 0) {
+      size_t idx = (size_t)((float)m * 0.99f);
+      if (idx >= m) idx = m - 1;
+      qsort(y, m, sizeof(float), cmp_float_asc);
+      p99 = y[idx];
+    }
+    free(y);
+  }
+  const float A = ho_participating_exposure_scale(spec->intensity_factor, total_intensity, p99);
+  if (A <= 0.0f) {
+    if (p99_out) *p99_out = p99;
+    if (out_rgb) memset(out_rgb, 0, n * 3 * sizeof(float)); /* the caller's buffer was "assigned" zeros before the early return (:189) */
+    return HALO_OK;
+  }
+  const float s = A * spec->display_exposure_scale;
+  for (size_t p = 0; p < n; p++) {
+    float out[3] = {0.0f, 0.0f, 0.0f};
+    if (spec->mode == HALO_COMPOSITE_DOMINANT) {
+      int best = -1;
+      float best_ey = 0.0f;
+      for (int a = 0; a < na; a++) {
+        float ey = lanes[(size_t)active[a] * n + p] * s;
+        if (ey > best_ey) {
+          best_ey = ey;
+          best = a;
+        }
+      }
+      if (best >= 0)
+        for (int j = 0; j < 3; j++) out[j] = spec->classes[active[best]].color[j] * best_ey;
+    } else if (spec->mode == HALO_COMPOSITE_ADDITIVE) {
+      float acc[3] = {0.0f, 0.0f, 0.0f};
+      for (int a = 0; a < na; a++) {
+        float ey = lanes[(size_t)active[a] * n + p] * s;
+        if (ey <= 0.0f) continue;
+        for (int j = 0; j < 3; j++) acc[j] += spec->classes[active[a]].color[j] * ey;
+      }
+      for (int j = 0; j < 3; j++) out[j] = acc[j] < 0.0f ? 0.0f : (acc[j] > 1.0f ? 1.0f : acc[j]);
+    } else {
+      float T = 1.0f;
+      for (int a = 0; a < na && T > 0.0f; a++) {
+        float alpha = lanes[(size_t)active[a] * n + p] * A;
+        if (alpha > 1.0f) alpha = 1.0f;
+        if (alpha <= 0.0f) continue;
+        for (int j = 0; j < 3; j++) out[j] += T * alpha * spec->classes[active[a]].color[j];
+        T *= (1.0f - alpha);
+      }
+      for (int j = 0; j < 3; j++) {
+        float v = out[j] * spec->display_exposure_scale;
+        out[j] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+      }
+    }
+    if (out_rgb)
+      for (int j = 0; j < 3; j++) out_rgb[p * 3 + j] = out[j];
+    if (out_srgb)
+      for (int j = 0; j < 3; j++) {
+        float c = out[j] < 0.0f ? 0.0f : (out[j] > 1.0f ? 1.0f : out[j]);
+        out_srgb[p * 3 + j] = (uint8_t)(ho_linear_to_srgb(c) * 255.0f);
+      }
+  }
+  if (p99_out) *p99_out = p99;
+  *produced = 1;
+  return HALO_OK;
+}

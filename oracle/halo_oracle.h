@@ -123,6 +123,13 @@ void ho_xyz_to_linear_rgb(const float xyz[3], float rgb[3]);
 float ho_linear_to_srgb(float linear);
 int ho_consumer_fold(HoBackend* b);
 int ho_consumer_snapshot(HoBackend* b, const HaloDisplay* display, uint8_t* rgb_out, float* xyz_out, double* total_intensity);
+/* display-side composite of the class lanes (server/component_compositor.cpp:24-303; ParticipatingExposureScale render.cpp:120-135).
+ * Stateless: `lanes` = class_count x W x H floats as ReadbackClassLanes hands them out, referenced_mask = OR of the classes' member
+ * bits, total_intensity = the consumer's snapshot intensity.  *produced = what CompositeColorClassesLinear returns. */
+float ho_participating_exposure_scale(float intensity_factor, float snapshot_intensity, float participating_p99_y);
+int ho_parse_composite_mode(const char* mode);
+int ho_composite(const float* lanes, int width, int height, int class_count, uint64_t referenced_mask, float total_intensity,
+                 const HaloComposite* spec, float* linear_rgb_out, uint8_t* srgb_out, float* participating_p99_y, int32_t* produced);
 /* continuation pool access for set-parity tests: n x {dx,dy,dz,w,wl_idx(as float)} */
 uint64_t ho_continuation_dump(HoBackend* b, float* out5, uint64_t cap);
 

@@ -121,6 +121,11 @@ def oracle(fma=False):
     L.ho_xyz_to_linear_rgb.restype = None; L.ho_xyz_to_linear_rgb.argtypes = [f32p, f32p]
     L.ho_linear_to_srgb.restype = C.c_float; L.ho_linear_to_srgb.argtypes = [C.c_float]
     L.ho_consumer_fold.restype = C.c_int; L.ho_consumer_fold.argtypes = [C.c_void_p]
+    L.ho_participating_exposure_scale.restype = C.c_float; L.ho_participating_exposure_scale.argtypes = [C.c_float] * 3
+    L.ho_parse_composite_mode.restype = C.c_int; L.ho_parse_composite_mode.argtypes = [C.c_char_p]
+    L.ho_composite.restype = C.c_int
+    L.ho_composite.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_float, C.POINTER(abi.HaloComposite), f32p, C.POINTER(C.c_uint8), f32p,
+                               C.POINTER(C.c_int32)]
     L.ho_consumer_snapshot.restype = C.c_int
     L.ho_consumer_snapshot.argtypes = [C.c_void_p, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]
     _oracle[fma] = L

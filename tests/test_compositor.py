@@ -1,0 +1,375 @@
+"""Display-side composite of the raypath-colour class lanes (reference src/server/component_compositor.cpp; RenderConsumer::
+ParticipatingExposureScale, src/server/render.cpp:120-135): `halo_consumer_composite` of the product and `ho_composite` of the oracle
+against the literal expectations of the reference's own unit tests, transcribed (inputs and expected outputs only) into
+tests/golden/ref_compositor_vectors.json from test/unit-correctness/server/test_component_compositor.cpp — every case's `source`
+has the lines.  The CPU half runs the oracle and the product's host pieces; the `-m gpu` half runs the same vectors through the
+HIP kernels (radix-select P99 + per-pixel composite), compares them bit for bit with the oracle on random lanes, and renders the
+reference's three-arc scene end to end.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, backend, scenes
+
+from _libs import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+V = json.load(open(os.path.join(HERE, "golden", "ref_compositor_vectors.json")))
+F = np.float32
+f32p = C.POINTER(C.c_float)
+
+
+def y550():
+    x, y, z = C.c_float(), C.c_float(), C.c_float()
+    oracle().ho_cmf(F(550.0), C.byref(x), C.byref(y), C.byref(z))
+    return F(y.value)
+
+
+def class_hits(c, mask):
+    return (mask & c["bits"]) == c["bits"] if c.get("combine", "any") == "all" else (mask & c["bits"]) != 0
+
+
+def lanes_of(classes, rays, res):
+    """The reference batch as the consumer's lanes: every ray lands on the centre pixel with cmf_y(550) * weight (float adds, ray order)."""
+    lanes = np.zeros((max(len(classes), 1), res, res), F)
+    for ci, c in enumerate(classes):
+        acc = F(0.0)
+        for mask, w in rays:
+            if class_hits(c, mask):
+                acc = F(acc + F(y550() * F(w)))
+        lanes[ci, res // 2, res // 2] = acc
+    total = F(0.0)
+    for _, w in rays:
+        total = F(total + F(w))
+    return lanes[:len(classes)] if classes else lanes[:0], float(total)
+
+
+def display_classes(classes):
+    return [{"color": c["color"], "visible": c.get("visible", True), "solo": c.get("solo", False), "z_order": c.get("z_order", i)}
+            for i, c in enumerate(classes)]
+
+
+def oracle_composite(lanes, total, classes, mode, display, intensity, sentinel=None):
+    O = oracle()
+    n, h, w = lanes.shape if lanes.size else (0, 0, 0)
+    spec = abi.composite(display_classes(classes), mode, display, intensity)
+    ref_mask = 0
+    for c in classes:
+        ref_mask |= c["bits"]
+    npix = max(h * w, 1)
+    lin = np.full((npix * 3,), sentinel if sentinel is not None else 0.0, F)
+    srgb = np.zeros((npix * 3,), np.uint8)
+    p99, produced = C.c_float(-12345.0), C.c_int32(-1)
+    flat = np.ascontiguousarray(lanes, F).reshape(-1) if lanes.size else np.zeros(1, F)
+    rc = O.ho_composite(flat.ctypes.data_as(f32p), w, h, n, C.c_uint64(ref_mask), F(total), C.byref(spec), lin.ctypes.data_as(f32p),
+                        srgb.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(p99), C.byref(produced))
+    assert rc == 0
+    return bool(produced.value), lin.reshape(-1, 3), srgb.reshape(-1, 3), p99.value
+
+
+class HipComposite:
+    """The same call through the product: halo_set_color (classes only), halo_consumer_load_lanes, halo_consumer_composite."""
+
+    def __init__(self):
+        self.b = backend.HipTraceBackend(device=0, seed=5)
+
+    def __call__(self, lanes, total, classes, mode, display, intensity, sentinel=None):
+        b = self.b
+        b.set_color([], [scenes.color_class([k for k in range(64) if (c["bits"] >> k) & 1], c.get("combine", "any")) for c in classes])
+        if classes:
+            b.LoadClassLanes(lanes, total)
+            n, h, w = lanes.shape
+        else:
+            h = w = 1
+        spec = abi.composite(display_classes(classes), mode, display, intensity)
+        lin = np.full((h * w * 3,), sentinel if sentinel is not None else 0.0, F)
+        srgb = np.zeros((h * w * 3,), np.uint8)
+        p99, produced = C.c_float(-12345.0), C.c_int32(-1)
+        b._check(b._L.halo_consumer_composite(b._h, C.byref(spec), lin.ctypes.data_as(f32p), srgb.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(p99),
+                                              C.byref(produced)))
+        return bool(produced.value), lin.reshape(-1, 3), srgb.reshape(-1, 3), p99.value
+
+
+def float_eq(a, b):
+    """gtest EXPECT_FLOAT_EQ: within 4 units in the last place"""
+    a, b = F(a), F(b)
+    if a == b:
+        return True
+    ia, ib = int(np.array(a).view(np.int32)), int(np.array(b).view(np.int32))
+    return (a > 0) == (b > 0) and abs(ia - ib) <= 4
+
+
+def scale_of(p99, intensity, total):
+    return F(oracle().ho_participating_exposure_scale(F(intensity), F(total), F(p99)))
+
+
+def check_case(case, impl):
+    classes = case["classes"]
+    intensity = case.get("intensity_factor", 1.0)
+    if "sequence" in case:   # ReusedOutputBufferMatchesFreshBuffer: big, small, big on one consumer
+        steps = case["sequence"]
+        fresh = []
+        for st in steps:
+            lanes, total = lanes_of(classes, st["rays"], st["res"])
+            fresh.append(oracle_composite(lanes, total, classes, case["runs"][0]["mode"], 1.0, intensity))
+        for k in (0, 1, 0):
+            lanes, total = lanes_of(classes, steps[k]["rays"], steps[k]["res"])
+            got = impl(lanes, total, classes, case["runs"][0]["mode"], 1.0, intensity)
+            assert got[0] and fresh[k][0]
+            assert np.array_equal(got[1], fresh[k][1]), (case["name"], k)
+            assert got[3] == fresh[k][3]
+        return
+    res = case["res"]
+    lanes, total = lanes_of(classes, case["rays"], res)
+    if "lane_expect" in case:
+        for ci, w in enumerate(case["lane_expect"]):
+            assert float_eq(lanes[ci, res // 2, res // 2], F(y550() * F(w)))
+    p = (res // 2) * res + res // 2
+    outs, p99s = {}, {}
+
+    def one(run, cls):
+        # a display given as an expression (DisplayExposureClampBitesAfterScale: 4 / ey0) needs the exposed value at display 1 first
+        disp = run["display"]
+        if isinstance(disp, str):
+            _, _, _, p99_1 = impl(lanes, total, cls, run["mode"], 1.0, intensity)
+            s1 = scale_of(p99_1, intensity, total)
+            env = {"ey%d" % k: F(lanes[k, res // 2, res // 2] * s1) for k in range(len(cls))}
+            disp = float(eval(disp, {"__builtins__": {}}, env))
+        sentinel = 42.0 if "output_untouched" in run.get("check", []) else None
+        produced, lin, srgb, p99 = impl(lanes, total, cls, run["mode"], disp, intensity, sentinel)
+        assert produced == run["produced"], (case["name"], run)
+        if "p99" in run:
+            assert p99 == run["p99"], (case["name"], p99)
+        if sentinel is not None:
+            assert np.all(lin == F(42.0)), "no composite must leave the caller's buffer alone"
+            return produced, lin, p99
+        if not produced:
+            return produced, lin, p99
+        # the expressions the reference asserts, over ey_k = lane_k * s (s = A * display; the painter's alpha takes A alone and the
+        # display multiplies the result — the cases that assert painter channels run at display 1)
+        A = scale_of(p99, intensity, total)
+        s = F(A * F(disp))
+        env = {"ey%d" % k: F(lanes[k, res // 2, res // 2] * (A if run["mode"] == "painter" else s)) for k in range(len(cls))}
+        env1 = {"ey%d" % k: F(lanes[k, res // 2, res // 2] * A) for k in range(len(cls))}   # the reference's preconditions are stated at display 1
+        for a in case.get("assert", []):
+            assert eval(a, {"__builtins__": {}}, env1), (case["name"], a, env1)
+        if "rgb" in run:
+            for ch, expr in enumerate(run["rgb"]):
+                if expr is None:
+                    continue
+                want = F(eval(expr.replace("1-", "F(1)-"), {"__builtins__": {}, "F": F}, env))
+                got = lin[p, ch]
+                if run["tol"] == "float_eq":
+                    assert float_eq(got, want), (case["name"], run["mode"], ch, got, want)
+                else:
+                    assert abs(float(got) - float(want)) <= run["tol"], (case["name"], run["mode"], ch, got, want)
+        lit = np.flatnonzero(np.any(lin != 0, axis=1))
+        for c in run.get("check", []):
+            if c == "g>r":
+                assert lin[p, 1] > lin[p, 0]
+            elif c == "lit_count==1":
+                assert len(lit) == 1
+            elif c == "lit_r>0":
+                assert np.all(lin[lit, 0] > 0)
+            elif c == "lit_g==0":
+                assert np.all(lin[lit, 1] == 0)
+            elif c == "lit_b==0":
+                assert np.all(lin[lit, 2] == 0)
+        if "scale_formula_rel_tol" in case:   # SharedExposureNoSelfNormalization: s = intensity * target_linear / P99, written out
+            ts = F(135.0) / F(255.0)
+            want = F(intensity) * F(np.power(F((ts + F(0.055)) / F(1.055)), F(2.4))) / F(p99)
+            assert abs(float(A) - float(want)) <= float(want) * case["scale_formula_rel_tol"]
+        # every pixel but the lit one stays black
+        assert not np.any(np.delete(lin, p, axis=0))
+        return produced, lin, p99
+
+    for run in case["runs"]:
+        produced, lin, p99 = one(run, classes)
+        if "label" in run:
+            outs[run["label"]], p99s[run["label"]] = lin, p99
+    for var in case.get("variants", []):
+        produced, lin, p99 = one({"mode": "dominant", "display": 1.0, "produced": True}, var["classes"])
+        outs[var["label"]], p99s[var["label"]] = lin, p99
+    for rel in case.get("relations", []):
+        if "factor" in rel:
+            for ch in rel["channels"]:
+                assert abs(float(outs[rel["a"]][p, ch]) - rel["factor"] * float(outs[rel["b"]][p, ch])) <= rel["abs_tol"], (case["name"], rel, ch)
+        if "zero" in rel:
+            for lab in rel["zero"]:
+                for ch in rel["channels"]:
+                    assert outs[lab][p, ch] == 0
+        if "below_one" in rel:
+            for ch in rel["channels"]:
+                assert outs[rel["below_one"]][p, ch] < 1
+    for r in case.get("p99_relations", []):
+        assert eval(r, {"__builtins__": {}, "abs": abs}, {k: float(v) for k, v in p99s.items()}), (case["name"], r, p99s)
+
+
+CASES = V["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_reference_compositor_expectations_on_the_oracle(case):
+    check_case(case, oracle_composite)
+
+
+def test_parse_composite_mode_oracle_and_product_host():
+    L, O = backend.load_library(), oracle()
+    for text, want in V["parse_composite_mode"]["cases"]:
+        assert O.ho_parse_composite_mode(text.encode()) == want
+        assert L.halo_host_parse_composite_mode(text.encode()) == want
+        assert abi.composite([], text).mode == want
+    assert L.halo_host_parse_composite_mode(None) == abi.COMPOSITE_PAINTER
+
+
+def test_participating_exposure_scale_guards_and_formula():
+    g = V["exposure_scale"]
+    for c in g["guards"]:
+        assert scale_of(c["p99"], c["intensity"], c["total"]) == c["expected"]
+    ts = F(g["target_white_srgb8"]) / F(255.0)
+    target_linear = F(np.power(F((ts + F(0.055)) / F(1.055)), F(2.4)))
+    for c in g["formula"]:
+        want = float(F(c["intensity"]) * target_linear / F(c["p99"]))
+        assert abs(float(scale_of(c["p99"], c["intensity"], c["total"])) - want) <= want * g["rel_tol"]
+
+
+def test_linear_to_srgb_u8_literals_on_the_oracle():
+    """LinearToSrgbU8Smoke: the additive composite of one white class at chosen lane values delivers the listed linear values (clamped),
+    and its sRGB bytes are u8(LinearToSrgb(clamped) * 255)."""
+    g = V["linear_to_srgb_u8"]
+    O = oracle()
+    O.ho_linear_to_srgb.restype = C.c_float
+    O.ho_linear_to_srgb.argtypes = [C.c_float]
+    srgb = lambda x: int(F(O.ho_linear_to_srgb(F(x))) * F(255.0))
+    want = [eval(e, {"__builtins__": {}, "srgb": srgb}) for e in g["expected"]]
+    assert want[0] == 0 and want[3] == 0 and want[1] == want[4] >= 254
+    # one white class; P99 of five pixels' values is their max (index int(5 * 0.99) = 4); display picks the scale so that lane * s = linear
+    lin_in = np.array(g["linear"], F)
+    lanes = np.zeros((1, 1, 5), F)
+    lanes[0, 0] = np.maximum(lin_in, 0)   # a lane holds no negative energy: -0.2 enters as 0 (clamped to 0 either way)
+    cls = [{"color": [1, 1, 1], "bits": 1}]
+    _, _, _, p99 = oracle_composite(lanes, 1.0, cls, "additive", 1.0, 1.0)
+    s1 = scale_of(p99, 1.0, 1.0)
+    produced, lin, out, _ = oracle_composite(lanes, 1.0, cls, "additive", float(F(1.0) / s1), 1.0)
+    assert produced
+    for i in range(5):
+        assert abs(int(out[i, 0]) - want[i]) <= 1 and out[i, 0] == out[i, 1] == out[i, 2], (i, out[i], want[i])
+
+
+def random_lanes(rng, n_cls, h, w, fill):
+    lanes = np.zeros((n_cls, h, w), F)
+    m = rng.random((n_cls, h, w)) < fill
+    lanes[m] = np.exp(rng.normal(-3.0, 2.0, size=int(m.sum()))).astype(F)
+    return lanes
+
+
+def random_classes(rng, n_cls):
+    out = []
+    for i in range(n_cls):
+        out.append({"color": [float(F(v)) for v in rng.random(3)], "bits": 1 << i, "visible": bool(rng.random() < 0.8), "solo": bool(rng.random() < 0.1),
+                    "z_order": int(rng.integers(0, 4))})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# GPU half: the same expectations through halo_consumer_composite, and the HIP kernels against the oracle on data the vectors do not reach
+@pytest.fixture(scope="module")
+def hip():
+    if backend.load_library().halo_device_count() <= 0:
+        pytest.fail("no MI355X visible: the -m gpu tests must run on the device")
+    return HipComposite()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_reference_compositor_expectations_on_the_device(case, hip):
+    check_case(case, hip)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_device_composite_equals_the_oracle_bit_for_bit(seed, hip):
+    """Random lanes (log-normal energies, 2 % … 60 % of the pixels lit), random class tables (colours, hidden / solo classes, tied and
+    permuted z_order), the three modes, display scales either side of the clamp: the radix-select P99 IS the order statistic the
+    oracle sorts out, and the linear image is equal bit for bit (every product and sum rounded on its own on both sides); the sRGB
+    bytes may differ by one level where powf does."""
+    rng = np.random.default_rng(9100 + seed)
+    n_cls = int(rng.integers(1, 9)) if seed else 16
+    h, w = [(7, 5), (64, 64), (33, 129), (256, 512)][seed % 4]
+    lanes = random_lanes(rng, n_cls, h, w, [0.02, 0.3, 0.6][seed % 3])
+    classes = random_classes(rng, n_cls)
+    total = float(lanes.sum())
+    for mode in ("dominant", "additive", "painter"):
+        for display in (1.0, 0.37, 6.0):
+            got = hip(lanes, total, classes, mode, display, 1.3)
+            want = oracle_composite(lanes, total, classes, mode, display, 1.3)
+            assert got[0] == want[0]
+            assert got[3] == want[3], ("P99", got[3], want[3])
+            if want[0]:
+                assert np.array_equal(got[1], want[1]), (mode, display, np.abs(got[1] - want[1]).max())
+                assert np.abs(got[2].astype(int) - want[2].astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_device_p99_on_ties_and_tiny_sets(hip):
+    """The select's edge cases: one positive value; all values equal; 100 and 101 values (index int(n * 0.99f) moves from 99 to 99 / 100);
+    denormals next to large values; a hidden class holding the maximum."""
+    cls = [{"color": [1, 1, 1], "bits": 1}, {"color": [1, 0, 0], "bits": 2}]
+    for vals in ([0.5], [0.25] * 40, list(np.linspace(0.01, 1.0, 100)), list(np.linspace(0.01, 1.0, 101)), [1e-42, 1e-40, 3.0, 1e30]):
+        lanes = np.zeros((2, 1, 128), F)
+        lanes[0, 0, :len(vals)] = np.array(vals, F)
+        lanes[1, 0, 5] = F(7e33)
+        for hide in (False, True):
+            c2 = [dict(cls[0]), dict(cls[1], visible=not hide)]
+            got = hip(lanes, 1.0, c2, "additive", 1.0, 1.0)
+            want = oracle_composite(lanes, 1.0, c2, "additive", 1.0, 1.0)
+            assert got[3] == want[3] and got[0] == want[0]
+            assert np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_three_arcs_no_phantom_hue_end_to_end():
+    """DominantThreeArcsNoPhantomHue: the reference's two-crystal scene (filters and three raypath-colour classes), traced and composited
+    on the device — lanes written by the kModeColor kernels, never read back."""
+    g = V["three_arcs"]
+    T = scenes.filter_term
+    b = backend.HipTraceBackend(device=0, seed=g["seed"])
+    ee = lambda lo=1, hi=None: T("entry_exit", min_len=lo, max_len=hi)
+    b.set_filters([scenes.simple_filter(ee(1)), scenes.complex_filter([[ee(2, 2)], [ee(3)]])])
+    b.set_color([scenes.color_set([(ee(1), "", 0)]), scenes.color_set([(ee(2, 2), "", 1), (ee(3), "", 2)])],
+                [scenes.color_class([0]), scenes.color_class([1]), scenes.color_class([2])])
+    fixed = scenes.axis()
+    sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.0), fixed, 0.5, 1, filter_id=1, color_id=1),
+                              scenes.entry(scenes.prism_crystal(1.0), fixed, 0.5, 2, filter_id=2, color_id=2)])],
+                      max_hits=g["max_hits"], sun_altitude=g["sun"][0], sun_azimuth=g["sun"][1], sun_diameter=g["sun"][2])
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, g["res"], g["res"], fov=180.0, az=0.0, el=90.0, ro=0.0, visible=abi.VISIBLE_UPPER)
+    b.BeginSession(sc, rd, scenes.wl_discrete(g["wavelength"]), g["rays"])
+    b.TraceLayer(g["rays"])
+    b.EndSession()
+    b.ConsumeDeviceFused()
+    disp = [{"color": c} for c in ([1, 0, 0], [0, 1, 0], [0, 0, 1])]
+    ok, out, _, p99 = b.CompositeColorClasses(disp, "dominant", 1.0, 1.0)
+    assert ok and p99 > 0
+    out = out.reshape(-1, 3)
+    lit = np.any(out != 0, axis=1)
+    assert np.all((out[lit] > 0).sum(axis=1) == 1), "phantom hue"
+    owners = np.argmax(out[lit], axis=1)
+    assert all(np.any(owners == k) for k in range(3)), np.bincount(owners, minlength=3)
+    ok2, half, _, p99b = b.CompositeColorClasses(disp, "dominant", 0.5, 1.0)
+    half = half.reshape(-1, 3)
+    assert ok2 and p99b == p99
+    assert not np.any(half[~lit])
+    assert np.array_equal(np.argmax(half[lit], axis=1), owners) and np.all((half[lit] > 0).sum(axis=1) == 1)
+    assert np.abs(half[lit] - out[lit] * F(0.5)).max() <= 1e-5
+    # the lanes are still there (the composite reads, the readback drains), and they are what the oracle composites to the same image
+    lanes = b.ReadbackClassLanes()
+    _, _, tot = b.Snapshot(want_xyz=False)
+    cls = [{"color": d["color"], "bits": 1 << i} for i, d in enumerate(disp)]
+    want = oracle_composite(lanes, tot, cls, "dominant", 1.0, 1.0)
+    assert want[0] and want[3] == p99 and np.array_equal(want[1], out)
+    ok3, _, _, p99c = b.CompositeColorClasses(disp, "dominant", 1.0, 1.0)
+    assert not ok3 and p99c == 0.0   # drained lanes: the early return publishes P99 = 0
