@@ -85,6 +85,9 @@ def main(argv=None):
     ap.add_argument("--out-rgb", default=None, help="write the sRGB image as binary PPM")
     ap.add_argument("--out-xyz", default=None, help="write the raw XYZ snapshot as .npy")
     ap.add_argument("--out-lanes", default=None, help="raypath_color configs: write the per-class Y lanes (classes, H, W) as .npy")
+    ap.add_argument("--out-composite", default=None, help="raypath_color configs: write the class composite (the config's mode: dominant | additive | "
+                    "painter; component_compositor.cpp) as binary PPM, composited on the device")
+    ap.add_argument("--display-ev", type=float, default=0.0, help="display-time EV of the composite (display_exposure_scale = 2^EV)")
     args = ap.parse_args(argv)
     try:
         job = config.load_config(args.config)
@@ -106,6 +109,12 @@ def main(argv=None):
         write_ppm(args.out_rgb, rgb)
     if args.out_xyz:
         np.save(args.out_xyz, xyz)
+    if args.out_composite and job.color_classes:   # before the lanes are drained: the composite reads them where they are
+        ok, _, srgb, p99 = be.CompositeColorClasses(job.color_meta, job.color_mode, 2.0 ** args.display_ev, meta.get("intensity_factor", 1.0))
+        if ok:
+            write_ppm(args.out_composite, srgb)
+        else:
+            print("no composite: the participating classes hold no energy (P99 %.3g)" % p99, file=sys.stderr)
     if args.out_lanes and job.color_classes:
         np.save(args.out_lanes, be.ReadbackClassLanes())
     if args.benchmark:
