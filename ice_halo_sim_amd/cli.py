@@ -103,7 +103,8 @@ def main(argv=None):
         return 2
     be = res["backend"]
     meta = job.render_meta.get(res["render_id"], {})
-    rgb, xyz, total_intensity = be.Snapshot(intensity_factor=meta.get("intensity_factor", 1.0))
+    rgb, xyz, total_intensity = be.Snapshot(intensity_factor=meta.get("intensity_factor", 1.0), ray_color=meta.get("ray_color", (-1.0, -1.0, -1.0)),
+                                            background=meta.get("background", (0.0, 0.0, 0.0)))
     wall = time.perf_counter() - wall0
     if args.out_rgb:
         write_ppm(args.out_rgb, rgb)

@@ -236,7 +236,7 @@ class TraceJob:
     def __init__(self):
         self.scene = None
         self.renders = {}          # id -> HaloRender
-        self.render_meta = {}      # id -> {"intensity_factor": ...}
+        self.render_meta = {}      # id -> {"intensity_factor", "ray_color", "background", "opacity"}
         self.wavelengths = []      # list of HaloWl (one per discrete wavelength, or a single illuminant entry)
         self.ray_num = 0           # total root rays requested (None = "infinite")
         self.geom_clock = None
@@ -271,7 +271,12 @@ def load_config(source):
     for jr in doc.get("render", []):
         r = parse_render(jr)
         job.renders[int(jr["id"])] = r
-        job.render_meta[int(jr["id"])] = {"intensity_factor": float(jr.get("intensity_factor", 1.0))}
+        # the appearance fields PostSnapshot reads (config_manager.cpp:62-73, render_config.hpp:84-92); opacity and the grids belong
+        # to the GUI's overlay pass and are carried, not drawn
+        job.render_meta[int(jr["id"])] = {"intensity_factor": float(jr.get("intensity_factor", 1.0)),
+                                          "ray_color": [float(v) for v in jr.get("ray_color", (-1.0, -1.0, -1.0))],
+                                          "background": [float(v) for v in jr.get("background", (0.0, 0.0, 0.0))],
+                                          "opacity": float(jr.get("opacity", 1.0))}
     js = doc["scene"]
     rn = js["ray_num"]
     job.ray_num = None if rn == "infinite" else int(rn)
