@@ -92,3 +92,20 @@ def test_run_to_run_psnr_of_a_class_composite_is_the_reference_binarys(d):
     assert got >= d["threshold"]
     lo, hi = expected_window(d)
     assert lo <= got <= hi, (d["name"], got, (lo, hi))   # measured 20.89 (reference 20.86 / 20.90 / 20.91) and 19.98 (19.99 / 19.99 / 20.01)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", CAL["pairs"], ids=[d["a"] + "__" + d["b"] for d in CAL["pairs"]])
+def test_psnr_between_two_equivalent_documents_is_the_reference_binarys(d):
+    """Two DIFFERENT documents the reference holds to be one picture: the [4, 6] and [7, 3] raypath filters (one P/B/D orbit; independent
+    renders, so the PSNR is the noise floor of that picture — and collapses if the symmetry expansion selected other rays), and the
+    GUI's sum-of-products export against the hand-written compound filter (same seed: the same rays, the same bytes)."""
+    a = jpeg_round_trip(render(d["a"], 1, 1001), CAL["jpeg_quality"])
+    b = jpeg_round_trip(render(d["b"], 1, 1001 if d["same_seed"] else 2002), CAL["jpeg_quality"])
+    got = psnr(a, b)
+    assert got >= d["threshold"]
+    if "stated" in d:
+        lo, hi = expected_window(d)
+        assert lo <= got <= hi, (got, lo, hi)
+    else:
+        assert got >= d["stated_min"], got
