@@ -66,6 +66,26 @@ def reduce_scalar(value, device, group=None, dst=0):
     return float(t.item()) if dist.get_rank(group) == dst else 0.0
 
 
+def reduce_class_lanes(lanes, total_intensity, group=None, dst=0, device=None):
+    """Raypath-colour jobs: sum-reduce every rank's class lanes (numpy (classes, H, W) float32, as ReadbackClassLanes hands them out)
+    and total intensity onto `dst` — ONE more reduce of classes * W * H floats at the drain point, next to the image's.  The root gets
+    (summed lanes, summed intensity) to load into its consumer (`HipTraceBackend.LoadClassLanes`) and composite once
+    (`CompositeColorClasses`: the participating P99 is a statistic of the WHOLE image, so compositing per rank and adding would be
+    wrong); other ranks get (None, 0.0).  `device`: where the transfer tensor lives (a cuda device under RCCL, None = CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return lanes, total_intensity
+    t = torch.from_numpy(np.ascontiguousarray(lanes, np.float32).reshape(-1))
+    if device is not None:
+        t = t.to(device)
+    t = reduce_image(t, group, dst)
+    tot = reduce_scalar(float(total_intensity), t.device, group, dst)
+    if dist.get_rank(group) != dst:
+        return None, 0.0
+    return t.cpu().numpy().reshape(np.shape(lanes)), tot
+
+
 class ShardedTracer:
     """One rank's slice of a trace job on one MI355X."""
 
@@ -122,3 +142,17 @@ class ShardedTracer:
         landed = self.landed
         self.zero()
         return img, landed
+
+    def composite(self, classes, mode="painter", display_exposure_scale=1.0, intensity_factor=1.0, total_intensity=None):
+        """COLLECTIVE, raypath-colour jobs: every rank hands over its class lanes, the root composites the sum on its device.
+        `total_intensity`: this rank's landed weight so far (default: what the backend has tallied, read without draining the image).
+        Returns (produced, linear_rgb, srgb, p99) on the root, None elsewhere."""
+        lanes = self.backend.ReadbackClassLanes()
+        mine = self.landed + self.backend.take_landed() if total_intensity is None else total_intensity
+        if total_intensity is None:
+            self.landed = mine      # the scalar was taken off the device: keep it for readback()
+        lanes, tot = reduce_class_lanes(lanes, mine, device=self.device)
+        if lanes is None:
+            return None
+        self.backend.LoadClassLanes(lanes, tot)
+        return self.backend.CompositeColorClasses(classes, mode, display_exposure_scale, intensity_factor)

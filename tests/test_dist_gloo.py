@@ -8,7 +8,7 @@ import socket
 import numpy as np
 import pytest
 
-from ice_halo_sim_amd import scenes
+from ice_halo_sim_amd import abi, scenes
 from ice_halo_sim_amd.dist import shard_range
 
 W, H, N = 96, 48, 30_000
@@ -162,3 +162,59 @@ def test_world8_gloo_strong_scaling_jobs(tmp_path):
         _, landed1 = ob.ReadbackXyzAccum()
         ob.close()
         assert total_landed == pytest.approx(landed1, rel=0.02)
+
+
+# ---- raypath-colour jobs: the class lanes reduce like the image, and the composite happens ONCE, on the root ---------------------------
+def _lane_shard(rank, world, n_total):
+    """one rank's class lanes of a two-crystal raypath-colour scene (the oracle tracer), and its landed weight"""
+    from tests._oracle_backend import OracleBackend, run_session
+    T = scenes.filter_term
+    ob = OracleBackend(seed=42, rank=rank)
+    ee = lambda lo=1, hi=None: T("entry_exit", min_len=lo, max_len=hi)
+    ob.set_color([scenes.color_set([(ee(1), "", 0)]), scenes.color_set([(ee(2, 2), "", 1), (ee(3), "", 2)])],
+                 [scenes.color_class([0]), scenes.color_class([1]), scenes.color_class([2])])
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    ax = scenes.axis(zenith={"type": "gauss", "mean": 90.0, "std": 20.0}, azimuth=full, roll=full)
+    sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.3), ax, 0.5, 1, color_id=1), scenes.entry(scenes.prism_crystal(0.4), ax, 0.5, 2, color_id=2)])],
+                      max_hits=6, sun_altitude=25.0)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 64, 32, visible=abi.VISIBLE_FULL)
+    _, count = shard_range(n_total, rank, world)
+    run_session(ob, sc, rd, scenes.wl_discrete(550.0), count)
+    _, landed = ob.ReadbackXyzAccum()
+    lanes = ob.ReadbackClassLanes()
+    ob.close()
+    return lanes, landed
+
+
+def _lane_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from ice_halo_sim_amd.dist import reduce_class_lanes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lanes, landed = _lane_shard(rank, world, N)
+    summed, tot = reduce_class_lanes(lanes, landed)
+    assert (summed is None) == (rank != 0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "lanes.npy"), summed)
+        np.save(os.path.join(out_dir, "tot.npy"), np.array([tot]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_class_lanes_reduce_and_one_composite_on_the_root(tmp_path):
+    import torch.multiprocessing as mp
+    from tests.test_compositor import oracle_composite
+    port = _free_port()
+    mp.spawn(_lane_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    summed, tot = np.load(tmp_path / "lanes.npy"), float(np.load(tmp_path / "tot.npy")[0])
+    (l0, w0), (l1, w1) = _lane_shard(0, 2, N), _lane_shard(1, 2, N)
+    assert np.array_equal(summed, l0 + l1) and tot == pytest.approx(w0 + w1, rel=1e-12)
+    assert all(float(l0[c].max()) > 0 and float(l1[c].max()) > 0 for c in range(3))
+    cls = [{"color": c, "bits": 1 << i} for i, c in enumerate(([1, 0, 0], [0, 1, 0], [0, 0, 1]))]
+    ok, whole, _, p99 = oracle_composite(summed, tot, cls, "painter", 1.0, 1.0)
+    assert ok and p99 > 0
+    # why the composite is not done per rank: each shard's own P99 anchors its own exposure, and the parts do not add up to the whole
+    parts = [oracle_composite(l, w, cls, "painter", 1.0, 1.0) for l, w in ((l0, w0), (l1, w1))]
+    assert all(p[0] for p in parts) and min(parts[0][3], parts[1][3]) < p99
+    assert np.abs(parts[0][1] + parts[1][1] - whole).max() > 0.05

@@ -65,3 +65,56 @@ def test_two_ranks_on_one_gpu_reduce_to_the_sum_of_their_images(tmp_path):
     assert not np.allclose(own[0], own[1])
     assert meta[0][0] == pytest.approx(meta[1][0], rel=5e-3)
     assert own[0].sum(dtype=np.float64) == pytest.approx(own[1].sum(dtype=np.float64), rel=5e-3)
+
+
+# ---- raypath-colour job over two ranks: lanes reduced, ONE composite on the root's device (ShardedTracer.composite) ---------------------
+def _colour_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from ice_halo_sim_amd.dist import ShardedTracer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = scenes.filter_term
+    ee = lambda lo=1, hi=None: T("entry_exit", min_len=lo, max_len=hi)
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    ax = scenes.axis(zenith={"type": "gauss", "mean": 90.0, "std": 20.0}, azimuth=full, roll=full)
+    sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.3), ax, 0.5, 1, color_id=1), scenes.entry(scenes.prism_crystal(0.4), ax, 0.5, 2, color_id=2)])],
+                      max_hits=6, sun_altitude=25.0)
+    rd = scenes.render(abi.LENS_DUAL_FISHEYE_EQUAL_AREA, 256, 128, visible=abi.VISIBLE_FULL)
+    tr = ShardedTracer(sc, rd, seed=42, device=0, rank=rank, world=world)
+    tr.backend.set_color([scenes.color_set([(ee(1), "", 0)]), scenes.color_set([(ee(2, 2), "", 1), (ee(3), "", 2)])],
+                         [scenes.color_class([0]), scenes.color_class([1]), scenes.color_class([2])])
+    tr.trace_session_layers(scenes.wl_discrete(550.0), 1 << 20)
+    torch.cuda.synchronize()
+    # this rank's own lanes, read without draining: composite() reads them back itself, so take a copy through a second readback + reload
+    own = tr.backend.ReadbackClassLanes()
+    tr.backend.LoadClassLanes(own)
+    disp = [{"color": c} for c in ([1, 0, 0], [0, 1, 0], [0, 0, 1])]
+    res = tr.composite(disp, "painter")
+    assert (res is None) == (rank != 0)
+    np.save(os.path.join(out_dir, "lanes%d.npy" % rank), own)
+    np.save(os.path.join(out_dir, "landed%d.npy" % rank), np.array([tr.landed]))
+    if rank == 0:
+        ok, lin, srgb, p99 = res
+        assert ok
+        np.save(os.path.join(out_dir, "lin.npy"), lin)
+        np.save(os.path.join(out_dir, "p99.npy"), np.array([p99], np.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_composite_their_summed_lanes_once_on_the_root(tmp_path):
+    import torch.multiprocessing as mp
+    from tests.test_compositor import oracle_composite
+    mp.spawn(_colour_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    lanes = [np.load(tmp_path / ("lanes%d.npy" % r)) for r in range(2)]
+    landed = [float(np.load(tmp_path / ("landed%d.npy" % r))[0]) for r in range(2)]
+    lin, p99 = np.load(tmp_path / "lin.npy"), float(np.load(tmp_path / "p99.npy")[0])
+    assert not np.array_equal(lanes[0], lanes[1]) and landed[0] == pytest.approx(landed[1], rel=2e-2)
+    cls = [{"color": c, "bits": 1 << i} for i, c in enumerate(([1, 0, 0], [0, 1, 0], [0, 0, 1]))]
+    ok, want, _, want_p99 = oracle_composite(lanes[0] + lanes[1], landed[0] + landed[1], cls, "painter", 1.0, 1.0)
+    assert ok and want_p99 == p99
+    assert np.array_equal(lin.reshape(-1, 3), want)
