@@ -390,12 +390,34 @@ def classify_by_color_direction(srgb, class_colors, luminance_floor=8.0, cos_tol
     px = srgb.reshape(-1, 3).astype(np.float64)
     lit = px.max(axis=1) >= luminance_floor
     dirs = np.array(class_colors, np.float64)
+    if np.any(np.linalg.norm(dirs, axis=1) <= 0.0):
+        raise ValueError("a class colour is the zero vector")
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     cos = (px[lit] @ dirs.T) / np.linalg.norm(px[lit], axis=1, keepdims=True)
     best = cos.argmax(axis=1)
     ok = cos.max(axis=1) >= cos_tol
     return {"background": int((~lit).sum()), "unclassified": int((~ok).sum()), "per_class": [int(((best == i) & ok).sum()) for i in range(len(dirs))],
             "total": int(px.shape[0])}
+
+
+@pytest.mark.parametrize("case", V["classifier_self_check"]["cases"], ids=[c["name"] for c in V["classifier_self_check"]["cases"]])
+def test_restated_classifier_passes_the_references_known_answer_cases(case):
+    """The yardstick before the measurement: the reference tests its classifier on synthetic images (blocks of raw class colour, scaled by a
+    per-class exposure, rounded to bytes); the restatement above must give the same counts."""
+    g = V["classifier_self_check"]
+    img = np.zeros((case["h"] * case["w"], 3), np.uint8)
+    cur = 0
+    for idx, cnt in enumerate(case.get("block_counts", [])):
+        rgb = [int(round(255 * c * case["exposure"][idx])) for c in g["class_colors"][idx]]
+        img[cur:cur + cnt] = rgb
+        cur += cnt
+    for i, px in enumerate(case.get("raw_pixels", [])):
+        img[i] = px
+    res = classify_by_color_direction(img.reshape(case["h"], case["w"], 3), g["class_colors"], luminance_floor=case.get("floor", 8.0))
+    for k, v in case["expect"].items():
+        assert res[k] == v, (case["name"], k, res)
+    with pytest.raises(ValueError):
+        classify_by_color_direction(img.reshape(case["h"], case["w"], 3), [(0.0, 0.0, 0.0)])
 
 
 def render_document(name, mode=None, seed=42):
