@@ -74,6 +74,40 @@ def write_ppm(path, rgb):
         f.write(rgb.tobytes())
 
 
+def write_image(path, rgb, fmt, quality):
+    """stbi_write_jpg / stbi_write_png of main.cpp:262-273 (JPEG: quality as given, no chroma subsampling above 90 like stb)"""
+    from PIL import Image
+    if fmt == "png":
+        Image.fromarray(rgb).save(path, "PNG")
+    else:
+        Image.fromarray(rgb).save(path, "JPEG", quality=int(quality), subsampling=0 if quality > 90 else 2)
+    print("Saved: %s (%dx%d)" % (path, rgb.shape[1], rgb.shape[0]))
+
+
+def save_all_renders(job, args):
+    """`-f cfg -o dir [--format png] [--quality q]`: what the reference CLI leaves in the output directory (SaveRenderResults /
+    SaveCompositeResults, main.cpp:251-315): img_<id>.<fmt> per render entry, img_<id>_components.<fmt> with raypath_color."""
+    os.makedirs(args.output_dir, exist_ok=True)
+    rc = 0
+    for rid in sorted(job.renders):
+        try:
+            res = run_job(job, rid, args.seed, args.device, args.max_rays)
+        except BackendUnavailableError as e:
+            print("backend unavailable: %s" % e, file=sys.stderr)
+            return 3
+        be = res["backend"]
+        meta = job.render_meta.get(rid, {})
+        rgb, _, total_intensity = be.Snapshot(intensity_factor=meta.get("intensity_factor", 1.0), ray_color=meta.get("ray_color", (-1.0, -1.0, -1.0)),
+                                              background=meta.get("background", (0.0, 0.0, 0.0)), want_xyz=False)
+        write_image(os.path.join(args.output_dir, "img_%02d.%s" % (rid, args.format)), rgb, args.format, args.quality)
+        if job.color_classes:
+            ok, _, srgb, p99 = be.CompositeColorClasses(job.color_meta, job.color_mode, 2.0 ** args.display_ev, meta.get("intensity_factor", 1.0))
+            if ok:
+                write_image(os.path.join(args.output_dir, "img_%02d_components.%s" % (rid, args.format)), srgb, args.format, args.quality)
+        be.close()
+    return rc
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="ice_halo_sim_amd.cli")
     ap.add_argument("-f", "--config", required=True, help="Lumice JSON configuration file")
@@ -82,6 +116,11 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max-rays", type=int, default=None, help="cap the total root rays (required for ray_num: infinite)")
     ap.add_argument("--benchmark", action="store_true", help="print the [BENCHMARK] JSON line")
+    ap.add_argument("-o", "--output-dir", default=None, help="the reference CLI's output contract (main.cpp:196-315): write img_<id>.<fmt> for EVERY "
+                    "render entry of the config (one run per entry: the seam carries one renderer) and, for raypath_color configs, img_<id>_components.<fmt>")
+    ap.add_argument("--format", default="jpg", choices=("jpg", "png"), help="image format of -o (default jpg)")
+    ap.add_argument("--quality", type=int, default=95, help="JPEG quality of -o (default 95, 4:4:4 like stb_image_write above 90)")
+    ap.add_argument("--backend", default="hip", help="accepted for the reference's command lines (auto | cpu | metal | cuda | hip); this engine has one backend")
     ap.add_argument("--out-rgb", default=None, help="write the sRGB image as binary PPM")
     ap.add_argument("--out-xyz", default=None, help="write the raw XYZ snapshot as .npy")
     ap.add_argument("--out-lanes", default=None, help="raypath_color configs: write the per-class Y lanes (classes, H, W) as .npy")
@@ -89,10 +128,15 @@ def main(argv=None):
                     "painter; component_compositor.cpp) as binary PPM, composited on the device")
     ap.add_argument("--display-ev", type=float, default=0.0, help="display-time EV of the composite (display_exposure_scale = 2^EV)")
     args = ap.parse_args(argv)
+    if not 1 <= args.quality <= 100:
+        print("Error: --quality must be between 1 and 100, got %d" % args.quality, file=sys.stderr)
+        return 2
     try:
         job = config.load_config(args.config)
         if job.ray_num is None and args.max_rays is None:
             raise config.ConfigError('ray_num is "infinite": pass --max-rays')
+        if args.output_dir is not None and not args.benchmark and args.render is None:
+            return save_all_renders(job, args)
         wall0 = time.perf_counter()
         res = run_job(job, args.render, args.seed, args.device, args.max_rays)
     except BackendUnavailableError as e:

@@ -241,3 +241,34 @@ def test_raypath_color_maps_onto_color_sets_and_classes():
     bad["raypath_color"]["classes"][1]["combine"] = "xor"
     with pytest.raises(config.ConfigError, match="unknown combine"):
         config.load_config(bad)
+
+
+@pytest.mark.gpu
+def test_cli_output_directory_contract_of_the_reference(tmp_path):
+    """The reference's e2e harness drives its binary as `-f <config> -o <dir> [--format png]` and looks for img_<id>.<fmt> per render entry
+    and img_<id>_components.<fmt> with raypath_color (main.cpp:244-315; test_smoke.py, test_raypath_color_painter_default.py::
+    test_bare_array_renders_default_painter: both files exist, non-empty, at the configured resolution)."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(name, *extra):
+        cfg = tmp_path / (name + ".json")
+        cfg.write_text(json.dumps(E2E_DOCS[name]))
+        out = tmp_path / ("out_" + name)
+        r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli", "-f", str(cfg), "-o", str(out)] + list(extra), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return out, r.stdout
+
+    out, log = run("multi_lens")                                  # three render entries, default format jpg
+    for rid in (1, 2, 3):
+        f = out / ("img_%02d.jpg" % rid)
+        assert f.exists() and f.stat().st_size > 0 and ("Saved: %s" % f) in log
+        assert Image.open(f).size == tuple(E2E_DOCS["multi_lens"]["render"][rid - 1]["resolution"])
+    assert not list(out.glob("*_components.*"))                   # no raypath_color section: the mono path alone
+    out, _ = run("painter_default_overlap", "--format", "png", "--backend", "cpu")
+    res = tuple(E2E_DOCS["painter_default_overlap"]["render"][0]["resolution"])
+    for name in ("img_01.png", "img_01_components.png"):
+        assert (out / name).exists() and (out / name).stat().st_size > 0 and Image.open(out / name).size == res
