@@ -133,6 +133,8 @@ def main(argv=None):
         return 2
     try:
         job = config.load_config(args.config)
+        for w in getattr(job, "warnings", []):
+            print("[warning] " + w)
         if job.ray_num is None and args.max_rays is None:
             raise config.ConfigError('ray_num is "infinite": pass --max-rays')
         if args.output_dir is not None and not args.benchmark and args.render is None:

@@ -44,7 +44,8 @@ def _dist(obj, default=0.0, default_spread=0.0):
         return abi.dist(float(obj))
     if isinstance(obj, dict):
         if "type" not in obj:
-            raise ConfigError('distribution object is missing required key "type"')
+            raise ConfigError('distribution object is missing required key "type". Write either a bare number (e.g. 20) or an object naming the '
+                              'distribution (e.g. {"type": "gauss", "mean": 20, "std": 5}).')   # math.cpp:611-615
         try:
             return abi.dist(obj, default, default_spread)
         except KeyError:
@@ -124,11 +125,14 @@ def parse_crystal(j):
     if ax is None:
         axis = scenes.axis()
     else:
-        if "zenith" not in ax:
-            raise ConfigError('axis is present but has no "zenith"')
+        hint = lambda key: ('Write axis.%s either as a bare number for a fixed angle (e.g. "%s": 20) or as an object naming the distribution '
+                            '(e.g. "%s": {"type": "gauss", "mean": 20, "std": 5}).' % (key, key, key))   # FormatAxisSlotHint, math.cpp:651-655
+        if "zenith" not in ax:   # from_json(AxisDistribution&), math.cpp:693-704
+            raise ConfigError('axis is present but has no "zenith", which is required whenever `axis` is written at all (omit `axis` entirely to get '
+                              'the default orientation instead). ' + hint("zenith"))
         for key in ("zenith", "azimuth", "roll"):
-            if isinstance(ax.get(key), dict) and "type" not in ax[key]:
-                raise ConfigError('axis.%s is a distribution object with no "type"' % key)
+            if isinstance(ax.get(key), dict) and "type" not in ax[key]:   # ParseAxisSlot, math.cpp:668-675
+                raise ConfigError('axis.%s is a distribution object with no "type". ' % key + hint(key))
         axis = scenes.axis(zenith=ax["zenith"], azimuth=ax.get("azimuth"), roll=ax.get("roll"))
     return c, axis
 
@@ -242,6 +246,7 @@ class TraceJob:
         self.geom_clock = None
         self.filters = []          # HaloFilter table; HaloEntry.filter_id is a 1-based index into it
         self.color_sets, self.color_classes, self.color_meta, self.color_mode = [], [], [], "painter"   # raypath_color
+        self.warnings = []         # what the reference CLI logs as warnings about a document it still runs
 
     def per_wavelength_ray_num(self):
         """ceil(ray_num / N_wl) — server/ray_num_semantics.hpp:13-17."""
@@ -300,7 +305,8 @@ def load_config(source):
     layers = []
     for li, jl in enumerate(js["scattering"]):
         if "prob" not in jl:
-            raise ConfigError('scene.scattering[%d] is missing required field "prob"' % li)
+            raise ConfigError('scene.scattering[%d] is missing required field "prob" (multi-scattering probability). The historical default '
+                              'was 0.0; add "prob": 0 explicitly to keep that behavior.' % li)   # config_manager.cpp:108-112: the text IS the migration guidance
         entries = []
         for je in jl["entries"]:
             cid = int(je["crystal"])
@@ -320,6 +326,10 @@ def load_config(source):
         layers.append((float(jl["prob"]), entries))
     if len(layers) > abi.MAX_LAYERS or any(len(e) > abi.MAX_ENTRIES for _, e in layers):
         raise UnsupportedConfig("more scattering layers / entries than the backend's caps")
+    job.warnings = []
+    if layers and layers[-1][0] > 0.0:   # WarnOnLastLayerProb, main.cpp:60-90
+        job.warnings.append("Last scattering layer has prob=%.4f > 0: that fraction of filter-pass rays will be discarded (no next layer to receive "
+                            "them). Set the last layer's prob to 0 unless this is intentional." % layers[-1][0])
     job.scene = scenes.scene(layers, max_hits=max_hits, sun_altitude=float(ls["altitude"]),
                              sun_azimuth=float(ls.get("azimuth", 0.0)), sun_diameter=float(ls.get("diameter", 0.0)))
     if "raypath_color" in doc and doc["raypath_color"]:

@@ -272,3 +272,45 @@ def test_cli_output_directory_contract_of_the_reference(tmp_path):
     res = tuple(E2E_DOCS["painter_default_overlap"]["render"][0]["resolution"])
     for name in ("img_01.png", "img_01_components.png"):
         assert (out / name).exists() and (out / name).stat().st_size > 0 and Image.open(out / name).size == res
+
+
+# ---- what the reference's CLI tests say about rejected and warned-about documents (test/e2e-correctness/test_cli.py:145-345) -------------
+def test_config_errors_carry_the_references_migration_guidance():
+    """Derived from a real reference document (halo_22.json), each differing from the working one in exactly one deleted key, like the
+    reference's tests: a missing `prob` names the layer, the field and the write-up that keeps the old behaviour; an axis slot without
+    `type` names the crystal, the slot and both legal spellings; an `axis` without `zenith` is rejected."""
+    from ice_halo_sim_amd import config
+    base = E2E_DOCS["halo_22"]
+    assert "prob" in base["scene"]["scattering"][0] and "type" in base["crystal"][0]["axis"]["zenith"] and "type" in base["crystal"][0]["axis"]["azimuth"]
+    config.load_config(copy.deepcopy(base))
+    doc = copy.deepcopy(base)
+    del doc["scene"]["scattering"][0]["prob"]
+    with pytest.raises(config.ConfigError) as e:
+        config.load_config(doc)
+    for part in ("scattering[0]", "prob", '"prob": 0'):          # TestScatteringProbRequired.test_error_message_is_actionable
+        assert part in str(e.value)
+    for slot in ("zenith", "azimuth"):                            # TestAxisSlotTypeRequired.test_cli_rejects_axis_slot_without_type
+        doc = copy.deepcopy(base)
+        del doc["crystal"][0]["axis"][slot]["type"]
+        with pytest.raises(config.ConfigError) as e:
+            config.load_config(doc)
+        for part in ("crystal[id=1]", "axis." + slot, '"%s": 20' % slot, '"type": "gauss"'):   # ...test_error_message_is_actionable
+            assert part in str(e.value), (part, str(e.value))
+    doc = copy.deepcopy(base)
+    del doc["crystal"][0]["axis"]["zenith"]
+    with pytest.raises(config.ConfigError) as e:                  # test_cli_rejects_axis_without_zenith / test_missing_zenith_message_is_actionable
+        config.load_config(doc)
+    assert "crystal[id=1]" in str(e.value) and "zenith" in str(e.value)
+    doc = copy.deepcopy(base)
+    doc["crystal"][0]["shape"]["height"] = {"mean": 1.2, "std": 0.1}            # the backstop in from_json(Distribution&): shape scalars too
+    with pytest.raises(config.ConfigError) as e:
+        config.load_config(doc)
+    assert '"type"' in str(e.value)
+
+
+def test_last_layer_prob_warning_like_the_reference_cli():
+    """TestLastLayerProbWarning: parity_single_ms_bd_filter.json has last-layer prob 0.5 (warned), halo_22.json 0.0 (silent)."""
+    from ice_halo_sim_amd import config
+    warned = config.load_config(E2E_DOCS["parity_single_ms_bd_filter"]).warnings
+    assert len(warned) == 1 and warned[0].startswith("Last scattering layer has prob=0.5000")
+    assert config.load_config(E2E_DOCS["halo_22"]).warnings == []
