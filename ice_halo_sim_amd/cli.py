@@ -87,7 +87,11 @@ def write_image(path, rgb, fmt, quality):
 def save_all_renders(job, args):
     """`-f cfg -o dir [--format png] [--quality q]`: what the reference CLI leaves in the output directory (SaveRenderResults /
     SaveCompositeResults, main.cpp:251-315): img_<id>.<fmt> per render entry, img_<id>_components.<fmt> with raypath_color."""
-    os.makedirs(args.output_dir, exist_ok=True)
+    if not os.path.isdir(args.output_dir):   # the reference fails on an output directory that does not exist (test_errors.py: nonexistent output dir)
+        print("Error: output directory does not exist: %s" % args.output_dir, file=sys.stderr)
+        return 2
+    if not job.renders:
+        raise config.ConfigError("config has no render entry")
     rc = 0
     for rid in sorted(job.renders):
         try:

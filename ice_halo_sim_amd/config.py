@@ -261,9 +261,27 @@ def load_config(source):
     else:
         text = source
         if not text.lstrip().startswith("{"):
-            with open(source) as f:
-                text = f.read()
-        doc = json.loads(text)
+            try:
+                with open(source) as f:
+                    text = f.read()
+            except OSError as e:
+                raise ConfigError("cannot read config file %s: %s" % (source, e.strerror or e))
+        try:
+            doc = json.loads(text)
+        except ValueError as e:
+            raise ConfigError("config is not valid JSON: %s" % e)
+    if not isinstance(doc, dict):
+        raise ConfigError("config root must be a JSON object")
+    for key in ("crystal", "scene", "render"):   # from_json(ConfigManager) reads all three with .at() (config_manager.cpp:170-231): a document without one fails
+        if key not in doc:
+            raise ConfigError('config is missing required section "%s"' % key)
+    try:
+        return _load_document(doc)
+    except (KeyError, TypeError, IndexError) as e:   # a required key the sections' own parsers read with .at()
+        raise ConfigError("config is missing or mistypes a required field: %s: %s" % (type(e).__name__, e))
+
+
+def _load_document(doc):
     crystals = {}
     for jc in doc["crystal"]:
         try:

@@ -314,3 +314,45 @@ def test_last_layer_prob_warning_like_the_reference_cli():
     warned = config.load_config(E2E_DOCS["parity_single_ms_bd_filter"]).warnings
     assert len(warned) == 1 and warned[0].startswith("Last scattering layer has prob=0.5000")
     assert config.load_config(E2E_DOCS["halo_22"]).warnings == []
+
+
+def test_cli_fails_gracefully_like_the_reference(tmp_path):
+    """test/regression-sentinel/test_errors.py: a nonexistent config, invalid JSON, documents missing `scene` / `render` / `crystal` (the
+    reference's own error fixtures, restated — each a few lines), a nonexistent output directory, an unknown option: non-zero exit, a
+    message, no traceback.  None of these reaches the GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = {"light_source": {"type": "sun", "altitude": 20.0, "spectrum": "E"}, "ray_num": 1000, "max_hits": 3,
+             "scattering": [{"prob": 0.0, "entries": [{"crystal": 1, "proportion": 1}]}]}
+    crystal = [{"id": 1, "type": "prism", "shape": {"height": 1.2}}]
+    render = [{"id": 1, "lens": {"type": "linear", "fov": 80}, "resolution": [64, 64]}]
+    docs = {"missing_crystal": {"filter": [], "scene": scene, "render": render},
+            "missing_render": {"crystal": crystal, "filter": [], "scene": scene},
+            "missing_scene": {"crystal": crystal, "filter": [], "render": render}}
+    cases = [(["-f", "nonexistent_file_that_does_not_exist.json"], "nonexistent config"), (["-z"], "unknown option")]
+    bad = tmp_path / "invalid_json.json"
+    bad.write_text("{bad json syntax here\n")
+    cases.append((["-f", str(bad)], "invalid JSON"))
+    for name, doc in docs.items():
+        f = tmp_path / (name + ".json")
+        f.write_text(json.dumps(doc))
+        cases.append((["-f", str(f), "-o", str(tmp_path)], name))
+    ok = tmp_path / "halo_22.json"
+    ok.write_text(json.dumps(E2E_DOCS["halo_22"]))
+    cases.append((["-f", str(ok), "-o", "/nonexistent/path/that/does/not/exist"], "nonexistent output dir"))
+    cases.append((["-f", str(ok), "-o", str(tmp_path), "--format", "bmp"], "invalid format"))        # test_cli.py:113-143
+    cases.append((["-f", str(ok), "-o", str(tmp_path), "--quality", "0"], "quality out of range"))
+    cases.append((["-f", str(ok), "-o", str(tmp_path), "--quality", "abc"], "quality not a number"))
+    cases.append((["-f", str(ok), "-o", str(tmp_path), "--quality"], "quality without a value"))
+    for args, what in cases:
+        r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli"] + args, capture_output=True, text=True, cwd=root)
+        assert r.returncode > 0, what
+        assert "Traceback" not in r.stderr, (what, r.stderr)
+        assert (r.stderr + r.stdout).strip(), what
+    assert not list(tmp_path.glob("img_*"))
+    r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli", "-h"], capture_output=True, text=True, cwd=root)   # test_help_flag
+    assert r.returncode == 0 and "usage:" in r.stdout.lower()
+    r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli"], capture_output=True, text=True, cwd=root)         # test_no_args
+    assert r.returncode != 0
