@@ -258,6 +258,7 @@ def test_cli_output_directory_contract_of_the_reference(tmp_path):
         cfg = tmp_path / (name + ".json")
         cfg.write_text(json.dumps(E2E_DOCS[name]))
         out = tmp_path / ("out_" + name)
+        out.mkdir()                                               # like the reference, the CLI does not create the output directory
         r = subprocess.run([sys.executable, "-m", "ice_halo_sim_amd.cli", "-f", str(cfg), "-o", str(out)] + list(extra), capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout + r.stderr
         return out, r.stdout
