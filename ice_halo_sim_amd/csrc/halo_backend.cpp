@@ -98,6 +98,7 @@ struct HaloBackend {
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int gen_serial = 0;          // 1: pyramids are generated one thread per crystal (the serial builder) instead of one team of 32 lanes
+  int lazy_fold = 1;           // the closing fold of a session waits for the first READER of the image (or a session with other planes) when the accumulator is the backend's own
   int hit_log = -1;            // hit-log accumulation of cache misses: -1 auto (one-plane sessions, launches >= 2 Mi rays), 0 off, 1 on
   uint32_t hit_log_cap = 0;    // test knob: records per log region (0 = sized from the launch); the tile lists then get half their even share
   int hex_fast = 1;            // 1: regular hexagonal prisms of one-shape dispatches run the literal-normal next-face search
@@ -260,6 +261,7 @@ const host::LatLut& cached_lut(HaloBackend* b, const HaloDist& d) {
 
 extern "C" {
 
+static int fold_if_dirty(HaloBackend* b);
 int halo_abi_version(void) { return HALO_ABI_VERSION; }
 
 int halo_device_count(void) {
@@ -384,8 +386,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     b->shuffle_chunk_log2 = 0;
     while ((1ll << b->shuffle_chunk_log2) < v) b->shuffle_chunk_log2++;
   }
+  else if (k == "lazy_fold") b->lazy_fold = v ? 1 : 0;
   else if (k == "mono_copies") {
-    if (b->mono_dirty) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
+    if (b->in_session) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
+    if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions may still wait for their fold (lazy_fold)
     int c = 1;
     while (c < v && c < 64) c <<= 1;
     if (c != b->mono_copies) b->mono.release();
@@ -418,6 +422,7 @@ int halo_set_stream(halo_handle_t b, void* s) {
 int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) {
   if (!b) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "bind_accumulator inside a session");
+  if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions belong to the accumulator they were traced for
   if (!device_ptr) {
     b->acc = b->acc_own.ptr;
     b->acc_floats = b->acc_own.cap;
@@ -445,7 +450,6 @@ int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) 
   return HALO_OK;
 }
 
-static int fold_if_dirty(HaloBackend* b);
 
 int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render, const HaloWl* wl, uint64_t ray_num) {
   if (!b || !scene || !render || !wl) return HALO_FATAL;
@@ -472,10 +476,6 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->render = *render;
   b->wl = *wl;
   b->proj = host::BuildProj(*render);
-  int rc = fold_if_dirty(b);  // a session that was never ended still owes its plane to the accumulator (old layout)
-  if (rc != HALO_OK) return rc;
-  rc = ensure_accumulator(b, render->width, render->height);
-  if (rc != HALO_OK) return rc;
   std::vector<WlEntryDev> pool = host::BuildWlPool(*wl);
   b->wl_pool_size = static_cast<uint32_t>(pool.size());
   if (pool.empty() || pool.size() > HALO_WL_POOL_MAX) return fail(b, HALO_FATAL, "wavelength pool size out of range");
@@ -501,10 +501,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   // takes <= 4 Ki-slot tiles x 512, scalar planes 16 Ki-slot tiles x 256.  A session the log cannot serve keeps the routes it had before
   // (one plane per pool entry + binned lists; privatised copies for the direct atomics).
   const bool log_xyz_fits = s_log2 <= 11u, log_mono_fits = s_log2 <= 12u;
-  b->xyz_log = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > HALO_XYZ_LOG_MIN_PIX && log_xyz_fits;
-  b->mono_by_wl = b->mono_enabled && !discrete && !b->xyz_log && npix <= (1u << 23) && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
-  b->mono_session = b->mono_enabled && (discrete || b->mono_by_wl);
-  b->plane_cnt = b->mono_by_wl ? static_cast<uint32_t>(pool.size()) : (b->mono_session ? 1u : 3u);
+  // (the layout is worked out in locals first: whether the planes of earlier sessions must be folded before this one starts depends on it)
+  const bool xyz_log_n = b->mono_enabled && !discrete && b->lambda_planes < 0 && b->hit_log != 0 && ray_num >= (2ull << 20) && npix > HALO_XYZ_LOG_MIN_PIX && log_xyz_fits;
+  const bool mono_by_wl_n = b->mono_enabled && !discrete && !xyz_log_n && npix <= (1u << 23) && (b->lambda_planes < 0 ? ray_num >= (8ull << 20) : b->lambda_planes != 0);
+  const bool mono_session_n = b->mono_enabled && (discrete || mono_by_wl_n);
+  const uint32_t plane_cnt_n = mono_by_wl_n ? static_cast<uint32_t>(pool.size()) : (mono_session_n ? 1u : 3u);
   // privatised copies spread the direct atomics of hot pixels; per-entry planes spread them already, and a session whose
   // launches all go through the hit log (copy 0 only) would just make the closing fold read seven empty copies
   // ("all" cannot be known here: a layer's rays are dealt out to its crystal entries, and an entry's launch under 2 Mi rays adds directly.
@@ -514,20 +515,42 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   for (int l = 0; l < scene->layer_count; l++) one_entry_layers = one_entry_layers && scene->layers[l].entry_count == 1;
   const bool fast_scene = plain_scene || (!b->capture && b->filter_fast && scene->max_hits <= 16);   // (a dispatch whose tables do not fit the fast form still adds directly: copy 0 only, correct, slower)
   const bool all_logged = fast_scene && one_entry_layers && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (2ull << 20) &&
-                          (discrete ? log_mono_fits : b->xyz_log) && (b->mono_session || b->xyz_log);
-  b->plane_copies = (b->mono_by_wl || all_logged) ? 1u : static_cast<uint32_t>(b->mono_copies);
-  b->plane_coef.clear();
-  for (uint32_t m = 0; m < b->plane_cnt; m++) {
-    if (b->mono_session) b->plane_coef.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
-    else b->plane_coef.push_back({m == 0 ? 1.0f : 0.0f, m == 1 ? 1.0f : 0.0f, m == 2 ? 1.0f : 0.0f});
+                          (discrete ? log_mono_fits : xyz_log_n) && (mono_session_n || xyz_log_n);
+  const uint32_t plane_copies_n = (mono_by_wl_n || all_logged) ? 1u : static_cast<uint32_t>(b->mono_copies);
+  std::vector<std::array<float, 3>> coef_n;
+  for (uint32_t m = 0; m < plane_cnt_n; m++) {
+    if (mono_session_n) coef_n.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
+    else coef_n.push_back({m == 0 ? 1.0f : 0.0f, m == 1 ? 1.0f : 0.0f, m == 2 ? 1.0f : 0.0f});
   }
+  {
+    // Planes that earlier sessions left unfolded (lazy_fold: halo_end of a session on the backend's own accumulator does not fold) stay as
+    // they are when this session adds to the SAME planes with the SAME coefficients — a server that sends one wavelength's rays as many small
+    // sessions (Lumice's CUDA-route dispatch is 2^18 rays, server.cpp:151) then pays one fold per readback instead of one per session (22 us
+    // of a 0.15 ms session at 1920x1080 x 8 copies).  Anything else — another wavelength, image size, plane count or copy count — is folded
+    // now, with the members still describing the old planes.
+    const bool same_planes = b->mono_dirty && b->lazy_fold && b->acc != nullptr && b->acc == b->acc_own.ptr && b->acc_w == render->width &&
+                             b->acc_h == render->height && b->mono_s_log2 == s_log2 && b->plane_cnt == plane_cnt_n && b->plane_copies == plane_copies_n &&
+                             b->plane_coef == coef_n;
+    if (!same_planes) {
+      int rc = fold_if_dirty(b);  // also: a session that was never ended still owes its plane to the accumulator (old layout)
+      if (rc != HALO_OK) return rc;
+    }
+    int rc = ensure_accumulator(b, render->width, render->height);
+    if (rc != HALO_OK) return rc;
+  }
+  b->xyz_log = xyz_log_n;
+  b->mono_by_wl = mono_by_wl_n;
+  b->mono_session = mono_session_n;
+  b->plane_cnt = plane_cnt_n;
+  b->plane_copies = plane_copies_n;
+  b->plane_coef = coef_n;
   {
     const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
     if (b->mono.cap < need) {
       HIPCHK(b, b->mono.reserve(need));
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
     }
-    b->mono_s_log2 = s_log2;  // planes are all-zero between sessions, so the layout may change freely
+    b->mono_s_log2 = s_log2;  // planes are all-zero whenever the layout changes (folded above), so it may change freely
     // the twin: as many doubles as the planes have floats (16.8 MB at configs[1]; a 64-plane session on 2048x1024 takes 1 GB), kept all-zero
     // between sessions like the planes; sessions whose planes pass 512 Mi floats go without (their overflow stays on the fp32 plane)
     if (b->ovf.cap < b->mono.cap && b->mono.cap <= (512ull << 20) && b->ovf.reserve(b->mono.cap) == hipSuccess) {
@@ -590,7 +613,11 @@ static int fold_if_dirty(HaloBackend* b) {
 
 int halo_end(halo_handle_t b) {
   if (!b) return HALO_FATAL;
-  int rc = fold_if_dirty(b);  // a discrete-wavelength session closes by applying its CMF to the scalar plane
+  // a session closes by folding its planes into the XYZ image (a discrete wavelength's CMF applied to the scalar plane) — at once when the image
+  // is the caller's memory (halo_bind_accumulator: the caller reads it without asking), otherwise when somebody reads it (every reader folds
+  // first) or a session with other planes begins
+  int rc = HALO_OK;
+  if (!(b->lazy_fold && b->acc != nullptr && b->acc == b->acc_own.ptr)) rc = fold_if_dirty(b);
   b->in_session = false;
   return rc;
 }
@@ -631,8 +658,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch, a long tail is paid per
     // round of resident workgroups: aim at >= 32 passes of the ray loop per workgroup, between 4 and blocks_per_cu per CU
     // (measured: 1 M rays 0.27 -> 0.20 ms at 4/CU; 50 M rays 4.02 -> 3.67 ms at 24/CU instead of 8/CU)
+    // Small launches — a Lumice server that keeps its CUDA-route dispatch of 2^18 rays per session (server.cpp:151) sends nothing else — are
+    // all fixed cost: one workgroup per CU up to 3 x 2^17 rays, two up to 2^22 (tools/dispatch_size_probe.py, wall per session at
+    // 1 / 2 / 4 per CU: 2^17 rays 0.127 / 0.150 / 0.150 ms, 2^18 0.146 / 0.159 / 0.222, 2^19 0.182 / 0.178 / 0.226, 2^20 0.259 / 0.225 / 0.258,
+    // 2^21 0.340 / 0.272 / 0.303, 2^22 0.570 / 0.390 / 0.380)
     const uint64_t want = m / (static_cast<uint64_t>(kBlock) * 32u);
-    const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, 4));
+    const int small_k = m <= (3ull << 17) ? 1 : (m < (1ull << 22) ? 2 : 4);
+    const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, small_k));
     const uint64_t cap = std::min<uint64_t>(static_cast<uint64_t>(max_blocks), std::max<uint64_t>(lo_cap, want));
     return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, cap));
   };

@@ -13,11 +13,12 @@ from tests._oracle_backend import run_session  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 only = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+opts = dict(kv.split("=") for kv in sys.argv[3:])   # backend options, e.g. blocks_per_cu=2
 sc, rd = scenes.config2_scene(), scenes.config2_render()
 wl = scenes.wl_discrete(550.0)
 for mode in (0, 1):
-    hb = HipTraceBackend(device=0, seed=42, **{"async": mode})
-    for log2 in ([only] if only else (16, 18, 20, 22, 24)):
+    hb = HipTraceBackend(device=0, seed=42, **dict({"async": mode}, **{k: int(v) for k, v in opts.items()}))
+    for log2 in ([only] if only else ((16, 18, 20, 22, 24) if not os.environ.get('PROBE_SIZES') else [int(v) for v in os.environ['PROBE_SIZES'].split(',')])):
         n = 1 << log2
         k = max(3, reps >> max(0, log2 - 18))
         for rep in range(2):

@@ -34,13 +34,16 @@ def run(label, sc, rd, wl, n):
     v = dump(True)
     hb.close()
     tot = max(v[11], 1)
-    print("%s: %d rays, kernels %.3f ms" % (label, n, sum(s.kernel_ms for s in st)))
+    print("%s: %d rays, kernels %.3f ms; wave-resident cycles per wave %.0f" % (label, n, sum(s.kernel_ms for s in st), tot / max(1, (n + 63) // 64 if n < (1 << 21) else 1)))
     for k in list(range(11)) + [12, 13]:
         print("   %-28s %6.2f %%" % (NAMES[k], 100.0 * v[k] / tot))
     print("   %-28s %6.2f %%   (loop overhead, stamps, divergence waits)" % ("unattributed", 100.0 * (tot - sum(v[:11]) - v[12] - v[13]) / tot))
 
 
 which = sys.argv[1:] or ["cfg1"]
+if "small" in which:   # one pass per workgroup: what a session of the reference's default GPU dispatch (2^18 rays, server.cpp:151) spends where
+    run("configs[1] 550 nm, 2^18 rays", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 1 << 18)
+    run("configs[1] 550 nm, 2^20 rays", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 1 << 20)
 if "cfg1" in which:
     run("configs[1] 550 nm", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 20_000_000)
 if "ms" in which:
