@@ -589,3 +589,34 @@ def test_panorama_of_two_to_the_25_pixels(spectrum):
     with pytest.raises(BackendUnavailableError):
         hb.BeginSession(sc, scenes.render(abi.LENS_RECTANGULAR, 8192, 4097, fov=360.0, el=0.0, visible=abi.VISIBLE_FULL), wl, n)
     hb.close()
+
+
+def test_many_small_sessions_fold_once_and_equal_the_eager_fold():
+    """A server that sends a wavelength's rays as many small sessions (Lumice's CUDA-route dispatch: 2^18 rays per session, server.cpp:151): with
+    the backend's own accumulator the closing fold waits for the first reader (option lazy_fold, the default) — the planes of equal sessions
+    add up, a session with OTHER planes (another wavelength, another image size) folds what is pending first.  Whatever the order of folds,
+    the image is the one the eager fold gives (same rays; only the float summation order differs)."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    sc = scenes.config2_scene()
+    wls = [scenes.wl_discrete(w) for w in (450.0, 450.0, 450.0, 610.0, 610.0, 450.0)]
+    sizes = [(480, 270)] * 5 + [(256, 128)]
+    out = {}
+    for lazy in (1, 0):
+        hb = HipTraceBackend(device=0, seed=11, lazy_fold=lazy)
+        imgs = []
+        for k, (wl, (w, h)) in enumerate(zip(wls, sizes)):
+            rd = scenes.config2_render(w, h)
+            if k == 5:
+                imgs.append(hb.ReadbackXyzAccum(480, 270))     # the 480x270 image, before the size changes
+            run_session(hb, sc, rd, wl, 1 << 18)
+        imgs.append(hb.ReadbackXyzAccum(256, 128))
+        out[lazy] = imgs
+        hb.close()
+    for (a, la), (b, lb) in zip(out[1], out[0]):
+        assert la == pytest.approx(lb, rel=1e-12)
+        assert a.sum(dtype=np.float64) == pytest.approx(b.sum(dtype=np.float64), rel=2e-6)
+        assert np.abs(a - b).max() <= 2e-5 * max(float(b.max()), 1e-30)
+    # the colours of the two wavelengths are both there (a fold with the wrong CMF would tint everything one way)
+    big = out[1][0][0]
+    assert big[..., 2].sum() > 0.2 * big[..., 1].sum() and big[..., 0].sum() > 0.2 * big[..., 1].sum()
