@@ -120,6 +120,17 @@ class HipTraceBackend {
   }
   // RenderConsumer on the device (server/render.cpp:138-330)
   void ConsumeDeviceFused() { Check(halo_consumer_fold(h_)); }
+  // CompositeColorClassesLinear + LinearRgbToSrgbU8 (server/component_compositor.cpp:180-303) on the device lanes, which stay; returns what the
+  // reference's function returns (false: nothing referenced, or no energy in the participating lanes); either output may be null
+  bool CompositeColorClasses(const HaloComposite& spec, float* linear_rgb_out, uint8_t* srgb_out, float* participating_p99_y = nullptr) {
+    int32_t produced = 0;
+    Check(halo_consumer_composite(h_, &spec, linear_rgb_out, srgb_out, participating_p99_y, &produced));
+    return produced != 0;
+  }
+  // lanes summed elsewhere (other ranks, a saved consumer) become this consumer's lanes; total_intensity < 0 keeps the consumer's own
+  void LoadClassLanes(const float* lanes, int width, int height, int class_count, double total_intensity = -1.0) {
+    Check(halo_consumer_load_lanes(h_, lanes, width, height, class_count, total_intensity));
+  }
   double Snapshot(const HaloDisplay& display, uint8_t* rgb_out, float* xyz_out = nullptr) {
     double total = 0.0;
     Check(halo_consumer_snapshot(h_, &display, rgb_out, xyz_out, &total));

@@ -103,6 +103,29 @@ int main() {
     for (uint8_t v : rgb) mx = v > mx ? v : mx;
     std::printf("consumer: total intensity %.3f max rgb %u\n", total, mx);
     ok = ok && total > 0.0 && mx > 0;
+    // the class composite of the same consumer (one class, white, painter): a lit pixel is lit in the composite, its three channels equal
+    {
+      HaloComposite comp = {};
+      comp.mode = HALO_COMPOSITE_PAINTER;
+      comp.display_exposure_scale = 1.0f;
+      comp.intensity_factor = 1.0f;
+      comp.class_count = 1;
+      comp.classes[0].color[0] = comp.classes[0].color[1] = comp.classes[0].color[2] = 1.0f;
+      comp.classes[0].visible = 1;
+      std::vector<float> lin(rgb.size());
+      std::vector<uint8_t> srgb(rgb.size());
+      float p99 = -1.0f;
+      const bool produced = be.CompositeColorClasses(comp, lin.data(), srgb.data(), &p99);
+      size_t lit = 0, grey = 0;
+      for (size_t i = 0; i < lin.size(); i += 3)
+        if (lin[i] > 0.0f) {
+          lit++;
+          grey += (lin[i] == lin[i + 1] && lin[i] == lin[i + 2] && srgb[i] == srgb[i + 2]) ? 1u : 0u;
+        }
+      std::printf("composite: produced %d P99 %.4g lit %zu grey %zu mode(bogus)=%d\n", produced ? 1 : 0, p99, lit, grey, halo_host_parse_composite_mode("bogus"));
+      ok = ok && produced && p99 > 0.0f && lit > 100 && grey == lit && halo_host_parse_composite_mode("bogus") == HALO_COMPOSITE_PAINTER &&
+           halo_host_parse_composite_mode("dominant") == HALO_COMPOSITE_DOMINANT;
+    }
 
     // multi-GPU drain from C++: a one-rank RCCL communicator — the reduce is the identity, the call path
     // (lazy dlopen of librccl, ncclReduce on the backend's stream) is what is exercised here
