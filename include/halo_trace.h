@@ -270,7 +270,11 @@ const char* halo_last_error(halo_handle_t h);
  * per-entry planes nor the X/Y/Z log; 1 = always per-entry planes),
  * "host_shapes" (1 = build stochastic shape pools on the host and upload them; default 0 = device generator),
  * "blocks_per_cu" (cap on workgroups per CU of one launch, default 24; launches are sized for >= 32 ray-loop passes per
- * workgroup below that cap),
+ * workgroup below that cap; small launches take one workgroup per CU up to 3 x 2^17 rays and two up to 2^22),
+ * "lazy_fold" (1 [default]: halo_end of a session on the backend's OWN accumulator leaves its planes unfolded; every reader of the
+ * image — readback, consumer fold, reduce, take_landed, bind — folds first, and so does halo_begin of a session with other planes
+ * (wavelength, image size, plane or copy count): many small equal sessions cost one fold per readback; an accumulator bound with
+ * halo_bind_accumulator is always folded at halo_end, its owner reads it without asking; 0: fold at every halo_end),
  * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
  * same builder the host runs; records are bit-identical either way, A/B knob),
  * "hit_log" (-1 [default]: production-mode launches >= 2 Mi rays on one scalar plane, or on the X/Y/Z planes of an illuminant
