@@ -29,5 +29,5 @@ def test_adapter_compiles_and_reports_unavailable_without_gpu():
 @pytest.mark.gpu
 def test_adapter_runs_a_session_on_the_gpu():
     _build()   # always: a binary that travelled with the snapshot may predate the header
-    r = subprocess.run([EXE], capture_output=True, text=True)
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)   # (a hang must fail this test, not stall the suite)
     assert r.returncode == 0, r.stdout + r.stderr
