@@ -98,6 +98,7 @@ struct HaloBackend {
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int gen_serial = 0;          // 1: pyramids are generated one thread per crystal (the serial builder) instead of one team of 32 lanes
+  int blocks_cap = 0;          // experiment knob: absolute cap on the workgroups of one launch (0 = none)
   int lazy_fold = 1;           // the closing fold of a session waits for the first READER of the image (or a session with other planes) when the accumulator is the backend's own
   int hit_log = -1;            // hit-log accumulation of cache misses: -1 auto (one-plane sessions, launches >= 2 Mi rays), 0 off, 1 on
   uint32_t hit_log_cap = 0;    // test knob: records per log region (0 = sized from the launch); the tile lists then get half their even share
@@ -387,6 +388,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     while ((1ll << b->shuffle_chunk_log2) < v) b->shuffle_chunk_log2++;
   }
   else if (k == "lazy_fold") b->lazy_fold = v ? 1 : 0;
+  else if (k == "blocks_cap") b->blocks_cap = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "mono_copies") {
     if (b->in_session) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
     if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions may still wait for their fold (lazy_fold)
@@ -666,7 +668,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     const int small_k = m <= (3ull << 17) ? 1 : (m < (1ull << 22) ? 2 : 4);
     const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, small_k));
     const uint64_t cap = std::min<uint64_t>(static_cast<uint64_t>(max_blocks), std::max<uint64_t>(lo_cap, want));
-    return static_cast<int>(std::min<uint64_t>((m + kBlock - 1) / kBlock, cap));
+    uint64_t nb = std::min<uint64_t>((m + kBlock - 1) / kBlock, cap);
+    if (b->blocks_cap > 0) nb = std::min<uint64_t>(nb, static_cast<uint64_t>(b->blocks_cap));
+    return static_cast<int>(nb);
   };
 
   // continuation output pool: kContShards regions; a region must hold everything its blocks can emit over the layer's
