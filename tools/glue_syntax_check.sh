@@ -3,11 +3,11 @@
 # a `patch`.  What this is: a syntax / type check of OUR two files against the reference's real headers.  What this is not: a build of the
 # reference, an oracle, or anything that ships — the third-party headers the image lacks (nlohmann/json.hpp >= 3.4, spdlog) are replaced by
 # empty throw-away stubs in a scratch directory, which is enough for -fsyntax-only of a header that touches neither, and pins nothing.
-#   tools/glue_syntax_check.sh [reference checkout, default /root/reference]      output: profiles/r04_glue_syntax_check.txt
+#   tools/glue_syntax_check.sh [reference checkout, default /root/reference]      output: profiles/r05_glue_syntax_check.txt
 set -uo pipefail
 REF=${1:-/root/reference}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/profiles/r04_glue_syntax_check.txt
+OUT=$ROOT/profiles/r05_glue_syntax_check.txt
 W=$(mktemp -d)
 trap 'rm -rf "$W"' EXIT
 mkdir -p "$W/stub/nlohmann" "$W/stub/spdlog/sinks"
@@ -41,6 +41,12 @@ struct json {
   static json object() { return json{}; }
   const json* begin() const { return nullptr; }
   const json* end() const { return nullptr; }
+  struct exception : std::exception { int id = 0; };
+  struct out_of_range : exception {};
+  struct parse_error : exception {};
+  struct type_error : exception {};
+  static json parse(const std::string&) { return json{}; }
+  std::string dump(int = -1) const { return {}; }
 };
 }  // namespace nlohmann
 #define NLOHMANN_JSON_SERIALIZE_ENUM(ENUM_TYPE, ...)                  \
@@ -121,4 +127,22 @@ cp "$ROOT/integration/hip_backend_glue.hpp" "$W/inc/core/backend/"
   mkdir -p "$W/tree" && cp -r "$REF/src" "$REF/CMakeLists.txt" "$W/tree/" 2>/dev/null
   [ -d "$REF/include" ] && cp -r "$REF/include" "$W/tree/"
   (cd "$W/tree" && patch -p1 --dry-run < "$ROOT/integration/lumice_hip_backend.patch") 2>&1 && echo "patch: applies cleanly" || echo "patch: does NOT apply cleanly"
+  echo
+  echo "# (3) the patched src/server/server.cpp (dispatch default: kDefaultHipDispatchRayNum behind IsHipRoute) through g++ -fsyntax-only -DLUMICE_HIP_ENABLED=1"
+  (cd "$W/tree" && patch -p1 -s < "$ROOT/integration/lumice_hip_backend.patch") >/dev/null 2>&1
+  if g++ -std=c++17 -fsyntax-only -DLUMICE_HIP_ENABLED=1 -I"$W/inc" -I"$W/stub" -I"$W/tree/src" -I"$ROOT/ice_halo_sim_amd/csrc" -I"$ROOT/include" "$W/tree/src/server/server.cpp" 2>&1 | head -30; then :; fi
+  g++ -std=c++17 -fsyntax-only -DLUMICE_HIP_ENABLED=1 -I"$W/inc" -I"$W/stub" -I"$W/tree/src" -I"$ROOT/ice_halo_sim_amd/csrc" -I"$ROOT/include" "$W/tree/src/server/server.cpp" >/dev/null 2>&1 \
+    && echo "server.cpp (patched, HIP enabled): syntax check PASSED" || echo "server.cpp (patched, HIP enabled): syntax check FAILED"
+  grep -n "kDefaultHipDispatchRayNum\|kIsHipRoute" "$W/tree/src/server/server.cpp"
+  echo
+  echo "# (4) the patched src/core/simulator.cpp (both CreateBackend sites construct HipBackendGlue) and src/server/c_api.cpp the same way"
+  cp "$ROOT/integration/hip_backend_glue.hpp" "$W/tree/src/core/backend/"
+  for f in core/simulator.cpp; do
+    if g++ -std=c++17 -fsyntax-only -DLUMICE_HIP_ENABLED=1 -I"$W/stub" -I"$W/tree/src" -I"$ROOT/ice_halo_sim_amd/csrc" -I"$ROOT/include" "$W/tree/src/$f" >"$W/err.txt" 2>&1; then
+      echo "$f (patched, HIP enabled): syntax check PASSED"
+    else
+      grep "error" "$W/err.txt" | head -20
+      echo "$f (patched, HIP enabled): syntax check FAILED"
+    fi
+  done
 } | sed "s#$W#<scratch>#g" | tee "$OUT"

@@ -86,6 +86,43 @@ def server(t):
   }
 #endif
 ''')
+    # the dispatch default (server.cpp:1449-1457): without this a kHip route would inherit Metal's 32768 rays per dispatch, a
+    # twentieth of this engine's rate (profiles/r05_dispatch_size.txt).  The route test below repeats ResolveGpuRoute's precedence
+    # (env override first, then preferred_backend) so that a build with CUDA and HIP both enabled tells the two apart.
+    t = after(t, "static constexpr size_t kDefaultCudaDispatchRayNum = 262144;", '''  // MI355X engine (libhalo_hip): a session costs ~60 us of fixed work whatever its size and the trace kernel needs ~2^22 rays to
+  // fill 256 CUs; 2^24 rays per dispatch is ~85 % of the plateau at <1 ms per dispatch, so UI commit cadence is unaffected.
+  static constexpr size_t kDefaultHipDispatchRayNum = size_t{1} << 24;
+''')
+    t = before(t, "ServerImpl::ServerImpl(int num_workers, uint32_t sim_seed, BackendKind preferred_backend)", '''#if defined(LUMICE_HIP_ENABLED)
+// True when the GPU route ResolveGpuRoute answered for is the HIP engine: same precedence (LUMICE_TRACE_BACKEND, then
+// preferred_backend), so a build that enables CUDA and HIP side by side still sizes each route's dispatch by its own default.
+bool IsHipRoute(BackendKind preferred_backend, Logger& logger) {
+  if (std::optional<std::string> override = env::TraceBackendOverride(logger)) {
+    if (*override == "hip") {
+      return halo_device_count() > 0;
+    }
+    if (*override == "cpu_backend" || *override == "legacy" || *override == "metal" || *override == "cuda") {
+      return false;
+    }
+  }
+  return preferred_backend == BackendKind::kHip && halo_device_count() > 0;
+}
+#endif
+
+''')
+    t = t.replace('''#if defined(LUMICE_CUDA_ENABLED) && !defined(__APPLE__)
+  const bool kIsCudaRoute = kGpuRoute;
+#else''', '''#if defined(LUMICE_HIP_ENABLED)
+  const bool kIsHipRoute = kGpuRoute && IsHipRoute(kPref, logger_);
+#else
+  const bool kIsHipRoute = false;
+#endif
+#if defined(LUMICE_CUDA_ENABLED) && !defined(__APPLE__)
+  const bool kIsCudaRoute = kGpuRoute && !kIsHipRoute;
+#else''')
+    t = t.replace("  const size_t kDefaultDispatch = kIsCudaRoute ? kDefaultCudaDispatchRayNum :\n",
+                  "  const size_t kDefaultDispatch = kIsHipRoute  ? kDefaultHipDispatchRayNum :\n                                  kIsCudaRoute ? kDefaultCudaDispatchRayNum :\n")
+    assert "kIsHipRoute  ? kDefaultHipDispatchRayNum" in t and "kIsCudaRoute = kGpuRoute && !kIsHipRoute" in t
     return t
 
 
