@@ -2,8 +2,8 @@
 """bench.py — rays/s of the MI355X trace hot path on BASELINE.json's workloads.
 
   python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4p|ref:<name>] [--repeats R] [--scaling weak|strong]
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, RCCL).  One "step" = one pass of the hot path over one batch of the selected configuration:
+N > 1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL);
+started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the file launches those N ranks itself (self_launch).  One "step" = one pass of the hot path over one batch of the selected configuration:
 
   --config 1 (default, BASELINE `metric`)  configs[1]: single-scatter hex column (examples/config_example.json crystal 3),
              9 wavelengths x 50 M root rays, fisheye_equal_area 1920x1080 -> 450 M root rays per GPU per step
@@ -568,6 +568,26 @@ def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
 OTHER_CONFIGS = ("2", "4", "4p") + tuple("ref:" + n for n in REF_SCENES) + ("ref:config_example",)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <a free port> bench.py <same arguments>`) and return its exit code.  Under
+    RCCL every rank needs its own device, so fewer visible devices than N is refused here, before any rank starts (HALO_BENCH_BACKEND=gloo
+    lets ranks share devices: the rehearsal of the N > 1 path on a one-GPU box)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("HALO_BENCH_BACKEND", "nccl") == "nccl" and have < n:
+        sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible (one rank per GPU under RCCL)\n" % (n, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,9 +610,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run, this
+        # process only relays rank 0's JSON line and the exit code
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
     # HALO_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box); default RCCL

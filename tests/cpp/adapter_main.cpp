@@ -139,21 +139,44 @@ int main() {
       void* comm = nullptr;
       const int dev0 = 0;
       if (init_all && destroy && init_all(&comm, 1, &dev0) == 0) {
-        be.SetOption("async", 0);
-        be.SetFilters({});
-        be.SetColor({}, {});
+        // two fresh backends, same seed, QUEUED sessions (async): one reads its image back directly, the other goes through
+        // halo_reduce_accumulator first.  A one-rank sum is the identity, so the images must agree — which also shows the
+        // collective ran in stream order behind the still-queued trace and the deferred fold, not beside them.
         sc.layers[0].entries[0].filter_id = 0;
         sc.layers[0].entries[0].color_id = 0;
-        be.BeginSession(sc, rd, wl, n);
-        be.TraceLayer(n);
-        be.EndSession();
-        be.ReduceAccumulator(comm, 0, 0);
-        float landed3 = 0.0f;
-        be.ReadbackXyzAccum(xyz, landed3);
+        const size_t big = 3u << 20;   // the production (hit log) route
+        std::vector<float> img_a(img.size()), img_b(img.size());
+        float landed_a = 0.0f, landed_b = 0.0f;
+        {
+          halo::HipTraceBackend a(0, 7);
+          a.SetOption("async", 1);
+          a.BeginSession(sc, rd, wl, big);
+          a.TraceLayer(big);
+          a.EndSession();
+          halo::XyzImageData xa{img_a.data(), rd.width, rd.height};
+          a.ReadbackXyzAccum(xa, landed_a);
+        }
+        {
+          halo::HipTraceBackend b(0, 7);
+          b.SetOption("async", 1);
+          b.BeginSession(sc, rd, wl, big);
+          b.TraceLayer(big);
+          b.EndSession();
+          b.ReduceAccumulator(comm, 0, 0);
+          halo::XyzImageData xb{img_b.data(), rd.width, rd.height};
+          b.ReadbackXyzAccum(xb, landed_b);
+        }
         double y3 = 0.0;
-        for (size_t i = 1; i < img.size(); i += 3) y3 += img[i];
-        std::printf("rccl one-rank reduce: landed %.3f sumY %.3f\n", landed3, y3);
-        ok = ok && landed3 > 0.4f * n && std::fabs(y3 / (0.995 * landed3) - 1.0) < 0.02;
+        for (size_t i = 1; i < img_b.size(); i += 3) y3 += img_b[i];
+        // (same rays, but the workgroup pixel caches add in LDS in whatever order the waves arrive: equal to float rounding, not bitwise)
+        double d2 = 0.0, n2 = 0.0;
+        for (size_t i = 0; i < img_a.size(); i++) {
+          d2 += (double(img_a[i]) - img_b[i]) * (double(img_a[i]) - img_b[i]);
+          n2 += double(img_a[i]) * img_a[i];
+        }
+        const bool same = n2 > 0.0 && std::sqrt(d2 / n2) < 1e-6 && std::fabs(landed_a / landed_b - 1.0) < 1e-6;
+        std::printf("rccl one-rank reduce: landed %.3f sumY %.3f image_unchanged %d\n", landed_b, y3, same ? 1 : 0);
+        ok = ok && same && landed_b > 0.4f * big && std::fabs(y3 / (0.995 * landed_b) - 1.0) < 0.02;
         destroy(comm);
       } else {
         std::printf("rccl not loadable here: reduce path skipped\n");

@@ -31,3 +31,6 @@ def test_adapter_runs_a_session_on_the_gpu():
     _build()   # always: a binary that travelled with the snapshot may predate the header
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)   # (a hang must fail this test, not stall the suite)
     assert r.returncode == 0, r.stdout + r.stderr
+    # the native multi-GPU drain (halo_reduce_accumulator: lazy dlopen of librccl, ncclReduce on the backend's stream) must have RUN,
+    # on a one-rank communicator, and left the root's image as it was
+    assert "rccl one-rank reduce:" in r.stdout and "image_unchanged 1" in r.stdout, r.stdout

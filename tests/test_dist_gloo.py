@@ -218,3 +218,21 @@ def test_world2_class_lanes_reduce_and_one_composite_on_the_root(tmp_path):
     parts = [oracle_composite(l, w, cls, "painter", 1.0, 1.0) for l, w in ((l0, w0), (l1, w1))]
     assert all(p[0] for p in parts) and min(parts[0][3], parts[1][3]) < p99
     assert np.abs(parts[0][1] + parts[1][1] - whole).max() > 0.05
+
+
+def test_bench_self_launch_starts_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset becomes the launcher (bench.self_launch).  Without a GPU the ranks refuse to run —
+    the product has no CPU path — and the launcher must hand that failure back; under RCCL it must refuse before starting anything."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU half is tests/test_gpu_dist.py::test_bench_launches_its_own_ranks_when_started_plainly")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, HALO_BENCH_BACKEND="nccl"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "only 0 HIP device(s) visible" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, HALO_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-1500:]      # both ranks started, both said why

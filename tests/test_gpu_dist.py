@@ -118,3 +118,23 @@ def test_two_ranks_composite_their_summed_lanes_once_on_the_root(tmp_path):
     ok, want, _, want_p99 = oracle_composite(lanes[0] + lanes[1], landed[0] + landed[1], cls, "painter", 1.0, 1.0)
     assert ok and want_p99 == p99
     assert np.array_equal(lin.reshape(-1, 3), want)
+
+
+# ---- `python bench.py --gpus N` started WITHOUT a launcher must launch its own ranks (round-4 review: it used to SystemExit) -------------
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HALO_BENCH_BACKEND"] = "gloo"            # two ranks on this box's one device; the driver's 8-GPU run is the same code over RCCL
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--repeats", "1",
+                        "--rays-per-wl", "3000000", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rays_per_step_per_gpu"] == 9 * 3_000_000
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and mg["backend"] == "gloo"
+    assert all(mg["check"][k] for k in ("rank_images_differ", "rank_energies_within_1pct", "reduced_image_is_the_sum", "nonroot_ranks_drained"))
