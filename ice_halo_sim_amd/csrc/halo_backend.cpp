@@ -98,6 +98,7 @@ struct HaloBackend {
   int blocks_per_cu = 24;      // cap on workgroups per CU of a launch (5 resident: several rounds even out the tail)
   int host_shapes = 0;         // 1: stochastic shape pools are built on the host and uploaded (A/B and test path)
   int gen_serial = 0;          // 1: pyramids are generated one thread per crystal (the serial builder) instead of one team of 32 lanes
+  int small_blocks_per_cu = 0; // experiment knob: workgroups per CU that a small launch may spread over (0 = five, see blocks_of)
   int blocks_cap = 0;          // experiment knob: absolute cap on the workgroups of one launch (0 = none)
   int lazy_fold = 1;           // the closing fold of a session waits for the first READER of the image (or a session with other planes) when the accumulator is the backend's own
   int hit_log = -1;            // hit-log accumulation of cache misses: -1 auto (one-plane sessions, launches >= 2 Mi rays), 0 off, 1 on
@@ -151,16 +152,32 @@ struct HaloBackend {
   DevBuf<uint32_t> comp_hist;            // radix-select histogram (2048 bins)
   int cons_w = 0, cons_h = 0;
   double total_intensity = 0.0;
-  DevBuf<double> sums;         // [kSumLanded] persistent landed-weight tally
+  DevBuf<double> tally;        // kTallyLines x kTallyStride doubles, [kSum*] per line: CUMULATIVE tallies of every kernel this backend ever launched
+  double* tally_host = nullptr;       // hipHostMalloc, one snapshot of `tally`
+  double tally_seen[kSumNum] = {};    // cumulative values already handed on: [kSumLanded] to a readback / take_landed, the rest to the layer statistics
+  bool tally_unread = false;          // a dispatch has been queued since the statistics were last pulled
   DevBuf<uint32_t> counters;   // kCntNum
   // dispatch ring: device slots, pinned host mirrors, pinned tally read-back, per-slot events
   static constexpr int kRing = 32;
   DevBuf<DispatchSlot> ring_dev;
   DispatchSlot* ring_host = nullptr;   // hipHostMalloc
-  double* ring_result = nullptr;       // hipHostMalloc, kRing x 4
   hipEvent_t ring_ev0[kRing] = {}, ring_ev1[kRing] = {}, ring_done[kRing] = {};
   bool ring_busy[kRing] = {};
   int ring_next = 0;
+  // Table cache (round 5): the dispatch-constant tables of a deterministic crystal entry (latitude LUT, wavelength pool, shape, entry-pick
+  // tables, filter / colour tables) stay on the device from one dispatch to the next while scene, wavelength, filters, colour and options
+  // are what they were — a server that sends one wavelength's rays as many equal small sessions (and every chunk of a long layer) then
+  // pays neither the host-side builds (closed-form geometry, LUT, predicate tables) nor the 25-49 KB copy per dispatch.
+  struct TableCacheEntry {
+    bool valid = false;
+    int mode = 0;
+    bool use_filter = false, use_color = false, entry_fast = false, hex_regular = false, has_fast = false;
+  };
+  TableCacheEntry tcache[HALO_MAX_LAYERS][HALO_MAX_ENTRIES];
+  DevBuf<DispatchSlot> tcache_dev;     // HALO_MAX_LAYERS x HALO_MAX_ENTRIES slots, reserved on first use
+  HaloScene tcache_scene{};            // what the valid entries were built for
+  HaloWl tcache_wl{};
+  int table_cache = 1;                 // option: 0 uploads the tables with every dispatch (round 4 behaviour)
   HaloLayerStats pending{};    // harvested tallies not yet handed to the caller (async mode)
   HaloLayerStats layer_acc{};  // tallies of the layer being traced
   std::vector<WlEntryDev> wl_pool_host;
@@ -181,7 +198,6 @@ struct HaloBackend {
   DevBuf<float> host_f;        // injected rays: d | p | w
   DevBuf<uint32_t> host_u;
   uint64_t sess_crystal_samples = 0, sess_orient_samples = 0;  // this session's stochastic draws (halo_last_sample_counts)
-  double landed_host = 0.0;    // landed weight already folded from `sums` (kept in fp64 on the host)
 };
 
 namespace {
@@ -215,7 +231,6 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
     HIPCHK(b, hipMemsetAsync(b->acc_own.ptr, 0, need * sizeof(float), b->stream));
     b->own_w = w;
     b->own_h = h;
-    b->landed_host = 0.0;
   }
   b->acc_w = w;
   b->acc_h = h;
@@ -224,19 +239,48 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
   return HALO_OK;
 }
 
-// take the tallies of one finished ring slot
+// take the timing of one finished ring slot (the tallies are cumulative device counters: pull_tally)
 void harvest_slot(HaloBackend* b, int k) {
   if (!b->ring_busy[k]) return;
   (void)hipEventSynchronize(b->ring_done[k]);
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
-  const double* r = b->ring_result + 4 * k;
-  b->layer_acc.exit_w_sum += r[kSumExitW];
-  b->layer_acc.exit_count += static_cast<uint64_t>(r[kSumExitN] + 0.5);
-  b->layer_acc.pixel_hits += static_cast<uint64_t>(r[kSumPixN] + 0.5);
   b->layer_acc.kernel_ms += ms;
   b->layer_acc.launches += 1;
   b->ring_busy[k] = false;
+}
+// Snapshot of the cumulative tallies (one 1 KB D2H copy + a stream sync): the sum over the lines, per tally.
+int read_tally(HaloBackend* b, double out[kSumNum]) {
+  HIPCHK(b, hipMemcpyAsync(b->tally_host, b->tally.ptr, kTallyLines * kTallyStride * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  for (int t = 0; t < kSumNum; t++) {
+    double v = 0.0;
+    for (uint32_t l = 0; l < kTallyLines; l++) v += b->tally_host[l * kTallyStride + static_cast<uint32_t>(t)];
+    out[t] = v;
+  }
+  return HALO_OK;
+}
+// What the kernels have tallied since the statistics were last pulled goes to layer_acc (exit weight, exit count, pixel hits).
+int pull_tally(HaloBackend* b) {
+  if (!b->tally_unread) return HALO_OK;
+  double now[kSumNum];
+  int rc = read_tally(b, now);
+  if (rc != HALO_OK) return rc;
+  b->layer_acc.exit_w_sum += now[kSumExitW] - b->tally_seen[kSumExitW];
+  b->layer_acc.exit_count += static_cast<uint64_t>(now[kSumExitN] - b->tally_seen[kSumExitN] + 0.5);
+  b->layer_acc.pixel_hits += static_cast<uint64_t>(now[kSumPixN] - b->tally_seen[kSumPixN] + 0.5);
+  for (int t : {kSumExitW, kSumExitN, kSumPixN}) b->tally_seen[t] = now[t];
+  b->tally_unread = false;
+  return HALO_OK;
+}
+// The landed weight since the last taker (readback, take_landed, consumer fold).
+int take_landed_delta(HaloBackend* b, double* landed) {
+  double now[kSumNum];
+  int rc = read_tally(b, now);
+  if (rc != HALO_OK) return rc;
+  *landed = now[kSumLanded] - b->tally_seen[kSumLanded];
+  b->tally_seen[kSumLanded] = now[kSumLanded];
+  return HALO_OK;
 }
 void harvest_all(HaloBackend* b) {
   for (int k = 0; k < HaloBackend::kRing; k++) harvest_slot(b, k);
@@ -249,6 +293,10 @@ void add_stats(HaloLayerStats& dst, const HaloLayerStats& src) {
   dst.kernel_ms += src.kernel_ms;
   dst.pixel_hits += src.pixel_hits;
   dst.launches += src.launches;
+}
+void drop_table_cache(HaloBackend* b) {
+  for (auto& layer : b->tcache)
+    for (auto& e : layer) e.valid = false;
 }
 const host::LatLut& cached_lut(HaloBackend* b, const HaloDist& d) {
   for (const auto& e : b->lut_cache)
@@ -289,7 +337,7 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
   }
   bool ring_ok = b->ring_dev.reserve(HaloBackend::kRing) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&b->ring_host), HaloBackend::kRing * sizeof(DispatchSlot), hipHostMallocDefault) == hipSuccess &&
-                 hipHostMalloc(reinterpret_cast<void**>(&b->ring_result), HaloBackend::kRing * 4 * sizeof(double), hipHostMallocDefault) == hipSuccess;
+                 hipHostMalloc(reinterpret_cast<void**>(&b->tally_host), kTallyLines * kTallyStride * sizeof(double), hipHostMallocDefault) == hipSuccess;
   for (int k = 0; ring_ok && k < HaloBackend::kRing; k++)
     ring_ok = hipEventCreate(&b->ring_ev0[k]) == hipSuccess && hipEventCreate(&b->ring_ev1[k]) == hipSuccess &&
               hipEventCreateWithFlags(&b->ring_done[k], hipEventDisableTiming) == hipSuccess;
@@ -298,11 +346,11 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
     return HALO_UNAVAILABLE;
   }
   b->stream = b->own_stream;
-  if (b->sums.reserve(kSumNum) != hipSuccess || b->counters.reserve(kCntNum) != hipSuccess) {
+  if (b->tally.reserve(kTallyLines * kTallyStride) != hipSuccess || b->counters.reserve(kCntNum) != hipSuccess) {
     halo_destroy(b);  // releases the stream, the ring, the pinned mirrors and the events as well
     return HALO_UNAVAILABLE;
   }
-  (void)hipMemsetAsync(b->sums.ptr, 0, kSumNum * sizeof(double), b->stream);
+  (void)hipMemsetAsync(b->tally.ptr, 0, kTallyLines * kTallyStride * sizeof(double), b->stream);
   (void)hipMemsetAsync(b->counters.ptr, 0, kCntNum * sizeof(uint32_t), b->stream);
   *out = b;
   return HALO_OK;
@@ -313,7 +361,7 @@ int halo_destroy(halo_handle_t b) {
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
   b->acc_own.release();
-  b->sums.release();
+  b->tally.release();
   b->mono.release();
   b->ovf.release();
   b->ovf_flag.release();
@@ -327,8 +375,9 @@ int halo_destroy(halo_handle_t b) {
   b->comp_hist.release();
   b->counters.release();
   b->ring_dev.release();
+  b->tcache_dev.release();
   if (b->ring_host) (void)hipHostFree(b->ring_host);
-  if (b->ring_result) (void)hipHostFree(b->ring_result);
+  if (b->tally_host) (void)hipHostFree(b->tally_host);
   for (int k = 0; k < HaloBackend::kRing; k++) {
     if (b->ring_ev0[k]) (void)hipEventDestroy(b->ring_ev0[k]);
     if (b->ring_ev1[k]) (void)hipEventDestroy(b->ring_ev1[k]);
@@ -356,6 +405,7 @@ const char* halo_last_error(halo_handle_t b) { return b ? b->error.c_str() : "nu
 int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (!b || !key) return HALO_FATAL;
   const std::string k(key);
+  drop_table_cache(b);   // (whatever the option: most of them shape the tables or the kernels that read them)
   // the session's plane layout (privatised copies, hit-log eligibility) was decided at halo_begin from these two: changing them with a session
   // open would send direct atomics to a layout made for another route
   if ((k == "capture_exits" || k == "filter_fast") && b->in_session) return fail(b, HALO_FATAL, k + " cannot change inside a session");
@@ -388,6 +438,8 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     while ((1ll << b->shuffle_chunk_log2) < v) b->shuffle_chunk_log2++;
   }
   else if (k == "lazy_fold") b->lazy_fold = v ? 1 : 0;
+  else if (k == "table_cache") b->table_cache = v ? 1 : 0;
+  else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "blocks_cap") b->blocks_cap = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "mono_copies") {
     if (b->in_session) return fail(b, HALO_FATAL, "mono_copies cannot change while a session's plane is pending");
@@ -432,7 +484,6 @@ int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) 
   }
   b->acc = static_cast<float*>(device_ptr);
   b->acc_floats = n_floats;
-  b->landed_host = 0.0;
   return HALO_OK;
 }
 
@@ -449,6 +500,7 @@ int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) 
     }
   }
   b->filters.assign(filters, filters + count);
+  drop_table_cache(b);
   return HALO_OK;
 }
 
@@ -474,6 +526,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     }
   }
   HIPCHK(b, hipSetDevice(b->device));
+  if (std::memcmp(&b->tcache_scene, scene, sizeof(HaloScene)) != 0 || std::memcmp(&b->tcache_wl, wl, sizeof(HaloWl)) != 0) {
+    drop_table_cache(b);   // another scene or wavelength: the cached tables are not this session's
+    b->tcache_scene = *scene;
+    b->tcache_wl = *wl;
+  }
   b->scene = *scene;
   b->render = *render;
   b->wl = *wl;
@@ -660,12 +717,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch, a long tail is paid per
     // round of resident workgroups: aim at >= 32 passes of the ray loop per workgroup, between 4 and blocks_per_cu per CU
     // (measured: 1 M rays 0.27 -> 0.20 ms at 4/CU; 50 M rays 4.02 -> 3.67 ms at 24/CU instead of 8/CU)
-    // Small launches — a Lumice server that keeps its CUDA-route dispatch of 2^18 rays per session (server.cpp:151) sends nothing else — are
-    // all fixed cost: one workgroup per CU up to 3 x 2^17 rays, two up to 2^22 (tools/dispatch_size_probe.py, wall per session at
-    // 1 / 2 / 4 per CU: 2^17 rays 0.127 / 0.150 / 0.150 ms, 2^18 0.146 / 0.159 / 0.222, 2^19 0.182 / 0.178 / 0.226, 2^20 0.259 / 0.225 / 0.258,
-    // 2^21 0.340 / 0.272 / 0.303, 2^22 0.570 / 0.390 / 0.380)
+    // Small launches — a Lumice server that keeps a GPU route's small dispatch (2^15 .. 2^18 rays per session, server.cpp:140-151) sends nothing
+    // else — are latency: one pass of the ray loop is ~11 us on a wave that has its SIMD to itself, so they spread over as many workgroups as
+    // a CU holds (five) before a workgroup takes a second pass.  (Round 4 had found the opposite — one per CU best — while every WAVE ended
+    // with four same-line fp64 atomics; with those gone, tools/dispatch_probe.cpp, us per session at 1 / 2 / 3 / 4 / 5 / 8 per CU:
+    // 2^18 rays 67 / 50 / 45 / 44 / 43 / 44, 2^20 188 / 133 / 122 / 115 / 110 / 111, 2^22 326 / 326 / 276 / 261 / 250 / 259.)
     const uint64_t want = m / (static_cast<uint64_t>(kBlock) * 32u);
-    const int small_k = m <= (3ull << 17) ? 1 : (m < (1ull << 22) ? 2 : 4);
+    const int small_k = b->small_blocks_per_cu > 0 ? b->small_blocks_per_cu : 5;
     const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, small_k));
     const uint64_t cap = std::min<uint64_t>(static_cast<uint64_t>(max_blocks), std::max<uint64_t>(lo_cap, want));
     uint64_t nb = std::min<uint64_t>((m + kBlock - 1) / kBlock, cap);
@@ -702,6 +760,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   const bool defer = b->async && final_layer && !b->capture;  // nothing the caller needs before the next call
   if (!defer) {  // earlier queued dispatches go to `pending`, so layer_acc ends up holding this layer alone
     harvest_all(b);
+    if (int rc = pull_tally(b)) return rc;   // (a copy + sync only when something was queued and never collected)
     add_stats(b->pending, b->layer_acc);
     b->layer_acc = HaloLayerStats{};
   }
@@ -791,14 +850,26 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.log_xyz = 0u;
     P.log_plane_stride = 0u;
     P.bin_shift = 0u;
-    P.landed = b->sums.ptr + kSumLanded;
+    P.tally = b->tally.ptr;
     P.exits = b->exits.ptr;
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
     P.aggregate = static_cast<uint32_t>(b->aggregate);
     P.geom_clock = b->geom_clock;
+    const bool deterministic = host::IsDeterministic(E.crystal);
+    // the entry's tables may still be on the device from an earlier dispatch (table cache, see HaloBackend::TableCacheEntry)
+    HaloBackend::TableCacheEntry* ce = (b->table_cache && deterministic && P.source != kSrcTransit) ? &b->tcache[layer][ci] : nullptr;
+    if (ce && !b->tcache_dev.ptr) {
+      if (b->tcache_dev.reserve(static_cast<size_t>(HALO_MAX_LAYERS) * HALO_MAX_ENTRIES) != hipSuccess) {
+        (void)hipGetLastError();
+        ce = nullptr;   // no room for the cache: every dispatch uploads its tables
+      }
+    }
+    DispatchSlot* const ce_dev = ce ? b->tcache_dev.ptr + (static_cast<size_t>(layer) * HALO_MAX_ENTRIES + static_cast<size_t>(ci)) : nullptr;
+    bool cached = ce && ce->valid;
     FilterDev fd{};
     bool use_filter = false;
-    if (E.filter_id > 0) {
+    if (cached) use_filter = ce->use_filter;
+    else if (E.filter_id > 0) {
       fd = host::BuildFilter(b->filters[static_cast<size_t>(E.filter_id - 1)], E.axis);
       use_filter = fd.is_complex || fd.terms[0].type != HALO_FILTER_NONE || fd.action != 0;
     }
@@ -806,7 +877,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // raypath colour: this entry's predicates (canonicalised like filter terms, each with its own symmetry) + the classes
     ColorDev cd{};
     const bool use_color = !b->color_classes.empty();
-    if (use_color) {
+    if (use_color && !cached) {
       cd.class_cnt = static_cast<uint32_t>(b->color_classes.size());
       for (uint32_t c = 0; c < cd.class_cnt; c++) {
         cd.class_bits[c] = b->color_classes[c].bits;
@@ -832,7 +903,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // Which kernels: capture (tests) > filter / colour in their fast form (paths <= 16 faces, tables fit) > the generic filter kernels > plain
     int mode = 0;
     FastTables* fast_host = nullptr;
-    if (b->capture) mode = 2;
+    if (cached) mode = ce->mode;
+    else if (b->capture) mode = 2;
     else if (use_filter || use_color) {
       mode = 3;
       if (b->filter_fast && b->scene.max_hits <= 16) {
@@ -852,7 +924,6 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
     const bool fast_mode = mode == 0 || mode == 1 || mode == 4;   // production-shaped kernels: exit queue, hit log, regular-prism search
 
-    const bool deterministic = host::IsDeterministic(E.crystal);
     // chunked launches: bounds the host-built shape pool for stochastic geometry and keeps n_rays < 2^32
     for (uint64_t off = 0; off < n_ci;) {
       const uint64_t m = chunk_of(n_ci - off, E.crystal);
@@ -860,7 +931,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const bool host_pool = !deterministic && b->host_shapes;
       // 0 = one shape per dispatch, 1 = pool of ShapeDev records, 2 = pool of ShapePrism records (device-generated prisms)
       const int geom = deterministic ? 0 : ((E.crystal.kind == HALO_CRYSTAL_PRISM && !host_pool) ? 2 : 1);
-      std::vector<ShapeDev> pool(deterministic || host_pool ? shape_cnt : 0u);
+      std::vector<ShapeDev> pool((deterministic && !cached) || host_pool ? shape_cnt : 0u);
       for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++)
         host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
       const uint64_t first_shape = b->shape_count;
@@ -875,34 +946,43 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->ring_next = (k + 1) % HaloBackend::kRing;
       harvest_slot(b, k);  // blocks only if the ring has wrapped onto a dispatch still in flight
       DispatchSlot& hs = b->ring_host[k];
-      DispatchSlot* ds = b->ring_dev.ptr + k;
-      if (P.lat_path == kLatLut) {
-        const host::LatLut& lut = cached_lut(b, E.axis.latitude);
-        std::copy(lut.theta.begin(), lut.theta.end(), hs.lut);
-        std::copy(lut.cdf.begin(), lut.cdf.end(), hs.lut + kLutNodes);
-        std::copy(lut.flip.begin(), lut.flip.end(), hs.lut + 2 * kLutNodes);
+      DispatchSlot* ds = ce ? ce_dev : b->ring_dev.ptr + k;
+      bool entry_fast = false, hex_regular = false, has_fast = fast_host != nullptr;
+      if (cached) {
+        entry_fast = ce->entry_fast, hex_regular = ce->hex_regular, has_fast = ce->has_fast;
+      } else {
+        if (P.lat_path == kLatLut) {
+          const host::LatLut& lut = cached_lut(b, E.axis.latitude);
+          std::copy(lut.theta.begin(), lut.theta.end(), hs.lut);
+          std::copy(lut.cdf.begin(), lut.cdf.end(), hs.lut + kLutNodes);
+          std::copy(lut.flip.begin(), lut.flip.end(), hs.lut + 2 * kLutNodes);
+        }
+        std::copy(b->wl_pool_host.begin(), b->wl_pool_host.end(), hs.wl);
+        if (deterministic) {
+          hs.shape = pool[0];
+          entry_fast = b->entry_fast && host::BuildEntryFast(pool[0], hs.efast);
+          hex_regular = entry_fast && hs.efast.hex_regular;
+        }
+        if (use_filter) hs.filter = fd;
+        if (use_color) hs.color = cd;
+        if (fast_host) std::memcpy(&hs.fast, fast_host, sizeof(FastTables));
+        if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
+        // (the fast filter tables are the slot's last member and travel only with the dispatches that use them; the pinned mirror is this
+        // ring slot's, so it stays as it is until the copy has run — harvest_slot above)
+        HIPCHK(b, hipMemcpyAsync(ds, &hs, fast_host ? sizeof(DispatchSlot) : offsetof(DispatchSlot, fast), hipMemcpyHostToDevice, b->stream));
+        if (ce) {   // the next dispatch of this entry — the layer's next chunk, the next equal session — finds the tables in place
+          ce->valid = true, ce->mode = mode, ce->use_filter = use_filter, ce->use_color = use_color;
+          ce->entry_fast = entry_fast, ce->hex_regular = hex_regular, ce->has_fast = has_fast;
+          cached = true;
+        }
       }
-      std::copy(b->wl_pool_host.begin(), b->wl_pool_host.end(), hs.wl);
-      bool entry_fast = false;
-      if (deterministic) {
-        hs.shape = pool[0];
-        entry_fast = b->entry_fast && host::BuildEntryFast(pool[0], hs.efast);
-      }
-      if (use_filter) hs.filter = fd;
-      if (use_color) hs.color = cd;
-      if (fast_host) std::memcpy(&hs.fast, fast_host, sizeof(FastTables));
-      for (double& v : hs.sums) v = 0.0;
-      if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
-      // (the fast filter tables are the slot's last member and travel only with the dispatches that use them)
-      HIPCHK(b, hipMemcpyAsync(ds, &hs, fast_host ? sizeof(DispatchSlot) : offsetof(DispatchSlot, fast), hipMemcpyHostToDevice, b->stream));
       P.lut = ds->lut;
       P.wl_pool = ds->wl;
       P.filter = use_filter ? &ds->filter : nullptr;
       P.color = use_color ? &ds->color : nullptr;
-      P.fast = fast_host ? &ds->fast : nullptr;
+      P.fast = has_fast ? &ds->fast : nullptr;
       P.lanes = b->lanes.ptr;
       P.lane_stride = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
-      P.sums = ds->sums;
       P.cont_in_seg = ds->seg;
       P.entry_fast = entry_fast ? &ds->efast : nullptr;
       if (deterministic) {
@@ -1064,7 +1144,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       P.no_land = (P.prob >= 1.0f && !P.final_layer && fast_mode && b->aggregate == 1) ? 1u : 0u;
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
-      const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hs.efast.hex_regular) ? 3 : geom;
+      const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hex_regular) ? 3 : geom;
       hipError_t le = launch_trace(P, blocks, b->stream, mode, launch_geom, b->mono_session);
       b->mono_dirty = true;
       b->route.launches++;
@@ -1109,7 +1189,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));
-      HIPCHK(b, hipMemcpyAsync(b->ring_result + 4 * k, ds->sums, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+      b->tally_unread = true;
       HIPCHK(b, hipEventRecord(b->ring_done[k], b->stream));
       b->ring_busy[k] = true;
       if (host_pool) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy
@@ -1133,7 +1213,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   std::vector<uint32_t> fill(final_layer ? 0 : kContShards * kContCntStride);
   HIPCHK(b, hipMemcpyAsync(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost, b->stream));
   if (!final_layer) HIPCHK(b, hipMemcpyAsync(fill.data(), b->cont_cnt.ptr, fill.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
+  if (b->tally_unread) {
+    if (int rc = pull_tally(b)) return rc;   // (one more small copy and THE stream sync of this call: the two copies above are complete behind it)
+  } else {
+    HIPCHK(b, hipStreamSynchronize(b->stream));
+  }
   harvest_all(b);
   uint64_t n_cont = 0;
   if (!final_layer) {  // the next layer addresses the pool through the prefix of the shard fill counts
@@ -1209,6 +1293,7 @@ int halo_set_color(halo_handle_t b, const HaloColorSet* sets, int n_sets, const 
   }
   b->color_sets.assign(sets, sets + n_sets);
   b->color_classes.assign(classes, classes + n_classes);
+  drop_table_cache(b);
   return HALO_OK;
 }
 
@@ -1269,6 +1354,7 @@ int halo_collect_stats(halo_handle_t b, HaloLayerStats* out) {
   HIPCHK(b, hipSetDevice(b->device));
   HIPCHK(b, hipStreamSynchronize(b->stream));
   harvest_all(b);
+  if (int rc = pull_tally(b)) return rc;
   add_stats(b->pending, b->layer_acc);
   b->layer_acc = HaloLayerStats{};
   *out = b->pending;
@@ -1331,10 +1417,7 @@ int halo_take_landed(halo_handle_t b, double* landed) {
     int rc = fold_if_dirty(b);
     if (rc != HALO_OK) return rc;
   }
-  HIPCHK(b, hipMemcpyAsync(landed, b->sums.ptr, sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
-  return HALO_OK;
+  return take_landed_delta(b, landed);
 }
 
 int halo_readback_xyz64(halo_handle_t b, float* xyz, int width, int height, double* landed) {
@@ -1346,13 +1429,11 @@ int halo_readback_xyz64(halo_handle_t b, float* xyz, int width, int height, doub
     if (rc != HALO_OK) return rc;
   }
   const size_t n = static_cast<size_t>(width) * height * 3;
-  double s[kSumNum];
   HIPCHK(b, hipMemcpyAsync(xyz, b->acc, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipMemcpyAsync(s, b->sums.ptr, sizeof(s), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(b, hipMemsetAsync(b->acc, 0, (n + 4) * sizeof(float), b->stream));  // readback ZEROES the accumulator (cu:4832-4846)
-  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
-  if (landed) *landed = s[kSumLanded];
+  double l = 0.0;
+  if (int rc = take_landed_delta(b, &l)) return rc;   // (syncs the stream: the image copy above is complete behind it)
+  if (landed) *landed = l;
   return HALO_OK;
 }
 
@@ -1396,9 +1477,7 @@ int halo_consumer_fold(halo_handle_t b) {
   hipError_t e = launch_consumer_fold(b->acc, b->cons_sum.ptr, b->cons_comp.ptr, static_cast<uint32_t>(n), b->cu_count * 8, b->stream);
   if (e != hipSuccess) return hip_fail(b, e, "halo_consumer_fold_kernel launch");
   double landed = 0.0;
-  HIPCHK(b, hipMemcpyAsync(&landed, b->sums.ptr, sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipMemsetAsync(b->sums.ptr, 0, sizeof(double), b->stream));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
+  if (int rc = take_landed_delta(b, &landed)) return rc;
   b->total_intensity += landed;  // total_intensity_ += xyz_landed_weight_ (render.cpp:149)
   return HALO_OK;
 }

@@ -224,7 +224,6 @@ struct DispatchSlot {
   alignas(16) WlEntryDev wl[HALO_WL_POOL_MAX + 1];
   alignas(16) ShapeDev shape;
   alignas(16) FilterDev filter;
-  alignas(16) double sums[4];
   alignas(16) uint32_t seg[kContShards + 4];
   alignas(16) ColorDev color;
   alignas(16) EntryFastDev efast;
@@ -305,8 +304,8 @@ struct DispatchParams {
                                // in ONE plane | CMF code << kLogWlShift, and the per-tile pass applies the code's CMF row
   uint32_t log_plane_stride;   // ... floats between the X, Y and Z planes (fallback atomics of a full log)
   uint32_t no_land;            // 1: production-mode layer with prob >= 1 that is not the last — every exit continues, nothing reaches the image
-  double* sums;                // per-dispatch tallies: [1] exit weight sum, [2] exit count, [3] pixel hits (as double)
-  double* landed;              // persistent landed-weight tally (until readback / take_landed)
+  double* tally;               // kTallyLines lines of kTallyStride doubles, [kSum*] in each: landed weight, exit weight sum, exit count, pixel hits —
+                               // cumulative over the backend's life (the host reads differences); a workgroup adds to line blockIdx % kTallyLines
   HaloExitRecord* exits;
   uint32_t exit_cap;
   uint32_t aggregate;          // 0 plain atomics | 1 LDS pixel cache | 2 diagnostic: no accumulation
@@ -352,6 +351,7 @@ inline uint32_t MonoSlot(uint32_t pix, uint32_t s_log2) {
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };
 enum { kSumLanded = 0, kSumExitW = 1, kSumExitN = 2, kSumPixN = 3, kSumNum = 4 };
+constexpr uint32_t kTallyLines = 16u, kTallyStride = 8u;   // 64-byte lines: same-line fp64 atomics serialise memory-side (~12 ns each)
 
 }  // namespace halo
 

@@ -37,7 +37,7 @@ namespace halo {
 __device__ unsigned long long g_halo_probe[16];
 struct Probe {
   uint64_t t0;
-  uint32_t acc[14];
+  uint32_t acc[16];
 };
 HD void probe_start(Probe& pr) {
   __builtin_amdgcn_sched_barrier(0);
@@ -58,7 +58,7 @@ struct Probe {};
 #define PROBE_MARK(pr, K) ((void)0)
 #endif
 enum { kPhStream = 0, kPhOrient = 1, kPhRotation = 2, kPhSun = 3, kPhEntry = 4, kPhFresnel = 5, kPhEmitGate = 6, kPhProject = 7,
-       kPhAccum = 8, kPhSlab = 9, kPhKernelFixed = 10, kPhTotal = 11, kPhStage = 12, kPhFlush = 13 };
+       kPhAccum = 8, kPhSlab = 9, kPhKernelFixed = 10, kPhTotal = 11, kPhStage = 12, kPhFlush = 13, kPhPrologue = 14, kPhFinalDrain = 15 };
 
 constexpr float kPiF = 3.14159265358979323846f;   // LM_PI_F  (lm_shims.h:84)
 constexpr float kPi2F = 1.5707963267948966f;      // LM_PI_2F (lm_shims.h:85)
@@ -2012,7 +2012,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   static_assert(!BIN || MONO, "binned accumulation is a one-plane mode");
   Probe pr;
 #ifdef HALO_PROBE
-  for (int k = 0; k < 14; k++) pr.acc[k] = 0u;
+  for (int k = 0; k < 16; k++) pr.acc[k] = 0u;
   probe_start(pr);
   const uint64_t t_begin = pr.t0;
 #endif
@@ -2135,7 +2135,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   Wl0 wl0;
   wl0.e = P.wl_pool[0];
   wl0.inv_n = 1.0f / wl0.e.n_idx;
-  PROBE_MARK(pr, kPhKernelFixed);
+  PROBE_MARK(pr, kPhPrologue);
   const uint32_t stride = gridDim.x * kBlock;
   uint32_t flush_every = 1u, since_flush = 0u;  // binned mode: passes between workgroup-wide flushes (adaptive, uniform)
   bool staged = false;
@@ -2185,8 +2185,12 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
     }
   }
   if constexpr (QUEUE) {   // what the last passes left on the wave's exit queue
+#ifdef HALO_PROBE
+    probe_start(pr);
+#endif
     sums.qn = acc.q->n;
     drain_exits<MODE, MONO, SMALLC>(P, acc, sums, true, pr);
+    PROBE_MARK(pr, kPhFinalDrain);
   }
   if constexpr (BIN) {
     __syncthreads();
@@ -2224,22 +2228,34 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
     __syncthreads();
     if (threadIdx.x == 0) P.bin_cnt[blockIdx.x] = min(s_log_n, P.bin_cap);
   }
-  // ---- per-wave reduction of the scalar tallies: one fp64 atomic per wave, not per exit ----
-  float landed = wave_sum(sums.landed);
-  float exit_w = wave_sum(sums.exit_w);
-  float exit_n = wave_sum(static_cast<float>(sums.exit_n));
-  float pix_n = wave_sum(static_cast<float>(sums.pix_n));
-  if ((threadIdx.x & 63) == 0) {
-    if (pix_n != 0.0f) atomicAdd(&P.sums[kSumPixN], static_cast<double>(pix_n));
-    if (landed != 0.0f) atomicAdd(P.landed, static_cast<double>(landed));
-    if (exit_w != 0.0f) atomicAdd(&P.sums[kSumExitW], static_cast<double>(exit_w));
-    if (exit_n != 0.0f) atomicAdd(&P.sums[kSumExitN], static_cast<double>(exit_n));
+  // ---- the scalar tallies: per-wave reduction, the four waves' sums joined in LDS, then ONE set of fp64 atomics per workgroup onto
+  // one of kTallyLines cache lines.  (Round 5: four atomics per WAVE onto one line were 4 x 1024 same-line atomics for a 256-workgroup
+  // launch — they serialise memory-side at ~12 ns each, 37 us behind a kernel whose waves were gone after 18: the fixed cost of every
+  // small session, tools/launch_ramp_bench.hip + tools/phase_probe.py tiny.)  The tallies are CUMULATIVE: nobody zeroes them, the host
+  // reads differences (halo_backend.cpp pull_tally).
+  __shared__ float s_tally[kBlock / 64][4];
+  {
+    const float landed = wave_sum(sums.landed);
+    const float exit_w = wave_sum(sums.exit_w);
+    const float exit_n = wave_sum(static_cast<float>(sums.exit_n));
+    const float pix_n = wave_sum(static_cast<float>(sums.pix_n));
+    if ((threadIdx.x & 63) == 0) {
+      float* t = s_tally[threadIdx.x >> 6];
+      t[kSumLanded] = landed, t[kSumExitW] = exit_w, t[kSumExitN] = exit_n, t[kSumPixN] = pix_n;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4u) {   // lane k sums tally k over the waves (exit and pixel counts: < 2^24 per wave and launch pass, exact in fp32)
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) v += static_cast<double>(s_tally[w][threadIdx.x]);
+      if (v != 0.0) atomicAdd(&P.tally[(blockIdx.x & (kTallyLines - 1u)) * kTallyStride + threadIdx.x], v);
+    }
   }
 #ifdef HALO_PROBE
   PROBE_MARK(pr, kPhKernelFixed);
   pr.acc[kPhTotal] = static_cast<uint32_t>(pr.t0 - t_begin);
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 14; k++) atomicAdd(&g_halo_probe[k], static_cast<unsigned long long>(pr.acc[k]));
+    for (int k = 0; k < 16; k++) atomicAdd(&g_halo_probe[k], static_cast<unsigned long long>(pr.acc[k]));
 #endif
 }
 

@@ -371,6 +371,8 @@ class HipBackendGlue final : public TraceBackend {
     explicit Handle(halo::LayerHandle h) : lh(h) {}
     halo::LayerHandle lh;
     size_t ContinuationCount() const override { return lh.ContinuationCount(); }
+    // (a queued last layer — option "async", see Create — reports zeros here: its tallies arrive with the next synchronising call;
+    // the production caller reads neither, simulator.cpp:1527-1545)
     LayerStats GetLayerStats() const override {   // trace_backend.hpp:296-299, :320
       return LayerStats{ static_cast<size_t>(lh.stats.exit_count), static_cast<float>(lh.stats.exit_w_sum) };
     }
@@ -389,6 +391,11 @@ class HipBackendGlue final : public TraceBackend {
   void Create(uint32_t seed) {
     try {
       be_ = std::make_unique<halo::HipTraceBackend>(device_, seed);
+      // The caller never looks at the LAST layer's handle (simulator.cpp:1527-1545: it goes out of scope; GetLayerStats has no production
+      // reader) and reads the image on its own clock (third-clock drain, :1585-1611), so the last layer's dispatches are queued, not waited
+      // for: back-to-back sessions then overlap the host's work with the device's.  Layers that feed a Recombine still return their
+      // continuation count synchronously.
+      be_->SetOption("async", 1);
     } catch (const halo::BackendUnavailableError& e) {
       throw BackendUnavailableError(e.what());
     }

@@ -620,3 +620,77 @@ def test_many_small_sessions_fold_once_and_equal_the_eager_fold():
     # the colours of the two wavelengths are both there (a fold with the wrong CMF would tint everything one way)
     big = out[1][0][0]
     assert big[..., 2].sum() > 0.2 * big[..., 1].sum() and big[..., 0].sum() > 0.2 * big[..., 1].sum()
+
+
+def _stats_tuple(st):
+    return int(st.root_count), int(st.exit_count), int(st.pixel_hits)
+
+
+def test_equal_small_sessions_equal_one_large_session():
+    """64 queued sessions of 2^15 rays — what a Lumice server at Metal's dispatch size would send (server.cpp:140) — are the SAME rays as one
+    session of 2^21 (monotone ray counters), so exits and pixel hits agree exactly and the image to float summation order, whichever way
+    the tables reach the device (cached on the device from the first session on, or uploaded with every dispatch) and however the tallies
+    are collected (cumulative device counters, read once at the end)."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    sc, rd, wl = scenes.config2_scene(), scenes.config2_render(480, 270), scenes.wl_discrete(550.0)
+    res = {}
+    for name, opts, sizes in (("small", {"async": 1}, [1 << 15] * 64), ("small_uploaded", {"async": 1, "table_cache": 0}, [1 << 15] * 64),
+                              ("small_sync", {}, [1 << 15] * 64), ("large", {}, [1 << 21])):
+        hb = HipTraceBackend(device=0, seed=5, **opts)
+        hb.collect_stats()
+        for n in sizes:
+            run_session(hb, sc, rd, wl, n)
+        st = hb.collect_stats()
+        img, landed = hb.ReadbackXyzAccum(480, 270)
+        res[name] = (_stats_tuple(st), landed, img)
+        hb.close()
+    ref_st, ref_landed, ref_img = res["large"]
+    assert ref_st[0] == 1 << 21 and ref_st[1] > 4 * ref_st[0] and ref_st[2] > ref_st[0]
+    for name in ("small", "small_uploaded", "small_sync"):
+        st, landed, img = res[name]
+        assert st == ref_st, (name, st, ref_st)
+        assert landed == pytest.approx(ref_landed, rel=1e-6)
+        assert np.abs(img - ref_img).max() <= 2e-5 * float(ref_img.max())
+        assert img.sum(dtype=np.float64) == pytest.approx(ref_img.sum(dtype=np.float64), rel=2e-6)
+
+
+def test_table_cache_follows_scene_wavelength_filters_and_options():
+    """The device-resident tables of a crystal entry (round 5) must be replaced whenever anything they were built from changes: the scene
+    (another crystal, another axis distribution), the wavelength, the filter table, an option.  A backend with the cache and one that
+    uploads its tables with every dispatch trace the same alternating sequence of sessions: same tallies after every session, same image."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    T = scenes.filter_term
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    col = scenes.config2_scene()
+    plate = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0.0, "std": 0.8}, azimuth=full, roll=full), 1.0, 6)])], max_hits=7)
+    flt_entry = scenes.column_crystal_entry()
+    flt_entry.filter_id = 1
+    filtered = scenes.scene([(0.0, [flt_entry])], max_hits=7)
+    rd = scenes.config2_render(320, 180)
+    f_a = [scenes.simple_filter(T("raypath", raypath=[3, 5]), "P")]
+    f_b = [scenes.simple_filter(T("entry_exit", entry=1, exit=3, min_len=2, max_len=5), "PBD")]
+    steps = [("scene", col, 550.0), ("scene", col, 550.0), ("scene", plate, 550.0), ("scene", col, 550.0), ("scene", col, 610.0), ("scene", col, 610.0),
+             ("filters", f_a, None), ("scene", filtered, 610.0), ("scene", filtered, 610.0), ("filters", f_b, None), ("scene", filtered, 610.0),
+             ("option", ("entry_fast", 0), None), ("scene", col, 610.0), ("option", ("entry_fast", 1), None), ("scene", col, 610.0)]
+    runs = {}
+    for cache in (1, 0):
+        hb = HipTraceBackend(device=0, seed=9, table_cache=cache)
+        tallies = []
+        for kind, what, w in steps:
+            if kind == "filters":
+                hb.set_filters(what)
+            elif kind == "option":
+                hb.set_option(*what)
+            else:
+                st = run_session(hb, what, rd, scenes.wl_discrete(w), 1 << 16)[0]
+                tallies.append((int(st.exit_count), int(st.pixel_hits), round(float(st.exit_w_sum), 3)))
+        runs[cache] = (tallies, hb.ReadbackXyzAccum(320, 180))
+        hb.close()
+    assert runs[1][0] == runs[0][0]
+    # (a stale table would show here: the two runs trace the same rays session by session, so a session that found its predecessor's
+    # crystal, wavelength or filter on the device has other tallies than the one that uploaded its own)
+    (img1, l1), (img0, l0) = runs[1][1], runs[0][1]
+    assert l1 == pytest.approx(l0, rel=1e-6)
+    assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())

@@ -14,7 +14,7 @@ from ice_halo_sim_amd.backend import HipTraceBackend, load_library  # noqa: E402
 from tests._oracle_backend import run_session  # noqa: E402
 
 NAMES = ["streams+wavelength", "orientation sample", "rotation matrix", "sun cone + R^T", "entry pick", "fresnel", "emit: rotate/filter/gate",
-         "emit: project", "emit: accumulate", "slab search + advance", "kernel prologue/epilogue", "TOTAL (wave resident)", "pool: stage shape record", "binned: flush hit buffer"]
+         "emit: project", "emit: accumulate", "slab search + advance", "kernel prologue/epilogue", "TOTAL (wave resident)", "pool: stage shape record", "binned: flush hit buffer", "prologue (zero cache, stage tables)", "final drain of the exit queue"]
 
 
 def dump(reset=True):
@@ -34,13 +34,16 @@ def run(label, sc, rd, wl, n):
     v = dump(True)
     hb.close()
     tot = max(v[11], 1)
-    print("%s: %d rays, kernels %.3f ms; wave-resident cycles per wave %.0f" % (label, n, sum(s.kernel_ms for s in st), tot / max(1, (n + 63) // 64 if n < (1 << 21) else 1)))
-    for k in list(range(11)) + [12, 13]:
+    print("%s: %d rays, kernels %.3f ms; wave-resident cycles per wave-ray (64 rays) %.0f" % (label, n, sum(s.kernel_ms for s in st), tot / max(1, (n + 63) // 64 if n < (1 << 21) else 1)))
+    for k in list(range(11)) + [12, 13, 14, 15]:
         print("   %-28s %6.2f %%" % (NAMES[k], 100.0 * v[k] / tot))
-    print("   %-28s %6.2f %%   (loop overhead, stamps, divergence waits)" % ("unattributed", 100.0 * (tot - sum(v[:11]) - v[12] - v[13]) / tot))
+    print("   %-28s %6.2f %%   (loop overhead, stamps, divergence waits)" % ("unattributed", 100.0 * (tot - sum(v[:11]) - v[12] - v[13] - v[14] - v[15]) / tot))
 
 
 which = sys.argv[1:] or ["cfg1"]
+if "tiny" in which:
+    for lg in (15, 16, 17, 18):
+        run("configs[1] 550 nm, 2^%d rays" % lg, scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 1 << lg)
 if "small" in which:   # one pass per workgroup: what a session of the reference's default GPU dispatch (2^18 rays, server.cpp:151) spends where
     run("configs[1] 550 nm, 2^18 rays", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 1 << 18)
     run("configs[1] 550 nm, 2^20 rays", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 1 << 20)
