@@ -30,10 +30,10 @@ hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap,
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream);
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                double* ovf, uint32_t* ovf_flag, hipStream_t stream);
+                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -43,6 +43,7 @@ hipError_t launch_lane_hist(const double* lanes, uint32_t n_pix, const Composite
                             hipStream_t stream);
 hipError_t launch_composite(const double* lanes, uint32_t n_pix, const CompositeDev& cd, float* rgb_out, uint8_t* srgb_out, int blocks, hipStream_t stream);
 hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream);
+hipError_t launch_lanes_drain(double* lanes, float* dst, uint64_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
 }
@@ -137,7 +138,7 @@ struct HaloBackend {
   DevBuf<FilterDev> filter_dev;
   std::unique_ptr<FastTables> fast_scratch;  // host staging of a dispatch's fast filter tables (20 KB: not on the stack)
   DevBuf<float> mono;          // accumulation planes (see MonoSlot): plane_cnt x plane_copies x (kMonoRows << s_log2) floats
-  DevBuf<double> ovf;          // fp64 twin of the planes (same offsets; only copy 0 is ever written): where full log regions / tile lists overflow to
+  DevBuf<double> ovf;          // fp64 twin of the planes' copy 0, laid out [plane][slot] (TwinOffset): where full log regions / tile lists overflow to
   DevBuf<uint32_t> ovf_flag;   // one word: something was written to the twin since the last fold
   bool mono_session = false;   // kernel variant: true = one scalar per hit (plane 0 or plane wl_idx), false = X,Y,Z planes
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
@@ -450,6 +451,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     b->mono_copies = c;
   }
   else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 64));
+  else if ((k == "rank" || k == "ray_base") && b->in_session) {
+    // the layers of an open session draw their gate / transit / shape streams at indices that follow on from the first layer's
+    return fail(b, HALO_FATAL, k + " cannot change inside a session");
+  }
   else if (k == "rank") {
     // disjoint 64-bit counter ranges per shard: the hi word feeds pcg_seed_with_high, so ranks never share a stream
     const uint64_t base = static_cast<uint64_t>(v) << 40;
@@ -610,13 +615,19 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
     }
     b->mono_s_log2 = s_log2;  // planes are all-zero whenever the layout changes (folded above), so it may change freely
-    // the twin: as many doubles as the planes have floats (16.8 MB at configs[1]; a 64-plane session on 2048x1024 takes 1 GB), kept all-zero
-    // between sessions like the planes; sessions whose planes pass 512 Mi floats go without (their overflow stays on the fp32 plane)
-    if (b->ovf.cap < b->mono.cap && b->mono.cap <= (512ull << 20) && b->ovf.reserve(b->mono.cap) == hipSuccess) {
-      HIPCHK(b, hipMemsetAsync(b->ovf.ptr, 0, b->ovf.cap * sizeof(double), b->stream));
-      if (!b->ovf_flag.ptr) {
-        HIPCHK(b, b->ovf_flag.reserve(1));
-        HIPCHK(b, hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream));
+    // the twin: one double per float of every plane's copy 0 (2.1 MB x planes at configs[1]'s image; a 64-plane session on 2048x1024 takes
+    // 1 GB), kept all-zero between sessions like the planes; sessions whose twin would pass 4 GB go without (their overflow stays on the fp32
+    // plane), and so does a session whose twin cannot be allocated
+    const size_t twin_need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_cnt;
+    if (b->ovf.cap < twin_need && twin_need <= (512ull << 20)) {
+      bool ok = b->ovf.reserve(twin_need) == hipSuccess;
+      if (ok && !b->ovf_flag.ptr) ok = b->ovf_flag.reserve(1) == hipSuccess && hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream) == hipSuccess;
+      if (ok) {
+        HIPCHK(b, hipMemsetAsync(b->ovf.ptr, 0, b->ovf.cap * sizeof(double), b->stream));
+      } else {
+        (void)hipGetLastError();   // out of memory is not this session's failure: the launches run without a twin
+        b->ovf.release();
+        b->ovf_flag.release();
       }
     }
   }
@@ -660,8 +671,9 @@ static int fold_if_dirty(HaloBackend* b) {
     FoldCoef coef{};
     for (uint32_t m = 0; m < n; m++)
       for (int a = 0; a < 3; a++) coef.c[m][a] = b->plane_coef[first + m][static_cast<size_t>(a)];
-    const bool twin = b->ovf.ptr != nullptr && b->ovf.cap >= b->mono.cap && b->ovf_flag.ptr != nullptr;
-    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? b->ovf.ptr + first * plane : nullptr,
+    const size_t twin_plane = static_cast<size_t>(kMonoRows) << b->mono_s_log2;
+    const bool twin = b->ovf.ptr != nullptr && b->ovf.cap >= twin_plane * b->plane_cnt && b->ovf_flag.ptr != nullptr;
+    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? b->ovf.ptr + first * twin_plane : nullptr,
                                b->ovf_flag.ptr, b->stream);
     if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   }
@@ -841,7 +853,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.counters = b->counters.ptr;
     P.mono = b->mono.ptr;
     P.mono_s_log2 = b->mono_s_log2;
-    P.ovf = (b->ovf.ptr != nullptr && b->ovf.cap >= b->mono.cap && b->ovf_flag.ptr != nullptr) ? b->ovf.ptr : nullptr;
+    P.ovf = (b->ovf.ptr != nullptr && b->ovf.cap >= (static_cast<size_t>(kMonoRows) << b->mono_s_log2) * b->plane_cnt && b->ovf_flag.ptr != nullptr) ? b->ovf.ptr : nullptr;
+    P.ovf_copies_log2 = static_cast<uint32_t>(__builtin_ctz(b->plane_copies));
     P.ovf_flag = b->ovf_flag.ptr;
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
@@ -1176,10 +1189,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const uint32_t frac_bits = fix_frac_bits(b->sess_max_w, m);
       if (use_log) {
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
-                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, b->stream)
+                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, b->stream)
                                     : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
                                                        b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
-                                                       P.ovf, P.ovf_flag, b->stream);
+                                                       P.ovf, P.ovf_flag, P.ovf_copies_log2, b->stream);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
       }
       if (use_bin) {
@@ -1303,11 +1316,13 @@ int halo_readback_class_lanes(halo_handle_t b, float* lanes, int width, int heig
     return fail(b, HALO_FATAL, "class lanes: size does not match the session (classes x width x height)");
   HIPCHK(b, hipSetDevice(b->device));
   const size_t n = static_cast<size_t>(class_count) * width * height;
-  std::vector<double> wide(n);   // the lanes are summed in fp64 on the device (hot pixels), the seam hands out floats (trace_backend.hpp:471-493)
-  HIPCHK(b, hipMemcpyAsync(wide.data(), b->lanes.ptr, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, n * sizeof(double), b->stream));
+  // the lanes are summed in fp64 on the device (hot pixels), the seam hands out floats (trace_backend.hpp:471-493): narrowed and drained by
+  // one kernel into the staging buffer, so half the bytes cross the bus and no host pass follows
+  HIPCHK(b, b->lanes_stage.reserve(n));
+  hipError_t e = launch_lanes_drain(b->lanes.ptr, b->lanes_stage.ptr, n, b->cu_count * 8, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_lanes_drain_kernel launch");
+  HIPCHK(b, hipMemcpyAsync(lanes, b->lanes_stage.ptr, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(b, hipStreamSynchronize(b->stream));
-  for (size_t i = 0; i < n; i++) lanes[i] = static_cast<float>(wide[i]);
   return HALO_OK;
 }
 

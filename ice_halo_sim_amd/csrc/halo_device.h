@@ -291,6 +291,7 @@ struct DispatchParams {
                                // HERE, not to the fp32 plane — a hot pixel's overflow is thousands of near-equal addends onto one large float, which
                                // fp32 atomics round the same way every time (5.6e-4 high, round 3); the closing fold takes the twin in when ovf_flag says so
   uint32_t* ovf_flag;          // set to 1 by whoever writes the twin
+  uint32_t ovf_copies_log2;    // the twin shadows copy 0 only and is laid out without the other copies: plane p's twin starts at p << (mono_s_log2 + 10) (TwinOffset)
   HitRec* bin_list;             // binned accumulation (nullptr = off): bin_tiles lists of bin_cap {slot, weight} records
   uint32_t bin_cap;
   uint32_t bin_tiles;
@@ -347,6 +348,14 @@ __host__ __device__
 inline uint32_t MonoSlot(uint32_t pix, uint32_t s_log2) {
   const uint32_t col = ((pix / kMonoRows) * kMonoMul) & ((1u << s_log2) - 1u);
   return ((pix % kMonoRows) << s_log2) + col;
+}
+
+// Offset in the planes' fp64 twin of the plane float at `off` (a copy-0 slot): the planes lie [plane][copy][slot], the twin [plane][slot].
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t TwinOffset(size_t off, uint32_t plane_log2, uint32_t copies_log2) {
+  return ((off >> (plane_log2 + copies_log2)) << plane_log2) | (off & ((static_cast<size_t>(1) << plane_log2) - 1u));
 }
 
 enum { kCntCont = 0, kCntExit = 1, kCntNum = 4 };

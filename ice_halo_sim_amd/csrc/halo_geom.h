@@ -365,6 +365,9 @@ HALO_GEOM_HD bool ConeApexZ(const Plane3* cone, double tol, int sign, double& z)
   return found;
 }
 
+HALO_GEOM_HD double PyrMergeRadius(double max_abs_dist) {   // one definition for the serial builder and the team builder
+  return 5.0 * static_cast<double>(kGeomFloatEps) * (0.25 * 1.7320508075688772935) * fmax(max_abs_dist, 1e-3);
+}
 constexpr int kPyrMaxVerts = 40;   // a hexagonal prism capped by two truncated hexagonal pyramids has 24 corners; the reference's pools peak at 24
 
 // Plane of slot s (2..7 prism sides, 8..13 upper cone, 14..19 lower cone) as FillHexCrystalCoef states it (geo3d.cpp:346-512);
@@ -410,8 +413,8 @@ HALO_GEOM_HD int PyrOrderFace(const double (*verts)[3], IndexT* on, int cnt, con
   for (int q = 0; q < cnt; q++) {
     const double r[3] = {verts[on[q]][0] - c[0], verts[on[q]][1] - c[1], verts[on[q]][2] - c[2]};
     // sort key: a pseudo-angle that grows with atan2(y, x) mapped to [0, 2 pi) — t = |y| / (|x| + |y|) per quadrant, in
-    // [0, 4) — so the order is the CCW order an atan2 would give (the vertices of a face are at least 2 tol apart after the
-    // duplicate filter, far beyond any rounding of either key) at the price of one division
+    // [0, 4) — so the order is the CCW order an atan2 would give (the vertices of a face are at least a merge radius, ~2e-5 of the
+    // crystal's width, apart after the duplicate filter: far beyond any rounding of either key) at the price of one division
     double a = 0.0;
     if (q != 0) {
       const double y = r[0] * e2[0] + r[1] * e2[1] + r[2] * e2[2], x = r[0] * e1[0] + r[1] * e1[1] + r[2] * e1[2];
@@ -462,6 +465,14 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     scale = fmax(scale, fabs(unit[s].d));
   }
   const double tol = 5.0 * static_cast<double>(kGeomFloatEps) * fmax(scale, 1e-3);
+  // The duplicate radius is LATERAL (geo3d_closedform.cpp:77-96 GapToleranceForScale, :393 LateralMergeTol, :702-710 InsertOrFindVertex, :927
+  // kApexMergeTol): 5 * kFloatEps x the scale of the m = 0 cross section, (sqrt3/4) max |dist_i| — the ruler the reference applies at the apex
+  // and the upper bound of the rulers it applies at every other inset.  (Until round 5: 2 tol, i.e. scaled by the largest plane constant — a
+  // steep wedge puts a cone plane's |d| far above the crystal's width, and the radius swallowed slivers the reference resolves:
+  // test_closed_form_pyramid.cpp:1579-1663 t10298 came out with 11 faces where the reference demands >= 12.)
+  double max_dist = 0.0;
+  for (int i = 0; i < 6; i++) max_dist = fmax(max_dist, fabs(static_cast<double>(dist[i])));
+  const double merge = PyrMergeRadius(max_dist);
   double z_top = half, z_bot = -half, apex = 0.0;
   if (upper) {
     if (!ConeApexZ(unit + 8, tol, +1, apex)) return false;
@@ -524,8 +535,8 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     if (!ok) return;
     for (int v = 0; v < nv; v++) {
       const double dx = verts[v][0] - x[0], dy = verts[v][1] - x[1], dz = verts[v][2] - x[2];
-      if (fabs(dx) > 4.0 * tol || fabs(dy) > 4.0 * tol || fabs(dz) > 4.0 * tol) continue;   // farther than 2 tol for certain: no sqrt
-      if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+      if (fabs(dx) > 2.0 * merge || fabs(dy) > 2.0 * merge || fabs(dz) > 2.0 * merge) continue;   // farther than the radius for certain: no sqrt
+      if (sqrt(dx * dx + dy * dy + dz * dz) <= merge) {
         vmask[v] |= mk;
         return;   // duplicate
       }
@@ -612,7 +623,7 @@ HALO_GEOM_HD bool BuildPyramidShape(double cot_u, double cot_l, float h1, float 
     const int cnt = member_cnt[s];
     if (cnt < 3) continue;
     double ang[HALO_MAX_FACE_VTX];
-    if (PyrOrderFace(verts, on[s], cnt, unit[s], tol, ang) == 0) continue;
+    if (PyrOrderFace(verts, on[s], cnt, unit[s], tight, ang) == 0) continue;   // (only a face whose vertices all coincide is no face: a sliver a few 1e-5 across is one, t10298)
     on_n[s] = cnt;
     present++;
   }

@@ -134,10 +134,12 @@ struct SplitXyz {              // what a record that finds its tile list full is
   uint32_t plane_stride;
   double* ovf;                 // the planes' fp64 twin (DispatchParams::ovf); nullptr = the fp32 plane itself
   uint32_t* ovf_flag;
+  uint32_t plane_log2;         // log2 of a plane copy's floats, and of the privatised copies per plane: the twin has no copies (TwinOffset)
+  uint32_t copies_log2;
 };
 __device__ __forceinline__ void split_overflow(float* plane, const SplitXyz& x, size_t off, float v) {
   if (x.ovf != nullptr) {
-    atomicAdd(x.ovf + off, static_cast<double>(v));
+    atomicAdd(x.ovf + TwinOffset(off, x.plane_log2, x.copies_log2), static_cast<double>(v));
     *x.ovf_flag = 1u;
   } else {
     atomic_add_f32(plane + off, v);
@@ -388,13 +390,13 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
 // ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 // `planes` > 1: the scalar planes of a per-entry-plane illuminant session (back to back), `tiles` interleaved tiles EACH, planes x tiles <= 512.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
   // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
   // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
   if (planes > 1u || tiles > 256u) {
     hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 512u, false, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, s_log2 + 10u, copies_log2});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles * planes), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -403,10 +405,10 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
   }
   if (interleaved)
     hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 256u, false, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, s_log2 + 10u, copies_log2});
   else
     hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 256u, false, false>), dim3(regions), dim3(kLogSplitThreads), 0, stream, plane, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u,
-                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
+                       1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, s_log2 + 10u, copies_log2});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (interleaved)
@@ -419,10 +421,10 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
 // the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of <= 4 Ki slots of one plane
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
+                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
   hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 512u, true, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
-                     reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride, ovf, ovf_flag});
+                     reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride, ovf, ovf_flag, s_log2 + 10u, copies_log2});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((halo_log_accumulate_kernel<3u>), dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -434,7 +436,7 @@ hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1
                                 uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
   hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u, false, false>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
-                     static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag});
+                     static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, 0u, 0u});   // (per-entry planes have no privatised copies: the twin's offsets are the planes')
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(kBlock) halo_fold_kernel(float* __restrict__ x
           }
         }
         if (take_ovf) {   // the twin shadows copy 0
-          double* qo = ovf + (qp - planes);
+          double* qo = ovf + (q - planes) + static_cast<size_t>(pl) * plane;   // the twin has no copies: plane pl's twin starts at pl * plane
           const double o = *qo;
           if (o != 0.0) {
             *qo = 0.0;
@@ -709,6 +711,15 @@ __global__ void __launch_bounds__(kBlock) halo_lanes_load_kernel(const float* __
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) lanes[i] = static_cast<double>(src[i]);
 }
 
+// the inverse at the seam (TraceBackend::ReadbackClassLanes hands out floats and drains the device lanes): narrow into the staging buffer, zero the lane
+__global__ void __launch_bounds__(kBlock) halo_lanes_drain_kernel(double* __restrict__ lanes, float* __restrict__ dst, uint64_t n) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    dst[i] = static_cast<float>(lanes[i]);
+    lanes[i] = 0.0;
+  }
+}
+
 hipError_t launch_lane_hist(const double* lanes, uint32_t n_pix, const CompositeDev& cd, uint32_t shift, uint32_t bits, uint32_t prefix, uint32_t* hist, int blocks,
                             hipStream_t stream) {
   hipLaunchKernelGGL(halo_lane_hist_kernel, dim3(blocks), dim3(kBlock), 0, stream, lanes, n_pix, cd, shift, bits, prefix, hist);
@@ -720,6 +731,11 @@ hipError_t launch_composite(const double* lanes, uint32_t n_pix, const Composite
 }
 hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream) {
   hipLaunchKernelGGL(halo_lanes_load_kernel, dim3(blocks), dim3(kBlock), 0, stream, src, lanes, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_lanes_drain(double* lanes, float* dst, uint64_t n, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_lanes_drain_kernel, dim3(blocks), dim3(kBlock), 0, stream, lanes, dst, n);
   return hipGetLastError();
 }
 

@@ -258,6 +258,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const double scale = team_max(fmax(fabs(half), side_active ? fabs(unit.d) : 0.0));
   const double tol = 5.0 * static_cast<double>(geom::kGeomFloatEps) * fmax(scale, 1e-3);
   const double tight = 1e-9 * fmax(scale, 1e-3);   // "on the plane" for a concurrence computed in double (geom::BuildPyramidShape)
+  const double merge = geom::PyrMergeRadius(team_max((s >= 2 && s < 8) ? fabs(static_cast<double>(my_dist)) : 0.0));   // the lateral duplicate radius (geom::BuildPyramidShape)
   if (s < 20) T.unit[s] = unit;
   team_publish();
   // --- cone apexes: extreme z over the feasible concurrences of each cone's own six planes ---
@@ -307,10 +308,10 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   const bool active = s < 2 || side_active;
   const uint32_t act_mask = team_ballot(active);
   // --- vertices: candidate triples in lexicographic order, 32 per round; kept in serial order ---
-  // The serial filter keeps a candidate unless a vertex kept before it lies within 2 tol.  Taking the feasible candidates one at a time
+  // The serial filter keeps a candidate unless a vertex kept before it lies within the merge radius.  Taking the feasible candidates one at a time
   // (broadcast, test against the kept list, append) cost ~40 instructions per candidate, ~35 candidates per crystal: a third of the
   // kernel.  Here a round's feasible candidates go to LDS, every feasible lane tests its own against the vertices kept in earlier rounds
-  // (a hit drops it, as in the serial filter) and against the round's other candidates, gathering the mask D of those within 2 tol; among
+  // (a hit drops it, as in the serial filter) and against the round's other candidates, gathering the mask D of those within the radius; among
   // the candidates that survive the first test the serial filter keeps exactly the lowest of each group when the groups are cliques
   // (D equal for all members: every duplicate of a vertex is a duplicate of its other duplicates) — checked, and when it does not hold
   // the greedy pass runs on the masks, which is the serial filter itself.  Kept candidates are appended in lane order = list order.
@@ -371,11 +372,11 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       feasible = ok;
     }
     const uint32_t fm = team_ballot(feasible);
-    // distance pre-test in float: a pair within 2 tol in fp64 is within thr in float whatever the vertices' magnitude (the float copies
+    // distance pre-test in float: a pair within the merge radius in fp64 is within thr in float whatever the vertices' magnitude (the float copies
     // are off by <= 2^-24 of each coordinate, |difference error| <= 1.2e-7 * (|x|+|y|+|z|) =: m), so a pair the pre-test calls far IS far
     // and only the pairs it calls near (real duplicates, nearly always) take the fp64 test of the serial filter
     const float fx = static_cast<float>(x[0]), fy = static_cast<float>(x[1]), fz = static_cast<float>(x[2]);
-    const float thr = 3.0f * static_cast<float>(tol) + 1e-6f * (fabsf(fx) + fabsf(fy) + fabsf(fz));
+    const float thr = 1.5f * static_cast<float>(merge) + 1e-6f * (fabsf(fx) + fabsf(fy) + fabsf(fz));
     const float thr2 = thr * thr;
     if (feasible) {
       for (int a = 0; a < 3; a++) cand_lds[lane][a] = x[a];
@@ -384,14 +385,14 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     team_publish();
     bool dupk = false;
     int dup_v = 0;   // the FIRST kept vertex it duplicates takes its incidences (the serial filter stops there)
-    uint32_t D = feasible ? (1u << lane) : 0u;   // (a candidate is within 2 tol of itself)
+    uint32_t D = feasible ? (1u << lane) : 0u;   // (a candidate is within the radius of itself)
     if (feasible) {
       for (int v = 0; v < nv; v++) {
         const float4 o = T.vtx.kept_f[v];
         const float ex = o.x - fx, ey = o.y - fy, ez = o.z - fz;
         if (!dupk && ex * ex + ey * ey + ez * ez <= thr2) {
           const double dx = T.verts[v][0] - x[0], dy = T.verts[v][1] - x[1], dz = T.verts[v][2] - x[2];
-          if (within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) {
+          if (within(dx * dx + dy * dy + dz * dz, merge)) {
             dupk = true;
             dup_v = v;
           }
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
         const float ex = o.x - fx, ey = o.y - fy, ez = o.z - fz;
         if (ex * ex + ey * ey + ez * ez <= thr2) {
           const double dx = cand_lds[e][0] - x[0], dy = cand_lds[e][1] - x[1], dz = cand_lds[e][2] - x[2];
-          if (within(dx * dx + dy * dy + dz * dz, 2.0 * tol)) D |= 1u << e;
+          if (within(dx * dx + dy * dy + dz * dz, merge)) D |= 1u << e;
         }
       }
     }
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
     const int rep = in_r ? __ffs(D) - 1 : lane;   // (D holds the lane's own bit)
     const uint32_t d_rep = static_cast<uint32_t>(__shfl(static_cast<int>(D), static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(rep))));
     uint32_t keep = team_ballot(in_r && rep == lane);
-    if (__ballot(in_r && d_rep != D) != 0ull) {   // not cliques (vertices ~2 tol apart in a chain): the greedy pass, in list order
+    if (__ballot(in_r && d_rep != D) != 0ull) {   // not cliques (vertices about a radius apart in a chain): the greedy pass, in list order
       keep = 0u;
       for (int e = 0; e < kTeam; e++) {
         const uint32_t d_e = static_cast<uint32_t>(__shfl(static_cast<int>(D), static_cast<int>((threadIdx.x & 32u) | static_cast<uint32_t>(e))));
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
       }
     }
     // incidences: a duplicate's planes go to the vertex the serial filter would have stopped at — the first earlier-round vertex within
-    // 2 tol, else the lowest kept candidate of this round within 2 tol
+    // the radius, else the lowest kept candidate of this round within it
     const bool kept = ((keep >> lane) & 1u) != 0u;
     if (kept) T.vtx.rmask[lane] = mk;
     team_publish();
@@ -468,7 +469,7 @@ __global__ void __launch_bounds__(kTeamBlock, 4) halo_pyrgen_team_kernel(ShapeDe
   on_n = 0;
   if (valid && active && cnt >= 3) {
     on_n = order_face_fast(T.verts, T.f.on[s], cnt, unit, tol, reinterpret_cast<float*>(T.f.key[s]));
-    if (on_n < 0) on_n = geom::PyrOrderFace(T.verts, T.f.on[s], cnt, unit, tol, T.f.key[s]);   // too close for float keys: the serial ordering itself
+    if (on_n < 0) on_n = geom::PyrOrderFace(T.verts, T.f.on[s], cnt, unit, tight, T.f.key[s]);   // too close for float keys: the serial ordering itself
   }
   present = team_ballot(on_n > 0);
   if (s < 20) T.f.tri_cnt[s] = on_n > 0 ? on_n - 2 : 0;

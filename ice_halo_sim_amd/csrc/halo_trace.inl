@@ -585,7 +585,7 @@ HD bool stage_hit(HitBuffer* hb, uint32_t key, float w) {
 // Where a record goes that found its log region or its tile list full: the planes' fp64 twin when the dispatch has one, else the fp32 plane.
 HD void overflow_add(const DispatchParams& P, size_t off, float v) {
   if (P.ovf != nullptr) {
-    atomicAdd(P.ovf + off, static_cast<double>(v));
+    atomicAdd(P.ovf + TwinOffset(off, P.mono_s_log2 + 10u, P.ovf_copies_log2), static_cast<double>(v));
     *P.ovf_flag = 1u;
   } else {
     atomic_add_f32(P.mono + off, v);

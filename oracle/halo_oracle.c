@@ -982,6 +982,14 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
   raw[0] = unit[0] = (HoPlane){0.0, 0.0, 1.0, -z_top};
   raw[1] = unit[1] = (HoPlane){0.0, 0.0, -1.0, z_bot};
   active[0] = active[1] = 1;
+  /* The duplicate radius is LATERAL (geo3d_closedform.cpp:77-96 GapToleranceForScale, :393 LateralMergeTol, :702-710 InsertOrFindVertex,
+   * :927 kApexMergeTol): 5 * kFloatEps x the scale of the crystal's m = 0 cross section, (sqrt3/4) max_i |dist_i| — the ruler the reference
+   * applies at the apex and the upper bound of the rulers it applies at every other inset.  (Until round 5 the radius here was twice
+   * 5 * kFloatEps x the largest plane constant; a steep wedge puts a cone plane's |d| far above the crystal's width, and the radius then
+   * swallowed slivers the reference resolves — test_closed_form_pyramid.cpp:1579-1663, t10298: 11 faces where the reference demands >= 12.) */
+  double max_dist0 = 0.0;
+  for (int i = 0; i < 6; i++) max_dist0 = fmax(max_dist0, fabs((double)dist[i]));
+  const double merge = 5.0 * (double)HO_FLOAT_EPS * (0.25 * 1.7320508075688772935) * fmax(max_dist0, 1e-3);
   /* vertices: feasible, de-duplicated concurrences of plane triples */
   /* Incidence: the planes that pass through a kept vertex exactly (|distance| <= 1e-9 of the crystal's size; the concurrence is computed
    * in double) — its own three and whatever else meets there — united over the candidates the duplicate filter folds into it.  (A face used
@@ -1012,7 +1020,7 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
         int dup = 0;
         for (int v = 0; v < nv && !dup; v++) {
           double dx = vx[v][0] - x[0], dy = vx[v][1] - x[1], dz = vx[v][2] - x[2];
-          if (sqrt(dx * dx + dy * dy + dz * dz) <= 2.0 * tol) {
+          if (sqrt(dx * dx + dy * dy + dz * dz) <= merge) {
             dup = 1;
             vmask[v] |= mk;
           }
@@ -1044,7 +1052,7 @@ int ho_pyramid_topology(float wedge_u, float wedge_l, float h1, float h2, float 
     double n[3] = {unit[s].a, unit[s].b, unit[s].c};
     double e1[3] = {vx[on[0]][0] - c[0], vx[on[0]][1] - c[1], vx[on[0]][2] - c[2]};
     double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-    if (l1 <= tol) continue;
+    if (l1 <= tight) continue;   /* a face whose vertices all coincide; a sliver a few 1e-5 across is a face (t10298) */
     for (int a = 0; a < 3; a++) e1[a] /= l1;
     double e2[3] = {n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0]};
     HoAngIdx ord[HALO_MAX_FACE_VTX];

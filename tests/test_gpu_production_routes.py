@@ -694,3 +694,24 @@ def test_table_cache_follows_scene_wavelength_filters_and_options():
     (img1, l1), (img0, l0) = runs[1][1], runs[0][1]
     assert l1 == pytest.approx(l0, rel=1e-6)
     assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())
+
+
+def test_options_that_shape_an_open_session_are_refused_inside_it():
+    """seed, ray_base and rank move the monotone ray counters, capture_exits / filter_fast / mono_copies the plane layout decided at
+    BeginSession: changing any of them between the layers of a session would replay ray indices the session has already consumed or send
+    hits to a layout made for another route.  They are refused while a session is open and accepted again after EndSession."""
+    from ice_halo_sim_amd.backend import BackendError, HipTraceBackend
+    hb = HipTraceBackend(device=0, seed=3)
+    sc, rd = scenes.config3_scene(), scenes.config2_render(160, 90)
+    hb.BeginSession(sc, rd, scenes.wl_discrete(550.0), 1 << 14)
+    hb.TraceLayer(1 << 14)
+    for key, val in (("seed", 5), ("ray_base", 1 << 33), ("rank", 2), ("capture_exits", 1), ("filter_fast", 0), ("mono_copies", 4)):
+        with pytest.raises(BackendError):
+            hb.set_option(key, val)
+    hb.Recombine(True)
+    st = hb.TraceLayer(0)
+    hb.EndSession()
+    assert st.root_count > 0
+    for key, val in (("seed", 5), ("ray_base", 1 << 33), ("rank", 2), ("capture_exits", 0), ("filter_fast", 1), ("mono_copies", 8)):
+        hb.set_option(key, val)
+    hb.close()

@@ -135,11 +135,20 @@ def test_pyramid_topology_matches_reference_goldens_and_oracle():
     O.ho_pyramid_geometry.restype = None
     O.ho_pyramid_geometry.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_float), C.POINTER(abi.HaloGeomTables)]
     G = np.load(os.path.join(ROOT, "tests", "golden", "ref_pyramid_goldens.npz"))
+    dropped = []
 
     def check(wu, wl, h1, h2, h3, dist, golden):
         n = C.c_int()
         mask = O.ho_pyramid_face_mask(wu, wl, h1, h2, h3, fptr(dist), C.byref(n))
-        assert (n.value, mask) == (int(golden[0]), int(golden[1]))
+        if int(golden[2]) & 0x40:
+            # kClosedFormPathTagClaimedFaceDropped (geo3d_closedform.hpp): the reference's own marker that ITS result lost a face it had
+            # reached and "the surface they bounded is left open" (geo3d_closedform.cpp:1213-1232; flat-tail 89.5 #2, one of the four open
+            # surfaces test_closed_form_pyramid.cpp:1664-1717 counts).  Not a topology to reproduce: here the face must be there —
+            # every face of the golden and the dropped ones, on a closed surface (tests/test_ref_pyramid_properties.py checks Euler).
+            dropped.append(1)
+            assert mask & int(golden[1]) == int(golden[1]) and mask != int(golden[1]) and n.value >= int(golden[0])
+        else:
+            assert (n.value, mask) == (int(golden[0]), int(golden[1]))
         a, b = abi.HaloGeomTables(), abi.HaloGeomTables()
         assert L.halo_host_pyramid_geometry(wu, wl, h1, h2, h3, fptr(dist), C.byref(a)) == 0
         O.ho_pyramid_geometry(wu, wl, h1, h2, h3, fptr(dist), C.byref(b))
@@ -155,6 +164,11 @@ def test_pyramid_topology_matches_reference_goldens_and_oracle():
     for s, t in zip(G["miller_samples"], G["miller_topology"]):
         wu, wl = scenes.miller_wedge_deg(int(s[0]), int(s[1])), scenes.miller_wedge_deg(int(s[2]), int(s[3]))
         check(wu, wl, float(s[4]), float(s[5]), float(s[6]), np.ascontiguousarray(s[7:13]), t)
+    # the six flat-tail pools (wedge 85 .. 89.5 degrees, pyramid_topology_golden_generated.hpp:184-264): the thin-cap regime
+    for tag in ("85", "87", "875", "88", "89", "895"):
+        for s, t in zip(G["flat%s_samples" % tag], G["flat%s_topology" % tag]):
+            check(float(s[0]), float(s[1]), float(s[2]), float(s[3]), float(s[4]), np.ascontiguousarray(s[5:11]), t)
+    assert len(dropped) == 1   # of 728 goldens, 727 are reproduced and one is the reference's acknowledged open surface
     # empty / degenerate inputs give the empty crystal on both sides
     e = abi.HaloGeomTables()
     assert L.halo_host_pyramid_geometry(28.0, 28.0, 0.0, 0.0, 0.0, fptr(np.ones(6, np.float32)), C.byref(e)) != 0 and e.face_cnt == 0
