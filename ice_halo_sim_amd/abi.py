@@ -90,7 +90,7 @@ class HaloWl(C.Structure):
 
 class HaloHostRays(C.Structure):
     _fields_ = [("d", C.POINTER(C.c_float)), ("p", C.POINTER(C.c_float)), ("w", C.POINTER(C.c_float)),
-                ("tf", C.POINTER(C.c_uint32))]
+                ("tf", C.POINTER(C.c_uint32)), ("crystal", C.c_void_p)]   # crystal: HaloGeomTables* or NULL
 
 
 class HaloLayerStats(C.Structure):

@@ -64,6 +64,7 @@ def load_library():
         "halo_collect_stats": (C.c_int, [H, C.POINTER(abi.HaloLayerStats)]),
         "halo_take_landed": (C.c_int, [H, C.POINTER(C.c_double)]),
         "halo_consumer_fold": (C.c_int, [H]),
+        "halo_consumer_consume": (C.c_int, [H, f32p, C.c_int, C.c_int, C.c_float, f32p, C.c_int]),
         "halo_consumer_snapshot": (C.c_int, [H, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]),
         "halo_consumer_reset": (C.c_int, [H]),
         "halo_consumer_composite": (C.c_int, [H, C.POINTER(abi.HaloComposite), f32p, C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_int32)]),
@@ -96,7 +97,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_snapshot", "halo_consumer_reset", "halo_consumer_composite", "halo_consumer_load_lanes", "halo_host_parse_composite_mode", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_consume", "halo_consumer_snapshot", "halo_consumer_reset", "halo_consumer_composite", "halo_consumer_load_lanes", "halo_host_parse_composite_mode", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_shape_scalars", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_color_fast_mask", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
 ]
@@ -226,8 +227,10 @@ class HipTraceBackend:
         d, p, w, tf = (np.ascontiguousarray(host_rays[0], np.float32), np.ascontiguousarray(host_rays[1], np.float32),
                        np.ascontiguousarray(host_rays[2], np.float32), np.ascontiguousarray(host_rays[3], np.uint32))
         n = w.shape[0]
+        crystal = host_rays[4] if len(host_rays) > 4 else None      # HostRayBatch::crystal: an abi.HaloGeomTables, or None = the entry's own
         hr = abi.HaloHostRays(d.ctypes.data_as(C.POINTER(C.c_float)), p.ctypes.data_as(C.POINTER(C.c_float)),
-                              w.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_uint32)))
+                              w.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              C.cast(C.pointer(crystal), C.c_void_p) if crystal is not None else None)
         self._check(self._L.halo_trace_layer(self._h, n, C.byref(hr), C.byref(stats)))
         self._pending_roots += int(stats.root_count)
         return stats
@@ -266,9 +269,21 @@ class HipTraceBackend:
         """Fold the device accumulator into the Neumaier running image and zero it (render.cpp:138-201)."""
         self._check(self._L.halo_consumer_fold(self._h))
 
+    def Consume(self, xyz, landed, lanes=None):
+        """RenderConsumer::ConsumeDeviceFused(const SimData&) for a drained image the caller holds: xyz float32[H,W,3] is Neumaier-folded
+        into the running image, `landed` added to the total intensity, lanes float32[classes,H,W] (optional) added to the class lanes."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        h, w = xyz.shape[0], xyz.shape[1]
+        lp, nc = None, 0
+        if lanes is not None:
+            lanes = np.ascontiguousarray(lanes, np.float32)
+            lp, nc = lanes.ctypes.data_as(C.POINTER(C.c_float)), lanes.shape[0]
+        self._check(self._L.halo_consumer_consume(self._h, xyz.ctypes.data_as(C.POINTER(C.c_float)), w, h, float(landed), lp, nc))
+        self._cons_size = (w, h)
+
     def Snapshot(self, intensity_factor=1.0, ray_color=(-1.0, -1.0, -1.0), background=(0.0, 0.0, 0.0), want_xyz=True):
         """PrepareSnapshot + PostSnapshot: returns (rgb uint8[H,W,3], xyz float32[H,W,3] | None, total_intensity)."""
-        w, h = self._render.width, self._render.height
+        w, h = getattr(self, "_cons_size", None) or (self._render.width, self._render.height)
         d = abi.HaloDisplay(float(intensity_factor), (C.c_float * 3)(*ray_color), (C.c_float * 3)(*background))
         rgb = np.empty((h, w, 3), np.uint8)
         xyz = np.empty((h, w, 3), np.float32) if want_xyz else None

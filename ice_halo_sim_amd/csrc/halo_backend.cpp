@@ -44,6 +44,7 @@ hipError_t launch_lane_hist(const double* lanes, uint32_t n_pix, const Composite
 hipError_t launch_composite(const double* lanes, uint32_t n_pix, const CompositeDev& cd, float* rgb_out, uint8_t* srgb_out, int blocks, hipStream_t stream);
 hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream);
 hipError_t launch_lanes_drain(double* lanes, float* dst, uint64_t n, int blocks, hipStream_t stream);
+hipError_t launch_lanes_add(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream);
 hipError_t launch_post_snapshot(const float* sum, const float* comp, uint8_t* rgb_out, float* xyz_out, uint32_t n_pix, float scale,
                                 const float ray_color[3], const float background[3], int blocks, hipStream_t stream);
 }
@@ -147,7 +148,7 @@ struct HaloBackend {
   uint32_t plane_cnt = 1, plane_copies = 8;
   std::vector<std::array<float, 3>> plane_coef;  // fold coefficients of the pending planes
   // consumer (RenderConsumer state, server/render.hpp): Neumaier running image + total landed intensity
-  DevBuf<float> cons_sum, cons_comp, cons_xyz_out;
+  DevBuf<float> cons_sum, cons_comp, cons_xyz_out, cons_stage;
   DevBuf<uint8_t> cons_rgb;
   DevBuf<float> comp_rgb, lanes_stage;   // halo_consumer_composite's linear image, halo_consumer_load_lanes' staging
   DevBuf<uint32_t> comp_hist;            // radix-select histogram (2048 bins)
@@ -370,6 +371,7 @@ int halo_destroy(halo_handle_t b) {
   b->cons_sum.release();
   b->cons_comp.release();
   b->cons_xyz_out.release();
+  b->cons_stage.release();
   b->cons_rgb.release();
   b->comp_rgb.release();
   b->lanes_stage.release();
@@ -719,7 +721,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // stochastic geometry: one pool record per geom_clock rays.  Device-generated prisms are 1360 B records (2.9 GB per
     // 64 Mi rays), other device-generated shapes 4.1 KB (2 GB per 16 Mi rays); host-built pools (pageable staging + H2D)
     // stay at 4 Mi rays
-    if (!host::IsDeterministic(crystal)) {
+    if (!host::IsDeterministic(crystal) && !(rays != nullptr && rays->crystal != nullptr && layer == 0)) {
       const uint64_t dev = b->stoch_chunk ? b->stoch_chunk : (1ull << 26);   // records: 2.9 GB (prism) / 8.6 GB (general) per 64 Mi rays
       m = std::min<uint64_t>(m, b->host_shapes ? (1ull << 22) : dev);
     }
@@ -868,9 +870,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.exit_cap = static_cast<uint32_t>(std::min<uint64_t>(b->exits.cap, 0xFFFFFFFFull));
     P.aggregate = static_cast<uint32_t>(b->aggregate);
     P.geom_clock = b->geom_clock;
-    const bool deterministic = host::IsDeterministic(E.crystal);
+    // HostRayBatch::crystal (trace_backend.hpp:230-239): injected rays may bring the crystal they were sampled on; it is traced as it is —
+    // one shape for the whole batch, no draw from the shape stream, no stochastic sample counted (test_cpu_trace_backend.cpp:737-777)
+    const bool host_crystal = rays != nullptr && rays->crystal != nullptr && layer == 0;
+    const bool deterministic = host_crystal || host::IsDeterministic(E.crystal);
     // the entry's tables may still be on the device from an earlier dispatch (table cache, see HaloBackend::TableCacheEntry)
-    HaloBackend::TableCacheEntry* ce = (b->table_cache && deterministic && P.source != kSrcTransit) ? &b->tcache[layer][ci] : nullptr;
+    HaloBackend::TableCacheEntry* ce = (b->table_cache && deterministic && !host_crystal && P.source != kSrcTransit) ? &b->tcache[layer][ci] : nullptr;
     if (ce && !b->tcache_dev.ptr) {
       if (b->tcache_dev.reserve(static_cast<size_t>(HALO_MAX_LAYERS) * HALO_MAX_ENTRIES) != hipSuccess) {
         (void)hipGetLastError();
@@ -945,8 +950,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // 0 = one shape per dispatch, 1 = pool of ShapeDev records, 2 = pool of ShapePrism records (device-generated prisms)
       const int geom = deterministic ? 0 : ((E.crystal.kind == HALO_CRYSTAL_PRISM && !host_pool) ? 2 : 1);
       std::vector<ShapeDev> pool((deterministic && !cached) || host_pool ? shape_cnt : 0u);
-      for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++)
-        host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
+      for (uint32_t k = 0; k < static_cast<uint32_t>(pool.size()); k++) {
+        if (host_crystal) host::ToShapeDev(*rays->crystal, pool[k]);
+        else host::MakeShapeDev(b->seed, E.crystal, deterministic ? 0 : (b->shape_count + k), pool[k]);
+      }
       const uint64_t first_shape = b->shape_count;
       if (!deterministic) {
         b->shape_count += shape_cnt;
@@ -1494,6 +1501,48 @@ int halo_consumer_fold(halo_handle_t b) {
   double landed = 0.0;
   if (int rc = take_landed_delta(b, &landed)) return rc;
   b->total_intensity += landed;  // total_intensity_ += xyz_landed_weight_ (render.cpp:149)
+  return HALO_OK;
+}
+
+int halo_consumer_consume(halo_handle_t b, const float* xyz, int width, int height, float landed, const float* lanes, int class_count) {
+  if (!b || !xyz) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "consumer_consume inside a session");
+  if (width <= 0 || height <= 0) return fail(b, HALO_FATAL, "consumer_consume: empty image");
+  if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > (1ull << 25)) return fail(b, HALO_UNAVAILABLE, "more than 2^25 pixels");
+  if (b->cons_sum.ptr && (b->cons_w != width || b->cons_h != height)) return fail(b, HALO_FATAL, "consumer_consume: image size differs from the consumer's (halo_consumer_reset first)");
+  HIPCHK(b, hipSetDevice(b->device));
+  const size_t n = static_cast<size_t>(width) * height * 3;
+  if (!b->cons_sum.ptr) {
+    HIPCHK(b, b->cons_sum.reserve(n));
+    HIPCHK(b, b->cons_comp.reserve(n));
+    b->cons_w = width;
+    b->cons_h = height;
+    HIPCHK(b, hipMemsetAsync(b->cons_sum.ptr, 0, n * sizeof(float), b->stream));
+    HIPCHK(b, hipMemsetAsync(b->cons_comp.ptr, 0, n * sizeof(float), b->stream));
+    b->total_intensity = 0.0;
+  }
+  // the caller's image goes through the staging buffer and the same Neumaier fold kernel the device accumulator takes (the kernel zeroes
+  // what it folds: the staging buffer here)
+  HIPCHK(b, b->cons_stage.reserve(n));
+  HIPCHK(b, hipMemcpyAsync(b->cons_stage.ptr, xyz, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  hipError_t e = launch_consumer_fold(b->cons_stage.ptr, b->cons_sum.ptr, b->cons_comp.ptr, static_cast<uint32_t>(n), b->cu_count * 8, b->stream);
+  if (e != hipSuccess) return hip_fail(b, e, "halo_consumer_fold_kernel launch");
+  if (lanes != nullptr && class_count > 0) {   // lane_pixel_data_: dst[p] += src[p] per class (render.cpp:176-185)
+    if (class_count != static_cast<int>(b->color_classes.size())) return fail(b, HALO_FATAL, "consumer_consume: class count must equal halo_set_color's");
+    const size_t nl = static_cast<size_t>(class_count) * width * height;
+    if (!b->lanes.ptr || b->lanes_w != width || b->lanes_h != height) {
+      HIPCHK(b, b->lanes.reserve(nl));
+      HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(double), b->stream));
+      b->lanes_w = width;
+      b->lanes_h = height;
+    }
+    HIPCHK(b, b->lanes_stage.reserve(nl));
+    HIPCHK(b, hipMemcpyAsync(b->lanes_stage.ptr, lanes, nl * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    e = launch_lanes_add(b->lanes_stage.ptr, b->lanes.ptr, nl, b->cu_count * 8, b->stream);
+    if (e != hipSuccess) return hip_fail(b, e, "halo_lanes_add_kernel launch");
+  }
+  HIPCHK(b, hipStreamSynchronize(b->stream));   // `xyz` / `lanes` are the caller's (pageable) memory
+  b->total_intensity += static_cast<double>(landed);   // total_intensity_ += xyz_landed_weight_ (render.cpp:149)
   return HALO_OK;
 }
 

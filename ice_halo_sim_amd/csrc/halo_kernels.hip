@@ -711,6 +711,11 @@ __global__ void __launch_bounds__(kBlock) halo_lanes_load_kernel(const float* __
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) lanes[i] = static_cast<double>(src[i]);
 }
 
+// ConsumeDeviceFused's lane half: lanes drained elsewhere are ADDED (render.cpp:176-185)
+__global__ void __launch_bounds__(kBlock) halo_lanes_add_kernel(const float* __restrict__ src, double* __restrict__ lanes, uint64_t n) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) lanes[i] += static_cast<double>(src[i]);
+}
 // the inverse at the seam (TraceBackend::ReadbackClassLanes hands out floats and drains the device lanes): narrow into the staging buffer, zero the lane
 __global__ void __launch_bounds__(kBlock) halo_lanes_drain_kernel(double* __restrict__ lanes, float* __restrict__ dst, uint64_t n) {
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
@@ -734,6 +739,10 @@ hipError_t launch_lanes_load(const float* src, double* lanes, uint64_t n, int bl
   return hipGetLastError();
 }
 
+hipError_t launch_lanes_add(const float* src, double* lanes, uint64_t n, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(halo_lanes_add_kernel, dim3(blocks), dim3(kBlock), 0, stream, src, lanes, n);
+  return hipGetLastError();
+}
 hipError_t launch_lanes_drain(double* lanes, float* dst, uint64_t n, int blocks, hipStream_t stream) {
   hipLaunchKernelGGL(halo_lanes_drain_kernel, dim3(blocks), dim3(kBlock), 0, stream, lanes, dst, n);
   return hipGetLastError();

@@ -120,6 +120,10 @@ class HipTraceBackend {
   }
   // RenderConsumer on the device (server/render.cpp:138-330)
   void ConsumeDeviceFused() { Check(halo_consumer_fold(h_)); }
+  // ... and the same for a drained image the caller holds (SimData::xyz_pixel_data_ / xyz_landed_weight_ / lane_pixel_data_ of another rank or backend)
+  void ConsumeDeviceFused(const float* xyz, int width, int height, float landed, const float* lanes = nullptr, int class_count = 0) {
+    Check(halo_consumer_consume(h_, xyz, width, height, landed, lanes, class_count));
+  }
   // CompositeColorClassesLinear + LinearRgbToSrgbU8 (server/component_compositor.cpp:180-303) on the device lanes, which stay; returns what the
   // reference's function returns (false: nothing referenced, or no energy in the participating lanes); either output may be null
   bool CompositeColorClasses(const HaloComposite& spec, float* linear_rgb_out, uint8_t* srgb_out, float* participating_p99_y = nullptr) {

@@ -25,10 +25,11 @@
 extern "C" {
 #endif
 
-#define HALO_ABI_VERSION 5   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
+#define HALO_ABI_VERSION 6   /* 2: HaloFilter holds up to 64 OR-clauses / 64 terms (was 8 / 16); 3: halo_last_route, piecewise
                                 halo_drain_exits, option "shuffle_chunk", exit records carry full 64-face paths; 4: HaloRouteInfo
                                 names the kernel mode (5 modes) and its specialisation, option "filter_fast"; 5: halo_consumer_composite /
-                                halo_consumer_load_lanes (additive: nothing that existed changed) */
+                                halo_consumer_load_lanes (additive: nothing that existed changed); 6: HaloHostRays::crystal (the
+                                seam's HostRayBatch::crystal), halo_consumer_consume (ConsumeDeviceFused of a drained image the CALLER holds) */
 
 enum { HALO_OK = 0, HALO_UNAVAILABLE = 1, HALO_FATAL = 2 };
 
@@ -212,6 +213,9 @@ typedef struct HaloHostRays {
   const float* p;      /* 3*count */
   const float* w;      /* count */
   const uint32_t* tf;  /* count — compact polygon-face id of the entry face */
+  const struct HaloGeomTables* crystal;   /* HostRayBatch::crystal (trace_backend.hpp:230-239): the crystal the rays were sampled on, or NULL =
+                                             the entry's own.  A supplied crystal is traced as it is — it consumes no MakeCrystal draw, so it is
+                                             not a stochastic sample (test_cpu_trace_backend.cpp:737-777) — whatever the entry's shape distributions */
 } HaloHostRays;
 
 /* LayerStats — trace_backend.hpp:296-299 (+ continuation count from LayerHandle). */
@@ -382,6 +386,11 @@ typedef struct HaloDisplay {
 /* ConsumeDeviceFused (render.cpp:138-201): fold the device accumulator into the running image with Neumaier-compensated
  * adds (accum_shared.h:70-74), add its landed weight to total_intensity, zero the accumulator.  All on device. */
 int halo_consumer_fold(halo_handle_t h);
+/* The same fold for a drained image the CALLER holds — RenderConsumer::ConsumeDeviceFused(const SimData&), render.cpp:138-201, as it is
+ * written: xyz = SimData::xyz_pixel_data_ (W*H*3 floats, Neumaier-folded into the running image), landed = xyz_landed_weight_ (added to
+ * total_intensity), lanes = lane_pixel_data_ (class_count x W x H floats added to the class lanes; NULL / 0 = none).  What another rank,
+ * another backend or the legacy path drained becomes part of this consumer; the first call sizes the consumer to width x height. */
+int halo_consumer_consume(halo_handle_t h, const float* xyz, int width, int height, float landed, const float* lanes, int class_count);
 /* PrepareSnapshot + PostSnapshot (render.cpp:465-578): snapshot = sum + compensation; scale = intensity_factor * 0.08 *
  * N_pix / total_intensity (ExposureScale :96-102); XYZ → gamut clip → linear RGB → sRGB u8 (util/color_space.cpp).
  * rgb_out: W*H*3 bytes (nullable); xyz_out: W*H*3 floats raw snapshot (nullable); total_intensity out (nullable). */
@@ -512,7 +521,7 @@ HALO_STATIC_ASSERT(sizeof(HaloLayer) == 8 + HALO_MAX_ENTRIES * sizeof(HaloEntry)
 HALO_STATIC_ASSERT(sizeof(HaloScene) == 20 + HALO_MAX_LAYERS * sizeof(HaloLayer), "HaloScene");
 HALO_STATIC_ASSERT(sizeof(HaloRender) == 44, "HaloRender");
 HALO_STATIC_ASSERT(sizeof(HaloWl) == 16, "HaloWl");
-HALO_STATIC_ASSERT(sizeof(HaloHostRays) == 4 * sizeof(void*), "HaloHostRays");
+HALO_STATIC_ASSERT(sizeof(HaloHostRays) == 5 * sizeof(void*), "HaloHostRays");
 HALO_STATIC_ASSERT(sizeof(HaloLayerStats) == 56, "HaloLayerStats");
 HALO_STATIC_ASSERT(sizeof(HaloExitRecord) == 40 + HALO_PATH_CAP, "HaloExitRecord");
 HALO_STATIC_ASSERT(sizeof(HaloRouteInfo) == 40, "HaloRouteInfo");

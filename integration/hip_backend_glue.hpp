@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "config/color_class_table.hpp"
+#include <cmath>
+#include <cstring>
+
 #include "config/color_gate_table.hpp"
 #include "config/crystal_config.hpp"
 #include "config/filter_config.hpp"
@@ -35,6 +38,7 @@
 #include "config/raypath_color_config.hpp"
 #include "config/render_config.hpp"
 #include "core/backend/trace_backend.hpp"
+#include "core/crystal.hpp"
 #include "core/backend/wl_pool.hpp"
 #include "hip_trace_backend.hpp"  // this repo: ice_halo_sim_amd/csrc/hip_trace_backend.hpp (header-only, includes halo_trace.h)
 
@@ -163,6 +167,45 @@ inline HaloRender ToHalo(const RenderConfig& r) {
 
 // ---- IlluminantType (util/illuminant_data.hpp:12-19) -> HALO_ILLUM_* (same order) ---------------------------------------
 inline int32_t ToHalo(IlluminantType t) { return static_cast<int32_t>(t); }
+
+// ---- Crystal (core/crystal.hpp: CfGeom(), the closed-form POD) -> HaloGeomTables: compact present faces with their unit normals, plane
+// distances (d / |n|, PopulateFromCfGeom crystal.cpp:304-347) and face numbers, and the entry fan triangles (0, k, k+1) of each face with
+// normal and area exactly as detail::BuildEntrySubTris forms them (simulator.cpp:90-129).  False when the crystal has no closed-form
+// geometry or exceeds the engine's caps (then the entry's own crystal is traced).
+inline bool ToHalo(const Crystal& crystal, HaloGeomTables& g) {
+  const CrystalGeom& cf = crystal.CfGeom();
+  g = HaloGeomTables{};
+  if (cf.face_cnt <= 0) return false;
+  int32_t faces = 0, tris = 0;
+  for (int slot = 0; slot < cf.face_cnt; slot++) {
+    if (!cf.face_present[slot]) continue;
+    if (faces >= HALO_MAX_FACES) return false;
+    const float* pc = cf.plane_coef + slot * 4;
+    const float len = std::sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    for (int a = 0; a < 3; a++) g.face_n[faces * 3 + a] = cf.face_normal[slot * 3 + a];
+    g.face_d[faces] = len > 0.0f ? pc[3] / len : 0.0f;
+    g.face_number[faces] = cf.face_number[slot];
+    const float* base = cf.face_vtx + static_cast<size_t>(slot) * kCrystalGeomMaxVtxPerFace * 3;
+    for (int k = 1; k + 1 < cf.face_vtx_cnt[slot]; k++) {
+      if (tris >= HALO_MAX_TRIS) return false;
+      float* v = g.tri_v + tris * 9;
+      std::memcpy(v + 0, base + 0, 3 * sizeof(float));
+      std::memcpy(v + 3, base + k * 3, 3 * sizeof(float));
+      std::memcpy(v + 6, base + (k + 1) * 3, 3 * sizeof(float));
+      const float e1[3] = { v[3] - v[0], v[4] - v[1], v[5] - v[2] }, e2[3] = { v[6] - v[0], v[7] - v[1], v[8] - v[2] };
+      float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+      const float raw = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      g.tri_area[tris] = raw / 2.0f;
+      for (int a = 0; a < 3; a++) g.tri_n[tris * 3 + a] = raw > 0.0f ? n[a] / raw : 0.0f;
+      g.tri_face[tris] = faces;
+      tris++;
+    }
+    faces++;
+  }
+  g.face_cnt = faces;
+  g.tri_cnt = tris;
+  return faces > 0;
+}
 
 // ---- SceneConfig (config/proj_config.hpp:15-38) -> HaloScene + filter table + colour tables ------------------------------
 struct SceneTables {
@@ -301,7 +344,10 @@ class HipBackendGlue final : public TraceBackend {
       } else if (roots.host.d && roots.host.p && roots.host.w && roots.host.tf) {
         std::vector<uint32_t> tf(roots.host.count);
         for (size_t i = 0; i < roots.host.count; i++) tf[i] = static_cast<uint32_t>(roots.host.tf[i]);   // IdType -> u32
-        const HaloHostRays hr{ roots.host.d, roots.host.p, roots.host.w, tf.data() };
+        // HostRayBatch::crystal (trace_backend.hpp:230-239): the crystal the rays were sampled on rides along as the engine's geometry tables
+        HaloGeomTables geom{};
+        const bool has_crystal = roots.host.crystal != nullptr && hip_glue::ToHalo(*roots.host.crystal, geom);
+        const HaloHostRays hr{ roots.host.d, roots.host.p, roots.host.w, tf.data(), has_crystal ? &geom : nullptr };
         lh = be_->TraceLayer(roots.host.count, &hr);
       } else {
         lh = be_->TraceLayer(roots.host.count);

@@ -1997,10 +1997,16 @@ int ho_trace_layer(HoBackend* b, uint64_t count, const HaloHostRays* rays, HaloL
     c->sun_half = (b->scene.sun_diameter * 0.5f) * HO_DEG2RAD;
     c->geom_clock = (uint32_t)b->geom_clock;
     /* shape pool: one shape per geom_clock rays when stochastic (simulator.cpp:1244-1275), else one */
-    int det = crystal_is_deterministic(&E->crystal);
+    /* HostRayBatch::crystal (trace_backend.hpp:230-239, cpu_trace_backend.cpp:121-144): injected rays may bring the crystal they were sampled
+     * on — traced as it is, no MakeCrystal draw */
+    const int host_crystal = rays && rays->crystal && layer == 0;
+    int det = host_crystal || crystal_is_deterministic(&E->crystal);
     uint32_t P = det ? 1u : (uint32_t)((n_ci + c->geom_clock - 1) / c->geom_clock);
     HaloGeomTables* shapes = (HaloGeomTables*)malloc((size_t)P * sizeof(HaloGeomTables));
-    for (uint32_t k = 0; k < P; k++) make_shape(b, &E->crystal, det ? 0 : (b->shape_count + k), &shapes[k]);
+    for (uint32_t k = 0; k < P; k++) {
+      if (host_crystal) shapes[k] = *rays->crystal;
+      else make_shape(b, &E->crystal, det ? 0 : (b->shape_count + k), &shapes[k]);
+    }
     if (!det) b->shape_count += P;
     c->shapes = shapes;
     c->shape_cnt = P;
@@ -2172,6 +2178,34 @@ int ho_consumer_fold(HoBackend* b) { /* ConsumeDeviceFused render.cpp:138-149 */
   memset(b->xyz, 0, n * sizeof(float));
   b->total_intensity += (float)b->landed;
   b->landed = 0.0;
+  return HALO_OK;
+}
+
+/* RenderConsumer::ConsumeDeviceFused(const SimData&) render.cpp:138-201 for a drained image the caller holds */
+int ho_consumer_consume(HoBackend* b, const float* xyz, int width, int height, float landed, const float* lanes, int class_count) {
+  if (!xyz || width <= 0 || height <= 0) return HALO_FATAL;
+  size_t n = (size_t)width * height * 3;
+  if (b->cons_sum && (b->cons_w != width || b->cons_h != height)) return HALO_FATAL;
+  if (!b->cons_sum) {
+    b->cons_sum = (float*)calloc(n, sizeof(float));
+    b->cons_comp = (float*)calloc(n, sizeof(float));
+    b->cons_w = width;
+    b->cons_h = height;
+    b->total_intensity = 0.0f;
+  }
+  for (size_t i = 0; i < n; i++) ho_neumaier_add(&b->cons_sum[i], &b->cons_comp[i], xyz[i]);
+  b->total_intensity += landed;
+  if (lanes && class_count > 0) {
+    if (class_count != b->color_class_count) return HALO_FATAL;
+    size_t nl = (size_t)class_count * width * height;
+    if (!b->lanes || b->lanes_w != width || b->lanes_h != height) {
+      free(b->lanes);
+      b->lanes = (float*)calloc(nl, sizeof(float));
+      b->lanes_w = width;
+      b->lanes_h = height;
+    }
+    for (size_t i = 0; i < nl; i++) b->lanes[i] += lanes[i];
+  }
   return HALO_OK;
 }
 

@@ -122,6 +122,7 @@ void ho_gamut_clip_xyz(const float xyz[3], float clipped[3]);
 void ho_xyz_to_linear_rgb(const float xyz[3], float rgb[3]);
 float ho_linear_to_srgb(float linear);
 int ho_consumer_fold(HoBackend* b);
+int ho_consumer_consume(HoBackend* b, const float* xyz, int width, int height, float landed, const float* lanes, int class_count);
 int ho_consumer_snapshot(HoBackend* b, const HaloDisplay* display, uint8_t* rgb_out, float* xyz_out, double* total_intensity);
 /* display-side composite of the class lanes (server/component_compositor.cpp:24-303; ParticipatingExposureScale render.cpp:120-135).
  * Stateless: `lanes` = class_count x W x H floats as ReadbackClassLanes hands them out, referenced_mask = OR of the classes' member

@@ -121,6 +121,7 @@ def oracle(fma=False):
     L.ho_xyz_to_linear_rgb.restype = None; L.ho_xyz_to_linear_rgb.argtypes = [f32p, f32p]
     L.ho_linear_to_srgb.restype = C.c_float; L.ho_linear_to_srgb.argtypes = [C.c_float]
     L.ho_consumer_fold.restype = C.c_int; L.ho_consumer_fold.argtypes = [C.c_void_p]
+    L.ho_consumer_consume.restype = C.c_int; L.ho_consumer_consume.argtypes = [C.c_void_p, f32p, C.c_int, C.c_int, C.c_float, f32p, C.c_int]
     L.ho_participating_exposure_scale.restype = C.c_float; L.ho_participating_exposure_scale.argtypes = [C.c_float] * 3
     L.ho_parse_composite_mode.restype = C.c_int; L.ho_parse_composite_mode.argtypes = [C.c_char_p]
     L.ho_composite.restype = C.c_int

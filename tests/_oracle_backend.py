@@ -59,8 +59,10 @@ class OracleBackend:
         else:
             d, p, w, tf = (np.ascontiguousarray(host_rays[0], np.float32), np.ascontiguousarray(host_rays[1], np.float32),
                            np.ascontiguousarray(host_rays[2], np.float32), np.ascontiguousarray(host_rays[3], np.uint32))
+            crystal = host_rays[4] if len(host_rays) > 4 else None
             hr = abi.HaloHostRays(d.ctypes.data_as(C.POINTER(C.c_float)), p.ctypes.data_as(C.POINTER(C.c_float)),
-                                  w.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_uint32)))
+                                  w.ctypes.data_as(C.POINTER(C.c_float)), tf.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  C.cast(C.pointer(crystal), C.c_void_p) if crystal is not None else None)
             assert self._L.ho_trace_layer(self._h, w.shape[0], C.byref(hr), C.byref(stats)) == 0
         self._pending_roots += int(stats.root_count)
         return stats
@@ -99,8 +101,18 @@ class OracleBackend:
     def ConsumeDeviceFused(self):
         assert self._L.ho_consumer_fold(self._h) == 0
 
+    def Consume(self, xyz, landed, lanes=None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        h, w = xyz.shape[0], xyz.shape[1]
+        lp, nc = None, 0
+        if lanes is not None:
+            lanes = np.ascontiguousarray(lanes, np.float32)
+            lp, nc = lanes.ctypes.data_as(C.POINTER(C.c_float)), lanes.shape[0]
+        assert self._L.ho_consumer_consume(self._h, xyz.ctypes.data_as(C.POINTER(C.c_float)), w, h, float(landed), lp, nc) == 0
+        self._cons_size = (w, h)
+
     def Snapshot(self, intensity_factor=1.0, ray_color=(-1.0, -1.0, -1.0), background=(0.0, 0.0, 0.0), want_xyz=True):
-        w, h = self._render.width, self._render.height
+        w, h = getattr(self, "_cons_size", None) or (self._render.width, self._render.height)
         d = abi.HaloDisplay(float(intensity_factor), (C.c_float * 3)(*ray_color), (C.c_float * 3)(*background))
         rgb = np.empty((h, w, 3), np.uint8)
         xyz = np.empty((h, w, 3), np.float32) if want_xyz else None

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, sym), "libhalo_hip.so does not export " + sym
     assert declared == set(backend.EXPORTED_SYMBOLS), declared ^ set(backend.EXPORTED_SYMBOLS)
     want = int(re.search(r"#define\s+HALO_ABI_VERSION\s+(\d+)", header).group(1))
-    assert L.halo_abi_version() == want == 5
+    assert L.halo_abi_version() == want == 6
     for i, t in enumerate([abi.HaloScene, abi.HaloRender, abi.HaloWl, abi.HaloExitRecord, abi.HaloGeomTables,
                            abi.HaloLayerStats, abi.HaloEntry, abi.HaloColorSet, abi.HaloColorClass, abi.HaloFilter, abi.HaloRouteInfo, abi.HaloComposite]):
         assert L.halo_abi_sizeof(i) == C.sizeof(t), t.__name__
