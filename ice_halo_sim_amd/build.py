@@ -9,6 +9,11 @@ CSRC = os.path.join(HERE, "csrc")
 PROBE = bool(os.environ.get("HALO_PROBE"))   # phase-probe build (tools/phase_probe.py): its own file, never the shipped library
 # HALO_BUILD_TAG=x builds libhalo_hip_x.so in build_x/ (A/B experiments: load it with HALO_LIB=...); HALO_DEFS="-DA=1 -DB" adds macros
 TAG = "probe" if PROBE else os.environ.get("HALO_BUILD_TAG", "")
+# HALO_BUILD_TAG=strict is a TESTED variant, not an experiment: the reference's roundings (separately rounded products and sums, IEEE division
+# and square root in the Fresnel split) — libhalo_hip_strict.so, held to the unconditioned per-ray bars by tests/test_gpu_strict_variant.py
+if TAG == "strict":
+    os.environ["HALO_DEFS"] = (os.environ.get("HALO_DEFS", "") + " -DHALO_STRICT=1 -DHALO_FRESNEL=1").strip()
+    os.environ["HALO_FP_CONTRACT"] = "off"
 LIB = os.path.join(HERE, "libhalo_hip_%s.so" % TAG if TAG else "libhalo_hip.so")
 SOURCES = ["halo_trace_m0.hip", "halo_trace_m1.hip", "halo_trace_m2.hip", "halo_trace_m3.hip", "halo_trace_m4.hip", "halo_kernels.hip", "halo_shapegen.hip", "halo_backend.cpp",
            "halo_host.cpp"]

@@ -80,6 +80,19 @@ HD float add_rn(float a, float b) {
 
 // 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32) for the inner-loop quotients whose last bit does
 // not steer a discrete decision; IEEE division costs ~10 VALU ops here and the loop had nine of them per hit.
+// Every sum of products on the ray's way is spelled as the fma chain it is evaluated as (round 4: the instantiations of one kernel must trace
+// bit-identical rays whatever code surrounds the expression).  HALO_STRICT builds — the tested variant `libhalo_hip_strict.so`, compiled with
+// -ffp-contract=off and HALO_FRESNEL=1 — spell the same chains as separately rounded products and sums in the same order: the REFERENCE's
+// roundings on a host without FMA contraction, which is what the oracle computes; tests/test_gpu_strict_variant.py holds that build to the
+// unconditioned per-ray bars.
+#ifndef HALO_STRICT
+#define HALO_STRICT 0
+#endif
+#if HALO_STRICT
+#define HALO_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define HALO_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 HD float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -175,13 +188,13 @@ HD float gaussian(Stream& s) {  // Box-Muller, pcg_shared.h:277-281
 
 HD float get_dist(Stream& s, uint32_t dtype, float mean, float spread) {  // pcg_shared.h:290-308
   if (dtype == HALO_DIST_NONE) return mean;
-  if (dtype == HALO_DIST_UNIFORM) return fmaf(uniform(s) - 0.5f, spread, mean);
-  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return fmaf(gaussian(s), spread, mean);
-  if (dtype == HALO_DIST_ZIGZAG) return fabsf(fmaf(spread, sinf(uniform(s) * 2.0f * kPiF), mean));
+  if (dtype == HALO_DIST_UNIFORM) return HALO_FMA(uniform(s) - 0.5f, spread, mean);
+  if (dtype == HALO_DIST_GAUSS || dtype == HALO_DIST_GAUSS_LEGACY) return HALO_FMA(gaussian(s), spread, mean);
+  if (dtype == HALO_DIST_ZIGZAG) return fabsf(HALO_FMA(spread, sinf(uniform(s) * 2.0f * kPiF), mean));
   float u = uniform(s);
   float sgn = (u < 0.5f) ? -1.0f : 1.0f;
   float arg = fmaxf(1.0f - 2.0f * fabsf(u - 0.5f), 1e-30f);
-  return fmaf(-(spread * sgn), logf(arg), mean);
+  return HALO_FMA(-(spread * sgn), logf(arg), mean);
 }
 
 // 4-round balanced Feistel + cycle walk on [0, n)  (pcg_shared.h:550-603)
@@ -240,7 +253,7 @@ HD float invert_lat_lut(float xi, const float* lut) {
   float c0 = cdf[lo], c1 = cdf[lo + 1u];
   float denom = c1 - c0;
   float w = denom > 0.0f ? (xi - c0) * fast_rcp(denom) : 0.0f;
-  return fmaf(w, th[lo + 1u] - th[lo], th[lo]);
+  return HALO_FMA(w, th[lo + 1u] - th[lo], th[lo]);
 }
 
 HD uint32_t lat_lut_bin(float theta, const float* lut) {
@@ -302,11 +315,11 @@ HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
   // (every sum of products on the ray's way is written as the fma chain it is evaluated as: which of a*b + c*d's two products gets fused is
   // otherwise the backend's choice, and it follows the code AROUND the expression — instantiations of one kernel then trace rays that differ
   // in the last bit, and one in a few million of them takes the other side of a decision; see dot3_fma)
-  R[0] = fmaf(-s3, t10, c3 * t00);
-  R[1] = fmaf(-s3, t11, c3 * t01);
+  R[0] = HALO_FMA(-s3, t10, c3 * t00);
+  R[1] = HALO_FMA(-s3, t11, c3 * t01);
   R[2] = c3 * t02;
-  R[3] = fmaf(c3, t10, s3 * t00);
-  R[4] = fmaf(c3, t11, s3 * t01);
+  R[3] = HALO_FMA(c3, t10, s3 * t00);
+  R[4] = HALO_FMA(c3, t11, s3 * t01);
   R[5] = s3 * t02;
   R[6] = k3 * t20;
   R[7] = k3 * t21;
@@ -314,9 +327,9 @@ HD void build_crystal_rotation(float lon, float lat, float roll, float* R) {
 }
 
 HD void apply_inverse(const float* R, float x, float y, float z, float* o) {  // o = R^T v
-  o[0] = fmaf(R[6], z, fmaf(R[3], y, R[0] * x));
-  o[1] = fmaf(R[7], z, fmaf(R[4], y, R[1] * x));
-  o[2] = fmaf(R[8], z, fmaf(R[5], y, R[2] * x));
+  o[0] = HALO_FMA(R[6], z, HALO_FMA(R[3], y, R[0] * x));
+  o[1] = HALO_FMA(R[7], z, HALO_FMA(R[4], y, R[1] * x));
+  o[2] = HALO_FMA(R[8], z, HALO_FMA(R[5], y, R[2] * x));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -468,7 +481,11 @@ HD void atomic_add_f32(float* addr, float v) {
 typedef float float2v __attribute__((ext_vector_type(2)));
 HD float2v pk_dot(float2v X, float2v Y, float2v Z, float gx, float gy, float gz) {   // (n.d, n.p) of one plane: explicit packed fma chain (see dot3_fma)
   const float2v vx = {gx, gx}, vy = {gy, gy}, vz = {gz, gz};
+#if HALO_STRICT
+  return Z * vz + (Y * vy + X * vx);
+#else
   return __builtin_elementwise_fma(Z, vz, __builtin_elementwise_fma(Y, vy, X * vx));
+#endif
 }
 
 // SMALLC: binned kernels of shape-pool dispatches halve the one-channel cache (their LDS also holds the pool slots and the
@@ -1251,7 +1268,7 @@ HD bool exit_may_land(const ProjDev& p, float wx, float wy, float wz, int lens =
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT || t == HALO_LENS_FISHEYE_STEREOGRAPHIC ||
       t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
     if ((vr == HALO_VISIBLE_UPPER && wz > 0.0f) || (vr == HALO_VISIBLE_LOWER && wz < 0.0f)) return false;
-    return fmaf(p.rot[8], -wz, fmaf(p.rot[5], -wy, p.rot[2] * (-wx))) > -1e-6f;
+    return HALO_FMA(p.rot[8], -wz, HALO_FMA(p.rot[5], -wy, p.rot[2] * (-wx))) > -1e-6f;
   }
   return true;
 }
@@ -1317,9 +1334,9 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
   const bool queued = ModeTraits<MODE>::kFast && cache.q != nullptr;
   if (!queued && !live) return;
   // crystal → world (trace_backend.hpp:71-89 invariant: everything leaving the crystal is world-space)
-  float wx = fmaf(R[2], lz, fmaf(R[1], ly, R[0] * lx));
-  float wy = fmaf(R[5], lz, fmaf(R[4], ly, R[3] * lx));
-  float wz = fmaf(R[8], lz, fmaf(R[7], ly, R[6] * lx));
+  float wx = HALO_FMA(R[2], lz, HALO_FMA(R[1], ly, R[0] * lx));
+  float wy = HALO_FMA(R[5], lz, HALO_FMA(R[4], ly, R[3] * lx));
+  float wz = HALO_FMA(R[8], lz, HALO_FMA(R[7], ly, R[6] * lx));
   // physical filter first: a failing exit terminates — neither emitted nor continued (simulator.cpp:689,725-728)
   if (ModeTraits<MODE>::kTables && filter != nullptr) {
     if (!filter_check(*filter, pv, wx, wy, wz, P.crystal_id)) return;
@@ -1421,8 +1438,8 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
 // variants below must pick the same triangle for the same uniform whatever else the instantiation around them compiles, and left to the
 // backend the choice between fma(a, b, c * d) and fma(c, d, a * b) follows the surrounding code (round 4: once the regular-prism kernels
 // stopped compiling the other two variants, one ray in 3 million entered through the neighbouring triangle).
-HD float dot3_fma(const float* d, float x, float y, float z) { return fmaf(d[2], z, fmaf(d[1], y, d[0] * x)); }
-HD float tri_point(float u, float v, float a, float b, float c) { return fmaf(u, b - a, fmaf(v, c - a, a)); }
+HD float dot3_fma(const float* d, float x, float y, float z) { return HALO_FMA(d[2], z, HALO_FMA(d[1], y, d[0] * x)); }
+HD float tri_point(float u, float v, float a, float b, float c) { return HALO_FMA(u, b - a, HALO_FMA(v, c - a, a)); }
 
 // Projected-area categorical entry pick + uniform point (InitRay_p_fid simulator.cpp:133-192 in its device form
 // gen_root_kernel cu:1556-1597).  Two passes over the fan table instead of a 64-float private array.
@@ -1651,9 +1668,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float sp, cp;
     sincos_small(phi, &sp, &cp);
     float y = cp * r, z = sp * r;
-    float dwx = fmaf(-(G.c_lon * G.s_lat), z, fmaf(-G.s_lon, y, (G.c_lon * G.c_lat) * x));
-    float dwy = fmaf(-(G.s_lon * G.s_lat), z, fmaf(G.c_lon, y, (G.s_lon * G.c_lat) * x));
-    float dwz = fmaf(G.c_lat, z, G.s_lat * x);
+    float dwx = HALO_FMA(-(G.c_lon * G.s_lat), z, HALO_FMA(-G.s_lon, y, (G.c_lon * G.c_lat) * x));
+    float dwy = HALO_FMA(-(G.s_lon * G.s_lat), z, HALO_FMA(G.c_lon, y, (G.s_lon * G.c_lat) * x));
+    float dwz = HALO_FMA(G.c_lat, z, G.s_lat * x);
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
     if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
@@ -1750,7 +1767,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   auto fresnel = [&](float cos_t, float rr, float rr2, float one_m_rr2, const float4& fn) {
     Split o;
 #if HALO_FRESNEL == 0
-    const float dd = fmaf(one_m_rr2, fast_rcp(cos_t * cos_t), rr2);
+    const float dd = HALO_FMA(one_m_rr2, fast_rcp(cos_t * cos_t), rr2);
 #else
     const float dd = add_rn(fresnel_div(one_m_rr2, cos_t * cos_t), rr2);   // quotient rounded, then the sum: the reference's order (optics.cpp:30)
 #endif
@@ -1758,14 +1775,14 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     const float sq = fresnel_sqrt(fmaxf(dd, 0.0f));
     float Rs = fresnel_div(rr - sq, rr + sq);
     Rs *= Rs;
-    float Rp = fresnel_div(fmaf(-rr, sq, 1.0f), fmaf(rr, sq, 1.0f));
+    float Rp = fresnel_div(HALO_FMA(-rr, sq, 1.0f), HALO_FMA(rr, sq, 1.0f));
     Rp *= Rp;
     o.w_refl = ((Rs + Rp) * 0.5f) * w;
     o.w_refr = w - o.w_refl;
     const float k_refl = 2.0f * cos_t;
     const float k_refr = (rr - sq) * cos_t;
-    o.rl[0] = fmaf(-k_refl, fn.x, d[0]), o.rl[1] = fmaf(-k_refl, fn.y, d[1]), o.rl[2] = fmaf(-k_refl, fn.z, d[2]);
-    o.rf[0] = fmaf(-k_refr, fn.x, rr * d[0]), o.rf[1] = fmaf(-k_refr, fn.y, rr * d[1]), o.rf[2] = fmaf(-k_refr, fn.z, rr * d[2]);
+    o.rl[0] = HALO_FMA(-k_refl, fn.x, d[0]), o.rl[1] = HALO_FMA(-k_refl, fn.y, d[1]), o.rl[2] = HALO_FMA(-k_refl, fn.z, d[2]);
+    o.rf[0] = HALO_FMA(-k_refr, fn.x, rr * d[0]), o.rf[1] = HALO_FMA(-k_refr, fn.y, rr * d[1]), o.rf[2] = HALO_FMA(-k_refr, fn.z, rr * d[2]);
     return o;
   };
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
@@ -1892,9 +1909,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       done = done || stray;
     }
     if (!done) {
-      p[0] = fmaf(t_best, d[0], p[0]);
-      p[1] = fmaf(t_best, d[1], p[1]);
-      p[2] = fmaf(t_best, d[2], p[2]);
+      p[0] = HALO_FMA(t_best, d[0], p[0]);
+      p[1] = HALO_FMA(t_best, d[1], p[1]);
+      p[2] = HALO_FMA(t_best, d[2], p[2]);
       face = hit;
       if constexpr (ModeTraits<MODE>::kFastPath) {   // (max_hits <= 16: the register holds every path; its length is the loop counter)
         uint32_t fn;

@@ -1,0 +1,61 @@
+"""The build with the reference's roundings, kept alive as a TESTED variant (round-4 review): `libhalo_hip_strict.so` = HALO_STRICT (every fma
+chain of the ray's way spelled as separately rounded products and sums, in the same order) + HALO_FRESNEL=1 (IEEE division and square root in the
+Fresnel split) + -ffp-contract=off, built by __graft_entry__.build() / `HALO_BUILD_TAG=strict python -m ice_halo_sim_amd.build`.
+
+The product contracts products into FMAs, and on fixed-orientation scenes — every ray meets the crystal the same way — a few percent of its exits
+then differ from the uncontracted oracle by more than the per-ray bars (direction 2e-5, weight 2e-4); tests/test_gpu_parity.py's
+match_exits_conditioned therefore widens each exit's bar by what the oracle's own two roundings differ by on that exit.  That yardstick is only
+as good as the claim behind it: "a build that rounds like the reference agrees with the oracle exit by exit".  This file keeps the claim
+falsifiable — the strict build is held to the UNCONDITIONED bars on the seeds that motivated the conditioning."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STRICT = os.path.join(ROOT, "ice_halo_sim_amd", "libhalo_hip_strict.so")
+# unconditioned match_exits of the strict build, measured (profiles/r05_strict_variant.txt): 0.99887 / 0.99962 / 0.99444 / 0.99957 — against
+# 0.9948 / 0.9968 / 0.9811 / 0.9096 of the product and 0.945 / 0.951 / 0.976 / 0.918 between the oracle's own two roundings
+BARS = {247: 0.998, 411: 0.998, 702: 0.993, 11584: 0.998}
+
+DRIVER = r"""
+import json, sys
+sys.path.insert(0, %r)
+from tests import test_gpu_fuzz as F
+out = {}
+for s in %r:
+    r = F.run_case(s)
+    out[s] = {"match": float(r["match"][0]), "cond": float(r["cond"][0]), "pair": float(r["oracle_pair"]), "fixed": int(r["fixed_axes"]),
+              "landed": [float(r["landed"][0]), float(r["landed"][1])]}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(lib):
+    env = dict(os.environ)
+    if lib:
+        env["HALO_LIB"] = lib
+    else:
+        env.pop("HALO_LIB", None)
+    r = subprocess.run([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS))], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return {int(k): v for k, v in json.loads(line[7:]).items()}
+
+
+def test_strict_build_meets_the_unconditioned_per_ray_bars():
+    assert os.path.exists(STRICT), "libhalo_hip_strict.so is not built: HALO_BUILD_TAG=strict python -m ice_halo_sim_amd.build (__graft_entry__.build() does it)"
+    strict, product = _run(STRICT), _run(None)
+    for seed, bar in BARS.items():
+        s, p = strict[seed], product[seed]
+        assert s["fixed"] >= 1                                    # the scenes that motivated the conditioning: fixed orientation axes
+        assert s["match"] >= bar, (seed, s)
+        assert s["landed"][0] == pytest.approx(s["landed"][1], rel=1e-4)
+        # ... and the comparison the conditioning rests on: the reference-rounding build is at least as close to the oracle as the product, which
+        # in turn sits inside the oracle's own two roundings' spread once conditioned
+        assert s["match"] >= p["match"] - 1e-3 and p["cond"] >= 0.995, (seed, s, p)
+    assert sum(strict[k]["match"] - product[k]["match"] for k in BARS) > 0.05      # (the product really does differ there: seed 11584 by 0.09)
