@@ -1367,6 +1367,7 @@ struct HoBackend {
    * the 3e-3 image tolerance of the production-size parity tests.  The per-thread caches also take the hot pixels off the shared image
    * (the contended omp atomics were what kept the all-cores CPU baseline from scaling). */
   int acc64;
+  int rehit_cuda; /* next-face strategy: 0 = legacy CPU (relaxed threshold, optics.cpp:127-146), 1 = CUDA (source-face skip, cu:1027-1050) */
   double* xyz64;
   double* lanes64;
   int acc_w, acc_h;
@@ -1424,6 +1425,7 @@ int ho_set_option(HoBackend* b, const char* key, int64_t v) {
   else if (!strcmp(key, "geom_clock")) b->geom_clock = (int)(v > 0 ? v : 32);
   else if (!strcmp(key, "threads")) b->threads = (int)(v > 0 ? v : 1);
   else if (!strcmp(key, "acc64")) b->acc64 = v ? 1 : 0;
+  else if (!strcmp(key, "rehit_strategy")) b->rehit_cuda = v ? 1 : 0;
   else if (!strcmp(key, "rank")) {
     uint64_t base = (uint64_t)v << 40; /* disjoint 64-bit counter ranges per shard */
     b->gen_count = b->gate_count = b->transit_count = b->shape_count = base;
@@ -1728,15 +1730,19 @@ static void emit_gate(const HoCiCtx* c, HoSink* sink, HoStream* gate, const floa
   }
 }
 
-/* PropagateSlab for one ray — optics.cpp:64-158 */
-static int propagate_slab(const HaloGeomTables* g, const float d[3], const float p[3], int src, float p_out[3]) {
+/* PropagateSlab for one ray — optics.cpp:64-158.  The reference excludes the face a ray stands on in two ways (traversal_shared.h:23-29):
+ * its CPU path by a relaxed accept threshold after the loop (here, skip_src = 0), its CUDA backend by skipping the face inside the loop
+ * (cu:1027-1050; skip_src = 1).  They agree on a convex body; they part ways where an entry point lies off its face's plane by more than
+ * 1e-5 (the fan of a face whose corners the vertex merge moved): the CPU path lets the outside reflection "re-hit" the entry face. */
+static int propagate_slab(const HaloGeomTables* g, const float d[3], const float p[3], int src, float p_out[3], int skip_src) {
   float t_far = 1e30f;
   int far_face = -1;
   for (int fi = 0; fi < g->face_cnt; fi++) {
+    if (skip_src && fi == src) continue;
     float t = ho_slab_face_t(d, p, g->face_n + fi * 3, g->face_d[fi]);
     if (t < t_far) { t_far = t; far_face = fi; }
   }
-  float eps_thr = (src >= 0 && far_face != src) ? -HO_FLOAT_EPS : HO_FLOAT_EPS;
+  float eps_thr = (skip_src || (src >= 0 && far_face != src)) ? -HO_FLOAT_EPS : HO_FLOAT_EPS;
   if (far_face >= 0 && t_far > eps_thr) {
     p_out[0] = p[0] + t_far * d[0];
     p_out[1] = p[1] + t_far * d[1];
@@ -1784,7 +1790,10 @@ static void trace_root(const HoCiCtx* c, HoSink* sink, const HaloGeomTables* g, 
       for (int ch = 0; ch < 2; ch++) {
         if (ws[ch] < 0) continue; /* TIR child: dropped (CollectData case 0) */
         float p_new[3];
-        int f_new = propagate_slab(g, dirs[ch], s->p, s->face, p_new);
+        /* CUDA strategy: the child that leaves through the face it stands on (the reflection of an entering ray, the refraction of an inner
+         * one) is emitted where it is — cu:1012-1170 propagates the inner ray only */
+        const int outward = (cos_theta < 0) ? (ch == 0) : (ch == 1 && !tir);
+        int f_new = (c->b->rehit_cuda && outward) ? -1 : propagate_slab(g, dirs[ch], s->p, s->face, p_new, c->b->rehit_cuda);
         if (f_new < 0) { /* outgoing candidate */
           emit_gate(c, sink, gate, rot, wle, wl_idx, dirs[ch], ws[ch], root, 2 * i + ch, path_cur[k], plen_cur[k], carried);
         } else if (n_nxt < 4) {
