@@ -1842,6 +1842,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     // <=> num_i*den_b < num_b*den_i.  One reciprocal at the end.
     float num_b = 1e30f, den_b = 1.0f;
     int hit = -1;
+    bool none_ahead;
     // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain
     const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
     if constexpr (HEX) {
@@ -1849,22 +1850,31 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       // values, here literals — and face ids (0,1), (2,5), (3,6), (4,7); both faces of a slab have the same plane constant.  The
       // generic search below with its table reads gone and the zero / unit components folded (x * 1 + 0 == x exactly): same
       // candidates, same order, same comparisons.
+      // Round 5: no select on the travel direction.  The face ahead in slab k is +n when n.d > 0 and -n otherwise, and its numerator is
+      // -(n.p + d_k) resp. (n.p - d_k) = -((-n.p) + d_k): both are (-d_k) - t with t = n.p carrying n.d's sign — one three-input bit
+      // operation and a subtraction where there were a compare, an add, a subtract and a select — and the face id is decoded once after
+      // the loop from the winner's code (slab index | sign bit of its n.d) instead of being selected per slab.  Same candidates, same
+      // order, the same products and comparisons: the values are bit for bit the old ones (negation is exact).
       constexpr float kS60 = 0.86602540378443864676f;
-      const float db = hex_d_basal, ds = hex_d_side;
+      const float ndb = -hex_d_basal, nds = -hex_d_side;
+      uint32_t cb = 0xFFFFFFFFu;   // winner's code; all ones = none
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float2v s60 = {kS60, kS60};
         const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? __builtin_elementwise_fma(Y, s60, X * 0.5f) : __builtin_elementwise_fma(Y, s60, X * -0.5f);
-        const float dk = (k == 0) ? db : ds;
-        const bool pos = r.x > 0.0f;
+        const uint32_t sgn = __float_as_uint(r.x) & 0x80000000u;
+        const float t = __uint_as_float(__float_as_uint(r.y) ^ sgn);
+        const float num = ((k == 0) ? ndb : nds) - t;
         const float den = fabsf(r.x);
-        const float num = pos ? -(r.y + dk) : (r.y - dk);
-        const int fi = (k == 0) ? (pos ? 0 : 1) : (pos ? 1 + k : 4 + k);
         const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
         num_b = better ? num : num_b;
         den_b = better ? den : den_b;
-        hit = better ? fi : hit;
+        // code = sign of n.d | id of the +n face << 2 | (id of the -n face - id of the +n face): faces (0,1), (2,5), (3,6), (4,7)
+        const uint32_t kCode = (k == 0) ? ((0u << 2) | 1u) : ((static_cast<uint32_t>(k + 1) << 2) | 3u);
+        cb = better ? (sgn | kCode) : cb;
       }
+      none_ahead = cb == 0xFFFFFFFFu;
+      hit = static_cast<int>(((cb >> 2) & 7u) + (cb >> 31) * (cb & 3u));   // (meaningless when none_ahead: the lane strays and never reads it)
     } else {
     const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
     for (int k = 0; k < slab_cnt; ++k) {
@@ -1895,12 +1905,13 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       hit = better ? fi : hit;
     }
     }
+    if constexpr (!HEX) none_ahead = hit < 0;
     const float t_best = num_b * fast_rcp(den_b);
     // No face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678).  Rare — a wave holds such a lane
     // once in thousands of passes — so it does not ride through the loop's emit site as a special case (selects on every operand of every
     // emit): the wave branches here when it has one, and the lane's exit goes out at once through the plain emit (filter, gate,
     // projection and accumulation at the site, no queue), with the path it has recorded so far.
-    const bool stray = !done && (hit < 0 || t_best <= -kSlabEps);
+    const bool stray = !done && (none_ahead || t_best <= -kSlabEps);
     if (__ballot(stray) != 0ull) {
       AccCtx<MONO, SMALLC> direct = acc;
       direct.q = nullptr;
