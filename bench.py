@@ -525,6 +525,7 @@ def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
     # the check pass: this rank's own image first ...
     tracer.zero()
     tracer.trace_session(wl, n_check)
+    tracer.backend.flush()                                   # (the closing fold is deferred: bring the bound tensor up to date before reading it)
     torch.cuda.synchronize()
     w, h = tracer.render.width, tracer.render.height
     own = tracer.acc[: w * h * 3].double()

@@ -92,8 +92,36 @@ struct HaloBackend {
   int aggregate = 1;
   int mono_enabled = 1;
   int bin = -1;                // binned accumulation: -1 auto (discrete session, full-sky render, launch >= 4 Mi rays), 0 off, 1 on
-  DevBuf<HitRec> bin_list, bin_list2;   // one-level tile lists / coarse lists; tile lists of the two-level route
-  DevBuf<uint32_t> bin_cnt, bin_cnt2;
+  // Two sets of the hit-log / tile-list buffers: launch k's accumulation passes (split + per-tile sums) run on the auxiliary stream under
+  // launch k+1's trace kernel, which meanwhile writes the other set (round 5, see `aux`)
+  DevBuf<HitRec> bin_list_s[2], bin_list2_s[2];   // one-level tile lists / coarse lists / log regions; tile lists of the two-level and log routes
+  DevBuf<uint32_t> bin_cnt_s[2], bin_cnt2_s[2];
+  int log_set = 0;                      // the set the next logged launch writes
+  bool set_used[2] = {false, false};    // ev_set_free[s] has been recorded: the set's last passes may still be running
+  hipEvent_t ev_set_free[2] = {};
+  // Auxiliary stream (round 5).  The trace kernel of a logged launch never touches the accumulation planes: it writes log records (and, when a
+  // region overflows, the planes' fp64 twin, atomically).  Everything that DOES touch the planes of such launches — the split and per-tile
+  // passes, the closing fold — is bandwidth-bound and is queued here, ordered among itself, so that it runs under the NEXT launch's (or the next
+  // session's) trace kernel, which is VALU-bound: two engines side by side on one GPU measured +14 % (configs[1]), +15 % (the reference's D65
+  // benchmark scene), +10 % (configs[4]) — tools/two_engines_probe.py — and this is that overlap inside one engine.  Launches that add to the
+  // planes from the trace kernel itself (direct atomics, the binned route) first wait for this stream; readers of the image wait for it too.
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool aux_pending = false;             // work has been queued on `aux` that the main stream has not waited for
+  // Two trace streams: consecutive launches alternate between them, so that launch k+1's workgroups fill the CUs that launch k's last
+  // workgroups leave idle (kernels of ONE stream run one after the other: the tail of every 1.8 ms trace kernel, and the whole of a
+  // latency-bound small launch, went unshared).  Trace kernels of different launches have nothing to order between them: each logs to its own
+  // buffer set or adds with atomics, tallies and continuation appends are atomic.  What they must follow is on the main stream (table
+  // uploads) or the auxiliary one (a fold or per-tile pass before a launch that adds to the planes itself): waited for by events.
+  hipStream_t cs[2] = {nullptr, nullptr};
+  hipEvent_t ev_cs[2] = {nullptr, nullptr}, ev_main = nullptr, ev_aux = nullptr;
+  bool cs_pending[2] = {false, false};
+  int cs_next = 0;
+  uint64_t aux_seq = 0, cs_seen_aux[2] = {0, 0};   // (a trace stream waits for the auxiliary stream only when that holds work it has not waited for yet)
+  int overlap = 1;                      // option: 0 queues the passes and folds on the main stream (round 4 behaviour)
+  int defer_fold = 0;                   // option: 1 = halo_end leaves the fold pending even when the accumulator is the caller's memory; the caller asks for
+                                        // it (halo_sync, or any reader) before it looks at its memory
+  int twin_set = 0;                     // which half of the fp64 twin the open / next session's overflows go to (the other half may still be folding)
   int lambda_planes = -1;      // illuminant sessions: -1 auto (by batch size), 0 never, 1 always one plane per pool entry
   int mono_copies = 8;         // power of two; copy = blockIdx & (copies-1)
   uint32_t mono_s_log2 = 0;    // log2 of the columns per row of the plane (kMonoRows rows; see MonoSlot)
@@ -163,7 +191,8 @@ struct HaloBackend {
   static constexpr int kRing = 32;
   DevBuf<DispatchSlot> ring_dev;
   DispatchSlot* ring_host = nullptr;   // hipHostMalloc
-  hipEvent_t ring_ev0[kRing] = {}, ring_ev1[kRing] = {}, ring_done[kRing] = {};
+  hipEvent_t ring_ev0[kRing] = {}, ring_ev1[kRing] = {}, ring_ev2[kRing] = {}, ring_ev3[kRing] = {}, ring_done[kRing] = {};   // ev0..ev1 the trace kernel (main stream), ev2..ev3 its passes (post stream)
+  bool ring_posts[kRing] = {};
   bool ring_busy[kRing] = {};
   int ring_next = 0;
   // Table cache (round 5): the dispatch-constant tables of a deterministic crystal entry (latitude LUT, wavelength pool, shape, entry-pick
@@ -186,7 +215,7 @@ struct HaloBackend {
   uint32_t wl_pool_size = 0;
   struct LutKey { int32_t type; float center, spread; host::LatLut lut; };
   std::vector<LutKey> lut_cache;
-  DevBuf<ShapeDev> shapes;
+  DevBuf<ShapeDev> shapes_s[2];   // sampled-crystal pools, one per trace stream (launch k+1's generator must not overwrite what launch k still traces)
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
   uint32_t cont_stride[2] = {0, 0};
   uint32_t cont_region[2] = {0, 0};          // slots per shard region
@@ -218,6 +247,80 @@ int hip_fail(HaloBackend* b, hipError_t e, const char* what) {
     if (e__ != hipSuccess) return hip_fail(b, e__, #call); \
   } while (0)
 
+// The stream the plane-touching passes of logged launches and the folds are queued on.
+inline hipStream_t post_stream(HaloBackend* b) { return b->overlap ? b->aux : b->stream; }
+// What is queued on the auxiliary stream from here on runs behind everything the main stream and the trace streams hold now.
+int fork_aux(HaloBackend* b) {
+  if (!b->overlap) return HALO_OK;
+  HIPCHK(b, hipEventRecord(b->ev_fork, b->stream));
+  HIPCHK(b, hipStreamWaitEvent(b->aux, b->ev_fork, 0));
+  for (int k = 0; k < 2; k++)
+    if (b->cs_pending[k]) {
+      HIPCHK(b, hipEventRecord(b->ev_cs[k], b->cs[k]));
+      HIPCHK(b, hipStreamWaitEvent(b->aux, b->ev_cs[k], 0));
+    }
+  b->aux_pending = true;
+  b->aux_seq++;
+  return HALO_OK;
+}
+// What the main stream is given from here on runs behind everything queued on the auxiliary and the trace streams (no host wait).
+int join_aux(HaloBackend* b) {
+  if (b->aux_pending) {
+    HIPCHK(b, hipEventRecord(b->ev_join, b->aux));
+    HIPCHK(b, hipStreamWaitEvent(b->stream, b->ev_join, 0));
+    b->aux_pending = false;
+  }
+  for (int k = 0; k < 2; k++)
+    if (b->cs_pending[k]) {
+      HIPCHK(b, hipEventRecord(b->ev_cs[k], b->cs[k]));
+      HIPCHK(b, hipStreamWaitEvent(b->stream, b->ev_cs[k], 0));
+      b->cs_pending[k] = false;
+    }
+  return HALO_OK;
+}
+// The stream the next trace kernel goes to: behind what the main stream holds now (table uploads, counter resets) and — for a launch that
+// adds to the planes itself — behind what the auxiliary stream holds (folds, per-tile passes).
+int next_trace_stream(HaloBackend* b, bool touches_planes, hipStream_t* out, int* which) {
+  if (!b->overlap) {
+    *out = b->stream;
+    *which = 0;
+    return HALO_OK;
+  }
+  const int i = b->cs_next;
+  b->cs_next ^= 1;
+  HIPCHK(b, hipEventRecord(b->ev_main, b->stream));
+  HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_main, 0));
+  if (touches_planes && b->aux_pending && b->cs_seen_aux[i] != b->aux_seq) {
+    HIPCHK(b, hipEventRecord(b->ev_aux, b->aux));
+    HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_aux, 0));
+    b->cs_seen_aux[i] = b->aux_seq;
+  }
+  b->cs_pending[i] = true;
+  *out = b->cs[i];
+  *which = i;
+  return HALO_OK;
+}
+// Host waits for all streams.
+int sync_all(HaloBackend* b) {
+  if (int rc = join_aux(b)) return rc;
+  HIPCHK(b, hipStreamSynchronize(b->stream));
+  return HALO_OK;
+}
+// DevBuf::reserve frees the old allocation when it grows: nothing on either stream may still be using it.
+template <typename T>
+int reserve_idle(HaloBackend* b, DevBuf<T>& buf, size_t n, hipError_t* err = nullptr) {
+  if (n > buf.cap) {
+    if (int rc = sync_all(b)) return rc;
+  }
+  const hipError_t e = buf.reserve(n);
+  if (err) {
+    *err = e;
+    return HALO_OK;
+  }
+  HIPCHK(b, e);
+  return HALO_OK;
+}
+
 int ensure_accumulator(HaloBackend* b, int w, int h) {
   const uint64_t need = static_cast<uint64_t>(w) * h * 3 + 4;
   if (b->acc && b->acc != b->acc_own.ptr) {  // external binding
@@ -229,7 +332,8 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
   // own_w/own_h describe the OWNED buffer's image (acc_w/acc_h are also written by the external-binding path above, so they
   // cannot decide whether the owned buffer fits); capacity is checked on its own
   if (!b->acc_own.ptr || b->acc_own.cap < need || b->own_w != w || b->own_h != h) {
-    HIPCHK(b, b->acc_own.reserve(need));
+    if (int rc = reserve_idle(b, b->acc_own, need)) return rc;
+    if (int rc = join_aux(b)) return rc;   // (a fold of the old image may still be queued there)
     HIPCHK(b, hipMemsetAsync(b->acc_own.ptr, 0, need * sizeof(float), b->stream));
     b->own_w = w;
     b->own_h = h;
@@ -245,9 +349,10 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
 void harvest_slot(HaloBackend* b, int k) {
   if (!b->ring_busy[k]) return;
   (void)hipEventSynchronize(b->ring_done[k]);
-  float ms = 0.0f;
+  float ms = 0.0f, ms2 = 0.0f;
   (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
-  b->layer_acc.kernel_ms += ms;
+  if (b->ring_posts[k]) (void)hipEventElapsedTime(&ms2, b->ring_ev2[k], b->ring_ev3[k]);   // the passes run under the next launch's trace: their own span, not the group's
+  b->layer_acc.kernel_ms += ms + ms2;
   b->layer_acc.launches += 1;
   b->ring_busy[k] = false;
 }
@@ -313,6 +418,7 @@ const host::LatLut& cached_lut(HaloBackend* b, const HaloDist& d) {
 extern "C" {
 
 static int fold_if_dirty(HaloBackend* b);
+static int fold_queue(HaloBackend* b);
 int halo_abi_version(void) { return HALO_ABI_VERSION; }
 
 int halo_device_count(void) {
@@ -337,11 +443,17 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
     delete b;
     return HALO_UNAVAILABLE;
   }
-  bool ring_ok = b->ring_dev.reserve(HaloBackend::kRing) == hipSuccess &&
+  bool aux_ok = hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&b->cs[0], hipStreamNonBlocking) == hipSuccess &&
+                hipStreamCreateWithFlags(&b->cs[1], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b->ev_cs[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_cs[1], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_aux, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_set_free[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_set_free[1], hipEventDisableTiming) == hipSuccess;
+  bool ring_ok = aux_ok && b->ring_dev.reserve(HaloBackend::kRing) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&b->ring_host), HaloBackend::kRing * sizeof(DispatchSlot), hipHostMallocDefault) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&b->tally_host), kTallyLines * kTallyStride * sizeof(double), hipHostMallocDefault) == hipSuccess;
   for (int k = 0; ring_ok && k < HaloBackend::kRing; k++)
-    ring_ok = hipEventCreate(&b->ring_ev0[k]) == hipSuccess && hipEventCreate(&b->ring_ev1[k]) == hipSuccess &&
+    ring_ok = hipEventCreate(&b->ring_ev0[k]) == hipSuccess && hipEventCreate(&b->ring_ev1[k]) == hipSuccess && hipEventCreate(&b->ring_ev2[k]) == hipSuccess && hipEventCreate(&b->ring_ev3[k]) == hipSuccess &&
               hipEventCreateWithFlags(&b->ring_done[k], hipEventDisableTiming) == hipSuccess;
   if (!ring_ok) {
     halo_destroy(b);
@@ -362,6 +474,9 @@ int halo_destroy(halo_handle_t b) {
   if (!b) return HALO_OK;
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
+  if (b->aux) (void)hipStreamSynchronize(b->aux);
+  for (int k = 0; k < 2; k++)
+    if (b->cs[k]) (void)hipStreamSynchronize(b->cs[k]);
   b->acc_own.release();
   b->tally.release();
   b->mono.release();
@@ -384,15 +499,30 @@ int halo_destroy(halo_handle_t b) {
   for (int k = 0; k < HaloBackend::kRing; k++) {
     if (b->ring_ev0[k]) (void)hipEventDestroy(b->ring_ev0[k]);
     if (b->ring_ev1[k]) (void)hipEventDestroy(b->ring_ev1[k]);
+    if (b->ring_ev2[k]) (void)hipEventDestroy(b->ring_ev2[k]);
+    if (b->ring_ev3[k]) (void)hipEventDestroy(b->ring_ev3[k]);
     if (b->ring_done[k]) (void)hipEventDestroy(b->ring_done[k]);
   }
-  b->shapes.release();
+  b->shapes_s[0].release();
+  b->shapes_s[1].release();
   b->cont_cnt.release();
   b->lanes.release();
-  b->bin_list.release();
-  b->bin_cnt.release();
-  b->bin_list2.release();
-  b->bin_cnt2.release();
+  for (int k = 0; k < 2; k++) {
+    b->bin_list_s[k].release();
+    b->bin_cnt_s[k].release();
+    b->bin_list2_s[k].release();
+    b->bin_cnt2_s[k].release();
+    if (b->ev_set_free[k]) (void)hipEventDestroy(b->ev_set_free[k]);
+  }
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
+  if (b->aux) (void)hipStreamDestroy(b->aux);
+  for (int k = 0; k < 2; k++) {
+    if (b->ev_cs[k]) (void)hipEventDestroy(b->ev_cs[k]);
+    if (b->cs[k]) (void)hipStreamDestroy(b->cs[k]);
+  }
+  if (b->ev_main) (void)hipEventDestroy(b->ev_main);
+  if (b->ev_aux) (void)hipEventDestroy(b->ev_aux);
   b->cont[0].release();
   b->cont[1].release();
   b->exits.release();
@@ -442,6 +572,11 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   }
   else if (k == "lazy_fold") b->lazy_fold = v ? 1 : 0;
   else if (k == "table_cache") b->table_cache = v ? 1 : 0;
+  else if (k == "overlap") {
+    if (int rc = sync_all(b)) return rc;
+    b->overlap = v ? 1 : 0;
+  }
+  else if (k == "defer_fold") b->defer_fold = v ? 1 : 0;
   else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "blocks_cap") b->blocks_cap = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "mono_copies") {
@@ -449,7 +584,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions may still wait for their fold (lazy_fold)
     int c = 1;
     while (c < v && c < 64) c <<= 1;
-    if (c != b->mono_copies) b->mono.release();
+    if (c != b->mono_copies) {
+      if (int rc = sync_all(b)) return rc;       // (nothing may still be reading what is freed)
+      b->mono.release();
+    }
     b->mono_copies = c;
   }
   else if (k == "blocks_per_cu") b->blocks_per_cu = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 1), 64));
@@ -475,7 +613,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
 
 int halo_set_stream(halo_handle_t b, void* s) {
   if (!b) return HALO_FATAL;
-  (void)hipStreamSynchronize(b->stream);
+  (void)sync_all(b);
   b->stream = s ? static_cast<hipStream_t>(s) : b->own_stream;
   return HALO_OK;
 }
@@ -598,8 +736,16 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
                              b->acc_h == render->height && b->mono_s_log2 == s_log2 && b->plane_cnt == plane_cnt_n && b->plane_copies == plane_copies_n &&
                              b->plane_coef == coef_n;
     if (!same_planes) {
-      int rc = fold_if_dirty(b);  // also: a session that was never ended still owes its plane to the accumulator (old layout)
+      // (queued on the auxiliary stream, NOT waited for: this session's trace kernels may start under it — they write log records, never the
+      // planes; whatever here does touch the planes or the image waits for that stream first)
+      int rc = fold_queue(b);  // also: a session that was never ended still owes its plane to the accumulator (old layout)
       if (rc != HALO_OK) return rc;
+      const bool caller_reads = b->acc != nullptr && b->acc != b->acc_own.ptr && !b->defer_fold;   // the caller's memory, read in stream order: the fold must be in that order too
+      const bool layout_changes = b->mono_s_log2 != s_log2 || b->plane_cnt != plane_cnt_n || b->plane_copies != plane_copies_n;   // the twin's halves move
+      if (caller_reads || layout_changes) {
+        rc = join_aux(b);
+        if (rc != HALO_OK) return rc;
+      }
     }
     int rc = ensure_accumulator(b, render->width, render->height);
     if (rc != HALO_OK) return rc;
@@ -613,17 +759,20 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   {
     const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
     if (b->mono.cap < need) {
-      HIPCHK(b, b->mono.reserve(need));
+      if (int rc = reserve_idle(b, b->mono, need)) return rc;
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
     }
     b->mono_s_log2 = s_log2;  // planes are all-zero whenever the layout changes (folded above), so it may change freely
     // the twin: one double per float of every plane's copy 0 (2.1 MB x planes at configs[1]'s image; a 64-plane session on 2048x1024 takes
     // 1 GB), kept all-zero between sessions like the planes; sessions whose twin would pass 4 GB go without (their overflow stays on the fp32
     // plane), and so does a session whose twin cannot be allocated
+    // (two halves: a session's overflows go to one while the fold of the session before may still be reading the other, `twin_set`)
     const size_t twin_need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_cnt;
-    if (b->ovf.cap < twin_need && twin_need <= (512ull << 20)) {
-      bool ok = b->ovf.reserve(twin_need) == hipSuccess;
-      if (ok && !b->ovf_flag.ptr) ok = b->ovf_flag.reserve(1) == hipSuccess && hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream) == hipSuccess;
+    if (b->ovf.cap < 2u * twin_need && twin_need <= (512ull << 20)) {
+      hipError_t oe = hipSuccess;
+      if (int rc = reserve_idle(b, b->ovf, 2u * twin_need, &oe)) return rc;
+      bool ok = oe == hipSuccess;
+      if (ok && !b->ovf_flag.ptr) ok = b->ovf_flag.reserve(2) == hipSuccess && hipMemsetAsync(b->ovf_flag.ptr, 0, 2 * sizeof(uint32_t), b->stream) == hipSuccess;
       if (ok) {
         HIPCHK(b, hipMemsetAsync(b->ovf.ptr, 0, b->ovf.cap * sizeof(double), b->stream));
       } else {
@@ -636,7 +785,8 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   if (!b->color_classes.empty()) {  // Y lanes persist like the accumulator, until halo_readback_class_lanes
     const size_t need = b->color_classes.size() * npix;
     if (b->lanes.cap < need || b->lanes_w != render->width || b->lanes_h != render->height) {
-      HIPCHK(b, b->lanes.reserve(need));
+      if (int rc = reserve_idle(b, b->lanes, need)) return rc;
+      if (int rc = join_aux(b)) return rc;
       HIPCHK(b, hipMemsetAsync(b->lanes.ptr, 0, b->lanes.cap * sizeof(double), b->stream));
       b->lanes_w = render->width;
       b->lanes_h = render->height;
@@ -663,25 +813,41 @@ static uint32_t fix_frac_bits(double max_w, uint64_t m) {
   return static_cast<uint32_t>(std::min(32, std::max(0, 62 - e)));
 }
 
-static int fold_if_dirty(HaloBackend* b) {
+// The twin half a session of the current layout uses: valid only when the buffer holds two halves of this layout.
+static double* twin_of(HaloBackend* b, int set) {
+  const size_t half = (static_cast<size_t>(kMonoRows) << b->mono_s_log2) * b->plane_cnt;
+  if (!b->ovf.ptr || !b->ovf_flag.ptr || b->ovf.cap < 2u * half) return nullptr;
+  return b->ovf.ptr + static_cast<size_t>(set) * half;
+}
+
+// Queue the closing fold of the pending planes on the post stream (behind everything both streams hold); the main stream does NOT wait.
+static int fold_queue(HaloBackend* b) {
   if (!b->mono_dirty) return HALO_OK;
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = fork_aux(b)) return rc;
+  hipStream_t ps = post_stream(b);
   const uint32_t npix = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
   const size_t plane = (static_cast<size_t>(kMonoRows) << b->mono_s_log2) * b->plane_copies;
+  const size_t twin_plane = static_cast<size_t>(kMonoRows) << b->mono_s_log2;
+  double* twin = twin_of(b, b->twin_set);
+  uint32_t* flag = twin ? b->ovf_flag.ptr + b->twin_set : nullptr;
   for (uint32_t first = 0; first < b->plane_cnt; first += kFoldGroup) {
     const uint32_t n = std::min<uint32_t>(kFoldGroup, b->plane_cnt - first);
     FoldCoef coef{};
     for (uint32_t m = 0; m < n; m++)
       for (int a = 0; a < 3; a++) coef.c[m][a] = b->plane_coef[first + m][static_cast<size_t>(a)];
-    const size_t twin_plane = static_cast<size_t>(kMonoRows) << b->mono_s_log2;
-    const bool twin = b->ovf.ptr != nullptr && b->ovf.cap >= twin_plane * b->plane_cnt && b->ovf_flag.ptr != nullptr;
-    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? b->ovf.ptr + first * twin_plane : nullptr,
-                               b->ovf_flag.ptr, b->stream);
+    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? twin + first * twin_plane : nullptr, flag, ps);
     if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   }
-  if (b->ovf_flag.ptr) HIPCHK(b, hipMemsetAsync(b->ovf_flag.ptr, 0, sizeof(uint32_t), b->stream));   // every group has seen it; the fold zeroed what it took
+  if (flag) HIPCHK(b, hipMemsetAsync(flag, 0, sizeof(uint32_t), ps));   // every group has seen it; the fold zeroed what it took
+  b->twin_set ^= 1;   // what traces from here on overflows into the other half
   b->mono_dirty = false;
   return HALO_OK;
+}
+// ... and with the main stream waiting for it: for readers of the image and for whoever hands the image to somebody else.
+static int fold_if_dirty(HaloBackend* b) {
+  if (int rc = fold_queue(b)) return rc;
+  return join_aux(b);
 }
 
 int halo_end(halo_handle_t b) {
@@ -690,7 +856,8 @@ int halo_end(halo_handle_t b) {
   // is the caller's memory (halo_bind_accumulator: the caller reads it without asking), otherwise when somebody reads it (every reader folds
   // first) or a session with other planes begins
   int rc = HALO_OK;
-  if (!(b->lazy_fold && b->acc != nullptr && b->acc == b->acc_own.ptr)) rc = fold_if_dirty(b);
+  const bool own = b->acc != nullptr && b->acc == b->acc_own.ptr;
+  if (!((b->lazy_fold && own) || (b->defer_fold && !own))) rc = fold_if_dirty(b);
   b->in_session = false;
   return rc;
 }
@@ -764,7 +931,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     region = (region + 63) & ~63ull;
     const uint64_t stride = region * kContShards;
     if (stride > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "continuation pool would exceed 2^32 rays; split the batch");
-    HIPCHK(b, b->cont[out_slot].reserve(stride * (b->color_classes.empty() ? 5 : 7)));  // + mask lo/hi planes with raypath colour
+    if (int rc = reserve_idle(b, b->cont[out_slot], stride * (b->color_classes.empty() ? 5 : 7))) return rc;  // + mask lo/hi planes with raypath colour
     b->cont_stride[out_slot] = static_cast<uint32_t>(stride);
     b->cont_region[out_slot] = static_cast<uint32_t>(region);
     out_cap = static_cast<uint32_t>(region);
@@ -785,7 +952,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       HIPCHK(b, bigger.reserve(need));
       if (b->exits_pending)
         HIPCHK(b, hipMemcpyAsync(bigger.ptr, b->exits.ptr, b->exits_pending * sizeof(HaloExitRecord), hipMemcpyDeviceToDevice, b->stream));
-      HIPCHK(b, hipStreamSynchronize(b->stream));
+      if (int rc = sync_all(b)) return rc;
       b->exits.release();
       b->exits = bigger;
     }
@@ -855,9 +1022,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.counters = b->counters.ptr;
     P.mono = b->mono.ptr;
     P.mono_s_log2 = b->mono_s_log2;
-    P.ovf = (b->ovf.ptr != nullptr && b->ovf.cap >= (static_cast<size_t>(kMonoRows) << b->mono_s_log2) * b->plane_cnt && b->ovf_flag.ptr != nullptr) ? b->ovf.ptr : nullptr;
+    P.ovf = twin_of(b, b->twin_set);
     P.ovf_copies_log2 = static_cast<uint32_t>(__builtin_ctz(b->plane_copies));
-    P.ovf_flag = b->ovf_flag.ptr;
+    P.ovf_flag = P.ovf ? b->ovf_flag.ptr + b->twin_set : nullptr;
     P.mono_copy_mask = b->plane_copies - 1u;
     P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
     P.bin_list = nullptr;
@@ -1008,14 +1175,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       if (deterministic) {
         P.shapes = &ds->shape;
       } else {
-        HIPCHK(b, b->shapes.reserve(shape_cnt));   // sized for ShapeDev records; prism pools use the front third
-        if (host_pool) {
-          HIPCHK(b, hipMemcpyAsync(b->shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
-        } else {  // device generator: one thread per sampled crystal, same stream → ordered before the trace kernel
-          hipError_t ge = launch_shapegen(b->shapes.ptr, geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, b->stream, b->gen_serial != 0);
-          if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
-        }
-        P.shapes = b->shapes.ptr;
+        // (the pool of the trace stream this launch will take: next_trace_stream below hands out b->cs_next)
+        DevBuf<ShapeDev>& shapes = b->shapes_s[b->overlap ? b->cs_next : 0];
+        if (int rc = reserve_idle(b, shapes, shape_cnt)) return rc;   // sized for ShapeDev records; prism pools use the front third
+        if (host_pool) HIPCHK(b, hipMemcpyAsync(shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        // (device generator: queued below on the launch's trace stream, in front of the trace kernel)
+        P.shapes = shapes.ptr;
       }
       P.shape_cnt = shape_cnt;
       P.n_rays = static_cast<uint32_t>(m);
@@ -1097,7 +1262,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         // want theirs), and a reserve that fails all the same sends this launch down the direct route instead of failing the trace.
         {
           size_t free_b = 0, total_b = 0;
-          const uint64_t have = (b->bin_list.cap + b->bin_list2.cap) * sizeof(HitRec);
+          const uint64_t have = (b->bin_list_s[b->log_set].cap + b->bin_list2_s[b->log_set].cap) * sizeof(HitRec);
           uint64_t need = (cap * static_cast<uint64_t>(blocks) + c2 * log_tiles) * sizeof(HitRec);
           if (need > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need - have > free_b / 2u) {
             const double shrink = static_cast<double>(have + free_b / 2u) / static_cast<double>(need);
@@ -1107,21 +1272,30 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         }
         cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
         log_cap = cap;
-        if (b->bin_list.reserve(cap * static_cast<uint64_t>(blocks)) != hipSuccess || b->bin_list2.reserve(c2 * log_tiles) != hipSuccess) {
+        hipError_t e1 = hipSuccess, e2 = hipSuccess;
+        if (int rc = reserve_idle(b, b->bin_list_s[b->log_set], cap * static_cast<uint64_t>(blocks), &e1)) return rc;
+        if (e1 == hipSuccess)
+          if (int rc = reserve_idle(b, b->bin_list2_s[b->log_set], c2 * log_tiles, &e2)) return rc;
+        if (e1 != hipSuccess || e2 != hipSuccess) {
           (void)hipGetLastError();   // out of memory: not this launch's route
           use_log = use_log_xyz = false;
         }
       }
+      const int ls = b->log_set;                                  // the buffer set of this launch
+      DevBuf<HitRec>&bin_list = b->bin_list_s[ls], &bin_list2 = b->bin_list2_s[ls];
+      DevBuf<uint32_t>&bin_cnt = b->bin_cnt_s[ls], &bin_cnt2 = b->bin_cnt2_s[ls];
+      if (use_bin)   // the staged-list route shares one buffer set and resets its counters on the main stream: one launch at a time
+        if (int rc = join_aux(b)) return rc;
       if (use_log) {
         const uint64_t cap = log_cap;
-        HIPCHK(b, b->bin_cnt.reserve(std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u)));
-        HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(512) * 16u));
-        HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), b->stream));
-        P.bin_list = b->bin_list.ptr;
+        if (int rc = reserve_idle(b, bin_cnt, std::max<size_t>(static_cast<size_t>(blocks), static_cast<size_t>(512) * 16u))) return rc;
+        if (int rc = reserve_idle(b, bin_cnt2, static_cast<size_t>(512) * 16u)) return rc;
+        if (b->set_used[ls]) HIPCHK(b, hipStreamWaitEvent(b->stream, b->ev_set_free[ls], 0));   // the passes of the launch that last wrote this set
+        P.bin_list = bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
         P.bin_tiles = log_tiles;
         P.bin_shift = 0u;
-        P.bin_cnt = b->bin_cnt.ptr;   // one fill count per region, written by the trace kernel
+        P.bin_cnt = bin_cnt.ptr;   // one fill count per region, written by the trace kernel
         P.bin_log = 1u;
         P.mono_copy_mask = 0u;   // logged slots and their fallbacks address copy 0
         P.log_xyz = use_log_xyz ? 1u : 0u;
@@ -1134,14 +1308,14 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         const uint64_t slack = two_level ? 2ull : 4ull;
         uint64_t cap = std::max<uint64_t>(slack * 6ull * m / lists1, 1ull << 16);
         cap = std::min<uint64_t>(cap, (8ull << 30) / (8ull * lists1));
-        HIPCHK(b, b->bin_cnt.reserve(static_cast<size_t>(512) * 16u));
-        HIPCHK(b, hipMemsetAsync(b->bin_cnt.ptr, 0, static_cast<size_t>(two_level ? 512u : bin_tiles) * 16u * sizeof(uint32_t), b->stream));
-        HIPCHK(b, b->bin_list.reserve(cap * lists1));
-        P.bin_list = b->bin_list.ptr;
+        if (int rc = reserve_idle(b, bin_cnt, static_cast<size_t>(512) * 16u)) return rc;
+        HIPCHK(b, hipMemsetAsync(bin_cnt.ptr, 0, static_cast<size_t>(two_level ? 512u : bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+        if (int rc = reserve_idle(b, bin_list, cap * lists1)) return rc;
+        P.bin_list = bin_list.ptr;
         P.bin_cap = static_cast<uint32_t>(cap);
         P.bin_tiles = two_level ? b->bin_l1 : bin_tiles;
         P.bin_shift = two_level ? 14u + fan_log2 : 0u;
-        P.bin_cnt = b->bin_cnt.ptr;
+        P.bin_cnt = bin_cnt.ptr;
         P.bin_log = 0u;
         P.log_xyz = 0u;
         P.mono_by_wl = b->mono_by_wl ? 1u : 0u;
@@ -1150,9 +1324,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
           uint64_t c2 = std::max<uint64_t>(slack * 6ull * m / bin_tiles, 1ull << 12);
           c2 = std::min<uint64_t>(c2, (8ull << 30) / (8ull * bin_tiles));
           cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
-          HIPCHK(b, b->bin_cnt2.reserve(static_cast<size_t>(bin_tiles) * 16u));
-          HIPCHK(b, hipMemsetAsync(b->bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
-          HIPCHK(b, b->bin_list2.reserve(c2 * bin_tiles));
+          if (int rc = reserve_idle(b, bin_cnt2, static_cast<size_t>(bin_tiles) * 16u)) return rc;
+          HIPCHK(b, hipMemsetAsync(bin_cnt2.ptr, 0, static_cast<size_t>(bin_tiles) * 16u * sizeof(uint32_t), b->stream));
+          if (int rc = reserve_idle(b, bin_list2, c2 * bin_tiles)) return rc;
         }
       } else {
         P.bin_list = nullptr;
@@ -1162,10 +1336,19 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       P.no_land = (P.prob >= 1.0f && !P.final_layer && fast_mode && b->aggregate == 1) ? 1u : 0u;
-      HIPCHK(b, hipEventRecord(b->ring_ev0[k], b->stream));  // HIP events on the launch stream bracket the kernel alone
+      // The launch's trace stream (alternating).  A launch that adds to the planes from the trace kernel itself — direct atomics, staged lists —
+      // goes behind whatever the auxiliary stream still does to them; a logged launch does not care.
+      hipStream_t ts = nullptr;
+      int ts_i = 0;
+      if (int rc = next_trace_stream(b, !use_log, &ts, &ts_i)) return rc;
+      if (!deterministic && !host_pool) {   // device generator: one team per sampled crystal, in front of the trace kernel on its stream
+        hipError_t ge = launch_shapegen(const_cast<ShapeDev*>(P.shapes), geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, ts, b->gen_serial != 0);
+        if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
+      }
+      HIPCHK(b, hipEventRecord(b->ring_ev0[k], ts));  // HIP events on the launch stream bracket the kernel alone
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hex_regular) ? 3 : geom;
-      hipError_t le = launch_trace(P, blocks, b->stream, mode, launch_geom, b->mono_session);
+      hipError_t le = launch_trace(P, blocks, ts, mode, launch_geom, b->mono_session);
       b->mono_dirty = true;
       b->route.launches++;
       b->route.mode_mask |= 1u << mode;
@@ -1195,24 +1378,39 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // fixed-point scale of the per-tile sums (halo_kernels.hip FixQ): no slot of this launch can sum to more than 4 x max weight x rays
       const uint32_t frac_bits = fix_frac_bits(b->sess_max_w, m);
       if (use_log) {
-        hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks),
-                                                           b->bin_list2.ptr, cap2, b->bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, b->stream)
-                                    : launch_log_route(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, static_cast<uint32_t>(blocks), b->bin_list2.ptr, cap2,
-                                                       b->bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
-                                                       P.ovf, P.ovf_flag, P.ovf_copies_log2, b->stream);
+        // the accumulation passes of this launch: on the post stream, behind the trace kernel just queued and behind the passes / folds queued
+        // there before; the main stream goes on to the next launch (which writes the other buffer set)
+        HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));          // the trace kernel alone: ev0 .. ev1 on its stream
+        if (int rc = fork_aux(b)) return rc;
+        hipStream_t ps = post_stream(b);
+        HIPCHK(b, hipEventRecord(b->ring_ev2[k], ps));
+        HIPCHK(b, hipMemsetAsync(bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), ps));
+        hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks),
+                                                           bin_list2.ptr, cap2, bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, ps)
+                                    : launch_log_route(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks), bin_list2.ptr, cap2,
+                                                       bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
+                                                       P.ovf, P.ovf_flag, P.ovf_copies_log2, ps);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
-      }
+        HIPCHK(b, hipEventRecord(b->ring_ev3[k], ps));
+        HIPCHK(b, hipEventRecord(b->ev_set_free[ls], ps));
+        b->set_used[ls] = true;
+        b->log_set ^= 1;
+        b->ring_posts[k] = true;
+        HIPCHK(b, hipEventRecord(b->ring_done[k], ps));
+      } else {
       if (use_bin) {
-        hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, lists1, b->bin_list2.ptr, cap2, b->bin_cnt2.ptr,
-                                                         bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, b->stream)
-                                  : launch_bin_accumulate(b->mono.ptr, b->bin_list.ptr, P.bin_cap, b->bin_cnt.ptr, bin_tiles, frac_bits, b->stream);
+        hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, lists1, bin_list2.ptr, cap2, bin_cnt2.ptr,
+                                                         bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, ts)
+                                  : launch_bin_accumulate(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, bin_tiles, frac_bits, ts);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
       }
-      HIPCHK(b, hipEventRecord(b->ring_ev1[k], b->stream));
+      HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));
+      b->ring_posts[k] = false;
+      HIPCHK(b, hipEventRecord(b->ring_done[k], ts));
+      }
       b->tally_unread = true;
-      HIPCHK(b, hipEventRecord(b->ring_done[k], b->stream));
       b->ring_busy[k] = true;
-      if (host_pool) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy
+      if (host_pool) HIPCHK(b, hipStreamSynchronize(b->stream));  // the pageable shape pool must outlive its copy (the copy is on the main stream)
       if (P.source == kSrcGen) b->gen_count += m;
       if (P.source == kSrcTransit) b->transit_count += m;
       b->gate_count += m;
@@ -1229,6 +1427,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     b->cont_in_n = 0;
     return HALO_OK;
   }
+  if (int rc = join_aux(b)) return rc;   // the copies below (and the caller) want this layer's kernels done: the main stream waits for the trace streams
   uint32_t cnt[kCntNum] = {0, 0, 0, 0};
   std::vector<uint32_t> fill(final_layer ? 0 : kContShards * kContCntStride);
   HIPCHK(b, hipMemcpyAsync(cnt, b->counters.ptr, sizeof(cnt), hipMemcpyDeviceToHost, b->stream));
@@ -1322,6 +1521,7 @@ int halo_readback_class_lanes(halo_handle_t b, float* lanes, int width, int heig
   if (class_count != static_cast<int>(b->color_classes.size()) || width != b->lanes_w || height != b->lanes_h || !b->lanes.ptr)
     return fail(b, HALO_FATAL, "class lanes: size does not match the session (classes x width x height)");
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   const size_t n = static_cast<size_t>(class_count) * width * height;
   // the lanes are summed in fp64 on the device (hot pixels), the seam hands out floats (trace_backend.hpp:471-493): narrowed and drained by
   // one kernel into the staging buffer, so half the bytes cross the bus and no host pass follows
@@ -1374,6 +1574,7 @@ int halo_reduce_accumulator(halo_handle_t b, void* nccl_comm, int root, int this
 int halo_collect_stats(halo_handle_t b, HaloLayerStats* out) {
   if (!b || !out) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   HIPCHK(b, hipStreamSynchronize(b->stream));
   harvest_all(b);
   if (int rc = pull_tally(b)) return rc;
@@ -1399,6 +1600,7 @@ int halo_recombine(halo_handle_t b, int shuffle, uint64_t* continuation_count) {
 int halo_drain_exits(halo_handle_t b, HaloExitRecord* out, uint64_t cap, uint64_t* count) {
   if (!b) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   HIPCHK(b, hipStreamSynchronize(b->stream));
   // Piecewise drain (trace_backend.hpp:430-448): a call takes at most `cap` records from the front and the rest stays
   // pending; *count = records copied by THIS call.  out == NULL reports how many are pending without consuming any.
@@ -1425,11 +1627,20 @@ int halo_drain_exits(halo_handle_t b, HaloExitRecord* out, uint64_t cap, uint64_
   return HALO_OK;
 }
 
+int halo_flush(halo_handle_t b) {
+  if (!b) return HALO_FATAL;
+  if (b->in_session) return fail(b, HALO_FATAL, "halo_flush inside a session");
+  HIPCHK(b, hipSetDevice(b->device));
+  return fold_if_dirty(b);   // queued; the backend's stream waits for it, the host does not
+}
+
 int halo_sync(halo_handle_t b) {
   if (!b) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
-  HIPCHK(b, hipStreamSynchronize(b->stream));
-  return HALO_OK;
+  // with option defer_fold a caller-bound accumulator is brought up to date HERE (and by every reader): the closing folds of the ended sessions
+  if (b->defer_fold && !b->in_session)
+    if (int rc = fold_if_dirty(b)) return rc;
+  return sync_all(b);
 }
 
 int halo_take_landed(halo_handle_t b, double* landed) {
@@ -1470,6 +1681,7 @@ int halo_readback_xyz(halo_handle_t b, float* xyz, int width, int height, float*
 int halo_consumer_reset(halo_handle_t b) {
   if (!b) return HALO_FATAL;
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   if (b->cons_sum.ptr) {
     const size_t n = static_cast<size_t>(b->cons_w) * b->cons_h * 3;
     HIPCHK(b, hipMemsetAsync(b->cons_sum.ptr, 0, n * sizeof(float), b->stream));
@@ -1511,6 +1723,7 @@ int halo_consumer_consume(halo_handle_t b, const float* xyz, int width, int heig
   if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > (1ull << 25)) return fail(b, HALO_UNAVAILABLE, "more than 2^25 pixels");
   if (b->cons_sum.ptr && (b->cons_w != width || b->cons_h != height)) return fail(b, HALO_FATAL, "consumer_consume: image size differs from the consumer's (halo_consumer_reset first)");
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   const size_t n = static_cast<size_t>(width) * height * 3;
   if (!b->cons_sum.ptr) {
     HIPCHK(b, b->cons_sum.reserve(n));
@@ -1583,6 +1796,7 @@ int halo_consumer_load_lanes(halo_handle_t b, const float* lanes, int width, int
     return fail(b, HALO_FATAL, "consumer_load_lanes: class count must equal halo_set_color's, image must not be empty");
   if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > (1ull << 25)) return fail(b, HALO_UNAVAILABLE, "more than 2^25 pixels");
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   const size_t n = static_cast<size_t>(class_count) * width * height;
   HIPCHK(b, b->lanes.reserve(n));
   b->lanes_w = width;
@@ -1606,6 +1820,7 @@ int halo_consumer_composite(halo_handle_t b, const HaloComposite* spec, float* l
   if (spec->class_count != static_cast<int>(b->color_classes.size())) return fail(b, HALO_FATAL, "consumer_composite: class_count differs from halo_set_color's");
   if (!b->lanes.ptr || b->lanes_w <= 0 || b->lanes_h <= 0) return fail(b, HALO_FATAL, "consumer_composite before any colour session (no lanes)");
   HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = join_aux(b)) return rc;   // (kernels of queued sessions may still be running on the trace / auxiliary streams)
   const uint32_t npix = static_cast<uint32_t>(b->lanes_w) * static_cast<uint32_t>(b->lanes_h);
   const size_t n3 = static_cast<size_t>(npix) * 3u;
   // GatherActiveClasses (component_compositor.cpp:24-54): solo beats visible; stable sort by z_order; lane binding by class index

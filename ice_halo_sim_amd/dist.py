@@ -102,6 +102,9 @@ class ShardedTracer:
         self.acc = torch.zeros(self.n_floats, dtype=torch.float32, device=self.device)
         self.backend.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
+        # the accumulator is this object's tensor: it reads it only at the drain points below, so a session's closing fold may stay pending at
+        # EndSession and run under the next session's trace kernels (flush() brings the tensor up to date before anything here touches it)
+        self.backend.set_option("defer_fold", 1)
         self.landed = 0.0
 
     def trace_session_layers(self, wl, n_rays, shuffle=True):
@@ -125,6 +128,7 @@ class ShardedTracer:
     def reduce_to_root(self):
         """The drain-point collective: ONE sum-reduce of the image accumulator, enqueued on the stream behind this rank's
         trace kernels; non-root ranks are drained.  The landed-weight scalars stay on their devices until readback()."""
+        self.backend.flush()
         self.acc = reduce_image(self.acc)
 
     def zero(self):

@@ -357,6 +357,11 @@ typedef struct HaloRouteInfo {
   uint32_t generic_launches; /* launches that ran an instantiation with none of those specialisations */
 } HaloRouteInfo;
 int halo_last_route(halo_handle_t h, HaloRouteInfo* out);
+/* Bring the accumulator up to date WITHOUT a host wait: the closing folds of the ended sessions are queued and the backend's stream is made
+ * to wait for them, so that work queued on that stream afterwards (a collective on a bound accumulator, a copy) sees the finished image.
+ * Needed with option "defer_fold" = 1 (halo_end then leaves the fold of a caller-bound accumulator pending so that the next session's trace
+ * kernels run under it); harmless otherwise.  Not inside a session. */
+int halo_flush(halo_handle_t h);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
  * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the

@@ -36,6 +36,7 @@ def _worker(rank, world, port, out_dir):
     tr = ShardedTracer(sc, rd, seed=42, device=0, rank=rank, world=world, **{"async": 1})
     for wl in (scenes.wl_discrete(530.0), scenes.wl_discrete(610.0)):
         tr.trace_session_layers(wl, N)
+    tr.backend.flush()                                         # (ShardedTracer defers the closing folds: the tensor is current after this)
     torch.cuda.synchronize()
     own = tr.acc[: W * H * 3].cpu().numpy().copy()          # this rank's image before the reduce
     own_landed = tr.backend.take_landed()
