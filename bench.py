@@ -55,7 +55,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r04"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
+PROFILE_ROUND = "r05"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
 
 # The reference's legacy CPU path measured by the survey in the build container (compiled with shims, 6 worker
 # threads, config_example-shaped scene): the only number that relates the oracle ("port") to the real reference.
@@ -261,6 +261,15 @@ def shape_record_bytes(crystal, prism_records, samples=256):
             "written_by_generator": rows + 36.0 * t, "read_by_trace_per_32_rays": rows + 36.0 * min(32.0, t)}
 
 
+def _profile_tag(cfg):
+    """prefix of the committed rocprofv3 summaries of a configuration (tools/collect_all_profiles.sh names them)"""
+    if cfg.startswith("ref:"):
+        return "%s_ref_%s" % (PROFILE_ROUND, cfg[4:])
+    if cfg.startswith("filter:"):
+        return "%s_filter_%s" % (PROFILE_ROUND, cfg[7:])
+    return "%s_bench%s" % (PROFILE_ROUND, cfg)
+
+
 def pmc_traffic_per_launch(cfg):
     """HBM-side bytes per launch GROUP — the trace kernel plus the accumulation passes that follow it on the stream (split,
     per-tile sums), which is also what the HIP events around a launch time — from the committed rocprofv3 PMC passes of this
@@ -269,7 +278,7 @@ def pmc_traffic_per_launch(cfg):
     counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced streaming reads (64 B tallied per 128-B
     request), so it is doubled; WRITE_SIZE is uncalibrated and taken as reported.  Sum of the per-dispatch means of the
     group's kernels."""
-    tag = "%s_bench%s" % (PROFILE_ROUND, cfg.replace(":", "_"))
+    tag = _profile_tag(cfg)
     tot, seen = 0.0, False
     for k in GROUP_KERNELS:
         f, w = _pmc_mean(tag + "_pmc_fetch_size.txt", "FETCH_SIZE", k), _pmc_mean(tag + "_pmc_write_size.txt", "WRITE_SIZE", k)
@@ -302,7 +311,7 @@ def pmc_valu(cfg, rays_per_launch):
         logic, lane moves) priced at the static mix of the kernel's hot loop.
       The older figure, SQ_ACTIVE_INST_VALU x 4 / 32 / SQ_BUSY_CYCLES, is kept as valu_active_frac: it charges every instruction four
         cycles and reads slightly above 1 when the pipe is saturated."""
-    tag = "%s_bench%s" % (PROFILE_ROUND, cfg.replace(":", "_"))
+    tag = _profile_tag(cfg)
     insts = _pmc_mean(tag + "_pmc_insts.txt", "SQ_INSTS_VALU")
     cyc = tag + "_pmc_cycles.txt"
     active, busy, wave = _pmc_mean(cyc, "SQ_ACTIVE_INST_VALU"), _pmc_mean(cyc, "SQ_BUSY_CYCLES"), _pmc_mean(cyc, "SQ_WAVE_CYCLES")
@@ -405,6 +414,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         step()
     tracer.zero()
     tracer.backend.collect_stats()                            # drop the warm-up tallies
+    tracer.backend.collect_timing()
     for k in first_layer:
         first_layer[k] = 0
     reduce_events.clear()
@@ -420,6 +430,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times.append(float(t.item()))
+    trace_ms, post_ms, timed_launches = tracer.backend.collect_timing()   # HIP events: the trace kernels' own spans / their accumulation passes' (auxiliary stream)
     st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
     route = tracer.backend.last_route()
     dt = statistics.median(times)
@@ -441,7 +452,11 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         return None
     # the dominant kernel: the last layer's launches (single-scatter: the only layer; multi-scatter: the transit-source layer)
     dom_launches = launches - first_layer["launches"]
-    dom_ms = kernel_ms - first_layer["ms"]
+    # the dominant KERNEL: the last layer's trace kernel, timed by the HIP events around it on its own stream; its accumulation passes (split,
+    # per-tile sums) run on the auxiliary stream UNDER the next launch's trace kernel since round 5, so "trace + passes" is no longer a span of
+    # wall time — group_ms (their sum) is reported beside it
+    dom_ms = trace_ms - first_layer["ms"]
+    group_ms = kernel_ms - first_layer["ms"]
     dom_hits = pixel_hits - first_layer["hits"]
     dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
     avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
@@ -483,13 +498,15 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                     "ms_per_step_all": [x * 1e3 / steps for x in times]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(cfg),
-                     "traffic_source": "profiles/%s_bench%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % (PROFILE_ROUND, cfg),
+                     "traffic_source": "profiles/%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % _profile_tag(cfg),
                      "kernel": wk["kernel"], "launches": dom_launches,
-                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_per_launch,
+                     "avg_launch_ms": avg_launch_s * 1e3, "avg_launch_group_ms": group_ms / max(dom_launches, 1), "passes_ms_per_launch": post_ms / max(dom_launches, 1),
+                     "wall_ms_per_launch": dt * 1e3 / steps / max(dom_launches / (reps * steps), 1),
+                     "algorithmic_bytes_per_launch": alg_per_launch,
                      "shape_record_bytes": shape_bytes,
                      "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
                      "valu": pmc_valu(cfg, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
-                     "note": "a launch = the trace kernel + the accumulation passes behind it (HIP events bracket the group). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+                     "note": "avg_launch_ms = the trace kernel alone (HIP events on its stream; the rocprofv3 summary's average for that kernel is the same figure); its accumulation passes run on an auxiliary stream under the NEXT launch's trace kernel (avg_launch_group_ms = both spans added, wall_ms_per_launch = the timed region / launches). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
     }
     if out["roofline"]["traffic"]:
         out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / alg_per_launch
@@ -640,7 +657,8 @@ def main():
             others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
                            "workload": r["config"]["workload"], "resolution": r["config"]["resolution"], "exits_per_root": r["config"]["exits_per_root"],
                            "route": r["config"]["route"],
-                           "roofline": {k: r["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "kernel_rays_per_s")}}
+                           "roofline": {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "avg_launch_group_ms", "launches", "kernel_rays_per_s",
+                                                                                  "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch")}}
             if "multi_scatter" in r:
                 others[cfg]["multi_scatter"] = r["multi_scatter"]
         out["other_configs"] = others

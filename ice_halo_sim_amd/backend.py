@@ -64,6 +64,7 @@ def load_library():
         "halo_collect_stats": (C.c_int, [H, C.POINTER(abi.HaloLayerStats)]),
         "halo_take_landed": (C.c_int, [H, C.POINTER(C.c_double)]),
         "halo_flush": (C.c_int, [H]),
+        "halo_collect_timing": (C.c_int, [H, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
         "halo_consumer_fold": (C.c_int, [H]),
         "halo_consumer_consume": (C.c_int, [H, f32p, C.c_int, C.c_int, C.c_float, f32p, C.c_int]),
         "halo_consumer_snapshot": (C.c_int, [H, C.POINTER(abi.HaloDisplay), C.POINTER(C.c_uint8), f32p, C.POINTER(C.c_double)]),
@@ -98,7 +99,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "halo_abi_version", "halo_abi_sizeof", "halo_device_count", "halo_create", "halo_destroy", "halo_last_error",
     "halo_set_option", "halo_set_stream", "halo_bind_accumulator", "halo_set_filters", "halo_begin", "halo_trace_layer", "halo_recombine",
-    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_flush", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_consume", "halo_consumer_snapshot", "halo_consumer_reset", "halo_consumer_composite", "halo_consumer_load_lanes", "halo_host_parse_composite_mode", "halo_host_prism_geometry",
+    "halo_drain_exits", "halo_end", "halo_readback_xyz", "halo_readback_xyz64", "halo_sync", "halo_flush", "halo_collect_timing", "halo_last_sample_counts", "halo_last_route", "halo_set_color", "halo_readback_class_lanes", "halo_generate_shapes", "halo_collect_stats", "halo_take_landed", "halo_consumer_fold", "halo_consumer_consume", "halo_consumer_snapshot", "halo_consumer_reset", "halo_consumer_composite", "halo_consumer_load_lanes", "halo_host_parse_composite_mode", "halo_host_prism_geometry",
     "halo_host_pyramid_geometry", "halo_host_shape_scalars", "halo_host_build_lat_lut", "halo_host_build_proj_params", "halo_host_partition",
     "halo_host_refractive_index", "halo_host_reduce_raypath", "halo_host_filter_fast_check", "halo_host_color_fast_mask", "halo_host_illuminant_spd", "halo_host_wl_pool", "halo_reduce_accumulator",
 ]
@@ -173,6 +174,13 @@ class HipTraceBackend:
 
     def sync(self):
         self._check(self._L.halo_sync(self._h))
+
+    def collect_timing(self):
+        """(trace_ms, post_ms, launches) since the previous call: the trace kernels' own spans and those of their accumulation passes (which run
+        under the next launch's trace kernel on the auxiliary stream)."""
+        t, p, n = C.c_double(), C.c_double(), C.c_uint64()
+        self._check(self._L.halo_collect_timing(self._h, C.byref(t), C.byref(p), C.byref(n)))
+        return t.value, p.value, n.value
 
     def flush(self):
         """Queue the pending closing folds and make the backend's stream wait for them (no host wait): what is queued on that stream afterwards

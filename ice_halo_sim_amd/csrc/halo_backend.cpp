@@ -185,7 +185,9 @@ struct HaloBackend {
   DevBuf<double> tally;        // kTallyLines x kTallyStride doubles, [kSum*] per line: CUMULATIVE tallies of every kernel this backend ever launched
   double* tally_host = nullptr;       // hipHostMalloc, one snapshot of `tally`
   double tally_seen[kSumNum] = {};    // cumulative values already handed on: [kSumLanded] to a readback / take_landed, the rest to the layer statistics
-  bool tally_unread = false;          // a dispatch has been queued since the statistics were last pulled
+  bool tally_unread = false;
+  double time_trace_ms = 0.0, time_post_ms = 0.0;   // halo_collect_timing: the trace kernels' own spans and their passes' (which run under the next trace), since the last call
+  uint64_t time_launches = 0;          // a dispatch has been queued since the statistics were last pulled
   DevBuf<uint32_t> counters;   // kCntNum
   // dispatch ring: device slots, pinned host mirrors, pinned tally read-back, per-slot events
   static constexpr int kRing = 32;
@@ -280,14 +282,17 @@ int join_aux(HaloBackend* b) {
 }
 // The stream the next trace kernel goes to: behind what the main stream holds now (table uploads, counter resets) and — for a launch that
 // adds to the planes itself — behind what the auxiliary stream holds (folds, per-tile passes).
-int next_trace_stream(HaloBackend* b, bool touches_planes, hipStream_t* out, int* which) {
+int next_trace_stream(HaloBackend* b, bool touches_planes, bool alternate, hipStream_t* out, int* which) {
   if (!b->overlap) {
     *out = b->stream;
     *which = 0;
     return HALO_OK;
   }
-  const int i = b->cs_next;
-  b->cs_next ^= 1;
+  // Launches alternate streams only while they are latency-bound (up to 2^21 rays: tools/dispatch_probe.cpp, us per session with / without,
+  // 2^16 18.8 / 30.6, 2^18 25.2 / 44.0, 2^20 65.5 / 110, 2^22 264 / 250, 2^24 817 / 820); a launch that fills the chip by itself gains nothing
+  // from a neighbour and keeps stream 0, where its HIP events time it undisturbed.
+  const int i = alternate ? b->cs_next : 0;
+  if (alternate) b->cs_next ^= 1;
   HIPCHK(b, hipEventRecord(b->ev_main, b->stream));
   HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_main, 0));
   if (touches_planes && b->aux_pending && b->cs_seen_aux[i] != b->aux_seq) {
@@ -353,6 +358,9 @@ void harvest_slot(HaloBackend* b, int k) {
   (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
   if (b->ring_posts[k]) (void)hipEventElapsedTime(&ms2, b->ring_ev2[k], b->ring_ev3[k]);   // the passes run under the next launch's trace: their own span, not the group's
   b->layer_acc.kernel_ms += ms + ms2;
+  b->time_trace_ms += ms;
+  b->time_post_ms += ms2;
+  b->time_launches += 1;
   b->layer_acc.launches += 1;
   b->ring_busy[k] = false;
 }
@@ -1176,7 +1184,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.shapes = &ds->shape;
       } else {
         // (the pool of the trace stream this launch will take: next_trace_stream below hands out b->cs_next)
-        DevBuf<ShapeDev>& shapes = b->shapes_s[b->overlap ? b->cs_next : 0];
+        DevBuf<ShapeDev>& shapes = b->shapes_s[(b->overlap && m <= (1ull << 21)) ? b->cs_next : 0];
         if (int rc = reserve_idle(b, shapes, shape_cnt)) return rc;   // sized for ShapeDev records; prism pools use the front third
         if (host_pool) HIPCHK(b, hipMemcpyAsync(shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
         // (device generator: queued below on the launch's trace stream, in front of the trace kernel)
@@ -1340,7 +1348,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // goes behind whatever the auxiliary stream still does to them; a logged launch does not care.
       hipStream_t ts = nullptr;
       int ts_i = 0;
-      if (int rc = next_trace_stream(b, !use_log, &ts, &ts_i)) return rc;
+      const bool alternate = m <= (1ull << 21);
+      if (int rc = next_trace_stream(b, !use_log, alternate, &ts, &ts_i)) return rc;
       if (!deterministic && !host_pool) {   // device generator: one team per sampled crystal, in front of the trace kernel on its stream
         hipError_t ge = launch_shapegen(const_cast<ShapeDev*>(P.shapes), geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, ts, b->gen_serial != 0);
         if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
@@ -1582,6 +1591,19 @@ int halo_collect_stats(halo_handle_t b, HaloLayerStats* out) {
   b->layer_acc = HaloLayerStats{};
   *out = b->pending;
   b->pending = HaloLayerStats{};
+  return HALO_OK;
+}
+
+int halo_collect_timing(halo_handle_t b, double* trace_ms, double* post_ms, uint64_t* launches) {
+  if (!b) return HALO_FATAL;
+  HIPCHK(b, hipSetDevice(b->device));
+  if (int rc = sync_all(b)) return rc;
+  harvest_all(b);   // (adds the kernel times to the layer tallies as well: each ring slot is harvested once, whoever asks first)
+  if (trace_ms) *trace_ms = b->time_trace_ms;
+  if (post_ms) *post_ms = b->time_post_ms;
+  if (launches) *launches = b->time_launches;
+  b->time_trace_ms = b->time_post_ms = 0.0;
+  b->time_launches = 0;
   return HALO_OK;
 }
 

@@ -362,6 +362,10 @@ int halo_last_route(halo_handle_t h, HaloRouteInfo* out);
  * Needed with option "defer_fold" = 1 (halo_end then leaves the fold of a caller-bound accumulator pending so that the next session's trace
  * kernels run under it); harmless otherwise.  Not inside a session. */
 int halo_flush(halo_handle_t h);
+/* Kernel time by stream since the previous call (HIP events around every launch, read after a host wait): trace_ms = the trace kernels' own
+ * spans on their streams, post_ms = the spans of their accumulation passes on the auxiliary stream — those run UNDER the next launch's trace,
+ * so the two do not add up to wall time — launches = dispatches timed.  HaloLayerStats::kernel_ms is their sum. */
+int halo_collect_timing(halo_handle_t h, double* trace_ms, double* post_ms, uint64_t* launches);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option
  * "async" = 1 a final-layer halo_trace_layer only queues its dispatches (its `stats` carry root_count alone) and the

@@ -124,16 +124,34 @@ def _pearson_blocks(a, b, k=4):
     return float(np.corrcoef(x, y)[0, 1])
 
 
+CONFIG3_N, CONFIG3_WLS = 600_000, tuple(scenes.CONFIG_WAVELENGTHS_9[::4])    # 3 of the 9 wavelengths: same launch sizes, a third of the oracle's time
+
+
+def oracle_config3(seed):
+    """the oracle's side of the test below: 4x4 block means of its image (what the Pearson reading takes), Y sum, landed weight, first-layer
+    continuation counts — a committed fixture (tests/_oracle_cache.py), rendered by tests/golden/make_oracle_render_fixtures.py"""
+    def compute():
+        sc, rd = scenes.config3_scene(), scenes.config2_render()
+        ob = OracleBackend(seed=seed, threads=THREADS)
+        cont = [run_session(ob, sc, rd, scenes.wl_discrete(w), CONFIG3_N)[0].continuation_count for w in CONFIG3_WLS]
+        img, landed = ob.ReadbackXyzAccum()
+        ob.close()
+        return {"blocks4": block_mean(img, 4).astype(np.float32), "sum_y": np.float64(img[..., 1].sum(dtype=np.float64)), "landed": np.float64(landed),
+                "cont": np.asarray(cont, np.int64)}
+    from tests._oracle_cache import cached
+    return cached("config3_two_layer_seed%d" % seed, compute)
+
+
 def test_config3_two_layer_multi_scatter_at_production_launch_sizes():
-    """BASELINE configs[2]: plate (prob 1.0) over a randomly oriented column, 9 wavelengths, fisheye 1920x1080 — with 600 k roots
-    per wavelength, so every second-layer launch reads >= 2.5 Mi continuation rays from the sharded pool through the Feistel
+    """BASELINE configs[2]: plate (prob 1.0) over a randomly oriented column, fisheye 1920x1080 — with 600 k roots per wavelength (three of
+    the nine), so every second-layer launch reads >= 2.5 Mi continuation rays from the sharded pool through the Feistel
     gather (`source_mask` bit 1) and the production kernels run (`mode_mask` == 1).  Layer 0 traces the same rays as the oracle
     (continuation count equal to boundary flips); the second layer is compared statistically against the oracle AND against the
-    oracle's own cross-seed floor (module docstring)."""
+    oracle's own cross-seed floor (module docstring).  The oracle's two renders are committed fixtures (oracle_config3)."""
     sc = scenes.config3_scene()
     rd = scenes.config2_render()
-    n = 600_000
-    wls = [scenes.wl_discrete(w) for w in scenes.CONFIG_WAVELENGTHS_9]
+    n = CONFIG3_N
+    wls = [scenes.wl_discrete(w) for w in CONFIG3_WLS]
     hb = hip_backend(seed=42)
     cont_h, launches = [], 0
     for wl in wls:
@@ -146,28 +164,19 @@ def test_config3_two_layer_multi_scatter_at_production_launch_sizes():
         launches += st[1].launches
     ih, lh = hb.ReadbackXyzAccum()
     hb.close()
-
-    def oracle(seed):
-        ob = OracleBackend(seed=seed, threads=THREADS)
-        cont = []
-        for wl in wls:
-            cont.append(run_session(ob, sc, rd, wl, n)[0].continuation_count)
-        img, landed = ob.ReadbackXyzAccum()
-        ob.close()
-        return img, landed, cont
-    ia, la, cont_a = oracle(42)
-    ib, lb, _ = oracle(7)
-    for ch, co in zip(cont_h, cont_a):
-        assert ch == pytest.approx(co, rel=3e-4)                        # layer 0: same rays on both sides
+    a, b = oracle_config3(42), oracle_config3(7)
+    for ch, co in zip(cont_h, a["cont"]):
+        assert ch == pytest.approx(int(co), rel=3e-4)                        # layer 0: same rays on both sides
+    pear = lambda x, y: float(np.corrcoef(x.ravel().astype(np.float64), y.ravel().astype(np.float64))[0, 1])
     # cross-seed floor of the oracle itself (the reference's G3 reading, test/e2e/_parity_metrics.py)
-    floor_corr = _pearson_blocks(ia, ib)
-    floor_y = abs(ia[..., 1].sum(dtype=np.float64) / ib[..., 1].sum(dtype=np.float64) - 1.0)
-    floor_l = abs(la / lb - 1.0)
-    corr = _pearson_blocks(ih, ia)
-    dy = abs(ih[..., 1].sum(dtype=np.float64) / ia[..., 1].sum(dtype=np.float64) - 1.0)
-    dl = abs(lh / la - 1.0)
-    print("configs[2] 9 x %d roots: corr %.5f (oracle cross-seed %.5f), sumY dev %.2e (floor %.2e), landed dev %.2e (floor %.2e), %d layer-1 launches"
-          % (n, corr, floor_corr, dy, floor_y, dl, floor_l, launches))
+    floor_corr = pear(a["blocks4"], b["blocks4"])
+    floor_y = abs(float(a["sum_y"]) / float(b["sum_y"]) - 1.0)
+    floor_l = abs(float(a["landed"]) / float(b["landed"]) - 1.0)
+    corr = pear(block_mean(ih, 4), a["blocks4"])
+    dy = abs(ih[..., 1].sum(dtype=np.float64) / float(a["sum_y"]) - 1.0)
+    dl = abs(lh / float(a["landed"]) - 1.0)
+    print("configs[2] %d x %d roots: corr %.5f (oracle cross-seed %.5f), sumY dev %.2e (floor %.2e), landed dev %.2e (floor %.2e), %d layer-1 launches"
+          % (len(wls), n, corr, floor_corr, dy, floor_y, dl, floor_l, launches))
     assert corr >= 0.95 and corr >= floor_corr - 0.02
     assert dy <= 0.05 and dy <= 4.0 * floor_y + 2e-3
     assert dl <= 4.0 * floor_l + 2e-3
