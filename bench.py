@@ -430,7 +430,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times.append(float(t.item()))
-    trace_ms, post_ms, timed_launches = tracer.backend.collect_timing()   # HIP events: the trace kernels' own spans / their accumulation passes' (auxiliary stream)
+    trace_ms, post_ms, timed_launches = tracer.backend.collect_timing()   # HIP events of the LAST layer's launches: the trace kernels' own spans / their accumulation passes'
     st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
     route = tracer.backend.last_route()
     dt = statistics.median(times)
@@ -452,10 +452,10 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         return None
     # the dominant kernel: the last layer's launches (single-scatter: the only layer; multi-scatter: the transit-source layer)
     dom_launches = launches - first_layer["launches"]
-    # the dominant KERNEL: the last layer's trace kernel, timed by the HIP events around it on its own stream; its accumulation passes (split,
-    # per-tile sums) run on the auxiliary stream UNDER the next launch's trace kernel since round 5, so "trace + passes" is no longer a span of
-    # wall time — group_ms (their sum) is reported beside it
-    dom_ms = trace_ms - first_layer["ms"]
+    # the dominant KERNEL: the last layer's trace kernel, timed by the HIP events around it on its own stream (halo_collect_timing counts the
+    # last layers' launches only); group_ms adds its accumulation passes (split, per-tile sums), which follow it on that stream
+    assert timed_launches == dom_launches, (timed_launches, dom_launches)
+    dom_ms = trace_ms
     group_ms = kernel_ms - first_layer["ms"]
     dom_hits = pixel_hits - first_layer["hits"]
     dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
@@ -506,7 +506,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                      "shape_record_bytes": shape_bytes,
                      "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
                      "valu": pmc_valu(cfg, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
-                     "note": "avg_launch_ms = the trace kernel alone (HIP events on its stream; the rocprofv3 summary's average for that kernel is the same figure); its accumulation passes run on an auxiliary stream under the NEXT launch's trace kernel (avg_launch_group_ms = both spans added, wall_ms_per_launch = the timed region / launches). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+                     "note": "avg_launch_ms = the trace kernel alone (HIP events on its stream; the rocprofv3 summary's average for that kernel is the same figure); its accumulation passes (split + per-tile sums) follow it on the same stream (avg_launch_group_ms = both spans added, wall_ms_per_launch = the timed region / launches: what is left over is the sampled-crystal generator, the closing fold and launch gaps). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
     }
     if out["roofline"]["traffic"]:
         out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / alg_per_launch

@@ -176,8 +176,8 @@ class HipTraceBackend:
         self._check(self._L.halo_sync(self._h))
 
     def collect_timing(self):
-        """(trace_ms, post_ms, launches) since the previous call: the trace kernels' own spans and those of their accumulation passes (which run
-        under the next launch's trace kernel on the auxiliary stream)."""
+        """(trace_ms, post_ms, launches) of the sessions' LAST layers since the previous call: the trace kernels' own spans (HIP events on the
+        launch's stream) and those of their accumulation passes."""
         t, p, n = C.c_double(), C.c_double(), C.c_uint64()
         self._check(self._L.halo_collect_timing(self._h, C.byref(t), C.byref(p), C.byref(n)))
         return t.value, p.value, n.value

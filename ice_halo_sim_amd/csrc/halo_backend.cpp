@@ -28,12 +28,13 @@ namespace halo {
 hipError_t launch_trace(const DispatchParams& P, int blocks, hipStream_t stream, int mode, int geom, bool mono);
 hipError_t launch_bin_accumulate(float* plane, const HitRec* list, uint32_t cap, uint32_t* cnt, uint32_t tiles, uint32_t frac_bits, hipStream_t stream);
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream);
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream, hipEvent_t before_sums);
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream);
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream,
+                            hipEvent_t before_sums);
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream);
+                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream, hipEvent_t before_sums);
 hipError_t launch_shapegen(void* pool, bool prism_records, uint32_t n, uint32_t seed, const geom::CrystalRecipe& rc, uint64_t first_index,
                            hipStream_t stream, bool serial_pyramid);
 hipError_t launch_fold(float* xyz, float* planes, uint32_t n_pix, uint32_t s_log2, uint32_t copies, uint32_t n_planes, const FoldCoef& coef,
@@ -92,19 +93,18 @@ struct HaloBackend {
   int aggregate = 1;
   int mono_enabled = 1;
   int bin = -1;                // binned accumulation: -1 auto (discrete session, full-sky render, launch >= 4 Mi rays), 0 off, 1 on
-  // Two sets of the hit-log / tile-list buffers: launch k's accumulation passes (split + per-tile sums) run on the auxiliary stream under
-  // launch k+1's trace kernel, which meanwhile writes the other set (round 5, see `aux`)
+  // Two sets of the hit-log / tile-list buffers, taken in turn by the launches that alternate between the two trace streams (<= 2^21 rays):
+  // the one of exactly 2^21 rays that logs may run beside a neighbour.  Launches that fill the chip keep set 0.
   DevBuf<HitRec> bin_list_s[2], bin_list2_s[2];   // one-level tile lists / coarse lists / log regions; tile lists of the two-level and log routes
   DevBuf<uint32_t> bin_cnt_s[2], bin_cnt2_s[2];
   int log_set = 0;                      // the set the next logged launch writes
   bool set_used[2] = {false, false};    // ev_set_free[s] has been recorded: the set's last passes may still be running
   hipEvent_t ev_set_free[2] = {};
-  // Auxiliary stream (round 5).  The trace kernel of a logged launch never touches the accumulation planes: it writes log records (and, when a
-  // region overflows, the planes' fp64 twin, atomically).  Everything that DOES touch the planes of such launches — the split and per-tile
-  // passes, the closing fold — is bandwidth-bound and is queued here, ordered among itself, so that it runs under the NEXT launch's (or the next
-  // session's) trace kernel, which is VALU-bound: two engines side by side on one GPU measured +14 % (configs[1]), +15 % (the reference's D65
-  // benchmark scene), +10 % (configs[4]) — tools/two_engines_probe.py — and this is that overlap inside one engine.  Launches that add to the
-  // planes from the trace kernel itself (direct atomics, the binned route) first wait for this stream; readers of the image wait for it too.
+  // Auxiliary stream (round 5): the closing folds are queued here, behind everything the other streams hold, and nobody waits for them until
+  // somebody reads the image or adds to the planes again — a session's fold (20 us) runs under the next session's first kernels instead of
+  // in front of them.  (Two engines side by side on one GPU had measured +10 .. 15 % over one, tools/two_engines_probe.py; what that was,
+  // looked at inside one engine, is the small things between kernels — folds, resets, uploads, the tails — not the trace kernels or their
+  // passes, which gain nothing from running under each other: see the passes in halo_trace_layer.)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool aux_pending = false;             // work has been queued on `aux` that the main stream has not waited for
@@ -186,7 +186,7 @@ struct HaloBackend {
   double* tally_host = nullptr;       // hipHostMalloc, one snapshot of `tally`
   double tally_seen[kSumNum] = {};    // cumulative values already handed on: [kSumLanded] to a readback / take_landed, the rest to the layer statistics
   bool tally_unread = false;
-  double time_trace_ms = 0.0, time_post_ms = 0.0;   // halo_collect_timing: the trace kernels' own spans and their passes' (which run under the next trace), since the last call
+  double time_trace_ms = 0.0, time_post_ms = 0.0;   // halo_collect_timing: the last layers' trace kernels' own spans and their passes', since the last call
   uint64_t time_launches = 0;          // a dispatch has been queued since the statistics were last pulled
   DevBuf<uint32_t> counters;   // kCntNum
   // dispatch ring: device slots, pinned host mirrors, pinned tally read-back, per-slot events
@@ -195,6 +195,7 @@ struct HaloBackend {
   DispatchSlot* ring_host = nullptr;   // hipHostMalloc
   hipEvent_t ring_ev0[kRing] = {}, ring_ev1[kRing] = {}, ring_ev2[kRing] = {}, ring_ev3[kRing] = {}, ring_done[kRing] = {};   // ev0..ev1 the trace kernel (main stream), ev2..ev3 its passes (post stream)
   bool ring_posts[kRing] = {};
+  bool ring_final[kRing] = {};         // the slot's launch belongs to its session's last layer (halo_collect_timing counts those)
   bool ring_busy[kRing] = {};
   int ring_next = 0;
   // Table cache (round 5): the dispatch-constant tables of a deterministic crystal entry (latitude LUT, wavelength pool, shape, entry-pick
@@ -217,7 +218,19 @@ struct HaloBackend {
   uint32_t wl_pool_size = 0;
   struct LutKey { int32_t type; float center, spread; host::LatLut lut; };
   std::vector<LutKey> lut_cache;
-  DevBuf<ShapeDev> shapes_s[2];   // sampled-crystal pools, one per trace stream (launch k+1's generator must not overwrite what launch k still traces)
+  DevBuf<ShapeDev> shapes_s[2];   // sampled-crystal pools: launch k+1's generator must not overwrite what launch k still traces
+  hipEvent_t ev_shapes_free[2] = {nullptr, nullptr};   // recorded behind the trace kernel that read the pool
+  hipEvent_t ev_gen = nullptr;                         // the generator of a chip-filling launch, queued on trace stream 1 (see gen_ahead)
+  bool shapes_used[2] = {false, false};
+  int shapes_next = 0;
+  // Plane ownership between the two trace streams.  The per-tile sums of a logged (or two-level binned) launch end in PLAIN read-modify-writes of
+  // the planes; everything else that adds to them uses atomics.  So (1) a launch's sums wait for what the OTHER trace stream held when the launch
+  // was queued (ev_gate), and (2) a later launch on the other stream whose trace kernel adds to the planes itself waits for those sums (ev_rmw).
+  // Logged trace kernels touch no plane (their overflow goes to the fp64 twin), so they run beside a neighbour's passes freely.
+  hipEvent_t ev_gate = nullptr, ev_rmw[2] = {nullptr, nullptr};
+  bool rmw_pending[2] = {false, false};
+  int alt_log2 = 25;              // option (experiment knob): launches of up to 2^alt_log2 rays alternate between the two trace streams
+  int gen_ahead = 0;              // option (experiment knob): 1 queues the generator of a chip-filling launch on trace stream 1, beside the previous launch's kernels
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
   uint32_t cont_stride[2] = {0, 0};
   uint32_t cont_region[2] = {0, 0};          // slots per shard region
@@ -277,6 +290,7 @@ int join_aux(HaloBackend* b) {
       HIPCHK(b, hipEventRecord(b->ev_cs[k], b->cs[k]));
       HIPCHK(b, hipStreamWaitEvent(b->stream, b->ev_cs[k], 0));
       b->cs_pending[k] = false;
+      b->rmw_pending[k] = false;   // (every later launch waits for the main stream, which now waits for these sums)
     }
   return HALO_OK;
 }
@@ -356,11 +370,13 @@ void harvest_slot(HaloBackend* b, int k) {
   (void)hipEventSynchronize(b->ring_done[k]);
   float ms = 0.0f, ms2 = 0.0f;
   (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
-  if (b->ring_posts[k]) (void)hipEventElapsedTime(&ms2, b->ring_ev2[k], b->ring_ev3[k]);   // the passes run under the next launch's trace: their own span, not the group's
+  if (b->ring_posts[k]) (void)hipEventElapsedTime(&ms2, b->ring_ev2[k], b->ring_ev3[k]);   // the passes' own span
   b->layer_acc.kernel_ms += ms + ms2;
-  b->time_trace_ms += ms;
-  b->time_post_ms += ms2;
-  b->time_launches += 1;
+  if (b->ring_final[k]) {
+    b->time_trace_ms += ms;
+    b->time_post_ms += ms2;
+    b->time_launches += 1;
+  }
   b->layer_acc.launches += 1;
   b->ring_busy[k] = false;
 }
@@ -456,7 +472,10 @@ int halo_create(int device_ordinal, uint32_t seed, halo_handle_t* out) {
                 hipEventCreateWithFlags(&b->ev_cs[1], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_main, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&b->ev_aux, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&b->ev_set_free[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_set_free[1], hipEventDisableTiming) == hipSuccess;
+                hipEventCreateWithFlags(&b->ev_set_free[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_set_free[1], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_shapes_free[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_shapes_free[1], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_gen, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_gate, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&b->ev_rmw[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&b->ev_rmw[1], hipEventDisableTiming) == hipSuccess;
   bool ring_ok = aux_ok && b->ring_dev.reserve(HaloBackend::kRing) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&b->ring_host), HaloBackend::kRing * sizeof(DispatchSlot), hipHostMallocDefault) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&b->tally_host), kTallyLines * kTallyStride * sizeof(double), hipHostMallocDefault) == hipSuccess;
@@ -521,7 +540,11 @@ int halo_destroy(halo_handle_t b) {
     b->bin_list2_s[k].release();
     b->bin_cnt2_s[k].release();
     if (b->ev_set_free[k]) (void)hipEventDestroy(b->ev_set_free[k]);
+    if (b->ev_shapes_free[k]) (void)hipEventDestroy(b->ev_shapes_free[k]);
+    if (b->ev_rmw[k]) (void)hipEventDestroy(b->ev_rmw[k]);
   }
+  if (b->ev_gen) (void)hipEventDestroy(b->ev_gen);
+  if (b->ev_gate) (void)hipEventDestroy(b->ev_gate);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   if (b->aux) (void)hipStreamDestroy(b->aux);
@@ -585,6 +608,8 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
     b->overlap = v ? 1 : 0;
   }
   else if (k == "defer_fold") b->defer_fold = v ? 1 : 0;
+  else if (k == "gen_ahead") b->gen_ahead = v ? 1 : 0;
+  else if (k == "alt_log2") b->alt_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 10), 28));
   else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "blocks_cap") b->blocks_cap = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "mono_copies") {
@@ -1180,13 +1205,23 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       P.lane_stride = static_cast<uint32_t>(b->acc_w) * static_cast<uint32_t>(b->acc_h);
       P.cont_in_seg = ds->seg;
       P.entry_fast = entry_fast ? &ds->efast : nullptr;
+      int shape_set = 0;
       if (deterministic) {
         P.shapes = &ds->shape;
       } else {
-        // (the pool of the trace stream this launch will take: next_trace_stream below hands out b->cs_next)
-        DevBuf<ShapeDev>& shapes = b->shapes_s[(b->overlap && m <= (1ull << 21)) ? b->cs_next : 0];
+        // Two pools, taken in turn by the launches that may run beside a neighbour: the records of launch k+1 are written while launch k still
+        // traces out of the other one.
+        const bool turn = b->overlap && (m <= (1ull << b->alt_log2) || b->gen_ahead);   // (a launch that fills the chip runs alone on stream 0: pool 0)
+        shape_set = turn ? b->shapes_next : 0;
+        if (turn) b->shapes_next ^= 1;
+        DevBuf<ShapeDev>& shapes = b->shapes_s[shape_set];
         if (int rc = reserve_idle(b, shapes, shape_cnt)) return rc;   // sized for ShapeDev records; prism pools use the front third
-        if (host_pool) HIPCHK(b, hipMemcpyAsync(shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        if (turn)   // (its twin with it, for the same reason as the log's second buffer set)
+          if (int rc = reserve_idle(b, b->shapes_s[shape_set ^ 1], shape_cnt)) return rc;
+        if (host_pool) {
+          if (b->shapes_used[shape_set]) HIPCHK(b, hipStreamWaitEvent(b->stream, b->ev_shapes_free[shape_set], 0));
+          HIPCHK(b, hipMemcpyAsync(shapes.ptr, pool.data(), pool.size() * sizeof(ShapeDev), hipMemcpyHostToDevice, b->stream));
+        }
         // (device generator: queued below on the launch's trace stream, in front of the trace kernel)
         P.shapes = shapes.ptr;
       }
@@ -1246,6 +1281,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
                            (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
       bool use_log_xyz = use_log && b->xyz_log;
       uint64_t log_cap = 0;
+      // Launches of <= 2^21 rays alternate between the two trace streams (next_trace_stream); only those can meet a neighbour that still reads
+      // or writes a buffer set, so only those take the sets in turn — a launch that fills the chip keeps stream 0 and set 0 (a second set
+      // allocated in the middle of a run is a host sync and a multi-gigabyte hipMalloc: 1.2 s in configs[4]'s first timed step)
+      const bool alternate = m <= (1ull << b->alt_log2);
+      const int ls = (b->overlap && alternate) ? b->log_set : 0;   // the buffer set of this launch
       if (use_log) {
         // a region takes 4 records per ray of its workgroup (configs[1]: 1.2 logged per ray), 8 for full-sky renders (5-6 per ray),
         // and a tile list twice its even share of that; what runs over falls back to direct atomics
@@ -1270,7 +1310,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         // want theirs), and a reserve that fails all the same sends this launch down the direct route instead of failing the trace.
         {
           size_t free_b = 0, total_b = 0;
-          const uint64_t have = (b->bin_list_s[b->log_set].cap + b->bin_list2_s[b->log_set].cap) * sizeof(HitRec);
+          const uint64_t have = (b->bin_list_s[ls].cap + b->bin_list2_s[ls].cap) * sizeof(HitRec);
           uint64_t need = (cap * static_cast<uint64_t>(blocks) + c2 * log_tiles) * sizeof(HitRec);
           if (need > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need - have > free_b / 2u) {
             const double shrink = static_cast<double>(have + free_b / 2u) / static_cast<double>(need);
@@ -1281,15 +1321,23 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         cap2 = static_cast<uint32_t>(c2 & ~15ull);   // whole 128-byte lines per tile list
         log_cap = cap;
         hipError_t e1 = hipSuccess, e2 = hipSuccess;
-        if (int rc = reserve_idle(b, b->bin_list_s[b->log_set], cap * static_cast<uint64_t>(blocks), &e1)) return rc;
+        if (int rc = reserve_idle(b, b->bin_list_s[ls], cap * static_cast<uint64_t>(blocks), &e1)) return rc;
         if (e1 == hipSuccess)
-          if (int rc = reserve_idle(b, b->bin_list2_s[b->log_set], c2 * log_tiles, &e2)) return rc;
+          if (int rc = reserve_idle(b, b->bin_list2_s[ls], c2 * log_tiles, &e2)) return rc;
+        if (b->overlap && alternate && e1 == hipSuccess && e2 == hipSuccess) {
+          // the other set with it: the next launch would otherwise stop the queue (a host sync and a multi-gigabyte hipMalloc) for it.  A speed
+          // matter only — if there is no room, the launch that finds the set short shrinks its log as above.
+          hipError_t e3 = hipSuccess, e4 = hipSuccess;
+          if (int rc = reserve_idle(b, b->bin_list_s[ls ^ 1], cap * static_cast<uint64_t>(blocks), &e3)) return rc;
+          if (e3 == hipSuccess)
+            if (int rc = reserve_idle(b, b->bin_list2_s[ls ^ 1], c2 * log_tiles, &e4)) return rc;
+          if (e3 != hipSuccess || e4 != hipSuccess) (void)hipGetLastError();
+        }
         if (e1 != hipSuccess || e2 != hipSuccess) {
           (void)hipGetLastError();   // out of memory: not this launch's route
           use_log = use_log_xyz = false;
         }
       }
-      const int ls = b->log_set;                                  // the buffer set of this launch
       DevBuf<HitRec>&bin_list = b->bin_list_s[ls], &bin_list2 = b->bin_list2_s[ls];
       DevBuf<uint32_t>&bin_cnt = b->bin_cnt_s[ls], &bin_cnt2 = b->bin_cnt2_s[ls];
       if (use_bin)   // the staged-list route shares one buffer set and resets its counters on the main stream: one launch at a time
@@ -1344,17 +1392,39 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.mono_copy_mask = b->plane_copies - 1u;
       }
       P.no_land = (P.prob >= 1.0f && !P.final_layer && fast_mode && b->aggregate == 1) ? 1u : 0u;
-      // The launch's trace stream (alternating).  A launch that adds to the planes from the trace kernel itself — direct atomics, staged lists —
-      // goes behind whatever the auxiliary stream still does to them; a logged launch does not care.
+      // The launch's trace stream (alternating for small launches), behind whatever the auxiliary stream still does to the planes (a closing
+      // fold): the launch adds to them — from the trace kernel itself (direct atomics, staged lists) or in its passes, which follow it on
+      // the same stream.
       hipStream_t ts = nullptr;
       int ts_i = 0;
-      const bool alternate = m <= (1ull << 21);
-      if (int rc = next_trace_stream(b, !use_log, alternate, &ts, &ts_i)) return rc;
-      if (!deterministic && !host_pool) {   // device generator: one team per sampled crystal, in front of the trace kernel on its stream
-        hipError_t ge = launch_shapegen(const_cast<ShapeDev*>(P.shapes), geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, ts, b->gen_serial != 0);
+      if (int rc = next_trace_stream(b, true, alternate, &ts, &ts_i)) return rc;
+      hipEvent_t before_sums = nullptr;   // rule (1), for the routes whose sums write the planes plainly
+#ifndef HALO_NO_PLANE_GATES   // (defined only to see tests/test_gpu_production_routes.py's two-stream test fail without the gates)
+      if (b->overlap && !use_log && b->rmw_pending[ts_i ^ 1])   // this trace kernel adds to the planes itself: behind the other stream's sums
+        HIPCHK(b, hipStreamWaitEvent(ts, b->ev_rmw[ts_i ^ 1], 0));
+      if (b->overlap && (use_log || (use_bin && two_level)) && b->cs_pending[ts_i ^ 1]) {
+        HIPCHK(b, hipEventRecord(b->ev_gate, b->cs[ts_i ^ 1]));
+        before_sums = b->ev_gate;
+      }
+#endif
+      if (!deterministic && !host_pool) {
+        // Device generator: one team per sampled crystal, in front of the trace kernel on its stream.  Option "gen_ahead" puts the one of a
+        // launch that fills the chip on trace stream 1 instead, beside the previous launch's trace kernel and passes (it needs nothing of
+        // them, only its pool back from the launch before that one).  Measured (25 M rays per launch): prism pools 4.43 -> 4.55 ms per launch,
+        // pyramid pools 7.78 -> 7.70: both kernels are VALU-bound, so sharing the chip conserves the work.  Off by default.
+        const bool ahead = b->overlap && b->gen_ahead && !alternate;
+        hipStream_t gs = ahead ? b->cs[1] : ts;
+        if (b->shapes_used[shape_set]) HIPCHK(b, hipStreamWaitEvent(gs, b->ev_shapes_free[shape_set], 0));
+        hipError_t ge = launch_shapegen(const_cast<ShapeDev*>(P.shapes), geom == 2, shape_cnt, b->seed, host::MakeRecipe(E.crystal), first_shape, gs, b->gen_serial != 0);
         if (ge != hipSuccess) return hip_fail(b, ge, "halo_shapegen_kernel launch");
+        if (ahead) {
+          HIPCHK(b, hipEventRecord(b->ev_gen, gs));
+          HIPCHK(b, hipStreamWaitEvent(ts, b->ev_gen, 0));
+          b->cs_pending[1] = true;
+        }
       }
       HIPCHK(b, hipEventRecord(b->ring_ev0[k], ts));  // HIP events on the launch stream bracket the kernel alone
+      b->ring_final[k] = P.final_layer != 0u;
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hex_regular) ? 3 : geom;
       hipError_t le = launch_trace(P, blocks, ts, mode, launch_geom, b->mono_session);
@@ -1384,34 +1454,46 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       }
       b->route.source_mask |= 1u << P.source;
       if (le != hipSuccess) return hip_fail(b, le, "halo_trace_kernel launch");
+      if (!deterministic) {
+        HIPCHK(b, hipEventRecord(b->ev_shapes_free[shape_set], ts));
+        b->shapes_used[shape_set] = true;
+      }
       // fixed-point scale of the per-tile sums (halo_kernels.hip FixQ): no slot of this launch can sum to more than 4 x max weight x rays
       const uint32_t frac_bits = fix_frac_bits(b->sess_max_w, m);
       if (use_log) {
-        // the accumulation passes of this launch: on the post stream, behind the trace kernel just queued and behind the passes / folds queued
-        // there before; the main stream goes on to the next launch (which writes the other buffer set)
-        HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));          // the trace kernel alone: ev0 .. ev1 on its stream
-        if (int rc = fork_aux(b)) return rc;
-        hipStream_t ps = post_stream(b);
+        // the accumulation passes of this launch: behind the trace kernel on its stream.  (Round 5 tried them on the auxiliary stream, under the
+        // next launch's trace kernel: configs[1] + 1.2 %, the trace kernel itself 5 % slower for the CUs the 134 KB split workgroups take, the
+        // passes' spans stretched sevenfold — profiles that no longer say what a kernel costs, for one percent.  Not kept.)
+        HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));          // the trace kernel alone: ev0 .. ev1
+        hipStream_t ps = ts;
         HIPCHK(b, hipEventRecord(b->ring_ev2[k], ps));
         HIPCHK(b, hipMemsetAsync(bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), ps));
         hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks),
-                                                           bin_list2.ptr, cap2, bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, ps)
+                                                           bin_list2.ptr, cap2, bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, ps, before_sums)
                                     : launch_log_route(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks), bin_list2.ptr, cap2,
                                                        bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
-                                                       P.ovf, P.ovf_flag, P.ovf_copies_log2, ps);
+                                                       P.ovf, P.ovf_flag, P.ovf_copies_log2, ps, before_sums);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
+        if (b->overlap) {
+          HIPCHK(b, hipEventRecord(b->ev_rmw[ts_i], ps));
+          b->rmw_pending[ts_i] = true;
+        }
         HIPCHK(b, hipEventRecord(b->ring_ev3[k], ps));
         HIPCHK(b, hipEventRecord(b->ev_set_free[ls], ps));
         b->set_used[ls] = true;
-        b->log_set ^= 1;
+        if (b->overlap && alternate) b->log_set ^= 1;
         b->ring_posts[k] = true;
         HIPCHK(b, hipEventRecord(b->ring_done[k], ps));
       } else {
       if (use_bin) {
         hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, lists1, bin_list2.ptr, cap2, bin_cnt2.ptr,
-                                                         bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, ts)
+                                                         bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, ts, before_sums)
                                   : launch_bin_accumulate(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, bin_tiles, frac_bits, ts);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
+        if (b->overlap && two_level) {
+          HIPCHK(b, hipEventRecord(b->ev_rmw[ts_i], ts));
+          b->rmw_pending[ts_i] = true;
+        }
       }
       HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));
       b->ring_posts[k] = false;

@@ -385,12 +385,15 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   }
 }
 
+// (`before_sums`, all three routes below: the per-tile sums end in PLAIN read-modify-writes of the planes, so they may not run beside another
+// launch that adds to the same planes; the event, when given, is waited for between the split pass and the sums — see halo_backend.cpp.)
 // hit-log route, one scalar plane: regions -> `tiles` (a power of two <= 256) tiles -> the plane.  Contiguous tiles (plain float4
 // write-out, 3-5 % faster at configs[1] / [2]) where the lists have room for an uneven image — renders that cull most exits,
 // ~1.2 records per ray against room for 8 — interleaved tiles (halo_log_accumulate_kernel) for full-sky renders.
 // `planes` > 1: the scalar planes of a per-entry-plane illuminant session (back to back), `tiles` interleaved tiles EACH, planes x tiles <= 512.
 hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2, uint32_t cap2, uint32_t* cnt2,
-                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream) {
+                            uint32_t tiles, uint32_t planes, uint32_t s_log2, bool interleaved, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream,
+                            hipEvent_t before_sums) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles)), tile_log2 = s_log2 + 10u - tiles_log2;   // slots per tile <= 16 Ki
   // more than 256 lists — several planes, or ONE plane of an 8 Mi-pixel image cut into 512 tiles (an illuminant pool of one entry on 4096 x 2048:
   // found by tests/test_gpu_fuzz.py, the 256-list kernel below wrote past its counters) — take the 512-list split kernel
@@ -399,6 +402,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, 0u, s_log2, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, s_log2 + 10u, copies_log2});
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (before_sums && (e = hipStreamWaitEvent(stream, before_sums, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles * planes), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                        static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2, frac_bits);
     return hipGetLastError();
@@ -411,6 +415,7 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
                        1u, reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, 0xFFFFFFFFu, tile_log2, 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, s_log2 + 10u, copies_log2});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (before_sums && (e = hipStreamWaitEvent(stream, before_sums, 0)) != hipSuccess) return e;
   if (interleaved)
     hipLaunchKernelGGL((halo_log_accumulate_kernel<1u>), dim3(tiles), dim3(kBinBlock), 0, stream, plane, 0u, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                        static_cast<const WlEntryDev*>(nullptr), 0u, tiles_log2, s_log2, frac_bits);
@@ -421,24 +426,26 @@ hipError_t launch_log_route(float* plane, const HitRec* log, uint32_t cap1, cons
 // the same for an illuminant session on X, Y, Z planes: `tiles` (a power of two <= 512) interleaved tiles of <= 4 Ki slots of one plane
 hipError_t launch_log_route_xyz(float* planes, uint32_t plane_stride, const HitRec* log, uint32_t cap1, const uint32_t* cnt1, uint32_t regions, HitRec* list2,
                                 uint32_t cap2, uint32_t* cnt2, uint32_t tiles, uint32_t s_log2, const WlEntryDev* pool, uint32_t pool_size, uint32_t frac_bits,
-                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream) {
+                                double* ovf, uint32_t* ovf_flag, uint32_t copies_log2, hipStream_t stream, hipEvent_t before_sums) {
   const uint32_t tiles_log2 = static_cast<uint32_t>(__builtin_ctz(tiles));
   hipLaunchKernelGGL((halo_split_kernel<kLogSplitThreads, kLogSplitPer, 512u, true, true>), dim3(regions), dim3(kLogSplitThreads), 0, stream, planes, reinterpret_cast<const uint2*>(log), cap1, cnt1, 1u, 1u,
                      reinterpret_cast<uint2*>(list2), cap2, cnt2, tiles_log2, 0u, (1u << kLogWlShift) - 1u, 0u, s_log2, SplitXyz{pool, pool_size, plane_stride, ovf, ovf_flag, s_log2 + 10u, copies_log2});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (before_sums && (e = hipStreamWaitEvent(stream, before_sums, 0)) != hipSuccess) return e;
   hipLaunchKernelGGL((halo_log_accumulate_kernel<3u>), dim3(tiles), dim3(kBinBlock), 0, stream, planes, plane_stride, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                      pool, pool_size, tiles_log2, s_log2, frac_bits);
   return hipGetLastError();
 }
 
 hipError_t launch_bin_two_level(float* plane, const HitRec* list1, uint32_t cap1, uint32_t* cnt1, uint32_t lists1, HitRec* list2, uint32_t cap2,
-                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream) {
+                                uint32_t* cnt2, uint32_t tiles, uint32_t fan_log2, uint32_t frac_bits, double* ovf, uint32_t* ovf_flag, hipStream_t stream, hipEvent_t before_sums) {
   hipLaunchKernelGGL((halo_split_kernel<256u, 16u, 256u, false, false>), dim3(lists1 * kSplitParts), dim3(256u), 0, stream, plane, reinterpret_cast<const uint2*>(list1), cap1,
                      cnt1, static_cast<uint32_t>(kBinCntStride), kSplitParts, reinterpret_cast<uint2*>(list2), cap2, cnt2, fan_log2, 1u, 0xFFFFFFFFu,
                      static_cast<uint32_t>(kBinTileLog2), 0u, SplitXyz{nullptr, 0u, 0u, ovf, ovf_flag, 0u, 0u});   // (per-entry planes have no privatised copies: the twin's offsets are the planes')
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (before_sums && (e = hipStreamWaitEvent(stream, before_sums, 0)) != hipSuccess) return e;
   hipLaunchKernelGGL(halo_bin_accumulate_range_kernel, dim3(tiles), dim3(kBinBlock), 0, stream, plane, reinterpret_cast<const uint2*>(list2), cap2, cnt2,
                      static_cast<uint32_t>(kBinTileLog2), frac_bits);
   return hipGetLastError();

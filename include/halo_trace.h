@@ -291,7 +291,12 @@ const char* halo_last_error(halo_handle_t h);
  * "entry_fast" (1 [default]: one-shape dispatches of a full 8-face prism pick the entry face slab by slab, in registers;
  * 0: the generic walk over faces — same uniform, same cumulative order, A/B knob),
  * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in
- * [1, 64], default 32 = one 128-byte line per plane read; 1 = the reference's per-ray permutation, cu:1633-1657). */
+ * [1, 64], default 32 = one 128-byte line per plane read; 1 = the reference's per-ray permutation, cu:1633-1657),
+ * scheduling (ABI 6; none of them changes a result): "overlap" (1 [default]: launches of <= 2 Mi rays alternate between two
+ * trace streams, closing folds run on an auxiliary stream; 0 = everything on the one stream), "table_cache" (1 [default]: equal
+ * sessions reuse their device tables), "small_blocks_per_cu" (default 5: workgroups per CU a small launch spreads over before a
+ * workgroup takes a second pass), "defer_fold" (see halo_flush), "gen_ahead" (experiment knob, 0 [default]; 1: the crystal generator of a
+ * launch that fills the chip is queued beside the previous launch's trace kernel — measured, gains nothing: both are VALU-bound). */
 int halo_set_option(halo_handle_t h, const char* key, int64_t value);
 /* Use an external HIP stream (e.g. torch's current stream) for all launches. NULL = own stream. */
 int halo_set_stream(halo_handle_t h, void* hip_stream);
@@ -362,9 +367,9 @@ int halo_last_route(halo_handle_t h, HaloRouteInfo* out);
  * Needed with option "defer_fold" = 1 (halo_end then leaves the fold of a caller-bound accumulator pending so that the next session's trace
  * kernels run under it); harmless otherwise.  Not inside a session. */
 int halo_flush(halo_handle_t h);
-/* Kernel time by stream since the previous call (HIP events around every launch, read after a host wait): trace_ms = the trace kernels' own
- * spans on their streams, post_ms = the spans of their accumulation passes on the auxiliary stream — those run UNDER the next launch's trace,
- * so the two do not add up to wall time — launches = dispatches timed.  HaloLayerStats::kernel_ms is their sum. */
+/* Kernel time of the sessions' LAST layers since the previous call (HIP events on the launch's stream, read after a host wait): trace_ms = the
+ * trace kernels' own spans, post_ms = the spans of their accumulation passes (split + per-tile sums), launches = dispatches timed.  For
+ * bench.py's roofline object, which prices the last layer's trace kernel; HaloLayerStats::kernel_ms is trace + passes of every layer. */
 int halo_collect_timing(halo_handle_t h, double* trace_ms, double* post_ms, uint64_t* launches);
 int halo_sync(halo_handle_t h);
 /* Tallies of every layer traced since the previous call (summed), after waiting for the stream. With option

@@ -664,6 +664,65 @@ def test_equal_small_sessions_equal_one_large_session():
         assert img.sum(dtype=np.float64) == pytest.approx(ref_img.sum(dtype=np.float64), rel=2e-6)
 
 
+def test_mixed_session_sizes_on_two_streams_equal_one_stream():
+    """Sessions of mixed sizes queued back to back take the two trace streams in turn (<= 2^25 rays), and their routes differ in HOW they add to
+    the planes: logged launches (>= 2^21 rays) end in plain read-modify-writes by their per-tile sums, smaller ones add with atomics from the
+    trace kernel.  Events keep a plain write-out from running beside any other writer of the same planes (halo_backend.cpp: ev_gate / ev_rmw).
+    What this test can show is that the two-stream run of such a mix gives the one-stream run's image pixel by pixel (a lost update would be
+    a pixel missing a whole tile sum, tens of per cent; float-order differences are ~1e-5 of a pixel) and its tallies exactly.  It is NOT a race
+    detector: a build without the gates (-DHALO_NO_PLANE_GATES) passes it too, the window being a few nanoseconds per slot — the ordering
+    holds by construction, not by this test."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    sc, rd, wl = scenes.config2_scene(), scenes.config2_render(640, 360), scenes.wl_discrete(550.0)
+    sizes = [1 << 22, 1 << 20, 1 << 16, 1 << 20, 1 << 16, 1 << 20, 1 << 22, 1 << 21, 1 << 20, 1 << 23, 1 << 18, 1 << 22, 1 << 21, 1 << 21, 1 << 19, 1 << 22]
+    res = {}
+    for name, opts in (("two_streams", {}), ("one_stream", {"overlap": 0})):
+        hb = HipTraceBackend(device=0, seed=29, **{"async": 1}, **opts)
+        hb.collect_stats()
+        for rep in range(6):
+            for n in sizes:
+                run_session(hb, sc, rd, wl, n)
+        st = hb.collect_stats()
+        img, landed = hb.ReadbackXyzAccum(640, 360)
+        res[name] = (_stats_tuple(st), landed, img.astype(np.float64))
+        hb.close()
+    (st2, l2, a), (st1, l1, b) = res["two_streams"], res["one_stream"]
+    assert st2 == st1 and st1[0] == 6 * sum(sizes)
+    assert l2 == pytest.approx(l1, rel=1e-6)
+    worst = np.abs(a - b) / (np.maximum(a, b) + 1e-9 * b.max())
+    assert worst.max() <= 1e-3, (worst.max(), np.unravel_index(worst.argmax(), worst.shape))
+
+
+def test_sampled_crystal_sessions_under_every_scheduling_option():
+    """Queued sessions of sampled crystals (device generator -> pool -> trace kernel -> passes) under the scheduling options of round 5: one
+    stream (overlap 0), the default, and the generator of a chip-filling launch queued beside the previous launch's kernels on the other
+    pool (gen_ahead 1).  Scheduling moves no ray: same tallies, same landed weight, same image to float summation order.  Launches of
+    2^22 rays (pool 0, stream 0 by default) and of 2^20 (alternating streams and pools), prisms (hit log on X/Y/Z planes) and pyramids."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    rd = scenes.config2_render(480, 270)
+    for entry_of, wl in ((scenes.stochastic_prism_entry, scenes.wl_illuminant("D65", 31)), (_stoch_pyramid_entry, scenes.wl_discrete(550.0))):
+        sc = scenes.scene([(0.0, [entry_of()])], max_hits=8)
+        res = {}
+        for name, opts in (("default", {}), ("one_stream", {"overlap": 0}), ("gen_ahead", {"gen_ahead": 1})):
+            hb = HipTraceBackend(device=0, seed=17, **{"async": 1}, **opts)
+            hb.collect_stats()
+            for n in (1 << 22, 1 << 22, 1 << 20, 1 << 20, 1 << 22):
+                run_session(hb, sc, rd, wl, n)
+            st = hb.collect_stats()
+            img, landed = hb.ReadbackXyzAccum(480, 270)
+            res[name] = (_stats_tuple(st), landed, img)
+            hb.close()
+        ref_st, ref_landed, ref_img = res["one_stream"]
+        assert ref_st[0] == 3 * (1 << 22) + 2 * (1 << 20) and ref_st[2] > ref_st[0]
+        for name in ("default", "gen_ahead"):
+            st, landed, img = res[name]
+            assert st == ref_st, (name, st, ref_st)
+            assert landed == pytest.approx(ref_landed, rel=1e-6)
+            assert np.abs(img - ref_img).max() <= 2e-5 * float(ref_img.max())
+
+
 def test_table_cache_follows_scene_wavelength_filters_and_options():
     """The device-resident tables of a crystal entry (round 5) must be replaced whenever anything they were built from changes: the scene
     (another crystal, another axis distribution), the wavelength, the filter table, an option.  A backend with the cache and one that

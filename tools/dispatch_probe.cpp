@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
   rd.visible = HALO_VISIBLE_UPPER;
   HaloWl wl = {550.0f, 1.0f, -1, 0};
   try {
-    for (int async = 0; async <= 1; async++) {
+    const char* only = std::getenv("PROBE_ASYNC_ONLY");
+    for (int async = only ? 1 : 0; async <= 1; async++) {
       halo::HipTraceBackend be(0, 42);
       be.SetOption("async", async);
       for (int a = 2; a < argc; a++) {
@@ -50,7 +51,19 @@ int main(int argc, char** argv) {
         if (eq != std::string::npos) be.SetOption(kv.substr(0, eq).c_str(), std::atoll(kv.c_str() + eq + 1));
       }
       std::vector<float> img(static_cast<size_t>(rd.width) * rd.height * 3);
-      for (int lg : {15, 16, 17, 18, 20, 22, 24}) {
+      const char* sizes_env = std::getenv("PROBE_SIZES");   // e.g. "20 21 22 23"
+      std::vector<int> sizes = {15, 16, 17, 18, 20, 22, 24};
+      if (sizes_env) {
+        sizes.clear();
+        for (const char* p = sizes_env; *p;) {
+          char* end = nullptr;
+          const long v = std::strtol(p, &end, 10);
+          if (end == p) break;
+          sizes.push_back(static_cast<int>(v));
+          p = end;
+        }
+      }
+      for (int lg : sizes) {
         const size_t n = size_t{1} << lg;
         const int k = std::max(3, lg <= 18 ? reps : reps >> (lg - 18));
         double best = 1e30, landed_sum = 0.0;

@@ -89,8 +89,9 @@ def server(t):
     # the dispatch default (server.cpp:1449-1457): without this a kHip route would inherit Metal's 32768 rays per dispatch, a
     # twentieth of this engine's rate (profiles/r05_dispatch_size.txt).  The route test below repeats ResolveGpuRoute's precedence
     # (env override first, then preferred_backend) so that a build with CUDA and HIP both enabled tells the two apart.
-    t = after(t, "static constexpr size_t kDefaultCudaDispatchRayNum = 262144;", '''  // MI355X engine (libhalo_hip): a session costs ~60 us of fixed work whatever its size and the trace kernel needs ~2^22 rays to
-  // fill 256 CUs; 2^24 rays per dispatch is ~85 % of the plateau at <1 ms per dispatch, so UI commit cadence is unaffected.
+    t = after(t, "static constexpr size_t kDefaultCudaDispatchRayNum = 262144;", '''  // MI355X engine (libhalo_hip): a session of 2^16 rays costs ~20 us however few rays it holds (one latency-bound pass of the ray
+  // loop) and the trace kernel needs ~2^22 rays to fill 256 CUs; 2^24 rays per dispatch run at the engine's plateau (~22.6 G rays/s)
+  // in ~0.75 ms per dispatch, so UI commit cadence is unaffected (2^18: ~46 % of it, 2^20: ~71 %, 2^22: ~84 %).
   static constexpr size_t kDefaultHipDispatchRayNum = size_t{1} << 24;
 ''')
     t = before(t, "ServerImpl::ServerImpl(int num_workers, uint32_t sim_seed, BackendKind preferred_backend)", '''#if defined(LUMICE_HIP_ENABLED)
