@@ -143,6 +143,8 @@ def main(argv=None):
             raise config.ConfigError('ray_num is "infinite": pass --max-rays')
         if args.output_dir is not None and not args.benchmark and args.render is None:
             return save_all_renders(job, args)
+        if args.output_dir is not None:
+            print("[warning] -o / --output-dir is ignored with --render / --benchmark (nothing is saved)", file=sys.stderr)
         wall0 = time.perf_counter()
         res = run_job(job, args.render, args.seed, args.device, args.max_rays)
     except BackendUnavailableError as e:
