@@ -229,6 +229,7 @@ struct HaloBackend {
   // Logged trace kernels touch no plane (their overflow goes to the fp64 twin), so they run beside a neighbour's passes freely.
   hipEvent_t ev_gate = nullptr, ev_rmw[2] = {nullptr, nullptr};
   bool rmw_pending[2] = {false, false};
+  int log_tiles_log2 = 7;         // option (experiment knob): the scalar hit-log route cuts a plane into up to 2^this tiles (<= 8)
   int alt_log2 = 25;              // option (experiment knob): launches of up to 2^alt_log2 rays alternate between the two trace streams
   int gen_ahead = 0;              // option (experiment knob): 1 queues the generator of a chip-filling launch on trace stream 1, beside the previous launch's kernels
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
@@ -609,6 +610,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   }
   else if (k == "defer_fold") b->defer_fold = v ? 1 : 0;
   else if (k == "gen_ahead") b->gen_ahead = v ? 1 : 0;
+  else if (k == "log_tiles_log2") b->log_tiles_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 0), 8));
   else if (k == "alt_log2") b->alt_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 10), 28));
   else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
   else if (k == "blocks_cap") b->blocks_cap = static_cast<int>(std::max<int64_t>(v, 0));
@@ -1272,7 +1274,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Tiles: as many as the split pass feeds whatever the image size — the per-tile pass has one workgroup per tile — of at least
       // 256 and at most 16 Ki slots (X/Y/Z: 4 Ki) of ONE plane: 512 for X/Y/Z; for a scalar plane 128 where that keeps them within
       // 16 Ki slots (longer runs in the split pass: 0.23 vs 0.25 ms at configs[1]).
-      const uint32_t log_t_log2 = log_planes_ok ? wl_t_log2 : b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(7u, b->mono_s_log2 + 2u));
+      const uint32_t log_t_log2 = log_planes_ok ? wl_t_log2 : b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(static_cast<uint32_t>(b->log_tiles_log2), b->mono_s_log2 + 2u));
       const uint32_t log_planes = log_planes_ok ? b->plane_cnt : 1u;
       const uint32_t log_tiles = log_planes << log_t_log2;   // lists the split pass feeds
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && (log_planes_ok || (!b->mono_by_wl && b->mono_s_log2 <= 12u)));

@@ -264,8 +264,34 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
   for (uint32_t j = threadIdx.x; j < slots; j += kBinBlock) acc[j] = 0ull;
   __syncthreads();
   const uint2* src = list + static_cast<size_t>(tile) * cap;
-  constexpr uint32_t kU = 4u;
+#ifndef HALO_ACC_U
+#define HALO_ACC_U 4
+#endif
+  constexpr uint32_t kU = HALO_ACC_U;
   uint32_t i = threadIdx.x;
+#ifndef HALO_ACC_NARROW
+  // two records per 16-byte load (the lists start on whole 128-byte lines): configs[1]'s pass 164 -> 137 us; eight or sixteen 8-byte loads in
+  // flight instead of four gave 152 / 149
+  const uint4* src4 = reinterpret_cast<const uint4*>(src);
+  const uint32_t n2 = n / 2u;
+  for (; i + (kU - 1u) * kBinBlock < n2; i += kU * kBinBlock) {
+    uint4 h[kU];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) h[u] = src4[i + u * kBinBlock];
+#pragma unroll
+    for (uint32_t u = 0; u < kU; ++u) {
+      atomicAdd(&acc[h[u].x & mask], fq.fix(__uint_as_float(h[u].y)));
+      atomicAdd(&acc[h[u].z & mask], fq.fix(__uint_as_float(h[u].w)));
+    }
+  }
+  for (uint32_t r = 2u * i; r < n; r += 2u * kBinBlock) {   // what is left of this thread's pairs, and the odd last record
+    for (uint32_t q = r; q < min(r + 2u, n); ++q) {
+      const uint2 h = src[q];
+      atomicAdd(&acc[h.x & mask], fq.fix(__uint_as_float(h.y)));
+    }
+  }
+  i = n;
+#else
   for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
     uint2 h[kU];
 #pragma unroll
@@ -273,6 +299,7 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
 #pragma unroll
     for (uint32_t u = 0; u < kU; ++u) atomicAdd(&acc[h[u].x & mask], fq.fix(__uint_as_float(h[u].y)));
   }
+#endif
   for (; i < n; i += kBinBlock) {
     const uint2 h = src[i];
     atomicAdd(&acc[h.x & mask], fq.fix(__uint_as_float(h.y)));
@@ -348,11 +375,20 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   // time (SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES, profiles/r03_bench4_pmc_lds.txt): a latency chain, not a throughput limit.  One workgroup per
   // CU (96 KB of tiles) is four waves per SIMD, and each record was its own chain: CMF row read from LDS -> wait -> three adds.  So a batch's
   // rows are all requested first, then its adds issued back to back.  (Requesting the next batch's global loads early changes nothing.)
+  // (two records per 16-byte load, as in halo_bin_accumulate_range_kernel: the lists start on whole 128-byte lines, and the order in which
+  // records reach the fixed-point sums changes nothing)
+  const uint4* src4 = reinterpret_cast<const uint4*>(src);
+  const uint32_t n2 = n / 2u;
+  constexpr uint32_t kU2 = kU / 2u;
   uint32_t i = threadIdx.x;
-  for (; i + (kU - 1u) * kBinBlock < n; i += kU * kBinBlock) {
+  for (; i + (kU2 - 1u) * kBinBlock < n2; i += kU2 * kBinBlock) {
     uint2 h[kU];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) h[u] = src[i + u * kBinBlock];
+    for (uint32_t u = 0; u < kU2; ++u) {
+      const uint4 q = src4[i + u * kBinBlock];
+      h[2u * u] = make_uint2(q.x, q.y);
+      h[2u * u + 1u] = make_uint2(q.z, q.w);
+    }
     if constexpr (CH == 3u) {
       float4 c4[kU];
       uint32_t sl[kU];
@@ -374,7 +410,10 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
       for (uint32_t u = 0; u < kU; ++u) add(h[u]);
     }
   }
-  for (; i < n; i += kBinBlock) add(src[i]);
+  for (uint32_t r = 2u * i; r < n; r += 2u * kBinBlock) {   // what is left of this thread's pairs, and the odd last record
+    add(src[r]);
+    if (r + 1u < n) add(src[r + 1u]);
+  }
   __syncthreads();
   for (uint32_t c = 0; c < CH; ++c) {
     float* dst = planes + static_cast<size_t>(c) * plane_stride + (static_cast<size_t>(plane_of_tile) << (s_log2 + 10u));
