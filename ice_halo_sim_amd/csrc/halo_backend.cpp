@@ -372,8 +372,13 @@ void harvest_slot(HaloBackend* b, int k) {
   float ms = 0.0f, ms2 = 0.0f;
   (void)hipEventElapsedTime(&ms, b->ring_ev0[k], b->ring_ev1[k]);
   if (b->ring_posts[k]) (void)hipEventElapsedTime(&ms2, b->ring_ev2[k], b->ring_ev3[k]);   // the passes' own span
-  b->layer_acc.kernel_ms += ms + ms2;
-  if (b->ring_final[k]) {
+  static const bool debug_timing = std::getenv("HALO_DEBUG_TIMING") != nullptr;
+  if (debug_timing) std::fprintf(stderr, "[halo timing] slot %d final %d posts %d trace %.4f ms passes %.4f ms\n", k, int(b->ring_final[k]), int(b->ring_posts[k]), ms, ms2);
+  // An event pair that reads backwards (seen once: two twelve-launch runs of one bench process summed to -10 ms; the rocprofv3 trace of the same
+  // command had every kernel in order) is a measurement that did not happen: it is left out of the timing sums and of their launch count.
+  const bool timed = ms >= 0.0f && ms2 >= 0.0f;
+  if (timed) b->layer_acc.kernel_ms += ms + ms2;
+  if (b->ring_final[k] && timed) {
     b->time_trace_ms += ms;
     b->time_post_ms += ms2;
     b->time_launches += 1;

@@ -1623,6 +1623,57 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
   return face;
 }
 
+// The next pass's pool record, a pass ahead (prism pools under the hit log, round 5).  A pass of a shape-pool kernel used to BEGIN with the staging
+// copy of its record: global loads, s_waitcnt vmcnt(0), LDS writes.  On gfx950 loads and stores share vmcnt and complete in order, so that wait
+// was also a wait for every hit-log store the wave had issued up to the last instruction of the pass before — 19 % of the waves' resident time
+// (tools/phase_probe.py stoch).  Now the record of pass k+1 is requested at the TOP of pass k, when the only stores in flight are a pass old, rides
+// in twelve registers through the generation phase (orientation, sun, entry pick: no vector-memory wait of the compiler's in there) and lands in
+// LDS right before the interaction loop issues this pass's first store: the rows only the entry pick reads (fan corners, normals and areas, 66
+// of the record's 85 sixteen-byte rows) go straight into the half-wave's slot — this pass is done with them — and the 19 rows the interaction
+// loop still reads (header, face and slab rows, face numbers) wait in a 304-byte mirror that the next pass copies over, LDS to LDS.  The loads
+// are asm the compiler does not track: the wait in front of the copy is explicit, and in-order completion means an untracked load can only
+// make the compiler's own vmcnt(N) waits longer, never shorter.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr uint32_t kPrismRows = sizeof(ShapePrism) / 16u;                                    // 85
+constexpr uint32_t kPrismHotLo = (16u + sizeof(ShapePrism::face) + sizeof(ShapePrism::slab)) / 16u;   // rows [0, 17): header, face, slab
+constexpr uint32_t kPrismHotHi = offsetof(ShapePrism, face_number) / 16u;                      // rows [83, 85): face_number, single (the row shares its first bytes with tri_face's tail, dead by then)
+constexpr uint32_t kPrismHotRows = kPrismHotLo + (kPrismRows - kPrismHotHi);                  // 19
+static_assert(offsetof(ShapePrism, tri_v) == kPrismHotLo * 16u && kPrismRows == 85u && kPrismHotHi == 83u && kPrismRows <= 96u, "ShapePrism row map");
+HD bool prism_row_hot(uint32_t row) { return row < kPrismHotLo || row >= kPrismHotHi; }
+HD uint32_t prism_hot_index(uint32_t row) { return row < kPrismHotLo ? row : row - kPrismHotHi + kPrismHotLo; }
+struct NextShape {
+  const f4v* src;   // the next pass's pool record (nullptr: this was the half-wave's last pass)
+  f4v* slot;        // the half-wave's LDS slot, as rows
+  f4v* mirror;      // kPrismHotRows rows
+  uint32_t l32;
+  f4v r0, r1, r2;   // rows l32, l32 + 32, l32 + 64
+  HD void request() {
+    r0 = r1 = r2 = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if (src != nullptr) {
+      const f4v* a = src + l32;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(a) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(r1) : "v"(a) : "memory");
+      if (l32 + 64u < kPrismRows) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(r2) : "v"(a) : "memory");
+    }
+  }
+  HD void put(uint32_t row, const f4v& v) {
+    if (prism_row_hot(row)) mirror[prism_hot_index(row)] = v;
+    else slot[row] = v;
+  }
+  HD void land() {
+    if (src != nullptr) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+      put(l32, r0);
+      slot[l32 + 32u] = r1;   // rows 32..63: fan corners
+      if (l32 + 64u < kPrismRows) put(l32 + 64u, r2);
+    }
+  }
+};
+// the mirror's rows go to their places in the slot: the first thing a pass does (the interaction loop that read the old ones is a pass behind)
+HD void prism_take_mirror(f4v* slot, const f4v* mirror, uint32_t l32) {
+  if (l32 < kPrismHotRows) slot[l32 < kPrismHotLo ? l32 : l32 - kPrismHotLo + kPrismHotHi] = mirror[l32];
+}
+
 struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kernel
   WlEntryDev e;
   float inv_n;
@@ -1630,7 +1681,8 @@ struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kern
 
 template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr) {
+                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextShape* next = nullptr, const WlEntryDev* wl_lds = nullptr) {
+  if (next != nullptr) next->request();
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
   int face;
@@ -1643,7 +1695,12 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 #endif
   Stream gate = make_stream(G.gate_seed, G.gate_lo, G.gate_hi, tid);
 
-  if (G.source == kSrcGen) {
+#ifdef HALO_FORCE_SRC_GEN   // experiment: what the kernel looks like when the ray source is known at compile time
+  const uint32_t source = kSrcGen;
+#else
+  const uint32_t source = G.source;
+#endif
+  if (source == kSrcGen) {
     Stream s = make_stream(G.gen_seed, G.gen_lo, G.gen_hi, tid);
     // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
     Stream wls = s;
@@ -1676,9 +1733,10 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
     else if (G.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
-    w = (G.wl_pool_size == 1u) ? wl0.e.spd_weight : G.wl_pool[wl_idx].spd_weight;
+    if (next != nullptr) w = 0.0f;   // (kernels that fetch their next record ahead read the pool entry once, below, from LDS when they can)
+    else w = (G.wl_pool_size == 1u) ? wl0.e.spd_weight : G.wl_pool[wl_idx].spd_weight;
     PROBE_MARK(pr, kPhEntry);
-  } else if (G.source == kSrcTransit) {
+  } else if (source == kSrcTransit) {
     Stream s = make_stream(G.transit_seed, G.transit_lo, G.transit_hi, tid);
     const uint32_t pos = G.ci_start + tid;
     // Recombine's shuffle, applied as a gather at read time.  The reference permutes single rays (shuffle_cont_kernel
@@ -1729,13 +1787,30 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     w = G.host_w[tid];
     face = static_cast<int>(G.host_tf[tid]);
   }
-  if (face < 0 || face >= face_cnt) return;  // empty crystal / invalid entry face: contributes nothing
+  if (face < 0 || face >= face_cnt) {   // empty crystal / invalid entry face: contributes nothing (its share of the next record's copy still lands)
+    if (next != nullptr) next->land();
+    return;
+  }
 
   // the wavelength pool (<= 8 KB) is read where it lies: a couple of L1-resident reads per ray — staging it cost every workgroup
   // 8 KB of LDS.  The one entry of a discrete session comes in registers (Wl0): a load here would also make the wave wait for
   // every store it has in flight (hit-log records, continuation rays) once per pass
   WlEntryDev wle = wl0.e;   // a one-entry pool (discrete wavelength): read once per kernel, not per pass
   float inv_n = wl0.inv_n;
+  if (next != nullptr) {
+    // A pass of these kernels must not WAIT for a load before its next record has landed (NextShape): the pool of an illuminant session (<= 64
+    // entries) is staged in LDS; a larger one is read where it lies, and the wait for it stays inside this branch (the empty asm is a use).
+    if (P.wl_pool_size != 1u) {
+      if (wl_lds != nullptr) {
+        wle = wl_lds[wl_idx];
+      } else {
+        wle = P.wl_pool[wl_idx];
+        asm volatile("" : "+v"(wle.n_idx), "+v"(wle.spd_weight), "+v"(wle.cmf_x), "+v"(wle.cmf_y), "+v"(wle.cmf_z));
+      }
+      inv_n = 1.0f / wle.n_idx;
+    }
+    if (source == kSrcGen) w = wle.spd_weight;
+  } else
   if (P.wl_pool_size != 1u) {
     wle = P.wl_pool[wl_idx];
     inv_n = 1.0f / wle.n_idx;  // once per ray, IEEE like the reference
@@ -1786,6 +1861,14 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     return o;
   };
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
+  // Shape-pool kernels: the NEXT pass's pool record is touched here — one dword per 128-byte line, a lane each — so that the staging copy at
+  // the top of that pass finds its lines in L2 instead of HBM (the generator wrote the pool a gigabyte ago).  Here and not earlier: every load
+  // this pass still waits for (wavelength entry, corner rows) is behind us, and the interaction loop below only stores — on gfx950 loads and
+  // stores share vmcnt, so a load anywhere else is also a wait for every log record in flight.  The value is never used; the wait behind the loop
+  // keeps the register from being reused under a load in flight (the compiler does not see one in the asm).
+  if (next != nullptr) next->land();   // (before the touch below: its wait would be a wait for that load too)
+  uint32_t prefetched = 0u;
+  if (prefetch != nullptr) asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(prefetch) : "memory");
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
@@ -1943,6 +2026,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     }
     PROBE_MARK(pr, kPhSlab);
   }
+  if (prefetch != nullptr) asm volatile("s_waitcnt vmcnt(0)" : : "v"(prefetched) : "memory");
   if (queued) {   // park the count: the lanes here agree on it, the first of them writes
     const uint64_t m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) == 0u) acc.q->n = sums.qn;
@@ -2004,6 +2088,12 @@ HD float wave_sum(float v) {
 #ifndef HALO_FILTER_SIX
 #define HALO_FILTER_SIX 1   // the logging filter kernels of one regular prism take the small cache and six waves too (round 4: +8 .. +14 %)
 #endif
+#ifndef HALO_POOL_PREFETCH
+#define HALO_POOL_PREFETCH 1   // shape-pool kernels touch the next pass's record before their interaction loop (trace_one)
+#endif
+#ifndef HALO_POOL_DB
+#define HALO_POOL_DB 1   // prism pools under the hit log: the next pass's record requested a pass ahead (NextShape)
+#endif
 #ifndef HALO_POOL_WAVES
 #define HALO_POOL_WAVES 4   // the logging shape-pool kernels
 #endif
@@ -2044,6 +2134,8 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   probe_start(pr);
   const uint64_t t_begin = pr.t0;
 #endif
+  // prism pools under the hit log fetch the next pass's record a pass ahead (NextShape): 304 more bytes per half-wave
+  constexpr bool POOLDB = HALO_POOL_DB && GEOM == kGeomPoolPrism && LOG;
   constexpr bool SMALLC = (BIN && GEOM != kGeomOne && GEOM != kGeomOneHex) || small_cache_hex<MODE, GEOM, MONO, ACC>();
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
@@ -2088,6 +2180,9 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
+  constexpr uint32_t kWlLds = 64u;   // the reference's default illuminant pool (BASELINE configs[4]: 31)
+  __shared__ __attribute__((aligned(16))) WlEntryDev s_wl[POOLDB ? kWlLds : 1u];
+  __shared__ __attribute__((aligned(16))) f4v s_pool_mirror[POOLDB ? (kBlock / 32) * kPrismHotRows : 1];   // ... and the rows of its next one that cannot land in the slot yet (NextShape)
   constexpr bool HEXK = GEOM == kGeomOneHex;
   typedef typename std::conditional<HEXK, ShapeHead, ShapeDev>::type OneShape;   // a regular prism's kernels stage the 464-byte prefix they read (halo_device.h ShapeHead)
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, OneShape, 1> s_shape;  // deterministic: the dispatch's one shape
@@ -2113,6 +2208,11 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   // ---- stage the dispatch-constant tables into LDS ----
   if (P.lat_path == kLatLut)
     for (int i = threadIdx.x; i < 3 * kLutNodes; i += kBlock) T.lut[i] = P.lut[i];
+  if constexpr (POOLDB) {
+    static_assert(sizeof(WlEntryDev) == 32u, "copied as two float4");
+    if (P.wl_pool_size <= kWlLds)
+      for (uint32_t i = threadIdx.x; i < 2u * P.wl_pool_size; i += kBlock) reinterpret_cast<f4v*>(s_wl)[i] = reinterpret_cast<const f4v*>(P.wl_pool)[i];
+  }
   if (P.source == kSrcTransit)
     for (int i = threadIdx.x; i <= kContShards; i += kBlock) T.seg[i] = P.cont_in_seg[i];
   if (threadIdx.x == 0) T.fidx.ok = 0u;
@@ -2175,8 +2275,45 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
     // (header, face_cnt plane rows, tri_cnt fan rows — 1.3 KB for a prism) from the pool into the half-wave's LDS slot
     // with coalesced 16-byte loads, and the interaction loop then reads them as LDS broadcasts exactly like the
     // deterministic path.  LDS operations of one wave retire in order, so no barrier is needed around the copy.
-    PoolSlot* slot = &s_pool.s[threadIdx.x >> 5];
     const uint32_t l32 = threadIdx.x & 31u;
+    if constexpr (POOLDB) {
+      static_assert(std::is_same<PoolRec, ShapePrism>::value && std::is_same<PoolSlot, ShapePrism>::value, "the slot is the record, copied whole");
+      PoolSlot* const slot = &s_pool.s[threadIdx.x >> 5];
+      f4v* const mirror = &s_pool_mirror[(threadIdx.x >> 5) * kPrismHotRows];
+      {
+        const uint32_t first0 = blockIdx.x * kBlock + (threadIdx.x & ~31u);
+        if (first0 < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolRec*>(P.shapes) + first0 / P.geom_clock, l32);   // the first pass's record: the old way
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      }
+      const WlEntryDev* const wl_lds = P.wl_pool_size <= kWlLds ? s_wl : nullptr;
+      bool mirrored = false;   // (half-wave-uniform)
+      for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
+        const uint32_t tid = base + threadIdx.x;
+        const uint32_t first = base + (threadIdx.x & ~31u);
+        if (mirrored) prism_take_mirror(reinterpret_cast<f4v*>(slot), mirror, l32);
+        // (LDS operations of one wave retire in order: all the copies need is that the compiler keeps them in order — NOT a workgroup-scope
+        // fence, which on gfx950 is a wait for every store in flight)
+        asm volatile("" : : : "memory");
+        __builtin_amdgcn_wave_barrier();
+        // (rays of one launch number < 2^28 + a stride: none of these sums wraps)
+        const uint32_t next_first = first + stride;
+        NextShape nx;
+        nx.src = next_first < P.n_rays ? reinterpret_cast<const f4v*>(reinterpret_cast<const PoolRec*>(P.shapes) + next_first / P.geom_clock) : nullptr;
+        nx.slot = reinterpret_cast<f4v*>(slot);
+        nx.mirror = mirror;
+        nx.l32 = l32;
+        mirrored = nx.src != nullptr;
+        const uint32_t* const touch = nullptr;   // (no line-touching here: the record itself is requested a whole generation phase before it is needed)
+        PROBE_MARK(pr, kPhStage);
+        // (a lane without a ray — the launch's last rays — has no next record either: next_first > tid >= n_rays)
+        if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, false>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch, &nx, wl_lds);
+        asm volatile("" : : : "memory");
+        __builtin_amdgcn_wave_barrier();
+        PROBE_MARK(pr, kPhSlab);
+      }
+    } else {
+    PoolSlot* slot = &s_pool.s[threadIdx.x >> 5];
     for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
       const uint32_t tid = base + threadIdx.x;
       const uint32_t first = base + (threadIdx.x & ~31u);
@@ -2185,13 +2322,24 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhStage);
-      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr);
+      // (the lines of the record this half-wave stages in its next pass: lane l touches line l — see trace_one)
+      const uint32_t* touch = nullptr;
+#if HALO_POOL_PREFETCH
+      {
+        const uint32_t next_first = first + stride;   // (a wrap past 2^32 rays per launch cannot happen: launches are chunks of <= 2^28)
+        constexpr uint32_t kLines = (sizeof(PoolRec) + 127u) / 128u;
+        if (next_first < P.n_rays && l32 < kLines)
+          touch = reinterpret_cast<const uint32_t*>(reinterpret_cast<const PoolRec*>(P.shapes) + next_first / P.geom_clock) + l32 * 32u;
+      }
+#endif
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch);
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhSlab);
       if constexpr (BIN) {
         if (++since_flush >= flush_every) flush_every = bin_flush_adaptive(P, s_hits.b, flush_every, since_flush);
       }
       PROBE_MARK(pr, kPhFlush);
+    }
     }
    }
   }
