@@ -231,6 +231,7 @@ struct HaloBackend {
   bool rmw_pending[2] = {false, false};
   int log_tiles_log2 = 7;         // option (experiment knob): the scalar hit-log route cuts a plane into up to 2^this tiles (<= 8)
   int alt_log2 = 25;              // option (experiment knob): launches of up to 2^alt_log2 rays alternate between the two trace streams
+  int pool_entry_fast = 1;        // option (A/B knob): prism pools under the hit log pick a sampled full prism's entry face slab by slab; 0 = the walk over its fan triangles
   int gen_ahead = 0;              // option (experiment knob): 1 queues the generator of a chip-filling launch on trace stream 1, beside the previous launch's kernels
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
   uint32_t cont_stride[2] = {0, 0};
@@ -615,6 +616,7 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   }
   else if (k == "defer_fold") b->defer_fold = v ? 1 : 0;
   else if (k == "gen_ahead") b->gen_ahead = v ? 1 : 0;
+  else if (k == "pool_entry_fast") b->pool_entry_fast = v ? 1 : 0;
   else if (k == "log_tiles_log2") b->log_tiles_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 0), 8));
   else if (k == "alt_log2") b->alt_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 10), 28));
   else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
@@ -1071,6 +1073,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.bin_log = 0u;
     P.log_xyz = 0u;
     P.log_plane_stride = 0u;
+    P.pool_entry_fast = b->pool_entry_fast ? 1u : 0u;
     P.bin_shift = 0u;
     P.tally = b->tally.ptr;
     P.exits = b->exits.ptr;

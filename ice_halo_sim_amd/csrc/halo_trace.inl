@@ -1548,8 +1548,9 @@ HD int sample_entry_by_face(Stream& s, ShapePtr sh, const FaceIndex& fi, int fac
 // and the seven candidate weights (face 0 or 1, then sides 2, 3, 4, then their opposites 5, 6, 7 — face order) are walked without
 // a branch.  Weights, partial sums and the uniform are those of sample_entry_by_face: the unlit face of a slab contributes an
 // exact zero there.
-template <typename ShapePtr>
-HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tri_cnt, const float* d, float* p) {
+// EF: EntryFastDev (one shape per dispatch, host-built) or SlotFast (a sampled prism's, rebuilt by its half-wave every pass — below)
+template <typename ShapePtr, typename EF>
+HD int sample_entry_prism(Stream& s, ShapePtr sh, const EF& ef, int tri_cnt, const float* d, float* p) {
   const float u_cat = uniform(s);
   float dn[4], ap[4], am[4];
 #pragma unroll
@@ -1615,12 +1616,72 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EntryFastDev& ef, int tr
     u = 1.0f - u;
     v = 1.0f - v;
   }
-  const float4* vt = reinterpret_cast<const float4*>(ef.tri_v[tri]);
-  const float4 q0 = vt[0], q1 = vt[1], q2 = vt[2];   // a = q0.xyz, b = (q0.w, q1.x, q1.y), c = (q1.z, q1.w, q2.x)
-  p[0] = tri_point(u, v, q0.x, q0.w, q1.z);
-  p[1] = tri_point(u, v, q0.y, q1.x, q1.w);
-  p[2] = tri_point(u, v, q0.z, q1.y, q2.x);
+  if constexpr (std::is_same<EF, EntryFastDev>::value) {
+    const float4* vt = reinterpret_cast<const float4*>(ef.tri_v[tri]);
+    const float4 q0 = vt[0], q1 = vt[1], q2 = vt[2];   // a = q0.xyz, b = (q0.w, q1.x, q1.y), c = (q1.z, q1.w, q2.x)
+    p[0] = tri_point(u, v, q0.x, q0.w, q1.z);
+    p[1] = tri_point(u, v, q0.y, q1.x, q1.w);
+    p[2] = tri_point(u, v, q0.z, q1.y, q2.x);
+  } else {   // the slot's own 36-byte corner rows
+    const float* vt = sh->tri_v[tri];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = tri_point(u, v, vt[k], vt[3 + k], vt[6 + k]);
+  }
   return face;
+}
+
+// The entry pick's view of a sampled FULL prism, per half-wave: EntryFastDev's first three tables (BuildEntryFast, halo_host.cpp), rebuilt from
+// the slot's fan table at the top of every pass by the half-wave itself — ~100 wave instructions against the ~300 the walk over all 20 fan
+// triangles (two passes, an LDS row each) costs every ray more than the slab-wise pick.  ok = 0 (a prism that lost a face to its neighbours'
+// distances, a fan the pick cannot index): the half-wave's rays take the walk over triangles as before.
+struct SlotFast {
+  float tri_area[kEntryFastFaces][4];
+  uint32_t tri0n[kEntryFastFaces];
+  float slab_area[4][2];
+  uint32_t ok, pad[3];
+};
+static_assert(sizeof(SlotFast) % 16 == 0, "rows are read as float4 / float2");
+// all 32 lanes of the half-wave call this together, after the slot's rows are in place
+HD void build_slot_fast(SlotFast* sf, const ShapePrism* sh, uint32_t l32) {
+  const int tc = sh->tri_cnt;
+  bool ok = sh->face_cnt == kEntryFastFaces && sh->slab_cnt == 4 && sh->single_cnt == 0 && tc >= 8 && tc <= kEntryFastTris;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {   // slabs (0,1), (2,5), (3,6), (4,7): what the pick's candidate order assumes
+    const int ip = __float_as_int(sh->slab[k][5]), im = __float_as_int(sh->slab[k][6]);
+    ok = ok && ip == (k == 0 ? 0 : k + 1) && im == (k == 0 ? 1 : k + 4);
+  }
+  const uint32_t tf = (ok && static_cast<int>(l32) < tc) ? sh->tri_face[l32] : 0xFFu;   // lane t holds triangle t's face
+  const uint32_t half_shift = threadIdx.x & 32u;
+  uint32_t next = 0u, my_t0 = 0u, my_tn = 0u;
+#pragma unroll
+  for (uint32_t f = 0; f < static_cast<uint32_t>(kEntryFastFaces); f++) {   // triangles grouped face by face, in face order, 1..4 per face
+    const uint32_t m = static_cast<uint32_t>(__ballot(tf == f) >> half_shift);
+    const uint32_t tn = static_cast<uint32_t>(__popc(m));
+    ok = ok && tn >= 1u && tn <= 4u && m == (((1u << tn) - 1u) << next);
+    if (l32 == f) {
+      my_t0 = next;
+      my_tn = tn;
+    }
+    next += tn;
+  }
+  ok = ok && next == static_cast<uint32_t>(tc);
+  float area = 0.0f;
+  if (ok && l32 < static_cast<uint32_t>(kEntryFastFaces)) {
+    float a[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      a[k] = k < my_tn ? sh->tri_na[my_t0 + k][3] : 0.0f;
+      area += a[k];   // (the host's partial sums in the same order; the padding adds exact zeros)
+    }
+    *reinterpret_cast<float4*>(sf->tri_area[l32]) = make_float4(a[0], a[1], a[2], a[3]);
+    sf->tri0n[l32] = my_t0 | (my_tn << 8);
+  }
+  // slab k's areas: {its +n face, its -n face}
+  const uint32_t kk = l32 & 3u;
+  const int base = static_cast<int>(threadIdx.x & 32u);
+  const float ap = __shfl(area, base | static_cast<int>(kk == 0u ? 0u : kk + 1u)), am = __shfl(area, base | static_cast<int>(kk == 0u ? 1u : kk + 4u));
+  if (ok && l32 < 4u) *reinterpret_cast<float2v*>(sf->slab_area[l32]) = float2v{ap, am};
+  if (l32 == 0u) sf->ok = ok ? 1u : 0u;
 }
 
 // The next pass's pool record, a pass ahead (prism pools under the hit log, round 5).  A pass of a shape-pool kernel used to BEGIN with the staging
@@ -1674,6 +1735,17 @@ HD void prism_take_mirror(f4v* slot, const f4v* mirror, uint32_t l32) {
   if (l32 < kPrismHotRows) slot[l32 < kPrismHotLo ? l32 : l32 - kPrismHotLo + kPrismHotHi] = mirror[l32];
 }
 
+// "This load has arrived": an empty asm that uses the value, right behind the load.  A load the compiler may still count as pending when a pass
+// ends (the pass's early exits skip the code that would have waited for it) makes it open EVERY pass of the ray loop with s_waitcnt vmcnt(0) —
+// on gfx950, where loads and stores share that counter, a wait for every hit-log and continuation STORE the wave has in flight, although at run
+// time no load is pending there.  With the wait pinned inside the branch that issued the load the top of the loop has nothing to wait for.
+// Used by the kernels that fetch their next pool record ahead (`pinned` = their NextShape is there), which must not wait before it has landed:
+// configs[4]'s trace kernel 2.40 -> 2.34 ms.  NOT by the others: measured on the one-shape kernels, the loop without that wait is SLOWER
+// (configs[1] 1.77 -> 1.85 ms per launch, configs[2] 9.15 -> 9.57) — the wait per pass meters the waves' stores; without it they queue up behind
+// the memory pipeline inside the interaction loop, where a stall costs more (tools/phase_probe.py cfg1 puts 38 % of the resident time in it, yet
+// the kernel is VALU-issue-bound: the other waves use the slots).
+#define HALO_ARRIVED(pinned, x) do { if (pinned) asm volatile("" : "+v"(x)); } while (0)
+
 struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kernel
   WlEntryDev e;
   float inv_n;
@@ -1681,7 +1753,9 @@ struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kern
 
 template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextShape* next = nullptr, const WlEntryDev* wl_lds = nullptr) {
+                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextShape* next = nullptr, const WlEntryDev* wl_lds = nullptr,
+                  const SlotFast* slot_fast = nullptr) {
+  const bool pinned = next != nullptr;   // (a compile-time constant after inlining: see HALO_ARRIVED)
   if (next != nullptr) next->request();
   uint64_t carried = 0ull;  // raypath-colour mask inherited from the previous scattering layers
   float R[9], d[3], p[3], w;
@@ -1731,6 +1805,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
     if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
+    else if (slot_fast != nullptr) face = slot_fast->ok ? sample_entry_prism(s, sh, *slot_fast, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     else if (G.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     if (next != nullptr) w = 0.0f;   // (kernels that fetch their next record ahead read the pool entry once, below, from LDS when they can)
@@ -1761,9 +1836,17 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     float dwx = G.cont_in[src], dwy = G.cont_in[st + src], dwz = G.cont_in[2u * st + src];
     w = G.cont_in[3u * st + src];
     wl_idx = reinterpret_cast<const uint32_t*>(G.cont_in)[4u * st + src];
-    if (MODE == kModeColor || (ModeTraits<MODE>::kTables && color != nullptr))
-      carried = static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(G.cont_in)[5u * st + src]) |
-                (static_cast<uint64_t>(reinterpret_cast<const uint32_t*>(G.cont_in)[6u * st + src]) << 32);
+    if (MODE == kModeColor || (ModeTraits<MODE>::kTables && color != nullptr)) {
+      uint32_t c_lo = reinterpret_cast<const uint32_t*>(G.cont_in)[5u * st + src], c_hi = reinterpret_cast<const uint32_t*>(G.cont_in)[6u * st + src];
+      HALO_ARRIVED(pinned, c_lo);
+      HALO_ARRIVED(pinned, c_hi);
+      carried = static_cast<uint64_t>(c_lo) | (static_cast<uint64_t>(c_hi) << 32);
+    }
+    HALO_ARRIVED(pinned, dwx);
+    HALO_ARRIVED(pinned, dwy);
+    HALO_ARRIVED(pinned, dwz);
+    HALO_ARRIVED(pinned, w);
+    HALO_ARRIVED(pinned, wl_idx);
     float lon, lat, roll;
     PROBE_MARK(pr, kPhStream);
     sample_lat_lon_roll(s, G, T.lut, lon, lat, roll);
@@ -1773,6 +1856,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     apply_inverse(R, dwx, dwy, dwz, d);
     PROBE_MARK(pr, kPhSun);
     if constexpr (HEX) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);   // a regular prism always comes with its EntryFastDev (halo_backend.cpp)
+    else if (slot_fast != nullptr) face = slot_fast->ok ? sample_entry_prism(s, sh, *slot_fast, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     else if (G.entry_fast != nullptr) face = sample_entry_prism(s, sh, T.efast, sh->tri_cnt, d, p);
     else face = T.fidx.ok ? sample_entry_by_face(s, sh, T.fidx, face_cnt, sh->tri_cnt, d, p) : sample_entry(s, sh, sh->tri_cnt, d, p);
     PROBE_MARK(pr, kPhEntry);
@@ -1786,6 +1870,13 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     }
     w = G.host_w[tid];
     face = static_cast<int>(G.host_tf[tid]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      HALO_ARRIVED(pinned, d[k]);
+      HALO_ARRIVED(pinned, p[k]);
+    }
+    HALO_ARRIVED(pinned, w);
+    HALO_ARRIVED(pinned, face);
   }
   if (face < 0 || face >= face_cnt) {   // empty crystal / invalid entry face: contributes nothing (its share of the next record's copy still lands)
     if (next != nullptr) next->land();
@@ -2180,6 +2271,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
+  __shared__ __attribute__((aligned(16))) SlotFast s_slot_fast[POOLDB ? kBlock / 32 : 1];
   constexpr uint32_t kWlLds = 64u;   // the reference's default illuminant pool (BASELINE configs[4]: 31)
   __shared__ __attribute__((aligned(16))) WlEntryDev s_wl[POOLDB ? kWlLds : 1u];
   __shared__ __attribute__((aligned(16))) f4v s_pool_mirror[POOLDB ? (kBlock / 32) * kPrismHotRows : 1];   // ... and the rows of its next one that cannot land in the slot yet (NextShape)
@@ -2292,6 +2384,13 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
         const uint32_t tid = base + threadIdx.x;
         const uint32_t first = base + (threadIdx.x & ~31u);
         if (mirrored) prism_take_mirror(reinterpret_cast<f4v*>(slot), mirror, l32);
+        asm volatile("" : : : "memory");
+        __builtin_amdgcn_wave_barrier();
+        SlotFast* const sfast = &s_slot_fast[threadIdx.x >> 5];
+        if (first < P.n_rays) {
+          if (P.pool_entry_fast != 0u) build_slot_fast(sfast, slot, l32);
+          else if (l32 == 0u) sfast->ok = 0u;
+        }
         // (LDS operations of one wave retire in order: all the copies need is that the compiler keeps them in order — NOT a workgroup-scope
         // fence, which on gfx950 is a wait for every store in flight)
         asm volatile("" : : : "memory");
@@ -2307,7 +2406,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
         const uint32_t* const touch = nullptr;   // (no line-touching here: the record itself is requested a whole generation phase before it is needed)
         PROBE_MARK(pr, kPhStage);
         // (a lane without a ray — the launch's last rays — has no next record either: next_first > tid >= n_rays)
-        if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, false>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch, &nx, wl_lds);
+        if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, false>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch, &nx, wl_lds, sfast);
         asm volatile("" : : : "memory");
         __builtin_amdgcn_wave_barrier();
         PROBE_MARK(pr, kPhSlab);

@@ -89,6 +89,40 @@ def test_bench_config_stoch_shape_runs_the_prism_pool_production_kernels(pool, r
     print("bench_config_stoch pool %d %s: block-mean rel L2 %.2e, exits/root %.3f" % (pool, route, err, st[0].exit_count / n))
 
 
+@pytest.mark.parametrize("std", [0.15, 0.6])
+def test_sampled_prisms_pick_their_entry_face_slab_by_slab_like_the_walk_over_triangles(std):
+    """Logged launches over sampled prisms (halo_trace_kernel<0,2,.,kAccLog>): every half-wave rebuilds the slab-wise entry pick's tables
+    (halo_trace.inl SlotFast) from its crystal's fan table, takes the next crystal's record a pass ahead (NextShape) and reads the
+    illuminant pool from LDS.  Option pool_entry_fast = 0 walks the fan triangles as before — same uniform, same cumulative order of the
+    faces, so the same entry face and point for (all but a rounding's worth of) the rays; 40 passes per workgroup, so every half-wave mostly traces
+    crystals whose records came through the mirror.
+    std 0.15: bench_config_stoch.json's face distances, every prism full.  std 0.6: two thirds of the prisms lose one or more side faces to their
+    neighbours (7, 6, 5 faces, some none at all: their half-waves keep the walk over triangles, the others pick slab by slab in the same launch).
+    Both against the oracle as well."""
+    g = {"type": "gauss", "mean": 1.0, "std": std}
+    e = scenes.entry(scenes.prism_crystal(1.0, [g] * 6), scenes.axis(zenith=FULL, azimuth=FULL, roll=FULL), 100.0, 1)
+    sc = scenes.scene([(0.0, [e])], max_hits=8)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)   # (above 512 Ki pixels: the X/Y/Z hit log)
+    wl = scenes.wl_illuminant("D65", 31)
+    n = 5 << 20
+    out = {}
+    for fast in (1, 0):
+        hb = hip_backend(seed=91, pool_entry_fast=fast, blocks_per_cu=2)
+        st = run_session(hb, sc, rd, wl, n)
+        r = hb.last_route()
+        assert (r.mode_mask, r.geom_mask, r.accum_mask) == (1, 1 << 2, abi.ACCUM_LOG_XYZ), (r.mode_mask, r.geom_mask, r.accum_mask)
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[fast] = (img, landed, st[0].exit_count, st[0].pixel_hits)
+    (i1, l1, e1, h1), (i0, l0, e0, h0) = out[1], out[0]
+    assert abs(e1 - e0) <= 2e-6 * e0 and abs(h1 - h0) <= 2e-6 * h0, (e1, e0, h1, h0)
+    assert l1 == pytest.approx(l0, rel=2e-6)
+    assert rel_l2(block_mean(i1), block_mean(i0)) <= 1e-4
+    img_o, landed_o, st_o = _oracle_image(sc, rd, wl, n, 91)
+    assert out[1][2] == pytest.approx(st_o[0].exit_count, rel=1e-4)
+    _check_single_layer((i1, l1), (img_o, landed_o))
+
+
 @pytest.mark.parametrize("case", ["prism_discrete", "prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65", "pyramid_d65_planes"])
 def test_stochastic_pool_production_kernels_vs_oracle(case):
     """The other production shape-pool instantiations at sizes where they are what the backend picks:
