@@ -1729,11 +1729,80 @@ struct NextShape {
       if (l32 + 64u < kPrismRows) put(l32 + 64u, r2);
     }
   }
+  HD void late() {}   // (nothing of a prism's record waits in registers)
+  static constexpr uint32_t kMirrorRows = kPrismHotRows;
+  // the mirror's rows go to their places in the slot: the first thing a pass does (the interaction loop that read the old ones is a pass behind)
+  HD static void take_mirror(f4v* slot, const f4v* mirror, uint32_t l32) {
+    if (l32 < kPrismHotRows) slot[l32 < kPrismHotLo ? l32 : l32 - kPrismHotLo + kPrismHotHi] = mirror[l32];
+  }
 };
-// the mirror's rows go to their places in the slot: the first thing a pass does (the interaction loop that read the old ones is a pass behind)
-HD void prism_take_mirror(f4v* slot, const f4v* mirror, uint32_t l32) {
-  if (l32 < kPrismHotRows) slot[l32 < kPrismHotLo ? l32 : l32 - kPrismHotLo + kPrismHotHi] = mirror[l32];
+// The same for a general pool shape: record ShapeDev (4 KB), slot ShapeSlot48 (96 rows = three per lane; the corner rows stay in the record).
+// Slot row -> record bytes: rows 0..40 (header, face, slab) lie where they lie in the record; row 41 is the slot's pointer to the record's corner
+// rows; 42..89 = tri_na[0..47]; 90..92 = tri_face[0..47]; 93..95 = face_number | single | pad (contiguous in the record too).  The interaction
+// loop reads rows 0..40 and 93..95.  Rows 0..31 — each lane's first — stay in four registers through the loop and go to the slot BEHIND it
+// (late()); rows 32..40 and 93..95 wait in a 192-byte mirror; everything else lands before the loop like a prism's rows.
+constexpr uint32_t kSlot48Rows = sizeof(ShapeSlot48) / 16u, kSlot48PtrRow = offsetof(ShapeSlot48, tri_v) / 16u, kSlot48NaRow = offsetof(ShapeSlot48, tri_na) / 16u,
+                   kSlot48FaceRow = offsetof(ShapeSlot48, tri_face) / 16u, kSlot48NumRow = offsetof(ShapeSlot48, face_number) / 16u;
+constexpr uint32_t kSlot48MirrorRows = (kSlot48PtrRow - 32u) + (kSlot48Rows - kSlot48NumRow);   // 9 + 3
+static_assert(kSlot48Rows == 96u && kSlot48PtrRow == 41u && kSlot48NaRow == 42u && kSlot48FaceRow == 90u && kSlot48NumRow == 93u, "ShapeSlot48 row map");
+static_assert(offsetof(ShapeDev, tri_v) == kSlot48PtrRow * 16u && offsetof(ShapeDev, tri_na) % 16u == 0 && offsetof(ShapeDev, tri_face) % 16u == 0 &&
+              offsetof(ShapeDev, face_number) % 16u == 0 && offsetof(ShapeDev, single) == offsetof(ShapeDev, face_number) + kMaxFaces &&
+              offsetof(ShapeSlot48, single) == offsetof(ShapeSlot48, face_number) + kMaxFaces, "ShapeDev rows the slot takes");
+HD uint32_t slot48_record_offset(uint32_t row) {   // (row != kSlot48PtrRow)
+  return row < kSlot48PtrRow ? row * 16u
+         : row < kSlot48FaceRow ? static_cast<uint32_t>(offsetof(ShapeDev, tri_na)) + (row - kSlot48NaRow) * 16u
+         : row < kSlot48NumRow ? static_cast<uint32_t>(offsetof(ShapeDev, tri_face)) + (row - kSlot48FaceRow) * 16u
+                               : static_cast<uint32_t>(offsetof(ShapeDev, face_number)) + (row - kSlot48NumRow) * 16u;
 }
+struct NextShape48 {
+  const f4v* src;   // the next pass's pool record (nullptr: this was the half-wave's last pass)
+  f4v* slot;
+  f4v* mirror;      // kSlot48MirrorRows rows
+  uint32_t l32;
+  f4v r0, r1, r2;   // slot rows l32, l32 + 32, l32 + 64
+  static constexpr uint32_t kMirrorRows = kSlot48MirrorRows;
+  HD void request() {
+    r0 = r1 = r2 = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if (src != nullptr) {
+      const char* base = reinterpret_cast<const char*>(src);
+      const char* a0 = base + l32 * 16u;
+      const char* a1 = base + slot48_record_offset(l32 + 32u == kSlot48PtrRow ? 0u : l32 + 32u);   // (the pointer row's lane loads row 0 again and drops it)
+      const char* a2 = base + slot48_record_offset(l32 + 64u);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(a0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r1) : "v"(a1) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r2) : "v"(a2) : "memory");
+    }
+  }
+  HD void land() {   // before the interaction loop
+    if (src != nullptr) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
+      if (l32 == 0u) {   // the header: counts clamped to the slot's capacity, as stage_shape does
+        int32_t* h = reinterpret_cast<int32_t*>(&r0);
+        h[0] = min(h[0], kMaxFaces);
+        h[1] = min(h[1], 48);
+        h[2] = min(h[2], kMaxSlabs);
+        h[3] = min(h[3], kMaxFaces);
+      }
+      const uint32_t row1 = l32 + 32u, row2 = l32 + 64u;
+      if (row1 < kSlot48PtrRow) mirror[row1 - 32u] = r1;
+      else if (row1 == kSlot48PtrRow) {
+        const uint64_t pv = reinterpret_cast<uint64_t>(reinterpret_cast<const char*>(src) + offsetof(ShapeDev, tri_v));
+        reinterpret_cast<uint64_t*>(slot + kSlot48PtrRow)[0] = pv;
+      } else slot[row1] = r1;
+      if (row2 >= kSlot48NumRow) mirror[(kSlot48PtrRow - 32u) + (row2 - kSlot48NumRow)] = r2;
+      else slot[row2] = r2;
+    }
+  }
+  HD void late() {   // behind the interaction loop: rows 0..31
+    if (src != nullptr) {
+      asm volatile("" : "+v"(r0));
+      slot[l32] = r0;
+    }
+  }
+  HD static void take_mirror(f4v* slot, const f4v* mirror, uint32_t l32) {
+    if (l32 < kSlot48MirrorRows) slot[l32 < kSlot48PtrRow - 32u ? 32u + l32 : kSlot48NumRow + (l32 - (kSlot48PtrRow - 32u))] = mirror[l32];
+  }
+};
 
 // "This load has arrived": an empty asm that uses the value, right behind the load.  A load the compiler may still count as pending when a pass
 // ends (the pass's early exits skip the code that would have waited for it) makes it open EVERY pass of the ray loop with s_waitcnt vmcnt(0) —
@@ -1751,9 +1820,9 @@ struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kern
   float inv_n;
 };
 
-template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr>
+template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr, typename NextT = NextShape>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextShape* next = nullptr, const WlEntryDev* wl_lds = nullptr,
+                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextT* next = nullptr, const WlEntryDev* wl_lds = nullptr,
                   const SlotFast* slot_fast = nullptr) {
   const bool pinned = next != nullptr;   // (a compile-time constant after inlining: see HALO_ARRIVED)
   if (next != nullptr) next->request();
@@ -1879,7 +1948,10 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     HALO_ARRIVED(pinned, face);
   }
   if (face < 0 || face >= face_cnt) {   // empty crystal / invalid entry face: contributes nothing (its share of the next record's copy still lands)
-    if (next != nullptr) next->land();
+    if (next != nullptr) {
+      next->land();
+      next->late();
+    }
     return;
   }
 
@@ -2118,6 +2190,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     PROBE_MARK(pr, kPhSlab);
   }
   if (prefetch != nullptr) asm volatile("s_waitcnt vmcnt(0)" : : "v"(prefetched) : "memory");
+  if (next != nullptr) next->late();
   if (queued) {   // park the count: the lanes here agree on it, the first of them writes
     const uint64_t m = __ballot(1);
     if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) == 0u) acc.q->n = sums.qn;
@@ -2182,6 +2255,9 @@ HD float wave_sum(float v) {
 #ifndef HALO_POOL_PREFETCH
 #define HALO_POOL_PREFETCH 1   // shape-pool kernels touch the next pass's record before their interaction loop (trace_one)
 #endif
+#ifndef HALO_POOL_DB48
+#define HALO_POOL_DB48 1   // ... general pool shapes (pyramids) too (NextShape48)
+#endif
 #ifndef HALO_POOL_DB
 #define HALO_POOL_DB 1   // prism pools under the hit log: the next pass's record requested a pass ahead (NextShape)
 #endif
@@ -2226,7 +2302,8 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   const uint64_t t_begin = pr.t0;
 #endif
   // prism pools under the hit log fetch the next pass's record a pass ahead (NextShape): 304 more bytes per half-wave
-  constexpr bool POOLDB = HALO_POOL_DB && GEOM == kGeomPoolPrism && LOG;
+  constexpr bool POOLDB = HALO_POOL_DB && (GEOM == kGeomPoolPrism || (HALO_POOL_DB48 && GEOM == kGeomPool)) && LOG;
+  typedef typename std::conditional<GEOM == kGeomPoolPrism, NextShape, NextShape48>::type NextT;
   constexpr bool SMALLC = (BIN && GEOM != kGeomOne && GEOM != kGeomOneHex) || small_cache_hex<MODE, GEOM, MONO, ACC>();
   __shared__ __attribute__((aligned(16))) LdsTables<MONO, SMALLC> T;
   __shared__ __attribute__((aligned(16))) HitSlot<BIN> s_hits;
@@ -2271,10 +2348,10 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   typedef typename PoolSlotType<GEOM>::type PoolSlot;
   typedef typename PoolSlotType<GEOM>::rec PoolRec;
   __shared__ __attribute__((aligned(16))) PoolSlots<POOL, PoolSlot> s_pool;       // stochastic: one shape per half-wave
-  __shared__ __attribute__((aligned(16))) SlotFast s_slot_fast[POOLDB ? kBlock / 32 : 1];
+  __shared__ __attribute__((aligned(16))) SlotFast s_slot_fast[(POOLDB && GEOM == kGeomPoolPrism) ? kBlock / 32 : 1];
   constexpr uint32_t kWlLds = 64u;   // the reference's default illuminant pool (BASELINE configs[4]: 31)
   __shared__ __attribute__((aligned(16))) WlEntryDev s_wl[POOLDB ? kWlLds : 1u];
-  __shared__ __attribute__((aligned(16))) f4v s_pool_mirror[POOLDB ? (kBlock / 32) * kPrismHotRows : 1];   // ... and the rows of its next one that cannot land in the slot yet (NextShape)
+  __shared__ __attribute__((aligned(16))) f4v s_pool_mirror[POOLDB ? (kBlock / 32) * NextT::kMirrorRows : 1];   // ... and the rows of its next one that cannot land in the slot yet (NextShape)
   constexpr bool HEXK = GEOM == kGeomOneHex;
   typedef typename std::conditional<HEXK, ShapeHead, ShapeDev>::type OneShape;   // a regular prism's kernels stage the 464-byte prefix they read (halo_device.h ShapeHead)
   __shared__ __attribute__((aligned(16))) PoolSlots<!POOL, OneShape, 1> s_shape;  // deterministic: the dispatch's one shape
@@ -2369,9 +2446,11 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
     // deterministic path.  LDS operations of one wave retire in order, so no barrier is needed around the copy.
     const uint32_t l32 = threadIdx.x & 31u;
     if constexpr (POOLDB) {
-      static_assert(std::is_same<PoolRec, ShapePrism>::value && std::is_same<PoolSlot, ShapePrism>::value, "the slot is the record, copied whole");
+      constexpr bool PRISM = GEOM == kGeomPoolPrism;
+      static_assert(!PRISM || (std::is_same<PoolRec, ShapePrism>::value && std::is_same<PoolSlot, ShapePrism>::value), "a prism's slot is its record, copied whole");
+      static_assert(PRISM || (std::is_same<PoolRec, ShapeDev>::value && std::is_same<PoolSlot, ShapeSlot48>::value), "NextShape48 maps ShapeDev onto ShapeSlot48");
       PoolSlot* const slot = &s_pool.s[threadIdx.x >> 5];
-      f4v* const mirror = &s_pool_mirror[(threadIdx.x >> 5) * kPrismHotRows];
+      f4v* const mirror = &s_pool_mirror[(threadIdx.x >> 5) * NextT::kMirrorRows];
       {
         const uint32_t first0 = blockIdx.x * kBlock + (threadIdx.x & ~31u);
         if (first0 < P.n_rays) stage_shape(slot, reinterpret_cast<const PoolRec*>(P.shapes) + first0 / P.geom_clock, l32);   // the first pass's record: the old way
@@ -2383,13 +2462,16 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
       for (uint32_t base = blockIdx.x * kBlock; base < P.n_rays; base += stride) {
         const uint32_t tid = base + threadIdx.x;
         const uint32_t first = base + (threadIdx.x & ~31u);
-        if (mirrored) prism_take_mirror(reinterpret_cast<f4v*>(slot), mirror, l32);
+        if (mirrored) NextT::take_mirror(reinterpret_cast<f4v*>(slot), mirror, l32);
         asm volatile("" : : : "memory");
         __builtin_amdgcn_wave_barrier();
-        SlotFast* const sfast = &s_slot_fast[threadIdx.x >> 5];
-        if (first < P.n_rays) {
-          if (P.pool_entry_fast != 0u) build_slot_fast(sfast, slot, l32);
-          else if (l32 == 0u) sfast->ok = 0u;
+        SlotFast* sfast = nullptr;
+        if constexpr (PRISM) {
+          sfast = &s_slot_fast[threadIdx.x >> 5];
+          if (first < P.n_rays) {
+            if (P.pool_entry_fast != 0u) build_slot_fast(sfast, slot, l32);
+            else if (l32 == 0u) sfast->ok = 0u;
+          }
         }
         // (LDS operations of one wave retire in order: all the copies need is that the compiler keeps them in order — NOT a workgroup-scope
         // fence, which on gfx950 is a wait for every store in flight)
@@ -2397,7 +2479,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
         __builtin_amdgcn_wave_barrier();
         // (rays of one launch number < 2^28 + a stride: none of these sums wraps)
         const uint32_t next_first = first + stride;
-        NextShape nx;
+        NextT nx;
         nx.src = next_first < P.n_rays ? reinterpret_cast<const f4v*>(reinterpret_cast<const PoolRec*>(P.shapes) + next_first / P.geom_clock) : nullptr;
         nx.slot = reinterpret_cast<f4v*>(slot);
         nx.mirror = mirror;

@@ -51,6 +51,12 @@ if "cfg1" in which:
     run("configs[1] 550 nm", scenes.config2_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 20_000_000)
 if "ms" in which:
     run("configs[2] 550 nm (both layers)", scenes.config3_scene(), scenes.config2_render(), scenes.wl_discrete(550.0), 10_000_000)
+if "stochp" in which:   # the pyramid variant (bench.py --config 4p)
+    g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    e = scenes.entry(scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6), scenes.axis(zenith=full, azimuth=full, roll=full), 100.0, 5)
+    run("stochastic pyramid D65/31", scenes.scene([(0.0, [e])], max_hits=8),
+        scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL), scenes.wl_illuminant("D65", 31), 20_000_000)
 if "stoch" in which:
     run("bench_config_stoch D65/31", scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8),
         scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL), scenes.wl_illuminant("D65", 31), 20_000_000)
