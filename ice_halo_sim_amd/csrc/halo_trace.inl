@@ -1692,8 +1692,10 @@ HD void build_slot_fast(SlotFast* sf, const ShapePrism* sh, uint32_t l32) {
 // LDS right before the interaction loop issues this pass's first store: the rows only the entry pick reads (fan corners, normals and areas, 66
 // of the record's 85 sixteen-byte rows) go straight into the half-wave's slot — this pass is done with them — and the 19 rows the interaction
 // loop still reads (header, face and slab rows, face numbers) wait in a 304-byte mirror that the next pass copies over, LDS to LDS.  The loads
-// are asm the compiler does not track: the wait in front of the copy is explicit, and in-order completion means an untracked load can only
-// make the compiler's own vmcnt(N) waits longer, never shorter.
+// are ordinary loads (the compiler waits for them where land() uses them — and before any copy of the registers it might decide to make;
+// hand-written asm loads with an explicit s_waitcnt measured the same and would not have that guarantee).  What makes it work is the ORDER of a
+// pass: nothing between request() and land() waits on a vector-memory load — the pool entry comes from LDS, loads of other ray sources are
+// waited for where they are issued (HALO_ARRIVED).
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr uint32_t kPrismRows = sizeof(ShapePrism) / 16u;                                    // 85
 constexpr uint32_t kPrismHotLo = (16u + sizeof(ShapePrism::face) + sizeof(ShapePrism::slab)) / 16u;   // rows [0, 17): header, face, slab
@@ -1712,9 +1714,9 @@ struct NextShape {
     r0 = r1 = r2 = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     if (src != nullptr) {
       const f4v* a = src + l32;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(a) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(r1) : "v"(a) : "memory");
-      if (l32 + 64u < kPrismRows) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(r2) : "v"(a) : "memory");
+      r0 = a[0];
+      r1 = a[32];
+      if (l32 + 64u < kPrismRows) r2 = a[64];
     }
   }
   HD void put(uint32_t row, const f4v& v) {
@@ -1723,7 +1725,6 @@ struct NextShape {
   }
   HD void land() {
     if (src != nullptr) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
       put(l32, r0);
       slot[l32 + 32u] = r1;   // rows 32..63: fan corners
       if (l32 + 64u < kPrismRows) put(l32 + 64u, r2);
@@ -1768,14 +1769,13 @@ struct NextShape48 {
       const char* a0 = base + l32 * 16u;
       const char* a1 = base + slot48_record_offset(l32 + 32u == kSlot48PtrRow ? 0u : l32 + 32u);   // (the pointer row's lane loads row 0 again and drops it)
       const char* a2 = base + slot48_record_offset(l32 + 64u);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r0) : "v"(a0) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r1) : "v"(a1) : "memory");
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r2) : "v"(a2) : "memory");
+      r0 = *reinterpret_cast<const f4v*>(a0);
+      r1 = *reinterpret_cast<const f4v*>(a1);
+      r2 = *reinterpret_cast<const f4v*>(a2);
     }
   }
   HD void land() {   // before the interaction loop
     if (src != nullptr) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) : : "memory");
       if (l32 == 0u) {   // the header: counts clamped to the slot's capacity, as stage_shape does
         int32_t* h = reinterpret_cast<int32_t*>(&r0);
         h[0] = min(h[0], kMaxFaces);
@@ -1822,7 +1822,7 @@ struct Wl0 {   // entry 0 of the wavelength pool and 1 / n, loaded once per kern
 
 template <int MODE, bool MONO, bool SMALLC, bool HEX, typename ShapePtr, typename NextT = NextShape>
 HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const AccCtx<MONO, SMALLC>& acc, const FilterDev* filter, const ColorDev* color, ShapePtr sh,
-                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, const uint32_t* prefetch = nullptr, NextT* next = nullptr, const WlEntryDev* wl_lds = nullptr,
+                  const Wl0& wl0, uint32_t tid, RaySums& sums, Probe& pr, NextT* next = nullptr, const WlEntryDev* wl_lds = nullptr,
                   const SlotFast* slot_fast = nullptr) {
   const bool pinned = next != nullptr;   // (a compile-time constant after inlining: see HALO_ARRIVED)
   if (next != nullptr) next->request();
@@ -2024,14 +2024,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     return o;
   };
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
-  // Shape-pool kernels: the NEXT pass's pool record is touched here — one dword per 128-byte line, a lane each — so that the staging copy at
-  // the top of that pass finds its lines in L2 instead of HBM (the generator wrote the pool a gigabyte ago).  Here and not earlier: every load
-  // this pass still waits for (wavelength entry, corner rows) is behind us, and the interaction loop below only stores — on gfx950 loads and
-  // stores share vmcnt, so a load anywhere else is also a wait for every log record in flight.  The value is never used; the wait behind the loop
-  // keeps the register from being reused under a load in flight (the compiler does not see one in the asm).
-  if (next != nullptr) next->land();   // (before the touch below: its wait would be a wait for that load too)
-  uint32_t prefetched = 0u;
-  if (prefetch != nullptr) asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(prefetch) : "memory");
+  if (next != nullptr) next->land();   // the next pass's pool record goes to LDS: behind every load wait of this pass, in front of its first store
   for (uint32_t i = 0u; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
@@ -2189,7 +2182,6 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     }
     PROBE_MARK(pr, kPhSlab);
   }
-  if (prefetch != nullptr) asm volatile("s_waitcnt vmcnt(0)" : : "v"(prefetched) : "memory");
   if (next != nullptr) next->late();
   if (queued) {   // park the count: the lanes here agree on it, the first of them writes
     const uint64_t m = __ballot(1);
@@ -2251,9 +2243,6 @@ HD float wave_sum(float v) {
 #endif
 #ifndef HALO_FILTER_SIX
 #define HALO_FILTER_SIX 1   // the logging filter kernels of one regular prism take the small cache and six waves too (round 4: +8 .. +14 %)
-#endif
-#ifndef HALO_POOL_PREFETCH
-#define HALO_POOL_PREFETCH 1   // shape-pool kernels touch the next pass's record before their interaction loop (trace_one)
 #endif
 #ifndef HALO_POOL_DB48
 #define HALO_POOL_DB48 1   // ... general pool shapes (pyramids) too (NextShape48)
@@ -2485,10 +2474,9 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
         nx.mirror = mirror;
         nx.l32 = l32;
         mirrored = nx.src != nullptr;
-        const uint32_t* const touch = nullptr;   // (no line-touching here: the record itself is requested a whole generation phase before it is needed)
         PROBE_MARK(pr, kPhStage);
         // (a lane without a ray — the launch's last rays — has no next record either: next_first > tid >= n_rays)
-        if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, false>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch, &nx, wl_lds, sfast);
+        if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, false>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, &nx, wl_lds, sfast);
         asm volatile("" : : : "memory");
         __builtin_amdgcn_wave_barrier();
         PROBE_MARK(pr, kPhSlab);
@@ -2503,17 +2491,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhStage);
-      // (the lines of the record this half-wave stages in its next pass: lane l touches line l — see trace_one)
-      const uint32_t* touch = nullptr;
-#if HALO_POOL_PREFETCH
-      {
-        const uint32_t next_first = first + stride;   // (a wrap past 2^32 rays per launch cannot happen: launches are chunks of <= 2^28)
-        constexpr uint32_t kLines = (sizeof(PoolRec) + 127u) / 128u;
-        if (next_first < P.n_rays && l32 < kLines)
-          touch = reinterpret_cast<const uint32_t*>(reinterpret_cast<const PoolRec*>(P.shapes) + next_first / P.geom_clock) + l32 * 32u;
-      }
-#endif
-      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr, touch);
+      if (tid < P.n_rays) trace_one<MODE, MONO, SMALLC, GEOM == kGeomOneHex>(P, T, acc, filter, color, static_cast<const PoolSlot*>(slot), wl0, tid, sums, pr);
       __builtin_amdgcn_wave_barrier();
       PROBE_MARK(pr, kPhSlab);
       if constexpr (BIN) {
