@@ -13,24 +13,12 @@ namespace halo {
 // for the CMF rows of the X/Y/Z pass), so the unsigned sums cannot wrap.  F = 32 (resolution 2.3e-10) for every launch of unit-weight
 // rays up to 2^28; an illuminant session (spd weights ~100) of 2^26 rays runs F = 28.  (Round 3 had F fixed at 32 on the assumption
 // "weight <= 1" and a signed read-out: 4e9 of weight in one slot wrapped negative — ADVICE r3.)  A NaN or negative weight adds nothing.
-#ifndef HALO_FIX_SLOW
-#define HALO_FIX_SLOW 0   // A/B knob: 1 = the double -> int64 conversion for every record (rounds 3-4)
-#endif
 struct FixQ {
   double to_fix, from_fix;
-  float fast_below;   // 2^(52 - F): below it, v * 2^F + 2^52 lies in [2^52, 2^53), where a double's mantissa IS the integer
   __device__ __forceinline__ explicit FixQ(uint32_t frac_bits)
-      : to_fix(__hiloint2double(static_cast<int>((1023u + frac_bits) << 20), 0)), from_fix(__hiloint2double(static_cast<int>((1023u - frac_bits) << 20), 0)),
-        fast_below(__uint_as_float((127u + 52u - frac_bits) << 23)) {}
-  // Round to nearest; v <= the launch's bound by construction.  The conversion double -> int64 is ~15 instructions on gfx950 (no native one) and
-  // the X/Y/Z pass makes three per record; adding 2^52 in the fma instead leaves the rounded integer in the low 52 bits of the result — one fma and
-  // one integer subtraction on the high word.  (Ties go to even there, half up in the general path: a measure-zero difference of 2^-F.)
-  __device__ __forceinline__ unsigned long long fix(float v) const {
-    const float u = fmaxf(v, 0.0f);   // (a NaN becomes 0 here)
-#if !HALO_FIX_SLOW
-    if (u < fast_below) return static_cast<unsigned long long>(__double_as_longlong(fma(static_cast<double>(u), to_fix, 4503599627370496.0)) - 0x4330000000000000ll);
-#endif
-    return static_cast<unsigned long long>(static_cast<long long>(fma(static_cast<double>(u), to_fix, 0.5)));
+      : to_fix(__hiloint2double(static_cast<int>((1023u + frac_bits) << 20), 0)), from_fix(__hiloint2double(static_cast<int>((1023u - frac_bits) << 20), 0)) {}
+  __device__ __forceinline__ unsigned long long fix(float v) const {   // round to nearest; v <= the launch's bound by construction
+    return static_cast<unsigned long long>(static_cast<long long>(fma(static_cast<double>(fmaxf(v, 0.0f)), to_fix, 0.5)));
   }
   __device__ __forceinline__ float unfix(unsigned long long a) const { return static_cast<float>(static_cast<double>(a) * from_fix); }
 };
