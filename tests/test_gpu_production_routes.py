@@ -123,6 +123,59 @@ def test_sampled_prisms_pick_their_entry_face_slab_by_slab_like_the_walk_over_tr
     _check_single_layer((i1, l1), (img_o, landed_o))
 
 
+@pytest.mark.parametrize("kind", ["prism", "pyramid"])
+@pytest.mark.parametrize("shape", ["filtered", "second_layer"])
+def test_pool_kernels_that_fetch_ahead_under_a_filter_and_behind_a_first_layer(kind, shape):
+    """The logged shape-pool kernels (next record a pass ahead, pool entries from LDS, load waits pinned where they are issued) in the two
+    places the benchmark configurations do not put them:
+      filtered      a sampled crystal with an emit-gate filter on its entry: halo_trace_kernel<kModeFilter, pool, ., kAccLog>
+      second_layer  a deterministic plate (prob 0.6) over the sampled crystal: the pool kernel reads its rays from the continuation pool
+                    (transit source: five more loads per ray in front of the landing of the next record)
+    Each against the SAME session on direct atomics (hit_log 0: the staging copy at the top of every pass, as before) — HIP against HIP, same
+    rays for `filtered` (tallies equal, image to float summation order); for `second_layer` the continuation order differs from run to run
+    (appends are atomic) and with it WHICH second-layer ray a continuation becomes (its streams go by its place in the pool): two runs are
+    two samples of the same scene — exit count to 1e-3 (3e7 exits), landed weight to 3e-3, 32x32 block means to 2e-2 of their norm."""
+    g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+    crystal = scenes.prism_crystal(1.0, [g] * 6) if kind == "prism" else scenes.pyramid_crystal(0.1, 1.2, 0.5, upper_miller=(2, 3), face_distance=[g] * 6)
+    sampled = scenes.entry(crystal, scenes.axis(zenith=FULL, azimuth=FULL, roll=FULL), 100.0, 1, filter_id=1 if shape == "filtered" else 0)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL)
+    wl = scenes.wl_illuminant("D65", 31)
+    if shape == "filtered":
+        sc, n = scenes.scene([(0.0, [sampled])], max_hits=8), 3 << 20
+        filters = [scenes.simple_filter(scenes.filter_term("entry_exit", entry=3, exit=5, min_len=2, max_len=6), "PBD")]
+    else:
+        plate = scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0, "std": 0.8}), 1.0, 6)
+        sc, n = scenes.scene([(0.6, [plate]), (0.0, [sampled])], max_hits=7), 2 << 20
+        filters = []
+    out = {}
+    for name, opts in (("log", {}), ("direct", {"hit_log": 0})):
+        hb = hip_backend(seed=57, blocks_per_cu=2, **opts)
+        if filters:
+            hb.set_filters(filters)
+        st = run_session(hb, sc, rd, wl, n)
+        r = hb.last_route()
+        img, landed = hb.ReadbackXyzAccum()
+        hb.close()
+        out[name] = (st, r, img, landed)
+    st, r, img, landed = out["log"]
+    st0, r0, img0, landed0 = out["direct"]
+    geom_bit = 1 << (2 if kind == "prism" else 1)
+    assert r.geom_mask & geom_bit and r.accum_mask & abi.ACCUM_LOG_XYZ, (r.geom_mask, r.accum_mask)
+    assert not (r0.accum_mask & abi.ACCUM_LOG_XYZ), r0.accum_mask
+    if shape == "filtered":
+        assert r.mode_mask == 1 << 1, r.mode_mask
+        assert (st[0].exit_count, st[0].pixel_hits) == (st0[0].exit_count, st0[0].pixel_hits)
+        assert 0 < st[0].exit_count < n          # the filter lets a fraction through
+        assert landed == pytest.approx(landed0, rel=1e-6)
+        assert rel_l2(img, img0) <= 2e-5, rel_l2(img, img0)
+    else:
+        assert st[1].root_count == st[0].continuation_count >= 2 << 20, (st[1].root_count, st[0].continuation_count)   # the second layer's launch takes the log
+        assert st[1].root_count == st0[1].root_count
+        assert st[1].exit_count == pytest.approx(st0[1].exit_count, rel=1e-3)
+        assert landed == pytest.approx(landed0, rel=3e-3)
+        assert rel_l2(block_mean(img, 32), block_mean(img0, 32)) <= 2e-2, rel_l2(block_mean(img, 32), block_mean(img0, 32))
+
+
 @pytest.mark.parametrize("case", ["prism_discrete", "prism_discrete_binned", "pyramid_discrete", "pyramid_discrete_direct", "pyramid_d65", "pyramid_d65_planes"])
 def test_stochastic_pool_production_kernels_vs_oracle(case):
     """The other production shape-pool instantiations at sizes where they are what the backend picks:
