@@ -490,6 +490,9 @@ HD float2v pk_dot(float2v X, float2v Y, float2v Z, float gx, float gy, float gz)
 
 // SMALLC: binned kernels of shape-pool dispatches halve the one-channel cache (their LDS also holds the pool slots and the
 // hit buffer; misses are cheap there) to stay at 4 workgroups per CU
+#ifndef HALO_CACHE_WAYS
+#define HALO_CACHE_WAYS 4   // ways of the X/Y/Z pixel cache's sets; 2: the two-way cache of rounds 2-4 (A/B knob).  The scalar caches have two.
+#endif
 #ifndef HALO_CACHE_LOG2
 #define HALO_CACHE_LOG2 11
 #endif
@@ -501,7 +504,7 @@ struct CacheGeom {  // 2048 one-channel slots (16 KB; 1024 with SMALLC) or 1024 
 
 template <bool MONO, bool SMALLC>
 struct PixCache {
-  uint32_t tag[CacheGeom<MONO, SMALLC>::kN];     // ((plane << 23) | pixel) + 1, 0 = free
+  __attribute__((aligned(16))) uint32_t tag[CacheGeom<MONO, SMALLC>::kN];     // ((plane << 23) | pixel) + 1, 0 = free; a set of four is read as one uint4
   float val[CacheGeom<MONO, SMALLC>::kN * (MONO ? 1 : 3)];
 };
 
@@ -657,6 +660,43 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
   const uint32_t pl = (MONO && P.mono_by_wl) ? wl_idx : 0u;
   if (P.aggregate == 1u || P.aggregate == 3u) {
     const uint32_t key = ((pl << 23) | pix) + 1u;
+    // X/Y/Z caches (round 5): four-way sets, one 16-byte read of the set's tags.  A hot pixel only misses when ALL its ways were claimed by other
+    // pixels before its first hit.  With two ways ~0.5 % of the workgroups lost a sun-disc pixel that way, and every record of theirs for it then
+    // met the same LDS address in the per-tile pass of the sun's tile — the tail of that pass: configs[4]'s passes 1.32 -> 0.98 ms per launch with
+    // four ways.  The probe itself is dearer in instructions than the two compare-and-swaps (a read, eight compares and selects: the trace kernel
+    // +2.7 %), which is why the scalar caches keep two ways: their passes measured the same either way, and configs[1]'s kernel lost 2 %.
+    // The key is there: the read finds it.  The set is full of other keys: the read says so.  A first sighting with a free way pays a
+    // compare-and-swap on top; the loser of a race for the way reads the set again, once.
+    if constexpr (!MONO && HALO_CACHE_WAYS == 4) {
+    const uint32_t set = ((key * 2654435761u) >> (32 - (CacheGeom<MONO, SMALLC>::kLog2 - 2))) << 2;
+    uint32_t slot = 0xFFFFFFFFu;
+#pragma unroll
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const uint4 t = *reinterpret_cast<const uint4*>(&C.tag[set]);
+      const uint32_t found = t.x == key ? 0u : t.y == key ? 1u : t.z == key ? 2u : t.w == key ? 3u : 4u;
+      if (found < 4u) {
+        slot = set + found;
+        break;
+      }
+      const uint32_t empty = t.x == 0u ? 0u : t.y == 0u ? 1u : t.z == 0u ? 2u : t.w == 0u ? 3u : 4u;
+      if (empty == 4u) break;   // the set belongs to four other pixels
+      const uint32_t old = atomicCAS(&C.tag[set + empty], 0u, key);
+      if (old == 0u || old == key) {
+        slot = set + empty;
+        break;
+      }
+    }
+    if (slot != 0xFFFFFFFFu) {
+      if (MONO) {
+        unsafeAtomicAdd(&C.val[slot], w);
+      } else {
+        unsafeAtomicAdd(&C.val[slot * 3 + 0], cx * w);
+        unsafeAtomicAdd(&C.val[slot * 3 + 1], cy * w);
+        unsafeAtomicAdd(&C.val[slot * 3 + 2], cz * w);
+      }
+      return;
+    }
+    } else {
     // two-way: a key may live in slot s or s^1.  A hot pixel only misses the cache when BOTH were claimed by other pixels
     // before its first hit (~0.2 % of workgroups instead of ~5 % one-way) — and every miss of a hot pixel is an atomic on
     // the same line as all its other misses, chip-wide.
@@ -675,6 +715,7 @@ HD void accumulate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& ctx, uin
         unsafeAtomicAdd(&C.val[slot * 3 + 2], cz * w);
       }
       return;
+    }
     }
     if (P.aggregate == 3u) return;  // diagnostic: cache only, misses dropped
   }
