@@ -1671,6 +1671,9 @@ HD int sample_entry_prism(Stream& s, ShapePtr sh, const EF& ef, int tri_cnt, con
   return face;
 }
 
+#ifndef HALO_POOL_HEXN
+#define HALO_POOL_HEXN 1   // sampled full prisms with the regular prism's normals search their next face with literal normals (A/B knob)
+#endif
 // The entry pick's view of a sampled FULL prism, per half-wave: EntryFastDev's first three tables (BuildEntryFast, halo_host.cpp), rebuilt from
 // the slot's fan table at the top of every pass by the half-wave itself — ~100 wave instructions against the ~300 the walk over all 20 fan
 // triangles (two passes, an LDS row each) costs every ray more than the slab-wise pick.  ok = 0 (a prism that lost a face to its neighbours'
@@ -1679,7 +1682,11 @@ struct SlotFast {
   float tri_area[kEntryFastFaces][4];
   uint32_t tri0n[kEntryFastFaces];
   float slab_area[4][2];
-  uint32_t ok, pad[3];
+  float d_plus[4], d_minus[4];   // the slabs' plane constants, for the literal-normal next-face search (hexn)
+  uint32_t ok;     // a full eight-face prism whose fan the slab-wise entry pick can index
+  uint32_t hexn;   // ... whose slab normals are the regular prism's, bit for bit (a sampled prism varies its face DISTANCES): the next-face search
+                   // then has the normals as literals like the one-shape regular-prism kernels, with a plane constant per face
+  uint32_t pad[2];
 };
 static_assert(sizeof(SlotFast) % 16 == 0, "rows are read as float4 / float2");
 // all 32 lanes of the half-wave call this together, after the slot's rows are in place
@@ -1722,7 +1729,20 @@ HD void build_slot_fast(SlotFast* sf, const ShapePrism* sh, uint32_t l32) {
   const int base = static_cast<int>(threadIdx.x & 32u);
   const float ap = __shfl(area, base | static_cast<int>(kk == 0u ? 0u : kk + 1u)), am = __shfl(area, base | static_cast<int>(kk == 0u ? 1u : kk + 4u));
   if (ok && l32 < 4u) *reinterpret_cast<float2v*>(sf->slab_area[l32]) = float2v{ap, am};
-  if (l32 == 0u) sf->ok = ok ? 1u : 0u;
+  bool hexn = ok;
+  if (ok && l32 < 4u) {   // lane k: slab k's normal against the literal the search uses, its two plane constants to the table
+    constexpr float kS60 = 0.86602540378443864676f;
+    const float4 g = *reinterpret_cast<const float4*>(sh->slab[l32]);
+    const float wx = l32 == 1u ? 1.0f : l32 == 2u ? 0.5f : l32 == 3u ? -0.5f : 0.0f, wy = l32 >= 2u ? kS60 : 0.0f, wz = l32 == 0u ? 1.0f : 0.0f;
+    hexn = g.x == wx && g.y == wy && g.z == wz;
+    sf->d_plus[l32] = g.w;
+    sf->d_minus[l32] = sh->slab[l32][4];
+  }
+  hexn = (static_cast<uint32_t>(__ballot(!hexn) >> half_shift) & 0xFu) == 0u && ok && HALO_POOL_HEXN != 0;
+  if (l32 == 0u) {
+    sf->ok = ok ? 1u : 0u;
+    sf->hexn = hexn ? 1u : 0u;
+  }
 }
 
 // The next pass's pool record, a pass ahead (prism pools under the hit log, round 5).  A pass of a shape-pool kernel used to BEGIN with the staging
@@ -2031,6 +2051,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   }
 
   bool done = false;
+  const bool slot_hexn = slot_fast != nullptr && slot_fast->hexn != 0u;
   float hex_d_basal = 0.0f, hex_d_side = 0.0f;
   if constexpr (HEX) {
     hex_d_basal = T.efast.hex_d_basal;
@@ -2155,6 +2176,29 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       }
       none_ahead = cb == 0xFFFFFFFFu;
       hit = static_cast<int>(((cb >> 2) & 7u) + (cb >> 31) * (cb & 3u));   // (meaningless when none_ahead: the lane strays and never reads it)
+    } else if (slot_fast != nullptr && slot_hexn) {
+      // A sampled FULL prism with the regular prism's normals (SlotFast::hexn): the search above with a plane constant per FACE — the one of the
+      // face ahead is picked by the sign of n.d (one select more per slab than the regular prism's, whose two faces share theirs).  Same
+      // candidates, order, products and comparisons as the table-driven search below: x * 1 + 0 and 0 * z + acc are exact.
+      constexpr float kS60 = 0.86602540378443864676f;
+      const float4 dp4 = *reinterpret_cast<const float4*>(slot_fast->d_plus), dm4 = *reinterpret_cast<const float4*>(slot_fast->d_minus);
+      uint32_t cb = 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2v s60 = {kS60, kS60};
+        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? __builtin_elementwise_fma(Y, s60, X * 0.5f) : __builtin_elementwise_fma(Y, s60, X * -0.5f);
+        const float dpk = (k == 0) ? dp4.x : (k == 1) ? dp4.y : (k == 2) ? dp4.z : dp4.w, dmk = (k == 0) ? dm4.x : (k == 1) ? dm4.y : (k == 2) ? dm4.z : dm4.w;
+        const bool pos = r.x > 0.0f;
+        const float den = fabsf(r.x);
+        const float num = pos ? -(r.y + dpk) : (r.y - dmk);   // (spelled like the table-driven search: the same roundings)
+        const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
+        num_b = better ? num : num_b;
+        den_b = better ? den : den_b;
+        const uint32_t kCode = (k == 0) ? ((0u << 2) | 1u) : ((static_cast<uint32_t>(k + 1) << 2) | 3u);
+        cb = better ? ((pos ? 0u : 0x80000000u) | kCode) : cb;
+      }
+      none_ahead = cb == 0xFFFFFFFFu;
+      hit = static_cast<int>(((cb >> 2) & 7u) + (cb >> 31) * (cb & 3u));
     } else {
     const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
     for (int k = 0; k < slab_cnt; ++k) {
@@ -2185,7 +2229,9 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       hit = better ? fi : hit;
     }
     }
-    if constexpr (!HEX) none_ahead = hit < 0;
+    if constexpr (!HEX) {
+      if (!(slot_fast != nullptr && slot_hexn)) none_ahead = hit < 0;
+    }
     const float t_best = num_b * fast_rcp(den_b);
     // No face ahead (numerical edge): legacy treats the child as an outgoing candidate (simulator.cpp:678).  Rare — a wave holds such a lane
     // once in thousands of passes — so it does not ride through the loop's emit site as a special case (selects on every operand of every
@@ -2500,7 +2546,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
           sfast = &s_slot_fast[threadIdx.x >> 5];
           if (first < P.n_rays) {
             if (P.pool_entry_fast != 0u) build_slot_fast(sfast, slot, l32);
-            else if (l32 == 0u) sfast->ok = 0u;
+            else if (l32 == 0u) sfast->ok = sfast->hexn = 0u;
           }
         }
         // (LDS operations of one wave retire in order: all the copies need is that the compiler keeps them in order — NOT a workgroup-scope

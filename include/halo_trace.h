@@ -291,7 +291,7 @@ const char* halo_last_error(halo_handle_t h);
  * "entry_fast" (1 [default]: one-shape dispatches of a full 8-face prism pick the entry face slab by slab, in registers;
  * 0: the generic walk over faces — same uniform, same cumulative order, A/B knob),
  * "pool_entry_fast" (1 [default]: logged launches over sampled PRISMS pick the entry face of every full eight-face prism slab by slab, from tables
- * its half-wave rebuilds each pass; 0: the walk over the fan triangles — same uniform, same cumulative order, A/B knob),
+ * its half-wave rebuilds each pass; 0: the walk over the fan triangles — same uniform, same cumulative order; the same prisms, when their slab normals are the regular prism's, search their next face with literal normals — same candidates and comparisons as the table-driven search; A/B knob),
  * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in
  * [1, 64], default 32 = one 128-byte line per plane read; 1 = the reference's per-ray permutation, cu:1633-1657),
  * scheduling (ABI 6; none of them changes a result): "overlap" (1 [default]: launches of <= 2 Mi rays alternate between two
