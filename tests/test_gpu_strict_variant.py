@@ -35,21 +35,36 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(lib):
+def _start(lib):
     env = dict(os.environ)
     if lib:
         env["HALO_LIB"] = lib
     else:
         env.pop("HALO_LIB", None)
-    r = subprocess.run([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS))], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return subprocess.Popen([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _finish(proc):
+    out, err = proc.communicate(timeout=900)
+    assert proc.returncode == 0, err[-2000:]
+    line = [l for l in out.splitlines() if l.startswith("RESULT ")][-1]
     return {int(k): v for k, v in json.loads(line[7:]).items()}
+
+
+def _run_both(lib_a, lib_b):
+    """the two libraries' runs side by side (each is mostly the CPU oracle's time: two roundings x four scenes)"""
+    a, b = _start(lib_a), _start(lib_b)
+    try:
+        return _finish(a), _finish(b)
+    finally:
+        for p in (a, b):
+            if p.poll() is None:
+                p.kill()
 
 
 def test_strict_build_meets_the_unconditioned_per_ray_bars():
     assert os.path.exists(STRICT), "libhalo_hip_strict.so is not built: HALO_BUILD_TAG=strict python -m ice_halo_sim_amd.build (__graft_entry__.build() does it)"
-    strict, product = _run(STRICT), _run(None)
+    strict, product = _run_both(STRICT, None)
     for seed, bar in BARS.items():
         s, p = strict[seed], product[seed]
         assert s["fixed"] >= 1                                    # the scenes that motivated the conditioning: fixed orientation axes
