@@ -1899,11 +1899,7 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
 #endif
   Stream gate = make_stream(G.gate_seed, G.gate_lo, G.gate_hi, tid);
 
-#ifdef HALO_FORCE_SRC_GEN   // experiment: what the kernel looks like when the ray source is known at compile time
-  const uint32_t source = kSrcGen;
-#else
   const uint32_t source = G.source;
-#endif
   if (source == kSrcGen) {
     Stream s = make_stream(G.gen_seed, G.gen_lo, G.gen_hi, tid);
     // per-ray wavelength in its own seed domain (BuildWlStream pcg_shared.h:213-219)
