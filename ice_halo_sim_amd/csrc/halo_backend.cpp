@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -206,12 +207,19 @@ struct HaloBackend {
     bool valid = false;
     int mode = 0;
     bool use_filter = false, use_color = false, entry_fast = false, hex_regular = false, has_fast = false;
+    // Two device slots per entry, taken in turn by the uploads: the kernels of the session before (queued on a trace stream, async) may still be
+    // staging their tables out of the slot they were given.  An upload waits (on the stream, not the host) for the last kernel that read ITS
+    // slot — two table sets back, as good as always finished — so consecutive sessions of different wavelengths still overlap.
+    int cur = 0;
+    hipEvent_t ev_read[2] = {nullptr, nullptr};
+    bool has_read[2] = {false, false};
   };
   TableCacheEntry tcache[HALO_MAX_LAYERS][HALO_MAX_ENTRIES];
-  DevBuf<DispatchSlot> tcache_dev;     // HALO_MAX_LAYERS x HALO_MAX_ENTRIES slots, reserved on first use
+  DevBuf<DispatchSlot> tcache_dev;     // HALO_MAX_LAYERS x HALO_MAX_ENTRIES x 2 slots, reserved on first use
   HaloScene tcache_scene{};            // what the valid entries were built for
   HaloWl tcache_wl{};
   int table_cache = 1;                 // option: 0 uploads the tables with every dispatch (round 4 behaviour)
+  std::map<std::string, int64_t> opt_last;   // halo_set_option: the value each key was last set to (an unchanged option keeps the table cache)
   HaloLayerStats pending{};    // harvested tallies not yet handed to the caller (async mode)
   HaloLayerStats layer_acc{};  // tallies of the layer being traced
   std::vector<WlEntryDev> wl_pool_host;
@@ -342,6 +350,16 @@ int reserve_idle(HaloBackend* b, DevBuf<T>& buf, size_t n, hipError_t* err = nul
   return HALO_OK;
 }
 
+// The cumulative landed tally up to here belongs to the image that is being left (rebinding, a re-sized owned image): whoever reads the NEW
+// accumulator must not be handed weight that landed in the old one and was never taken.
+int take_landed_delta(HaloBackend* b, double* landed);
+int forget_landed(HaloBackend* b) {
+  if (!b->tally.ptr) return HALO_OK;
+  if (int rc = join_aux(b)) return rc;
+  double unused = 0.0;
+  return take_landed_delta(b, &unused);
+}
+
 int ensure_accumulator(HaloBackend* b, int w, int h) {
   const uint64_t need = static_cast<uint64_t>(w) * h * 3 + 4;
   if (b->acc && b->acc != b->acc_own.ptr) {  // external binding
@@ -355,6 +373,8 @@ int ensure_accumulator(HaloBackend* b, int w, int h) {
   if (!b->acc_own.ptr || b->acc_own.cap < need || b->own_w != w || b->own_h != h) {
     if (int rc = reserve_idle(b, b->acc_own, need)) return rc;
     if (int rc = join_aux(b)) return rc;   // (a fold of the old image may still be queued there)
+    if (b->own_w != 0 || b->own_h != 0)
+      if (int rc = forget_landed(b)) return rc;   // the old image goes, and its landed weight with it
     HIPCHK(b, hipMemsetAsync(b->acc_own.ptr, 0, need * sizeof(float), b->stream));
     b->own_w = w;
     b->own_h = h;
@@ -528,6 +548,10 @@ int halo_destroy(halo_handle_t b) {
   b->counters.release();
   b->ring_dev.release();
   b->tcache_dev.release();
+  for (auto& layer : b->tcache)
+    for (auto& e : layer)
+      for (hipEvent_t ev : e.ev_read)
+        if (ev) (void)hipEventDestroy(ev);
   if (b->ring_host) (void)hipHostFree(b->ring_host);
   if (b->tally_host) (void)hipHostFree(b->tally_host);
   for (int k = 0; k < HaloBackend::kRing; k++) {
@@ -576,7 +600,13 @@ const char* halo_last_error(halo_handle_t b) { return b ? b->error.c_str() : "nu
 int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   if (!b || !key) return HALO_FATAL;
   const std::string k(key);
-  drop_table_cache(b);   // (whatever the option: most of them shape the tables or the kernels that read them)
+  {  // most options shape the tables or the kernels that read them: a CHANGED option drops the table cache.  A caller that sets its options before
+     // every session (the Lumice glue does) sets them to what they are: the cache stays.  Counter / seed options always act (they move state).
+    auto it = b->opt_last.find(k);
+    const bool same = it != b->opt_last.end() && it->second == v && k != "rank" && k != "ray_base" && k != "seed";
+    if (!same) drop_table_cache(b);
+    b->opt_last[k] = v;
+  }
   // the session's plane layout (privatised copies, hit-log eligibility) was decided at halo_begin from these two: changing them with a session
   // open would send direct atomics to a layout made for another route
   if ((k == "capture_exits" || k == "filter_fast") && b->in_session) return fail(b, HALO_FATAL, k + " cannot change inside a session");
@@ -664,6 +694,8 @@ int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) 
   if (!b) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "bind_accumulator inside a session");
   if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions belong to the accumulator they were traced for
+  if ((device_ptr ? static_cast<float*>(device_ptr) : b->acc_own.ptr) != b->acc && b->acc != nullptr)
+    if (int rc = forget_landed(b)) return rc;   // ... and so does the weight that landed in it
   if (!device_ptr) {
     b->acc = b->acc_own.ptr;
     b->acc_floats = b->acc_own.cap;
@@ -686,6 +718,9 @@ int halo_set_filters(halo_handle_t b, const HaloFilter* filters, int32_t count) 
       if (terms > HALO_FILTER_MAX_TERMS) return fail(b, HALO_FATAL, "complex filter: too many terms");
     }
   }
+  // (the Lumice glue hands the filter table over at every BeginSession: equal tables keep the table cache — ADVICE r5)
+  const bool same = static_cast<size_t>(count) == b->filters.size() && (count == 0 || std::memcmp(b->filters.data(), filters, sizeof(HaloFilter) * static_cast<size_t>(count)) == 0);
+  if (same) return HALO_OK;
   b->filters.assign(filters, filters + count);
   drop_table_cache(b);
   return HALO_OK;
@@ -778,8 +813,9 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
                              b->acc_h == render->height && b->mono_s_log2 == s_log2 && b->plane_cnt == plane_cnt_n && b->plane_copies == plane_copies_n &&
                              b->plane_coef == coef_n;
     if (!same_planes) {
-      // (queued on the auxiliary stream, NOT waited for: this session's trace kernels may start under it — they write log records, never the
-      // planes; whatever here does touch the planes or the image waits for that stream first)
+      // (queued on the auxiliary stream; the HOST does not wait.  This session's trace kernels are queued behind it all the same
+      // (next_trace_stream is always told the launch touches the planes): letting a logged kernel start under the fold was measured — the step
+      // did not shrink, DESIGN.md 3.6 — so the simpler order stays, and the twin's two halves only keep a LATE fold and the open session apart)
       int rc = fold_queue(b);  // also: a session that was never ended still owes its plane to the accumulator (old layout)
       if (rc != HALO_OK) return rc;
       const bool caller_reads = b->acc != nullptr && b->acc != b->acc_own.ptr && !b->defer_fold;   // the caller's memory, read in stream order: the fold must be in that order too
@@ -882,7 +918,7 @@ static int fold_queue(HaloBackend* b) {
     if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   }
   if (flag) HIPCHK(b, hipMemsetAsync(flag, 0, sizeof(uint32_t), ps));   // every group has seen it; the fold zeroed what it took
-  b->twin_set ^= 1;   // what traces from here on overflows into the other half
+  b->twin_set ^= 1;   // what traces from here on overflows into the other half (trace kernels queue behind this fold anyway: see halo_begin)
   b->mono_dirty = false;
   return HALO_OK;
 }
@@ -915,6 +951,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   const bool final_layer = (layer == b->scene.layer_count - 1);
   if (n > 0xFFFFFFF0ull) return fail(b, HALO_FATAL, "more than 2^32 rays in one layer dispatch; split the batch");
   if (layer > 0 && rays) return fail(b, HALO_FATAL, "host rays are first-layer only");
+  if (rays && rays->crystal) {   // an injected crystal is copied into fixed-size device tables: its counts and indices are the caller's, check them
+    const HaloGeomTables& g = *rays->crystal;
+    if (g.face_cnt < 0 || g.face_cnt > HALO_MAX_FACES || g.tri_cnt < 0 || g.tri_cnt > HALO_MAX_TRIS)   // (0 faces = the empty crystal: its rays carry no weight)
+      return fail(b, HALO_FATAL, "host crystal: face_cnt / tri_cnt outside 0..HALO_MAX_FACES / 0..HALO_MAX_TRIS");
+    for (int t = 0; t < g.tri_cnt; t++)
+      if (g.tri_face[t] < 0 || g.tri_face[t] >= g.face_cnt) return fail(b, HALO_FATAL, "host crystal: tri_face refers to a face outside the table");
+  }
 
   float props[HALO_MAX_ENTRIES];
   for (int ci = 0; ci < L.entry_count; ci++) props[ci] = L.entries[ci].proportion;
@@ -1003,8 +1046,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   if (rays && layer == 0)   // host rays bring their own weights (and hand them on to the layers behind)
     for (uint64_t i = 0; i < n; i++) b->sess_max_w = std::max(b->sess_max_w, static_cast<double>(std::fabs(rays->w[i])));
   if (rays && layer == 0) {
-    HIPCHK(b, b->host_f.reserve(n * 7));
-    HIPCHK(b, b->host_u.reserve(n));
+    // a queued session's kernel on a trace stream (async + overlap) may still be reading the previous batch out of these buffers: the copies
+    // go behind everything the trace / auxiliary streams hold, and a buffer only grows with all streams idle
+    if (int rc = join_aux(b)) return rc;
+    if (int rc = reserve_idle(b, b->host_f, n * 7)) return rc;
+    if (int rc = reserve_idle(b, b->host_u, n)) return rc;
     HIPCHK(b, hipMemcpyAsync(b->host_f.ptr, rays->d, n * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream));
     HIPCHK(b, hipMemcpyAsync(b->host_f.ptr + n * 3, rays->p, n * 3 * sizeof(float), hipMemcpyHostToDevice, b->stream));
     HIPCHK(b, hipMemcpyAsync(b->host_f.ptr + n * 6, rays->w, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
@@ -1087,12 +1133,12 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // the entry's tables may still be on the device from an earlier dispatch (table cache, see HaloBackend::TableCacheEntry)
     HaloBackend::TableCacheEntry* ce = (b->table_cache && deterministic && !host_crystal && P.source != kSrcTransit) ? &b->tcache[layer][ci] : nullptr;
     if (ce && !b->tcache_dev.ptr) {
-      if (b->tcache_dev.reserve(static_cast<size_t>(HALO_MAX_LAYERS) * HALO_MAX_ENTRIES) != hipSuccess) {
+      if (b->tcache_dev.reserve(static_cast<size_t>(HALO_MAX_LAYERS) * HALO_MAX_ENTRIES * 2u) != hipSuccess) {
         (void)hipGetLastError();
         ce = nullptr;   // no room for the cache: every dispatch uploads its tables
       }
     }
-    DispatchSlot* const ce_dev = ce ? b->tcache_dev.ptr + (static_cast<size_t>(layer) * HALO_MAX_ENTRIES + static_cast<size_t>(ci)) : nullptr;
+    DispatchSlot* const ce_dev = ce ? b->tcache_dev.ptr + (static_cast<size_t>(layer) * HALO_MAX_ENTRIES + static_cast<size_t>(ci)) * 2u : nullptr;   // the entry's two slots
     bool cached = ce && ce->valid;
     FilterDev fd{};
     bool use_filter = false;
@@ -1176,7 +1222,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       b->ring_next = (k + 1) % HaloBackend::kRing;
       harvest_slot(b, k);  // blocks only if the ring has wrapped onto a dispatch still in flight
       DispatchSlot& hs = b->ring_host[k];
-      DispatchSlot* ds = ce ? ce_dev : b->ring_dev.ptr + k;
+      if (ce && !cached) ce->cur ^= 1;   // an upload takes the entry's other slot
+      DispatchSlot* ds = ce ? ce_dev + ce->cur : b->ring_dev.ptr + k;
       bool entry_fast = false, hex_regular = false, has_fast = fast_host != nullptr;
       if (cached) {
         entry_fast = ce->entry_fast, hex_regular = ce->hex_regular, has_fast = ce->has_fast;
@@ -1199,6 +1246,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         if (P.source == kSrcTransit) std::copy(b->cont_seg, b->cont_seg + kContShards + 1, hs.seg);
         // (the fast filter tables are the slot's last member and travel only with the dispatches that use them; the pinned mirror is this
         // ring slot's, so it stays as it is until the copy has run — harvest_slot above)
+        // A cache slot is a fixed device address: a kernel of an earlier, queued session (async: nobody harvested it) may still be staging its
+        // tables out of it on a trace stream.  The upload goes behind the last kernel that read this slot (no host wait; ring slots are
+        // protected by harvest_slot above).  Without this the earlier kernel's late workgroups could pick up THIS session's wavelength pool or
+        // shape (tests/test_gpu_production_routes.py::test_async_sessions_alternating_wavelengths).
+        if (ce && ce->has_read[ce->cur]) HIPCHK(b, hipStreamWaitEvent(b->stream, ce->ev_read[ce->cur], 0));
         HIPCHK(b, hipMemcpyAsync(ds, &hs, fast_host ? sizeof(DispatchSlot) : offsetof(DispatchSlot, fast), hipMemcpyHostToDevice, b->stream));
         if (ce) {   // the next dispatch of this entry — the layer's next chunk, the next equal session — finds the tables in place
           ce->valid = true, ce->mode = mode, ce->use_filter = use_filter, ce->use_color = use_color;
@@ -1438,6 +1490,11 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hex_regular) ? 3 : geom;
       hipError_t le = launch_trace(P, blocks, ts, mode, launch_geom, b->mono_session);
+      if (ce) {   // the slot's last reader (see TableCacheEntry)
+        if (!ce->ev_read[ce->cur]) HIPCHK(b, hipEventCreateWithFlags(&ce->ev_read[ce->cur], hipEventDisableTiming));
+        HIPCHK(b, hipEventRecord(ce->ev_read[ce->cur], ts));
+        ce->has_read[ce->cur] = true;
+      }
       b->mono_dirty = true;
       b->route.launches++;
       b->route.mode_mask |= 1u << mode;
@@ -1611,6 +1668,10 @@ int halo_set_color(halo_handle_t b, const HaloColorSet* sets, int n_sets, const 
     for (int k = 0; k < sets[i].term_count; k++)
       if (sets[i].terms[k].bit < 0 || sets[i].terms[k].bit > 63) return fail(b, HALO_FATAL, "colour bit outside 0..63");
   }
+  const bool same = static_cast<size_t>(n_sets) == b->color_sets.size() && static_cast<size_t>(n_classes) == b->color_classes.size() &&
+                    (n_sets == 0 || std::memcmp(b->color_sets.data(), sets, sizeof(HaloColorSet) * static_cast<size_t>(n_sets)) == 0) &&
+                    (n_classes == 0 || std::memcmp(b->color_classes.data(), classes, sizeof(HaloColorClass) * static_cast<size_t>(n_classes)) == 0);
+  if (same) return HALO_OK;   // (handed over again unchanged, as the Lumice glue does at every BeginSession: the table cache stays)
   b->color_sets.assign(sets, sets + n_sets);
   b->color_classes.assign(classes, classes + n_classes);
   drop_table_cache(b);

@@ -175,7 +175,7 @@ def oracle_doc_multilayer(name, seed):
                 "y16": block_mean(o["img"], 16)[..., 1].astype(np.float32),
                 "lane_sums": o["lanes"].sum(axis=(1, 2), dtype=np.float64) if colors else np.zeros(0)}
     from tests._oracle_cache import cached
-    return cached("filterdoc_%s_seed%d" % (name, seed), compute)
+    return cached("filterdoc_%s_seed%d" % (name, seed), compute, inputs=("ice_halo_sim_amd/config.py", ("doc", __import__("json").dumps(_E2E_DOCS[name], sort_keys=True))))
 
 
 def multilayer_docs():

@@ -1084,7 +1084,7 @@ def oracle_e2e_multilayer(name, seed):
                 "img_sum": np.float64(io.sum(dtype=np.float64)), "y16": block_mean(io, 16)[..., 1].astype(np.float32),
                 "lane_sums": lanes.sum(axis=(1, 2), dtype=np.float64)}
     from tests._oracle_cache import cached
-    return cached("e2e_%s_seed%d" % (name, seed), compute)
+    return cached("e2e_%s_seed%d" % (name, seed), compute, inputs=("ice_halo_sim_amd/config.py", ("doc", __import__("json").dumps(_E2E_DOCS[name], sort_keys=True))))
 
 
 def e2e_multilayer_names():

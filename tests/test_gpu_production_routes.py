@@ -851,6 +851,55 @@ def test_table_cache_follows_scene_wavelength_filters_and_options():
     assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())
 
 
+def test_async_sessions_alternating_wavelengths_and_crystals_keep_their_own_tables():
+    """Back-to-back single-layer sessions that nobody reads between (option async: what the Lumice glue does, simulator.cpp:1099 loops over
+    the wavelengths with no readback) alternate wavelength and crystal: every session misses the table cache and uploads its tables while the
+    kernel of the session before may still be staging ITS tables on a trace stream.  The two slots per cache entry and their reader events
+    (HaloBackend::TableCacheEntry) keep them apart: image and landed weight equal a run with no cache, one stream and synchronous sessions.
+    Injected rays share the hazard (their device buffers are re-filled per session): the same comparison with host rays."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    col = scenes.config2_scene()
+    plate = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(0.3), scenes.axis(zenith={"type": "gauss", "mean": 0.0, "std": 0.8}, azimuth=full, roll=full), 1.0, 6)])], max_hits=7)
+    rd = scenes.config2_render(480, 270)
+    seq = [(col, 450.0), (plate, 770.0), (col, 610.0), (plate, 450.0), (col, 770.0), (col, 450.0), (plate, 610.0), (col, 530.0)] * 6
+    runs = {}
+    for tag, opts in (("queued", dict(async_=1, overlap=1, table_cache=1)), ("plain", dict(async_=0, overlap=0, table_cache=0))):
+        hb = HipTraceBackend(device=0, seed=31, **{k.rstrip("_"): v for k, v in opts.items()})
+        for sc, w in seq:
+            run_session(hb, sc, rd, scenes.wl_discrete(w), 1 << 19)
+        runs[tag] = hb.ReadbackXyzAccum(480, 270)
+        hb.close()
+    (img1, l1), (img0, l0) = runs["queued"], runs["plain"]
+    assert l1 == pytest.approx(l0, rel=1e-6)
+    # a session traced with its neighbour's wavelength puts its refracted light elsewhere: far above the float-order noise of equal rays
+    assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())
+    # host-injected rays: per-session device buffers, re-filled while the session before may still be reading them
+    runs = {}
+    for tag, opts in (("queued", dict(async_=1, overlap=1)), ("plain", dict(async_=0, overlap=0))):
+        hb = HipTraceBackend(device=0, seed=31, **{k.rstrip("_"): v for k, v in opts.items()})
+        g = np.random.default_rng(5)
+        for k in range(12):
+            n = 20000 + 4000 * (k % 3)
+            d = g.normal(size=(n, 3)).astype(np.float32)
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            d[:, 2] = -np.abs(d[:, 2]) - 0.2
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            p = np.zeros((n, 3), np.float32)
+            p[:, 2] = 0.65   # on the top basal face (h = 1.3)
+            p[:, :2] = g.uniform(-0.3, 0.3, size=(n, 2)).astype(np.float32)
+            w = np.full(n, 1.0 + k, np.float32)
+            hb.BeginSession(col, rd, scenes.wl_discrete(450.0 + 40.0 * (k % 8)), n)
+            hb.TraceLayer(n, host_rays=(d, p, w, np.zeros(n, np.uint32)))
+            hb.EndSession()
+        runs[tag] = hb.ReadbackXyzAccum(480, 270)
+        hb.close()
+    (img1, l1), (img0, l0) = runs["queued"], runs["plain"]
+    assert l0 > 0 and l1 == pytest.approx(l0, rel=1e-6)
+    assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())
+
+
 def test_options_that_shape_an_open_session_are_refused_inside_it():
     """seed, ray_base and rank move the monotone ray counters, capture_exits / filter_fast / mono_copies the plane layout decided at
     BeginSession: changing any of them between the layers of a session would replay ray indices the session has already consumed or send

@@ -22,7 +22,7 @@ from tests._oracle_backend import OracleBackend
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 V = json.load(open(os.path.join(HERE, "golden", "ref_test_vectors.json")))
-needs_ref = pytest.mark.skipif(not _libs.have_ref(), reason="oracle/_ref/libref_shared.so is built only where /root/reference exists (it travels to the GPU box)")
+needs_ref = pytest.mark.skipif(not _libs.have_ref(), reason="oracle/_ref/libref_shared.so is built only where /root/reference exists (build container; .gpurunignore keeps it there)")
 
 
 # ---- ray_num semantics --------------------------------------------------------------------------------------------------------------------
