@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — rays/s of the MI355X trace hot path on BASELINE.json's workloads.
 
-  python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4p|ref:<name>] [--repeats R] [--scaling weak|strong]
+  python bench.py --gpus N --steps K --warmup W [--config 1|2|4|4d|4p|ref:<name>] [--repeats R] [--scaling weak|strong]
 N > 1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL);
 started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the file launches those N ranks itself (self_launch).  One "step" = one pass of the hot path over one batch of the selected configuration:
 
@@ -12,6 +12,9 @@ started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the fi
   --config 4  configs[4] on the reference's file as shipped (examples/bench_config_stoch.json: stochastic PRISM, six
              gauss(1, 0.15) face distances, D65, rectangular 2048x1024 full sky, max_hits 8), D65 pool of 31 wavelengths,
              25 M rays per GPU per step (200 M over 8 GPUs)
+  --config 4d the same file under the PRIMARY reading of "31 wavelengths" (SURVEY.md 8(d) item 5): a discrete 31-entry spectrum, 380..780 nm,
+             weight = the D65 SPD at each wavelength (src/include/lumice.h:292-293 allows <= 255 entries) -> 31 sessions per step that share the
+             25 M rays per GPU (per_wavelength_ray_num = ceil(25 M / 31) = 806 452 roots per session)
   --config 4p the pyramidal variant of the same (examples/config_example.json crystal 5 with the same face distances)
   --config ref:<name>  a config DOCUMENT of the reference, through the JSON reader (ice_halo_sim_amd.config), at its own resolution:
              ref:bench_light_single_ms, ref:ms_multi_crystal, ref:ms_multi_crystal_complex_filter, ref:ms_multi_crystal_filtered_bd —
@@ -20,8 +23,8 @@ started WITHOUT a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the fi
              ref:config_example, examples/config_example.json as shipped (README quick start: 9 wavelengths x 50 M rays, renderer 4;
              fixture tests/golden/ref_example_configs.json)
 
-With the default configuration on one GPU the JSON line also carries `other_configs`: short runs (1 warm-up + 3 timed steps, one
-repeat) of configs 2, 4, 4p and of the five reference documents — metric, ms/step, route and roofline of each — so that the
+With the default configuration on one GPU the JSON line also carries `other_configs`: short runs (1 warm-up step, then 3 repeats of 3 timed
+steps: median + CoV) of configs 2, 4, 4d, 4p and of the five reference documents — metric, ms/step, route and roofline of each — so that the
 driver's record holds them; the headline fields are those of configs[1] alone.
 
 Rays shard by index range (disjoint RNG counter ranges per rank, no data-path collective); every step ends with ONE RCCL
@@ -34,8 +37,10 @@ steps the timed region — EXACTLY K steps between barrier + synchronize — is 
 `ms_per_step` are the MEDIAN repeat, `repeats` carries every repeat and the coefficient of variation.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel of the configuration against HBM (no dense contraction
--> no MFMA): achieved = ALGORITHMIC bytes per launch / mean launch duration from HIP events on the launch
-stream.  `cpu_baseline` times the CPU oracle (a port of the reference's algorithm; the reference's own CPU path cannot be
+-> no MFMA), as the contract asks: achieved = ALGORITHMIC bytes per launch (accumulator + continuation bytes, SURVEY 8(d)'s
+fused definition) / mean launch duration from HIP events on the launch stream; peak 8 TB/s.  `bound` names the roof that actually BINDS the
+kernel — `valu_issue` for every trace kernel of this repo (rays live in registers; `roofline.valu` prices the instruction stream with the
+rates tools/valu_rate_bench.hip measures on the part) — and `hbm_frac` / `frac` keep the HBM fraction beside it.  `cpu_baseline` times the CPU oracle (a port of the reference's algorithm; the reference's own CPU path cannot be
 built in this image without stand-ins for spdlog / nlohmann-json — DESIGN.md §5) on the host cores on a bounded sample of the
 same workload — a reported baseline, not the target.
 """
@@ -55,7 +60,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUND = "r05"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
+PROFILE_ROUND = "r06"  # committed rocprofv3 summaries this file reads counters from: profiles/<round>_bench<cfg>_*.txt
 
 # The reference's legacy CPU path measured by the survey in the build container (compiled with shims, 6 worker
 # threads, config_example-shaped scene): the only number that relates the oracle ("port") to the real reference.
@@ -80,9 +85,25 @@ def workload(cfg):
                     name="configs[2]: two-layer full multi-scattering (plate h=0.3 zenith gauss(0,0.8) prob 1.0 over random column h=1.3), 9 wavelengths x %d root rays per GPU per step, max_hits 7, fisheye_equal_area fov 180 1920x1080 visible upper",
                     kernel="halo_trace_kernel<0,3,true,kAccLogFinal,FISHEYE_EQUAL_AREA,UPPER,nogate> (transit source: layer 1 reads the continuation pool) + halo_split_kernel<1024,16,256> + halo_bin_accumulate_range_kernel",
                     metric="root rays/sec (whole node) at 9 wavelengths, two-layer full multi-scattering")
-    if cfg in ("4", "4p"):
+    if cfg in ("4", "4d", "4p"):
         full = {"type": "uniform", "mean": 0.0, "std": 360.0}
         g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+        if cfg == "4d":
+            # the discrete reading: 31 spectrum entries 380..780 nm, weight = D65 SPD (GetIlluminantSpd, util/illuminant.cpp:113-134),
+            # one session each (simulator.cpp:1099 loops over wl_params), rays per session = PerWavelengthRayNum = ceil(total / 31)
+            import ctypes as C
+            from ice_halo_sim_amd import backend
+            L = backend.load_library()
+            L.halo_host_illuminant_spd.restype, L.halo_host_illuminant_spd.argtypes = C.c_float, [C.c_int, C.c_float]
+            lam = [380.0 + 400.0 * i / 30.0 for i in range(31)]
+            wls = [scenes.wl_discrete(w, float(L.halo_host_illuminant_spd(abi.ILLUM["D65"], w))) for w in lam]
+            return dict(scene=scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8),
+                        render=scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL),
+                        wls=wls, rays=-(-25_000_000 // 31),
+                        name="configs[4], discrete reading (primary, SURVEY 8(d) item 5): stochastic prism (examples/bench_config_stoch.json as shipped), full-sphere axis, "
+                             "a 31-entry spectrum 380..780 nm weighted by the D65 SPD = 31 sessions x %d root rays per GPU per step (25 M per GPU, 200 M over 8 GPUs), max_hits 8, rectangular 2048x1024 visible full",
+                        kernel="halo_trace_kernel<0,2,true,...> (sampled-prism pool, scalar plane of a discrete wavelength) + the route's accumulation passes (config.route)",
+                        metric="rays/sec (whole node), stochastic-geometry crystal, 31 discrete wavelengths")
         if cfg == "4":
             e = scenes.stochastic_prism_entry()
             what = "stochastic prism (examples/bench_config_stoch.json as shipped: h=1, six gauss(1,0.15) face distances)"
@@ -166,11 +187,35 @@ def ref_workload(name):
                 metric="root rays/sec, reference document %s" % name)
 
 
+def physical_cores():
+    """physical cores of the host (SURVEY 8(d) / BASELINE.md 4 ask for the count to be stated): distinct (physical id, core id) pairs of
+    /proc/cpuinfo; falls back to the logical count"""
+    pairs, sockets, model = set(), set(), ""
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif line.startswith("model name") and not model:
+                model = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                    sockets.add(phys)
+                phys = core = None
+    except OSError:
+        pass
+    return {"cores": len(pairs) or (os.cpu_count() or 1), "sockets": len(sockets) or 1, "model": model}
+
+
 def cpu_baseline(wk, budget_s=12.0):
     """CPU oracle ("port") on all host cores, bounded to ~budget_s of work on the same workload shape."""
     from tests._oracle_backend import OracleBackend, run_session
     cores = os.cpu_count() or 1
     threads = min(cores, 128)
+    physical = physical_cores()
     sc, rd, wls = wk["scene"], wk["render"], wk["wls"]
     ob = OracleBackend(seed=42, threads=threads, acc64=1)   # per-thread pixel caches: the shared float image's contended atomics kept the all-cores run from scaling
     if wk.get("geom_clock"):
@@ -189,6 +234,8 @@ def cpu_baseline(wk, budget_s=12.0):
     dt = time.perf_counter() - t0
     ob.close()
     return {"value": len(wls) * per_wl / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "host": {"threads_used": threads, "logical_cpus": cores, "physical_cores": physical["cores"], "sockets": physical["sockets"], "model": physical["model"],
+                     "note": "`cores` above = OpenMP threads used (the contract's field); physical_cores = sockets x cores per socket from /proc/cpuinfo"},
             "sample": "same workload shape, %d session(s) x %d root rays (%.1f s of CPU work), OpenMP over rays" % (len(wls), per_wl, dt),
             "note": "kind=port: the reference's own CPU path (Simulator / CpuTraceBackend) needs spdlog + nlohmann-json >= 3.4, absent from this image, "
                     "and may not be built against stand-ins; this is the repo's C restatement of it (oracle/halo_oracle.c). Calibration of the real "
@@ -288,17 +335,66 @@ def pmc_traffic_per_launch(cfg):
     return tot if seen else None
 
 
+def _micro_costs_file():
+    """the committed output of tools/valu_rate_bench.hip: this round's, else the newest round present (instruction costs are a property of
+    the part, not of the tree; the file used is named in the line)"""
+    rounds = [PROFILE_ROUND] + ["r%02d" % k for k in range(int(PROFILE_ROUND[1:]) - 1, 0, -1)]
+    for r in rounds:
+        path = os.path.join(ROOT, "profiles", "%s_micro_valu_rate_bench.txt" % r)
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def _micro_costs():
     """SIMD cycles per wave64 instruction from the committed micro-benchmark output (profiles/<round>_micro_valu_rate_bench.txt,
     tools/valu_rate_bench.hip run on the GPU box): {instruction label: cycles}."""
-    path = os.path.join(ROOT, "profiles", "%s_micro_valu_rate_bench.txt" % PROFILE_ROUND)
+    path = _micro_costs_file()
     out = {}
-    if os.path.exists(path):
+    if path:
         for line in open(path):
             if "cycles per wave64 instruction" in line:
                 name = line[:38].strip()
                 out[name] = float(line.split("ms")[1].split("cycles")[0])
     return out
+
+
+PMC_PASSES = ("kernel_stats", "pmc_fetch_size", "pmc_write_size", "pmc_insts", "pmc_cycles", "pmc_classes", "pmc_wait")
+
+
+def _full_counters(cfg):
+    """BASELINE configurations carry the compute-side counter passes; the reference's documents only the kernel table and the HBM traffic pair"""
+    return not cfg.startswith("ref:")
+
+
+def profile_files_read(cfgs=None):
+    """every file under profiles/ that a default `python bench.py` run reads (repo-relative): the seven summaries per configuration of
+    tools/collect_profiles.sh and the micro-benchmark's output.  tests/test_bench_profiles.py fails when one is absent."""
+    cfgs = cfgs if cfgs is not None else ("1",) + OTHER_CONFIGS
+    out = ["profiles/%s_%s.txt" % (_profile_tag(c), p) for c in cfgs for p in (PMC_PASSES if _full_counters(c) else PMC_PASSES[:3])]
+    out.append("profiles/%s_micro_valu_rate_bench.txt" % PROFILE_ROUND)
+    return out
+
+
+def rocprof_kernel_avg(cfg, kernel="halo_trace_kernel"):
+    """(average, minimum, calls, average without the first call's share) in ms of the dominant trace kernel in the committed rocprofv3
+    --kernel-trace --stats summary of this configuration (profiles/<round>_bench<cfg>_kernel_stats.txt): the LAST listed instantiation with
+    the most total time, like _pmc_mean."""
+    path = os.path.join(ROOT, "profiles", _profile_tag(cfg) + "_kernel_stats.txt")
+    if not os.path.exists(path):
+        return None
+    best = None
+    for line in open(path):
+        if kernel in line and not line.startswith(" "):
+            f = line.rsplit(None, 6)
+            try:
+                calls, total, avg, mn, mx = int(f[1]), float(f[2]), float(f[3]), float(f[4]), float(f[5])
+            except (ValueError, IndexError):
+                continue
+            if best is None or total > best["total_us"]:
+                best = {"kernel": f[0].strip(), "calls": calls, "total_us": total, "avg_ms": avg / 1e3, "min_ms": mn / 1e3, "max_ms": mx / 1e3,
+                        "avg_ms_without_slowest_call": (total - mx) / max(calls - 1, 1) / 1e3, "file": "profiles/" + os.path.basename(path)}
+    return best
 
 
 def pmc_valu(cfg, rays_per_launch):
@@ -325,6 +421,8 @@ def pmc_valu(cfg, rays_per_launch):
     counts = {k: _pmc_mean(cls, "SQ_INSTS_VALU_" + k) for k in keys}
     total = _pmc_mean(cls, "SQ_INSTS_VALU")
     costs = _micro_costs()
+    if costs:
+        out["instruction_costs_file"] = "profiles/" + os.path.basename(_micro_costs_file())
     if total and all(v is not None for v in counts.values()) and costs:
         c = lambda name, default: costs.get(name, default)
         fma = c("v_fma_f32", 2.81)
@@ -463,18 +561,22 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
     dom_hits = pixel_hits - first_layer["hits"]
     dom_rays = (first_layer["cont"] if layers > 1 else rays_per_rank)
     avg_launch_s = dom_ms * 1e-3 / max(dom_launches, 1)
-    # ALGORITHMIC bytes: 3 ch x 4 B x (read + write) per in-frame pixel hit; a transit-source launch also
-    # reads its 20-byte continuation records (and the layer before wrote them: 20 B out + 20 B in per continuation);
-    # a shape-pool launch reads one sampled-crystal record per 32 rays (and the generator wrote it)
+    # ALGORITHMIC bytes (the fused definition): 3 ch x 4 B x (read + write) per in-frame pixel hit; a
+    # transit-source launch also reads its 20-byte continuation records (and the layer before wrote them: 20 B out + 20 B in per continuation).
+    # What a shape-pool launch moves for its sampled-crystal records (the generator writes one per 32 rays, the trace reads it) exists only
+    # because THIS design stages shapes through HBM: it is reported beside the roofline as design traffic, not priced as algorithmic.
     alg = dom_hits * 24.0
     if layers > 1:
         alg += dom_rays * 40.0
-    shape_bytes = None
-    if cfg in ("4", "4p"):
-        shape_bytes = shape_record_bytes(sc.layers[0].entries[0].crystal, prism_records=(cfg == "4"))
-        alg += dom_rays / 32.0 * (shape_bytes["written_by_generator"] + shape_bytes["read_by_trace_per_32_rays"])
+    shape_bytes, design = None, 0.0
+    if cfg in ("4", "4d", "4p"):
+        shape_bytes = shape_record_bytes(sc.layers[0].entries[0].crystal, prism_records=(cfg != "4p"))
+        design = dom_rays / 32.0 * (shape_bytes["written_by_generator"] + shape_bytes["read_by_trace_per_32_rays"])
     alg_per_launch = alg / max(dom_launches, 1)
+    design_per_launch = design / max(dom_launches, 1)
     achieved = alg_per_launch / max(avg_launch_s, 1e-12) / 1e9
+    valu = pmc_valu(cfg, dom_rays / max(dom_launches, 1)) if _full_counters(cfg) else None   # counters of the dominant layer's kernel (the last listed instantiation)
+    rp = rocprof_kernel_avg(cfg)
     total_rays_step = rays_per_rank_step * world
     out = {
         "metric": wk["metric"],
@@ -499,20 +601,31 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         "repeats": {"n": reps, "protocol": "reference doc/performance-testing.md:109-131 (>= 5 repeats, median + CoV); each repeat times exactly --steps steps",
                     "median_ms_per_step": dt * 1e3 / steps, "cov": cov,
                     "ms_per_step_all": [x * 1e3 / steps for x in times]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_per_launch(cfg),
+                     "priced_against": "hbm: achieved / peak / frac are the contract's HBM reading (algorithmic bytes per launch / the trace kernel's mean duration / 8 TB/s); `bound` names the roof that binds — VALU issue, see `binding`",
+                     "hbm_frac": achieved / HBM_PEAK_GBS,
+                     "binding": {"roof": "valu_issue", "frac": (valu or {}).get("issue_frac"),
+                                 "meaning": "share of the kernel's own duration that its VALU instruction stream needs at the per-class issue costs measured on this part (`valu`); ~0.9-1.0 = the SIMDs' issue slots are the limit, not memory"},
                      "traffic_source": "profiles/%s_pmc_{fetch,write}_size.txt (separate rocprofv3 --pmc passes of this command; bytes per launch group = sum over the trace kernel and its split / per-tile-sum passes of (2 x FETCH_SIZE + WRITE_SIZE) KB, per-dispatch means: gfx950 FETCH_SIZE counts half of coalesced reads, WRITE_SIZE uncalibrated)" % _profile_tag(cfg),
                      "kernel": wk["kernel"], "launches": dom_launches,
                      "avg_launch_ms": avg_launch_s * 1e3, "avg_launch_group_ms": group_ms / max(dom_launches, 1), "passes_ms_per_launch": post_ms / max(timed_launches, 1), "timed_launches": timed_launches,
                      "wall_ms_per_launch": dt * 1e3 / steps / max(dom_launches / (reps * steps), 1),
                      "algorithmic_bytes_per_launch": alg_per_launch,
+                     "design_bytes_per_launch": design_per_launch if shape_bytes else None,
+                     "frac_with_design_bytes": ((alg_per_launch + design_per_launch) / max(avg_launch_s, 1e-12) / 1e9 / HBM_PEAK_GBS) if shape_bytes else None,
                      "shape_record_bytes": shape_bytes,
                      "kernel_rays_per_s": dom_rays / max(dom_ms * 1e-3, 1e-12),
-                     "valu": pmc_valu(cfg, dom_rays / max(dom_launches, 1)),   # counters of the dominant layer's kernel (the last listed instantiation)
-                     "note": "avg_launch_ms = the trace kernel alone (HIP events on its stream; the rocprofv3 summary's average for that kernel is the same figure); its accumulation passes (split + per-tile sums) follow it on the same stream (avg_launch_group_ms = both spans added, wall_ms_per_launch = the timed region / launches: what is left over is the sampled-crystal generator, the closing fold and launch gaps). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation / shape records), so the path is VALU-issue-bound, not HBM-bound (see `valu`; DESIGN.md §4)"},
+                     "rocprof": None if rp is None else dict(rp, frac_at_rocprof_avg=alg_per_launch / (rp["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             frac_at_rocprof_avg_without_slowest_call=alg_per_launch / (rp["avg_ms_without_slowest_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             hip_events_over_rocprof_avg=avg_launch_s * 1e3 / rp["avg_ms"]),
+                     "valu": valu,
+                     "note": "avg_launch_ms = the trace kernel alone, HIP events on its stream inside THIS run's timed region (warm launches only). `rocprof` = the same kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (every call of a short profiled run, its first cold call included; kernels run a few per cent slower under the profiler): the two durations and both fractions are given, hip_events_over_rocprof_avg says by how much they differ. The kernel's accumulation passes (split + per-tile sums) follow it on the same stream (avg_launch_group_ms = both spans added, wall_ms_per_launch = the timed region / launches: what is left over is the sampled-crystal generator, the closing fold and launch gaps). The fused kernel keeps rays in registers: HBM sees hit records / accumulator RMWs (+ continuation records; + the sampled-crystal records of a shape-pool launch, reported as design_bytes_per_launch and NOT priced as algorithmic), so the path is VALU-issue-bound, not HBM-bound (DESIGN.md §4)"},
     }
     if out["roofline"]["traffic"]:
         out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / alg_per_launch
+        if shape_bytes:
+            out["roofline"]["traffic_over_algorithmic_plus_design"] = out["roofline"]["traffic"] / (alg_per_launch + design_per_launch)
     if layers > 1:
         traced = rays_per_rank + first_layer["cont"]
         out["multi_scatter"] = {"root_rays_per_s": out["value"], "traced_rays_per_s": traced / (reps * steps) * world / (dt / steps),
@@ -586,7 +699,7 @@ def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
     return out
 
 
-OTHER_CONFIGS = ("2", "4", "4p") + tuple("ref:" + n for n in REF_SCENES) + ("ref:config_example",)
+OTHER_CONFIGS = ("2", "4", "4d", "4p") + tuple("ref:" + n for n in REF_SCENES) + ("ref:config_example",)
 
 
 def self_launch(n):
@@ -614,7 +727,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="1", help="1 | 2 | 4 | 4p | ref:<document> (see the module docstring)")
+    ap.add_argument("--config", default="1", help="1 | 2 | 4 | 4d | 4p | ref:<document> (see the module docstring)")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (median reported)")
     ap.add_argument("--rays-per-wl", type=int, default=0, help="root rays per session per GPU per step (0 = the configuration's own)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: per-GPU work fixed; strong: the configuration's rays are the whole job")
@@ -656,12 +769,15 @@ def main():
     if args.config == "1" and world == 1 and not args.no_others and not args.rays_per_wl:
         others = {}
         for cfg in OTHER_CONFIGS:
-            r = measure(cfg, args, ctx, 3, 1, 1, with_cpu=False)
+            r = measure(cfg, args, ctx, 3, 1, 3, with_cpu=False)
             others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 1,
+                           "repeats": r["repeats"]["n"], "cov": r["repeats"]["cov"],
                            "workload": r["config"]["workload"], "resolution": r["config"]["resolution"], "exits_per_root": r["config"]["exits_per_root"],
                            "route": r["config"]["route"],
                            "roofline": {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "avg_launch_group_ms", "launches", "kernel_rays_per_s",
-                                                                                  "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch")}}
+                                                                                  "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch", "design_bytes_per_launch",
+                                                                                  "frac_with_design_bytes")}}
+            others[cfg]["roofline"]["valu_issue_frac"] = (r["roofline"].get("valu") or {}).get("issue_frac")
             if "multi_scatter" in r:
                 others[cfg]["multi_scatter"] = r["multi_scatter"]
         out["other_configs"] = others
