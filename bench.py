@@ -489,7 +489,7 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
             dist.barrier()
         torch.cuda.synchronize()
 
-    reduce_events = []                                       # (start, end) torch events around each step's collective, read after the timed region
+    reduce_events = []                                       # in-line mode only: (start, end) torch events around each step's collective on the trace stream
 
     def step():
         for wl in wls:
@@ -499,14 +499,14 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
                 first_layer["launches"] += st.launches
                 first_layer["hits"] += st.pixel_hits
                 first_layer["cont"] += st.continuation_count
-        if world > 1:
+        if world > 1 and not tracer.two:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            tracer.reduce_to_root()                          # one RCCL sum-reduce at the drain point
+            tracer.reduce_to_root()                          # one RCCL sum-reduce at the drain point, in line with the trace kernels
             e1.record()
             reduce_events.append((e0, e1))
         else:
-            tracer.reduce_to_root()
+            tracer.reduce_to_root()                          # N > 1: queued on the side stream, the next step traces into the other tensor (dist.ShardedTracer)
 
     for _ in range(warmup):
         step()
@@ -516,21 +516,53 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
     for k in first_layer:
         first_layer[k] = 0
     reduce_events.clear()
-    times = []
-    for _ in range(max(repeats, 1)):
+    del tracer.reduce_spans[:]
+
+    def timed_region():
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()                                           # dispatches are queued; nothing waits on the host per launch
+        if world > 1:
+            tracer._join()                                   # the last drains' collectives are part of the steps that queued them
         barrier()
         dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        times.append(float(t.item()))
+        return float(t.item())
+
+    # N > 1: which drain?  dist.ShardedTracer can queue the collective on a side stream (the next step traces into a second tensor meanwhile)
+    # or keep it in line.  The side stream wins when every rank has its own GPU and the collective is a device-side RCCL kernel; it LOSES in
+    # the one-GPU gloo rehearsal, where N processes with deep queues time-slice one device and every all_reduce needs all of them to get a
+    # turn (profiles/r06_gloo_rehearsal.txt).  So the mode is chosen by measurement, outside the timed region: two regions of each after the
+    # warm-up, the faster one ships (all ranks see the same MAX-reduced times, so they agree), and the line reports both.
+    drain_probe = None
+    if world > 1 and len(tracer.accs) == 2:
+        drain_probe = {}
+        for mode in (True, False):
+            tracer.set_overlap(mode)
+            drain_probe[mode] = min(timed_region() for _ in range(2))
+        tracer.set_overlap(drain_probe[True] <= 1.02 * drain_probe[False])
+        tracer.backend.collect_stats()
+        tracer.backend.collect_timing()
+        for k in first_layer:
+            first_layer[k] = 0
+        reduce_events.clear()
+        del tracer.reduce_spans[:]
+    times = [timed_region() for _ in range(max(repeats, 1))]
     trace_ms, post_ms, timed_launches = tracer.backend.collect_timing()   # HIP events of the LAST layer's launches: the trace kernels' own spans / their accumulation passes'
     st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
     route = tracer.backend.last_route()
+    overlap_ab = None
+    if drain_probe is not None:
+        spans = [a.elapsed_time(b) for a, b, _, _ in tracer.reduce_spans]
+        overlap_ab = {"drain_chosen": "side_stream" if tracer.two else "in_line",
+                      "probe_ms_per_step": {"side_stream": drain_probe[True] * 1e3 / steps, "in_line": drain_probe[False] * 1e3 / steps},
+                      "reduce_ms_events_mean": (sum(spans) / len(spans)) if spans else None, "reduces_timed": len(spans),
+                      "note": "probe = the faster of two untimed regions per mode, after the warm-up; `value` is measured in the chosen mode. reduce_ms: events on the "
+                              "side stream around the queued collective and the drain of the other ranks (under gloo with the side-stream drain the end event is "
+                              "recorded when this rank next needs the tensor)"}
     dt = statistics.median(times)
     cov = (statistics.pstdev(times) / statistics.mean(times)) if len(times) > 1 else 0.0
 
@@ -543,6 +575,8 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
 
     img, landed = tracer.readback()                          # collective: landed-weight scalars are summed here, once
     multi = certify_multi_gpu(ctx, tracer, wls[0], min(n, 4_000_000), reduce_events, dist_backend=ctx.get("dist_backend", "nccl")) if world > 1 else None
+    if multi is not None and overlap_ab is not None:
+        multi["reduce_overlap"] = overlap_ab
     tracer.backend.close()
     del tracer
     torch.cuda.empty_cache()
@@ -649,7 +683,7 @@ def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
     torch, dist = ctx["torch"], ctx["dist"]
     world, rank, local_rank = ctx["world"], ctx["rank"], ctx["local_rank"]
     torch.cuda.synchronize()
-    reduce_ms = [a.elapsed_time(b) for a, b in reduce_events]
+    reduce_ms = [a.elapsed_time(b) for a, b in reduce_events]   # the in-line pass's events (on the trace stream: they include the wait for the slowest rank)
     prop = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "name": prop.name,
           "uuid": str(getattr(prop, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0)),
@@ -670,9 +704,10 @@ def certify_multi_gpu(ctx, tracer, wl, n_check, reduce_events, dist_backend):
     me["check_landed"] = float(tracer.backend.take_landed())
     # ... then the collective, and what it leaves on the root
     tracer.reduce_to_root()
+    held = tracer.total()                                    # behind the queued reduce: the root's running total, nothing on the others
     torch.cuda.synchronize()
-    reduced_y = float(tracer.acc[: w * h * 3].double()[1::3].sum().item())
-    nonroot_drained = bool(rank == 0 or not tracer.acc.any().item())
+    reduced_y = float(held[: w * h * 3].double()[1::3].sum().item())
+    nonroot_drained = bool(rank == 0 or not held.any().item())
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(me, nonroot_drained=nonroot_drained))
     tracer.zero()

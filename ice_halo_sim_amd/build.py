@@ -61,7 +61,17 @@ def build(force=False, verbose=False):
         else:  # host tables must round like the reference's host build: no FMA contraction
             cmd = [cc, "-O2", "-ffp-contract=off", "-fno-fast-math", "-D__HIP_PLATFORM_AMD__"] + common + os.environ.get("HALO_DEFS", "").split()
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        # an object is rebuilt when it is missing, older than its source or a header it can see (the kernels' .inl only matters to the .hip
+        # translation units), or was made by another command line (flags, macros)
+        deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS if src.endswith(".hip") or not h.endswith(".inl")]
+        stamp = obj + ".cmd"
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) and \
+                all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            return src, obj, subprocess.CompletedProcess(cmd, 0, "", "")
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
         if src.endswith(".hip") and r.returncode == 0:
             with open(os.path.join(bdir, "resource_usage_%s.txt" % src.split(".")[0]), "w") as f:
                 f.write(r.stderr)

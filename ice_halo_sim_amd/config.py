@@ -66,11 +66,27 @@ def _canonical_sync_groups(groups, applicable):
     return out
 
 
+_atanf = None
+
+
 def _miller_to_alpha(i1, i4):
-    # MillerToAlpha, crystal_config.cpp:328-336 (i1 == 0 → default 28 degrees)
+    """MillerToAlpha, crystal_config.cpp:328-340 (i1 == 0 → default 28 degrees) — in FLOAT like the reference: its constants are float
+    literals, the products and quotients round to float one by one and the arctangent is libm's atanf.  (Evaluated in double and rounded at
+    the end, the (2,0,3) wedge came out one ulp above the reference's — found by tests/test_glue_mapping.py.)"""
+    global _atanf
     if i1 == 0:
         return 28.0
-    return math.degrees(math.atan(0.866025403784 * i4 / i1 / 1.629))
+    import ctypes
+    import numpy as np
+    f = np.float32
+    x = f(f(f(f(0.866025403784) * f(i4)) / f(i1)) / f(1.629))
+    if _atanf is None:
+        try:
+            _atanf = ctypes.CDLL("libm.so.6").atanf
+            _atanf.restype, _atanf.argtypes = ctypes.c_float, [ctypes.c_float]
+        except OSError:
+            _atanf = lambda v: float(np.arctan(f(v)))
+    return float(f(f(_atanf(float(x))) * f(57.2957795131)))
 
 
 def parse_crystal(j):

@@ -350,8 +350,8 @@ int reserve_idle(HaloBackend* b, DevBuf<T>& buf, size_t n, hipError_t* err = nul
   return HALO_OK;
 }
 
-// The cumulative landed tally up to here belongs to the image that is being left (rebinding, a re-sized owned image): whoever reads the NEW
-// accumulator must not be handed weight that landed in the old one and was never taken.
+// The cumulative landed tally up to here belongs to the OWNED image that is being left (re-sized: its light is discarded with it): whoever
+// reads the new image must not be handed weight that landed in the old one and was never taken.
 int take_landed_delta(HaloBackend* b, double* landed);
 int forget_landed(HaloBackend* b) {
   if (!b->tally.ptr) return HALO_OK;
@@ -694,8 +694,8 @@ int halo_bind_accumulator(halo_handle_t b, void* device_ptr, uint64_t n_floats) 
   if (!b) return HALO_FATAL;
   if (b->in_session) return fail(b, HALO_FATAL, "bind_accumulator inside a session");
   if (int rc = fold_if_dirty(b)) return rc;   // planes of ended sessions belong to the accumulator they were traced for
-  if ((device_ptr ? static_cast<float*>(device_ptr) : b->acc_own.ptr) != b->acc && b->acc != nullptr)
-    if (int rc = forget_landed(b)) return rc;   // ... and so does the weight that landed in it
+  // (The landed tally is NOT touched: it belongs to the sessions traced, and goes to whoever takes it — halo_take_landed, a readback — whichever
+  //  tensor holds their light.  A caller that alternates two bound tensors, dist.ShardedTracer's drain, rebinds with nothing waiting on the host.)
   if (!device_ptr) {
     b->acc = b->acc_own.ptr;
     b->acc_floats = b->acc_own.cap;

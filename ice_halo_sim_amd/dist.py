@@ -5,6 +5,8 @@ tensor (so torch.distributed — RCCL on ROCm, gloo in CPU tests — can reduce 
 Reference: there is no multi-GPU code in Lumice; the only reduction is N worker threads → one consumer
 (src/server/server.cpp:1189).  The drain point we reduce at is Simulator::DrainDeviceXyz (simulator.cpp:1409-1477).
 """
+import time
+
 import numpy as np
 
 
@@ -87,9 +89,15 @@ def reduce_class_lanes(lanes, total_intensity, group=None, dst=0, device=None):
 
 
 class ShardedTracer:
-    """One rank's slice of a trace job on one MI355X."""
+    """One rank's slice of a trace job on one MI355X.
 
-    def __init__(self, scene, render, seed=42, device=0, rank=0, world=1, **options):
+    The drain-point collective is OFF the critical path (round 6): the rank owns TWO accumulator tensors.  reduce_to_root() queues the reduce
+    of the tensor just traced into on a side stream (behind everything the trace stream holds for it) and binds the other tensor, so step
+    k + 1's sessions trace while step k's image crosses xGMI; a tensor is traced into again only behind the reduce that last read it (an
+    event wait on the stream, never the host).  On the root the two tensors hold the running totals of the even and the odd drains: the image
+    is their sum (total(), readback()).  With one rank there is no collective and one tensor."""
+
+    def __init__(self, scene, render, seed=42, device=0, rank=0, world=1, overlap_reduce=True, **options):
         import torch
         from .backend import HipTraceBackend
         self.torch = torch
@@ -99,13 +107,25 @@ class ShardedTracer:
         self.backend = HipTraceBackend(device=device, seed=seed, **options)
         self.backend.set_option("rank", rank)      # disjoint 64-bit RNG counter range per shard
         self.n_floats = render.width * render.height * 3 + 4
-        self.acc = torch.zeros(self.n_floats, dtype=torch.float32, device=self.device)
+        self.two = bool(overlap_reduce) and world > 1
+        self.accs = [torch.zeros(self.n_floats, dtype=torch.float32, device=self.device) for _ in range(2 if self.two else 1)]
+        self.cur = 0
+        self.side = torch.cuda.Stream(device=self.device) if world > 1 else None
+        self.reduced = [None] * len(self.accs)      # event behind the last reduce (and drain) of each tensor, on the side stream
+        self.pending = [None] * len(self.accs)      # (work, start event, host time) of a queued reduce whose completion has not been ordered yet
+        self.reduce_spans = []                      # (start event, end event, host t_call, host t_completed) of every reduce, events ON THE SIDE STREAM
+        self.reduce_log = []                        # host times of every queued reduce: {"t_call", "t_done"}
         self.backend.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
         # the accumulator is this object's tensor: it reads it only at the drain points below, so a session's closing fold may stay pending at
         # EndSession and run under the next session's trace kernels (flush() brings the tensor up to date before anything here touches it)
         self.backend.set_option("defer_fold", 1)
         self.landed = 0.0
+
+    @property
+    def acc(self):
+        """the tensor the backend is tracing into"""
+        return self.accs[self.cur]
 
     def trace_session_layers(self, wl, n_rays, shuffle=True):
         """BeginSession → layers → EndSession for this rank's `n_rays` roots. Returns every layer's stats (with option async=1
@@ -126,14 +146,100 @@ class ShardedTracer:
         return self.trace_session_layers(wl, n_rays, shuffle)[-1]
 
     def reduce_to_root(self):
-        """The drain-point collective: ONE sum-reduce of the image accumulator, enqueued on the stream behind this rank's
-        trace kernels; non-root ranks are drained.  The landed-weight scalars stay on their devices until readback()."""
+        """The drain-point collective: ONE sum-reduce of the image accumulator, queued behind this rank's trace kernels; non-root ranks
+        are drained.  With two tensors it runs on the side stream while the backend goes on tracing into the other one.  The landed-weight
+        scalars stay on their devices until readback()."""
+        torch = self.torch
+        self.backend.flush()                          # the pending planes belong to the tensor that is about to leave
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        main = torch.cuda.current_stream(self.device)
+        k = self.cur
+        buf = self.accs[k]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)
+        gloo = dist.get_backend() == "gloo"
+        with torch.cuda.stream(self.side):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.side)
+            # async_op: under gloo (the one-GPU rehearsal: device -> host -> TCP -> device on gloo's own threads) a blocking call would hold
+            # THIS thread until the image is back, and nothing of the next step could be queued; under RCCL the call never blocks the host
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True) if gloo else dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        self.pending[k] = (work, e0, time.perf_counter())
+        # when the collective really ended, whenever this thread next looks (gloo completes lazily, below): its future's callback stamps the host time
+        idx = len(self.reduce_log)
+        self.reduce_log.append({"t_call": time.perf_counter(), "t_done": None})
+        try:
+            work.get_future().add_done_callback(lambda f, i=idx: self.reduce_log[i].__setitem__("t_done", time.perf_counter()))
+        except Exception:   # a backend without futures: the spans' events still say what happened
+            pass
+        if not self.two:
+            # serialised drain (overlap_reduce=False, bench.py's A/B): the same queue, but the trace stream waits for the collective before anything else
+            self._complete(k)
+            main.wait_event(self.reduced[k])
+            return
+        if not gloo:
+            self._complete(k)                         # RCCL: wait() only orders streams — the side stream behind the collective, the drain behind that
+        self.cur ^= 1
+        self._complete(self.cur)                      # the tensor about to be traced into: its last reduce (two drains ago) must be through
+        if self.reduced[self.cur] is not None:
+            main.wait_event(self.reduced[self.cur])
+        self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
+
+    def _complete(self, k):
+        """finish the queued reduce of tensor k: the side stream waits for the collective (gloo: so does this thread), the other ranks' copy
+        is drained, and the event later users of the tensor wait for is recorded"""
+        if self.pending[k] is None:
+            return
+        work, e0, t_call = self.pending[k]
+        self.pending[k] = None
+        torch = self.torch
+        import torch.distributed as dist
+        with torch.cuda.stream(self.side):
+            work.wait()
+            if dist.get_rank() != 0:
+                self.accs[k].zero_()
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.side)
+        self.reduced[k] = e1
+        self.reduce_spans.append((e0, e1, t_call, time.perf_counter()))
+
+    def _join(self):
+        """the current stream waits for every queued reduce"""
+        main = self.torch.cuda.current_stream(self.device)
+        for k in range(len(self.accs)):
+            self._complete(k)
+            if self.reduced[k] is not None:
+                main.wait_event(self.reduced[k])
+
+    def set_overlap(self, on):
+        """switch the drain between the side-stream reduce (two tensors) and the in-line one (what round 5 shipped) — bench.py times both"""
+        if len(self.accs) < 2:
+            return
+        self._join()
+        if self.cur != 0:                             # in-line mode keeps everything in tensor 0
+            self.backend.flush()
+            self.accs[0] += self.accs[1]
+            self.accs[1].zero_()
+            self.cur = 0
+            self.backend.bind_accumulator(self.acc.data_ptr(), self.n_floats)
+        self.two = bool(on)
+
+    def total(self):
+        """The image this rank holds (root: the reduced running total; others: what they have traced since their last drain), as a
+        tensor of n_floats — behind the pending folds and every queued reduce."""
         self.backend.flush()
-        self.acc = reduce_image(self.acc)
+        self._join()
+        return self.accs[0].clone() if len(self.accs) == 1 else self.accs[0] + self.accs[1]
 
     def zero(self):
         self.backend.take_landed()
-        self.acc.zero_()
+        self.backend.flush()
+        self._join()
+        for a in self.accs:
+            a.zero_()
         self.landed = 0.0
         self.torch.cuda.synchronize(self.device)
 
@@ -142,7 +248,7 @@ class ShardedTracer:
         left drained."""
         self.landed = reduce_scalar(self.landed + self.backend.take_landed(), self.device)
         w, h = self.render.width, self.render.height
-        img = self.acc[: w * h * 3].cpu().numpy().reshape(h, w, 3).copy()
+        img = self.total()[: w * h * 3].cpu().numpy().reshape(h, w, 3).copy()
         landed = self.landed
         self.zero()
         return img, landed

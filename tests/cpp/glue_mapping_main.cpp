@@ -1,0 +1,277 @@
+// Build-container-only driver (tools/glue_mapping_build.sh; tests/test_glue_mapping.py): EXECUTES the field mapping of
+// integration/hip_backend_glue.hpp — hip_glue::ToHalo(SceneConfig / RenderConfig / FilterConfig / CrystalParam / AxisDistribution / colour
+// tables) — on scenes built programmatically from the reference's own config structs, the way /root/reference/test/cpu_test_helpers.hpp:26-68
+// builds its scenes, and prints the resulting Halo* structs byte for byte (hex, one JSON line per scene).  The test compares them with what
+// ice_halo_sim_amd/config.py makes of the equivalent JSON document: a field the glue swaps, drops or mis-scales shows up as differing bytes.
+// The struct VALUES below are what the reference's from_json leaves in its structs for those documents (zenith -> latitude = 90 - zenith,
+// canonical sync groups with members carrying their leader's distribution, Miller indices resolved to wedge angles, symmetry letters as
+// bits): the JSON readers themselves cannot be compiled here (nlohmann-json >= 3.4 is absent) and are not what this checks.
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "core/backend/hip_backend_glue.hpp"
+
+using namespace lumice;
+
+namespace {
+std::string Hex(const void* p, size_t n) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; i++) {
+    s.push_back(d[b[i] >> 4]);
+    s.push_back(d[b[i] & 15]);
+  }
+  return s;
+}
+Distribution D(DistributionType t, float c, float s) { return Distribution{ t, c, s }; }
+Distribution Fixed(float v) { return D(DistributionType::kNoRandom, v, 0.0f); }
+const auto kU = DistributionType::kUniform;
+const auto kG = DistributionType::kGaussian;
+
+// axis as from_json(AxisDistribution&) leaves it for {"zenith": z, ["azimuth": a], ["roll": r]} (math.cpp:693-726)
+AxisDistribution Axis(Distribution zenith, Distribution az = D(kU, 0.0f, 360.0f), Distribution roll = D(kU, 0.0f, 360.0f)) {
+  AxisDistribution a;
+  a.latitude_dist = zenith;
+  a.latitude_dist.center = 90.0f - zenith.center;
+  a.azimuth_dist = az;
+  a.roll_dist = roll;
+  return a;
+}
+// what from_json leaves in wedge_angle_* for Miller indices (crystal_config.cpp:328-340): float throughout, and evaluated at RUN time there
+// (libm's atanf on the document's integers) — the volatile keeps the compiler from folding the call here with its own, correctly rounded,
+// arctangent, which is one ulp away for (2, 0, 3)
+float MillerToAlpha(volatile int i1, volatile int i4) {
+  if (i1 == 0) return 28.0f;
+  return std::atan(0.866025403784f * static_cast<float>(i4) / static_cast<float>(i1) / 1.629f) * 57.2957795131f;
+}
+PrismCrystalParam Prism(float h) {
+  PrismCrystalParam p;
+  p.h_ = Fixed(h);
+  for (auto& d : p.d_) d = Fixed(1.0f);
+  return p;
+}
+ScatteringSetting Setting(IdType crystal_id, CrystalParam param, AxisDistribution axis, float proportion, FilterConfig filter = FilterConfig{}) {
+  ScatteringSetting s;
+  s.crystal_.id_ = crystal_id;
+  s.crystal_.param_ = std::move(param);
+  s.crystal_.axis_ = axis;
+  s.crystal_proportion_ = proportion;
+  s.filter_ = std::move(filter);
+  return s;
+}
+SceneConfig Scene(size_t max_hits, float alt, float az, float diameter) {
+  SceneConfig s;
+  s.ray_num_ = 1000;
+  s.max_hits_ = max_hits;
+  s.light_source_.param_ = SunParam{ alt, az, diameter };
+  s.light_source_.spectrum_ = std::vector<WlParam>{ { 550.0f, 1.0f } };
+  return s;
+}
+FilterConfig Simple(IdType id, SimpleFilterParam p, uint8_t sym, FilterConfig::Action act = FilterConfig::kFilterIn) {
+  FilterConfig f{};
+  f.id_ = id;
+  f.symmetry_ = sym;
+  f.action_ = act;
+  f.param_ = std::move(p);
+  return f;
+}
+
+void Emit(const char* name, const SceneConfig& sc, const RaypathColorConfig* color, const std::vector<RenderConfig>& renders) {
+  const hip_glue::SceneTables t = hip_glue::ToHalo(sc, color);
+  std::printf("{\"name\": \"%s\", \"representable\": %s, \"scene\": \"%s\", \"entries\": [", name, t.representable ? "true" : "false", Hex(&t.scene, sizeof(HaloScene)).c_str());
+  bool first = true;
+  for (int l = 0; l < t.scene.layer_count; l++)
+    for (int e = 0; e < t.scene.layers[l].entry_count; e++) {
+      const HaloEntry& he = t.scene.layers[l].entries[e];
+      std::printf("%s{\"layer\": %d, \"entry\": %d, \"filter\": \"%s\", \"color\": \"%s\"}", first ? "" : ", ", l, e,
+                  he.filter_id > 0 ? Hex(&t.filters[static_cast<size_t>(he.filter_id - 1)], sizeof(HaloFilter)).c_str() : "",
+                  he.color_id > 0 ? Hex(&t.color_sets[static_cast<size_t>(he.color_id - 1)], sizeof(HaloColorSet)).c_str() : "");
+      first = false;
+    }
+  std::printf("], \"classes\": [");
+  for (size_t c = 0; c < t.color_classes.size(); c++) std::printf("%s\"%s\"", c ? ", " : "", Hex(&t.color_classes[c], sizeof(HaloColorClass)).c_str());
+  std::printf("], \"renders\": [");
+  for (size_t r = 0; r < renders.size(); r++) {
+    const HaloRender hr = hip_glue::ToHalo(renders[r]);
+    std::printf("%s\"%s\"", r ? ", " : "", Hex(&hr, sizeof(HaloRender)).c_str());
+  }
+  std::printf("]}\n");
+}
+
+RenderConfig Render(IdType id, LensParam::LensType lens, float fov, int w, int h, float az, float el, float ro, RenderConfig::VisibleRange vis, float overlap = 0.0f, int sx = 0,
+                    int sy = 0) {
+  RenderConfig r;
+  r.id_ = id;
+  r.lens_.type_ = lens;
+  r.lens_.fov_ = fov;
+  r.resolution_[0] = w;
+  r.resolution_[1] = h;
+  r.lens_shift_[0] = sx;
+  r.lens_shift_[1] = sy;
+  r.view_.az_ = az;
+  r.view_.el_ = el;
+  r.view_.ro_ = ro;
+  r.visible_ = vis;
+  r.overlap_ = overlap;
+  return r;
+}
+}  // namespace
+
+int main() {
+  // 1. configs[1]'s column, one layer; every lens type among the renders (distinct view angles, shifts, visible ranges, an overlap)
+  {
+    SceneConfig sc = Scene(7, 20.0f, 0.0f, 0.5f);
+    MsInfo ms;
+    ms.prob_ = 0.0f;
+    ms.setting_.push_back(Setting(3, Prism(1.3f), Axis(D(kG, 90.0f, 0.3f)), 10.0f));
+    sc.ms_.push_back(ms);
+    std::vector<RenderConfig> rs;
+    const LensParam::LensType lenses[11] = { LensParam::kLinear, LensParam::kFisheyeEqualArea, LensParam::kFisheyeEquidistant, LensParam::kFisheyeStereographic,
+                                             LensParam::kDualFisheyeEqualArea, LensParam::kDualFisheyeEquidistant, LensParam::kDualFisheyeStereographic, LensParam::kRectangular,
+                                             LensParam::kFisheyeOrthographic, LensParam::kDualFisheyeOrthographic, LensParam::kGlobe };
+    for (int i = 0; i < 11; i++)
+      rs.push_back(Render(static_cast<IdType>(i + 1), lenses[i], 40.0f + 5.0f * static_cast<float>(i), 640 + 16 * i, 360 + 8 * i, 10.0f * static_cast<float>(i), 5.0f + static_cast<float>(i),
+                          i == 0 ? 0.0f : -3.0f * static_cast<float>(i), i % 3 == 0 ? RenderConfig::kUpper : i % 3 == 1 ? RenderConfig::kLower : RenderConfig::kFull, i == 4 ? 0.25f : 0.0f, i, -2 * i));
+    Emit("prism_all_lenses", sc, nullptr, rs);
+  }
+  // 2. pyramid with Miller wedges and stochastic face distances, full-sphere axis (configs[4p]'s crystal); sun off the meridian
+  {
+    SceneConfig sc = Scene(8, 35.0f, 120.0f, 1.0f);
+    PyramidCrystalParam p;
+    p.h_pyr_u_ = Fixed(0.1f);
+    p.h_prs_ = Fixed(1.2f);
+    p.h_pyr_l_ = Fixed(0.5f);
+    for (auto& d : p.d_) d = D(kG, 1.0f, 0.15f);
+    p.wedge_angle_u_ = MillerToAlpha(2, 3);
+    p.wedge_angle_l_ = MillerToAlpha(1, 1);
+    MsInfo ms;
+    ms.prob_ = 0.0f;
+    ms.setting_.push_back(Setting(5, p, Axis(D(kU, 0.0f, 360.0f)), 100.0f));
+    sc.ms_.push_back(ms);
+    Emit("pyramid_miller_stochastic", sc, nullptr, { Render(1, LensParam::kRectangular, 0.0f, 2048, 1024, 0.0f, 0.0f, 0.0f, RenderConfig::kFull) });
+  }
+  // 3. sync groups: prism height + faces in two groups (members carry their leader's distribution, crystal_config.cpp:102-133), a pyramid whose
+  //    three heights share one draw; explicit wedge angles; a laplacian / zigzag / legacy-gauss axis
+  {
+    SceneConfig sc = Scene(5, 10.0f, 0.0f, 0.5f);
+    PrismCrystalParam a;
+    a.h_ = D(kG, 1.2f, 0.1f);
+    a.d_[0] = a.d_[1] = D(kG, 1.0f, 0.1f);
+    a.d_[2] = a.d_[3] = D(kU, 1.0f, 0.2f);
+    a.d_[4] = Fixed(0.9f);
+    a.d_[5] = Fixed(1.0f);
+    a.sync_group_[kShapeScalarFace0] = a.sync_group_[kShapeScalarFace1] = 1;
+    a.sync_group_[kShapeScalarFace2] = a.sync_group_[kShapeScalarFace3] = 2;
+    PyramidCrystalParam b;
+    b.h_pyr_u_ = b.h_prs_ = b.h_pyr_l_ = D(kU, 0.4f, 0.2f);
+    b.sync_group_[kShapeScalarUpperH] = b.sync_group_[kShapeScalarPrismH] = b.sync_group_[kShapeScalarLowerH] = 1;
+    for (auto& d : b.d_) d = Fixed(1.0f);
+    b.wedge_angle_u_ = 31.5f;
+    b.wedge_angle_l_ = 24.25f;
+    MsInfo ms;
+    ms.prob_ = 0.0f;
+    ms.setting_.push_back(Setting(1, a, Axis(D(DistributionType::kLaplacian, 30.0f, 2.0f), D(DistributionType::kZigzag, 10.0f, 20.0f), Fixed(15.0f)), 2.0f));
+    ms.setting_.push_back(Setting(2, b, Axis(D(DistributionType::kGaussianLegacy, 80.0f, 5.0f), D(kG, 45.0f, 3.0f), D(kU, 30.0f, 60.0f)), 3.0f));
+    sc.ms_.push_back(ms);
+    Emit("sync_groups_and_axes", sc, nullptr, { Render(2, LensParam::kLinear, 60.0f, 800, 600, 0.0f, 20.0f, 0.0f, RenderConfig::kUpper) });
+  }
+  // 4. every filter term kind, symmetries, filter_out, entry/exit wildcards and bounds — three layers (prob 0.6, 0.25, 0), several entries
+  {
+    SceneConfig sc = Scene(9, 25.0f, 0.0f, 0.5f);
+    const AxisDistribution col = Axis(D(kG, 90.0f, 0.5f));
+    const AxisDistribution plate = Axis(D(kG, 0.0f, 1.0f));
+    MsInfo l0, l1, l2;
+    l0.prob_ = 0.6f;
+    l0.setting_.push_back(Setting(1, Prism(1.5f), col, 1.0f, Simple(1, RaypathFilterParam{ { 3, 5 } }, FilterConfig::kSymP)));
+    EntryExitFilterParam ee;
+    ee.entry_ = 1;
+    ee.exit_ = 3;
+    ee.min_len_ = 2;
+    ee.max_len_ = 5;
+    l0.setting_.push_back(Setting(2, Prism(0.3f), plate, 2.5f, Simple(2, ee, FilterConfig::kSymP | FilterConfig::kSymB | FilterConfig::kSymD)));
+    l0.setting_.push_back(Setting(7, Prism(1.0f), col, 0.5f));   // pass-all: no filter slot
+    l1.prob_ = 0.25f;
+    l1.setting_.push_back(Setting(1, Prism(1.5f), col, 1.0f, Simple(3, DirectionFilterParam{ 180.0f, 20.0f, 2.0f }, FilterConfig::kSymNone, FilterConfig::kFilterOut)));
+    EntryExitFilterParam wild;   // exit only, no upper bound
+    wild.exit_ = 8;
+    wild.min_len_ = 1;
+    l1.setting_.push_back(Setting(2, Prism(0.3f), plate, 1.0f, Simple(4, wild, FilterConfig::kSymB)));
+    l2.prob_ = 0.0f;
+    l2.setting_.push_back(Setting(1, Prism(1.5f), col, 1.0f, Simple(5, CrystalFilterParam{ 2 }, FilterConfig::kSymNone, FilterConfig::kFilterOut)));
+    sc.ms_ = { l0, l1, l2 };
+    Emit("filter_terms_three_layers", sc, nullptr, { Render(1, LensParam::kDualFisheyeEqualArea, 180.0f, 1024, 512, 0.0f, 90.0f, 0.0f, RenderConfig::kFull, 0.1f) });
+  }
+  // 5. complex filters: OR of AND-lists over simple terms (ids 1..4), symmetry on the complex filter itself, one filter_out
+  {
+    SceneConfig sc = Scene(8, 20.0f, 0.0f, 0.5f);
+    const SimpleFilterParam t1 = RaypathFilterParam{ { 1, 3, 2 } };
+    EntryExitFilterParam e1;
+    e1.entry_ = 1;
+    e1.min_len_ = 1;
+    const SimpleFilterParam t2 = e1;
+    const SimpleFilterParam t3 = CrystalFilterParam{ 3 };
+    const SimpleFilterParam t4 = RaypathFilterParam{ { 3, 1, 5, 7, 4 } };
+    ComplexFilterParam cx;
+    cx.filters_ = { { { 1, t1 } }, { { 2, t2 }, { 3, t3 } }, { { 4, t4 } } };
+    FilterConfig f{};
+    f.id_ = 10;
+    f.symmetry_ = FilterConfig::kSymP | FilterConfig::kSymB | FilterConfig::kSymD;
+    f.action_ = FilterConfig::kFilterIn;
+    f.param_ = cx;
+    ComplexFilterParam cy;
+    cy.filters_ = { { { 2, t2 }, { 1, t1 } }, { { 3, t3 } } };
+    FilterConfig g{};
+    g.id_ = 11;
+    g.symmetry_ = FilterConfig::kSymD;
+    g.action_ = FilterConfig::kFilterOut;
+    g.param_ = cy;
+    MsInfo ms;
+    ms.prob_ = 0.0f;
+    ms.setting_.push_back(Setting(3, Prism(1.3f), Axis(D(kG, 90.0f, 0.3f)), 10.0f, f));
+    ms.setting_.push_back(Setting(6, Prism(0.3f), Axis(D(kG, 0.0f, 0.8f)), 4.0f, g));
+    sc.ms_.push_back(ms);
+    Emit("complex_filters", sc, nullptr, { Render(4, LensParam::kFisheyeEqualArea, 120.0f, 1920, 1080, 0.0f, 30.0f, 0.0f, RenderConfig::kUpper) });
+  }
+  // 6. raypath colour: two layers, classes with any / all, predicates with symmetry, a whole-crystal (match-all) member, one predicate shared
+  //    by two classes (one bit), a class over two placements
+  {
+    SceneConfig sc = Scene(7, 20.0f, 0.0f, 0.5f);
+    MsInfo l0, l1;
+    l0.prob_ = 0.5f;
+    l0.setting_.push_back(Setting(1, Prism(1.4f), Axis(D(kG, 90.0f, 0.4f)), 1.0f));
+    l0.setting_.push_back(Setting(2, Prism(0.25f), Axis(D(kG, 0.0f, 1.0f)), 1.0f));
+    l1.prob_ = 0.0f;
+    l1.setting_.push_back(Setting(1, Prism(1.4f), Axis(D(kG, 90.0f, 0.4f)), 1.0f));
+    sc.ms_ = { l0, l1 };
+    RaypathColorConfig rc;
+    auto ref = [](IdType layer, IdType crystal, SimpleFilterParam p, uint8_t sym) {
+      RaypathColorRef r;
+      r.layer_ = layer;
+      r.crystal_ = crystal;
+      r.predicate_ = std::move(p);
+      r.symmetry_ = sym;
+      return r;
+    };
+    EntryExitFilterParam ee;
+    ee.entry_ = 3;
+    ee.exit_ = 5;
+    ee.min_len_ = 2;
+    ee.max_len_ = 4;
+    ColorClassConfig c0, c1, c2;
+    c0.color_[0] = 1.0f;
+    c0.combine_ = "any";
+    c0.match_ = { ref(0, 1, RaypathFilterParam{ { 3, 5 } }, FilterConfig::kSymP), ref(1, 1, ee, FilterConfig::kSymP | FilterConfig::kSymB) };
+    c1.color_[1] = 1.0f;
+    c1.combine_ = "all";
+    c1.match_ = { ref(0, 1, RaypathFilterParam{ { 3, 5 } }, FilterConfig::kSymP), ref(0, 2, NoneFilterParam{}, FilterConfig::kSymNone) };
+    c2.color_[2] = 1.0f;
+    c2.combine_ = "any";
+    c2.match_ = { ref(0, 2, DirectionFilterParam{ 0.0f, 22.0f, 3.0f }, FilterConfig::kSymNone) };
+    rc.classes_ = { c0, c1, c2 };
+    Emit("raypath_color_two_layers", sc, &rc, { Render(1, LensParam::kFisheyeEqualArea, 180.0f, 512, 256, 0.0f, 30.0f, 0.0f, RenderConfig::kUpper) });
+  }
+  return 0;
+}

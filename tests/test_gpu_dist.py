@@ -68,6 +68,70 @@ def test_two_ranks_on_one_gpu_reduce_to_the_sum_of_their_images(tmp_path):
     assert own[0].sum(dtype=np.float64) == pytest.approx(own[1].sum(dtype=np.float64), rel=5e-3)
 
 
+# ---- the drain off the critical path: several steps, reduce on the side stream into alternating tensors == reduce in line ---------------------
+def _worker_steps(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from ice_halo_sim_amd.dist import ShardedTracer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc, rd = scenes.config2_scene(), scenes.config2_render(W, H)
+    steps = [(scenes.wl_discrete(530.0), scenes.wl_discrete(610.0 + 10.0 * k)) for k in range(5)]   # an odd count: the root's light ends up spread over BOTH tensors
+    out = {}
+    for tag, overlap in (("side", True), ("inline", False)):
+        tr = ShardedTracer(sc, rd, seed=42, device=0, rank=rank, world=world, overlap_reduce=overlap, **{"async": 1})
+        assert tr.two == overlap and len(tr.accs) == (2 if overlap else 1)
+        for wls in steps:
+            for wl in wls:
+                tr.trace_session_layers(wl, N)
+            tr.reduce_to_root()                                  # nothing is read between the steps
+        assert len(tr.reduce_log) == 5 and tr.cur == (1 if overlap else 0)
+        img, landed = tr.readback()
+        assert not any(a.any().item() for a in tr.accs)         # readback leaves every tensor drained
+        out[tag] = (img, landed)
+        tr.backend.close()
+    # the truth both are held to: every rank's shard traced alone (no collective anywhere near it), the images added on the host
+    truth = np.zeros(W * H * 3, np.float64)
+    for r in range(world):
+        t1 = ShardedTracer(sc, rd, seed=42, device=0, rank=r, world=1, **{"async": 1})
+        for wls in steps:
+            for wl in wls:
+                t1.trace_session_layers(wl, N)
+        t1.backend.flush()
+        torch.cuda.synchronize()
+        truth += t1.acc[: W * H * 3].cpu().numpy().astype(np.float64)
+        t1.backend.close()
+    np.save(os.path.join(out_dir, "truth%d.npy" % rank), truth)
+    np.save(os.path.join(out_dir, "side%d.npy" % rank), out["side"][0].ravel())
+    np.save(os.path.join(out_dir, "inline%d.npy" % rank), out["inline"][0].ravel())
+    np.save(os.path.join(out_dir, "landed%d.npy" % rank), np.array([out["side"][1], out["inline"][1]], np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_drain_on_the_side_stream_equals_the_in_line_drain_over_several_steps(tmp_path):
+    """dist.ShardedTracer's two accumulator tensors (round 6): five steps of two sessions each, every step closed by reduce_to_root with
+    nothing read in between — once with the collective queued on the side stream while the next step traces into the other tensor, once
+    serialised (the trace stream waits for every collective).  Both are held to the TRUTH: each rank's shard traced alone, with no
+    collective, and the images added on the host.  Same rays (rank-offset counters, same seed), so the root's image is that sum taken in
+    another order, the landed weight is equal, and the other rank holds nothing."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_steps, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    side = [np.load(tmp_path / ("side%d.npy" % r)) for r in range(2)]
+    inline = [np.load(tmp_path / ("inline%d.npy" % r)) for r in range(2)]
+    landed = [np.load(tmp_path / ("landed%d.npy" % r)) for r in range(2)]
+    truth = np.load(tmp_path / "truth0.npy")
+    assert truth.sum() > 0
+    for name, img in (("side stream", side[0]), ("serialised", inline[0])):
+        assert np.abs(img - truth).max() <= 2e-6 * float(truth.max()), name       # float sums in another order
+        assert img.sum(dtype=np.float64) == pytest.approx(truth.sum(), rel=1e-6), name
+    assert landed[0][0] == pytest.approx(landed[0][1], rel=1e-9) and landed[0][0] > 0
+    assert not side[1].any() and not inline[1].any() and landed[1][0] == 0.0 and landed[1][1] == 0.0
+
+
 # ---- raypath-colour job over two ranks: lanes reduced, ONE composite on the root's device (ShardedTracer.composite) ---------------------
 def _colour_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

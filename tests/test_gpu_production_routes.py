@@ -206,6 +206,36 @@ def test_stochastic_pool_production_kernels_vs_oracle(case):
     print("%s: block-mean rel L2 %.2e" % (case, err))
 
 
+def test_bench_config_4d_discrete_31_entry_spectrum_at_its_own_launch_size():
+    """bench.py --config 4d — the PRIMARY reading of BASELINE configs[4]'s "31 wavelengths" (SURVEY.md 8(d) item 5): a discrete 31-entry
+    spectrum 380..780 nm weighted by the D65 SPD, one session per entry, ceil(25 M / 31) = 806 452 roots each, stochastic prism, full sky.
+    The workload object is bench.py's own.  Seven of its 31 sessions (every fifth wavelength: both ends, the SPD's peak, weights from 49.98
+    to 117.8) run back to back at THEIR launch size on the route the backend picks for them — sampled-prism pool (GEOM 2), scalar plane of a
+    discrete wavelength, direct atomics (launches under 2 Mi rays stay off the hit log) — and the image, landed weight and exit count are
+    the oracle's for the same seeded rays and the same per-session weights."""
+    import bench
+    wk = bench.workload("4d")
+    assert len(wk["wls"]) == 31 and wk["rays"] == -(-25_000_000 // 31)
+    ws = [w.weight for w in wk["wls"]]
+    assert wk["wls"][0].wavelength == 380.0 and wk["wls"][30].wavelength == pytest.approx(780.0) and min(ws) > 20.0 and max(ws) < 130.0   # D65 SPD, not ones
+    sc, rd, n = wk["scene"], wk["render"], wk["rays"]
+    pick = wk["wls"][::5]
+    hb, ob = hip_backend(seed=61, **{"async": 1}), OracleBackend(seed=61, threads=THREADS, acc64=1)
+    exits_h = exits_o = 0
+    for wl in pick:
+        run_session(hb, sc, rd, wl, n)        # queued: nothing is read between the sessions (what bench.py and the Lumice glue do)
+        exits_o += run_session(ob, sc, rd, wl, n)[0].exit_count
+    exits_h = hb.collect_stats().exit_count
+    route = hb.last_route()
+    hip, ora = hb.ReadbackXyzAccum(), ob.ReadbackXyzAccum()
+    hb.close(), ob.close()
+    assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, 1 << 2, abi.ACCUM_SCALAR), (route.mode_mask, route.geom_mask, route.accum_mask)
+    assert route.plane_cnt == 1
+    assert exits_h == pytest.approx(exits_o, rel=1e-4)
+    err = _check_single_layer(hip, ora)
+    print("config 4d, 7 of 31 sessions x %d rays: block-mean rel L2 %.2e" % (n, err))
+
+
 def _pearson_blocks(a, b, k=4):
     x, y = block_mean(a, k).ravel().astype(np.float64), block_mean(b, k).ravel().astype(np.float64)
     return float(np.corrcoef(x, y)[0, 1])

@@ -13,6 +13,7 @@ print(json.dumps({k:d[k] for k in ('metric','value','unit','n_gpus','steps','ms_
 print('  ranks_seen', m['ranks_seen'], 'backend', m['backend'], 'distinct_devices', m['distinct_devices'], 'reduce_floats', m['reduce_floats'], 'reduce_ms_mean_over_ranks %.3f' % m['reduce_ms_mean_over_ranks'])
 for r in m['ranks']: print('  rank', r['rank'], 'local', r['local_rank'], 'dev', r['device_index'], r['name'], 'uuid', r['uuid'], 'pci', r['pci'], 'pid', r['pid'], 'reduce_ms mean %.3f max %.3f (%d timed)' % (r['reduce_ms_mean'], r['reduce_ms_max'], r['reduces_timed']), 'check sumY %.6g landed %.6g' % (r['check_sum_y'], r['check_landed']))
 print('  check', json.dumps(m['check']))
+print('  reduce_overlap', json.dumps(m.get('reduce_overlap')))
 "
 done
 echo "## --gpus 1 (same box, for reference)"
