@@ -21,6 +21,10 @@ STRICT = os.path.join(ROOT, "ice_halo_sim_amd", "libhalo_hip_strict.so")
 # unconditioned match_exits of the strict build, measured (profiles/r05_strict_variant.txt): 0.99887 / 0.99962 / 0.99444 / 0.99957 — against
 # 0.9948 / 0.9968 / 0.9811 / 0.9096 of the product and 0.945 / 0.951 / 0.976 / 0.918 between the oracle's own two roundings
 BARS = {247: 0.998, 411: 0.998, 702: 0.993, 11584: 0.998}
+# Round 6: the strict build over ALL 49 seeds of test_random_scene_traces_the_same_rays_as_the_oracle against the unconditioned bars
+# (tools/strict_sweep.py, profiles/r06_strict_sweep.txt): every seed >= 0.99915 (the product build >= 0.9985 on the same list — the conditioning is
+# only ever needed on fixed-orientation scenes like the four above).  The worst eight of that sweep stay pinned here at 0.998.
+SWEEP_WORST = {137: 0.998, 20234: 0.998, 104: 0.998, 121: 0.998, 100: 0.998, 130: 0.998, 129: 0.998, 122: 0.998}
 
 DRIVER = r"""
 import json, sys
@@ -41,7 +45,7 @@ def _start(lib):
         env["HALO_LIB"] = lib
     else:
         env.pop("HALO_LIB", None)
-    return subprocess.Popen([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    return subprocess.Popen([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS) + sorted(SWEEP_WORST))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
 def _finish(proc):
@@ -74,3 +78,6 @@ def test_strict_build_meets_the_unconditioned_per_ray_bars():
         # in turn sits inside the oracle's own two roundings' spread once conditioned
         assert s["match"] >= p["match"] - 1e-3 and p["cond"] >= 0.995, (seed, s, p)
     assert sum(strict[k]["match"] - product[k]["match"] for k in BARS) > 0.05      # (the product really does differ there: seed 11584 by 0.09)
+    for seed, bar in SWEEP_WORST.items():                                          # the whole seed list's worst eight, no conditioning
+        assert strict[seed]["match"] >= bar, (seed, strict[seed])
+        assert product[seed]["match"] >= 0.995, (seed, product[seed])               # (random orientations: the product meets the plain bar too)
