@@ -174,6 +174,14 @@ struct HaloBackend {
   bool mono_by_wl = false;     // illuminant session with one plane per wavelength-pool entry
   bool xyz_log = false;        // illuminant session on X, Y, Z planes whose big production launches go through the hit log
   bool mono_dirty = false;
+  // Two plane SETS for sessions whose every launch goes through the hit log onto one scalar plane (round 6): a fold reads and zeroes the set its
+  // session added to while the passes of the session after it add to the other set — on a discrete spectrum of short sessions the passes of
+  // session k + 1 otherwise wait for the fold of session k, which waits for the passes of session k: one serial chain (bench.py --config 4d).
+  bool mono_two = false;
+  int mono_set = 0;
+  size_t mono_half = 0;                                   // floats per set
+  hipEvent_t ev_set_folded[2] = {nullptr, nullptr};      // behind the fold that last zeroed the set
+  bool set_folded_pending[2] = {false, false};
   uint32_t plane_cnt = 1, plane_copies = 8;
   std::vector<std::array<float, 3>> plane_coef;  // fold coefficients of the pending planes
   // consumer (RenderConsumer state, server/render.hpp): Neumaier running image + total landed intensity
@@ -239,6 +247,9 @@ struct HaloBackend {
   bool rmw_pending[2] = {false, false};
   int log_tiles_log2 = 7;         // option (experiment knob): the scalar hit-log route cuts a plane into up to 2^this tiles (<= 8)
   int alt_log2 = 25;              // option (experiment knob): launches of up to 2^alt_log2 rays alternate between the two trace streams
+  int rehit_strategy = 1;         // option: 1 [default] the reference's CUDA next-face strategy (the child that leaves through the face it stands on is emitted where it is);
+                                  // 0 its legacy CPU strategy (that child is propagated over all faces with the relaxed accept threshold, optics.cpp:116-155 —
+                                  // SURVEY's stated ground truth): every launch then takes the generic kernels, which carry the re-hit test
   int pool_entry_fast = 1;        // option (A/B knob): prism pools under the hit log pick a sampled full prism's entry face slab by slab; 0 = the walk over its fan triangles
   int gen_ahead = 0;              // option (experiment knob): 1 queues the generator of a chip-filling launch on trace stream 1, beside the previous launch's kernels
   DevBuf<float> cont[2];       // SoA continuation pools, 5 planes
@@ -272,6 +283,8 @@ int hip_fail(HaloBackend* b, hipError_t e, const char* what) {
     if (e__ != hipSuccess) return hip_fail(b, e__, #call); \
   } while (0)
 
+// The plane set the open / pending session adds to (HaloBackend::mono_two).
+inline float* planes_of(HaloBackend* b) { return b->mono.ptr + (b->mono_two ? static_cast<size_t>(b->mono_set) * b->mono_half : 0u); }
 // The stream the plane-touching passes of logged launches and the folds are queued on.
 inline hipStream_t post_stream(HaloBackend* b) { return b->overlap ? b->aux : b->stream; }
 // What is queued on the auxiliary stream from here on runs behind everything the main stream and the trace streams hold now.
@@ -304,6 +317,15 @@ int join_aux(HaloBackend* b) {
     }
   return HALO_OK;
 }
+// Trace stream i goes on behind what the auxiliary stream holds now (a closing fold: it reads and zeroes the planes).
+int wait_for_aux(HaloBackend* b, int i) {
+  if (b->overlap && b->aux_pending && b->cs_seen_aux[i] != b->aux_seq) {
+    HIPCHK(b, hipEventRecord(b->ev_aux, b->aux));
+    HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_aux, 0));
+    b->cs_seen_aux[i] = b->aux_seq;
+  }
+  return HALO_OK;
+}
 // The stream the next trace kernel goes to: behind what the main stream holds now (table uploads, counter resets) and — for a launch that
 // adds to the planes itself — behind what the auxiliary stream holds (folds, per-tile passes).
 int next_trace_stream(HaloBackend* b, bool touches_planes, bool alternate, hipStream_t* out, int* which) {
@@ -319,16 +341,18 @@ int next_trace_stream(HaloBackend* b, bool touches_planes, bool alternate, hipSt
   if (alternate) b->cs_next ^= 1;
   HIPCHK(b, hipEventRecord(b->ev_main, b->stream));
   HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_main, 0));
-  if (touches_planes && b->aux_pending && b->cs_seen_aux[i] != b->aux_seq) {
-    HIPCHK(b, hipEventRecord(b->ev_aux, b->aux));
-    HIPCHK(b, hipStreamWaitEvent(b->cs[i], b->ev_aux, 0));
-    b->cs_seen_aux[i] = b->aux_seq;
-  }
+  if (touches_planes)
+    if (int rc = wait_for_aux(b, i)) return rc;
   b->cs_pending[i] = true;
   *out = b->cs[i];
   *which = i;
   return HALO_OK;
 }
+// Smallest launch the hit log takes by itself (option hit_log = -1).  Direct atomics retire memory-side at ~21 G/s whatever they hit; the log's
+// passes cost a fixed ~75 us per launch plus ~10 ps per record, and on a small launch they run beside the next session's trace kernel.  A
+// full-sky render lands every exit (5-6 per root: 0.8 M roots = 4.4 M atomics = 210 us against 102 us of logged trace kernel, bench.py --config 4d),
+// a lens that sees part of the sky 1-2 per root.
+inline uint64_t log_min_rays(int visible) { return visible == HALO_VISIBLE_FULL ? (1ull << 19) : (2ull << 20); }
 // Host waits for all streams.
 int sync_all(HaloBackend* b) {
   if (int rc = join_aux(b)) return rc;
@@ -574,6 +598,8 @@ int halo_destroy(halo_handle_t b) {
     if (b->ev_shapes_free[k]) (void)hipEventDestroy(b->ev_shapes_free[k]);
     if (b->ev_rmw[k]) (void)hipEventDestroy(b->ev_rmw[k]);
   }
+  for (hipEvent_t ev : b->ev_set_folded)
+    if (ev) (void)hipEventDestroy(ev);
   if (b->ev_gen) (void)hipEventDestroy(b->ev_gen);
   if (b->ev_gate) (void)hipEventDestroy(b->ev_gate);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
@@ -647,6 +673,10 @@ int halo_set_option(halo_handle_t b, const char* key, int64_t v) {
   else if (k == "defer_fold") b->defer_fold = v ? 1 : 0;
   else if (k == "gen_ahead") b->gen_ahead = v ? 1 : 0;
   else if (k == "pool_entry_fast") b->pool_entry_fast = v ? 1 : 0;
+  else if (k == "rehit_strategy") {
+    if (b->in_session) return fail(b, HALO_FATAL, "rehit_strategy cannot change inside a session");
+    b->rehit_strategy = v ? 1 : 0;
+  }
   else if (k == "log_tiles_log2") b->log_tiles_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 0), 8));
   else if (k == "alt_log2") b->alt_log2 = static_cast<int>(std::min<int64_t>(std::max<int64_t>(v, 10), 28));
   else if (k == "small_blocks_per_cu") b->small_blocks_per_cu = static_cast<int>(std::max<int64_t>(v, 0));
@@ -794,10 +824,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   // threshold, a last chunk or a thin continuation layer, is little work by definition)
   bool one_entry_layers = true;
   for (int l = 0; l < scene->layer_count; l++) one_entry_layers = one_entry_layers && scene->layers[l].entry_count == 1;
-  const bool fast_scene = plain_scene || (!b->capture && b->filter_fast && scene->max_hits <= 16);   // (a dispatch whose tables do not fit the fast form still adds directly: copy 0 only, correct, slower)
-  const bool all_logged = fast_scene && one_entry_layers && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (2ull << 20) &&
+  const bool fast_scene = b->rehit_strategy != 0 && (plain_scene || (!b->capture && b->filter_fast && scene->max_hits <= 16));   // (a dispatch whose tables do not fit the fast form still adds directly: copy 0 only, correct, slower)
+  const bool all_logged = fast_scene && one_entry_layers && b->hit_log < 0 && b->aggregate == 1 && ray_num >= (discrete ? log_min_rays(render->visible) : (2ull << 20)) &&
                           (discrete ? log_mono_fits : xyz_log_n) && (mono_session_n || xyz_log_n);
   const uint32_t plane_copies_n = (mono_by_wl_n || all_logged) ? 1u : static_cast<uint32_t>(b->mono_copies);
+  const bool two_sets_n = all_logged && discrete && mono_session_n && !mono_by_wl_n && b->overlap != 0;   // (see HaloBackend::mono_two)
   std::vector<std::array<float, 3>> coef_n;
   for (uint32_t m = 0; m < plane_cnt_n; m++) {
     if (mono_session_n) coef_n.push_back({pool[m].cmf_x, pool[m].cmf_y, pool[m].cmf_z});
@@ -811,7 +842,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
     // now, with the members still describing the old planes.
     const bool same_planes = b->mono_dirty && b->lazy_fold && b->acc != nullptr && b->acc == b->acc_own.ptr && b->acc_w == render->width &&
                              b->acc_h == render->height && b->mono_s_log2 == s_log2 && b->plane_cnt == plane_cnt_n && b->plane_copies == plane_copies_n &&
-                             b->plane_coef == coef_n;
+                             b->mono_two == two_sets_n && b->plane_coef == coef_n;
     if (!same_planes) {
       // (queued on the auxiliary stream; the HOST does not wait.  This session's trace kernels are queued behind it all the same
       // (next_trace_stream is always told the launch touches the planes): letting a logged kernel start under the fold was measured — the step
@@ -819,7 +850,7 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
       int rc = fold_queue(b);  // also: a session that was never ended still owes its plane to the accumulator (old layout)
       if (rc != HALO_OK) return rc;
       const bool caller_reads = b->acc != nullptr && b->acc != b->acc_own.ptr && !b->defer_fold;   // the caller's memory, read in stream order: the fold must be in that order too
-      const bool layout_changes = b->mono_s_log2 != s_log2 || b->plane_cnt != plane_cnt_n || b->plane_copies != plane_copies_n;   // the twin's halves move
+      const bool layout_changes = b->mono_s_log2 != s_log2 || b->plane_cnt != plane_cnt_n || b->plane_copies != plane_copies_n || b->mono_two != two_sets_n;   // the twin's halves (and the plane sets) move
       if (caller_reads || layout_changes) {
         rc = join_aux(b);
         if (rc != HALO_OK) return rc;
@@ -835,7 +866,11 @@ int halo_begin(halo_handle_t b, const HaloScene* scene, const HaloRender* render
   b->plane_copies = plane_copies_n;
   b->plane_coef = coef_n;
   {
-    const size_t need = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
+    const size_t one = (static_cast<size_t>(kMonoRows) << s_log2) * b->plane_copies * b->plane_cnt;
+    b->mono_two = two_sets_n;
+    b->mono_half = one;
+    if (!b->mono_two) b->mono_set = 0;
+    const size_t need = one * (b->mono_two ? 2u : 1u);
     if (b->mono.cap < need) {
       if (int rc = reserve_idle(b, b->mono, need)) return rc;
       HIPCHK(b, hipMemsetAsync(b->mono.ptr, 0, b->mono.cap * sizeof(float), b->stream));
@@ -914,11 +949,17 @@ static int fold_queue(HaloBackend* b) {
     FoldCoef coef{};
     for (uint32_t m = 0; m < n; m++)
       for (int a = 0; a < 3; a++) coef.c[m][a] = b->plane_coef[first + m][static_cast<size_t>(a)];
-    hipError_t e = launch_fold(b->acc, b->mono.ptr + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? twin + first * twin_plane : nullptr, flag, ps);
+    hipError_t e = launch_fold(b->acc, planes_of(b) + first * plane, npix, b->mono_s_log2, b->plane_copies, n, coef, twin ? twin + first * twin_plane : nullptr, flag, ps);
     if (e != hipSuccess) return hip_fail(b, e, "halo_fold_kernel launch");
   }
   if (flag) HIPCHK(b, hipMemsetAsync(flag, 0, sizeof(uint32_t), ps));   // every group has seen it; the fold zeroed what it took
-  b->twin_set ^= 1;   // what traces from here on overflows into the other half (trace kernels queue behind this fold anyway: see halo_begin)
+  b->twin_set ^= 1;   // what traces from here on overflows into the other half
+  if (b->mono_two) {    // ... and adds to the other plane set, once the fold that last zeroed THAT one is through (ev_set_folded)
+    if (!b->ev_set_folded[b->mono_set]) HIPCHK(b, hipEventCreateWithFlags(&b->ev_set_folded[b->mono_set], hipEventDisableTiming));
+    HIPCHK(b, hipEventRecord(b->ev_set_folded[b->mono_set], ps));
+    b->set_folded_pending[b->mono_set] = true;
+    b->mono_set ^= 1;
+  }
   b->mono_dirty = false;
   return HALO_OK;
 }
@@ -1108,7 +1149,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.cont_in_region = b->cont_region[out_slot ^ 1];
     P.cont_cnt = b->cont_cnt.ptr;
     P.counters = b->counters.ptr;
-    P.mono = b->mono.ptr;
+    P.mono = planes_of(b);
     P.mono_s_log2 = b->mono_s_log2;
     P.ovf = twin_of(b, b->twin_set);
     P.ovf_copies_log2 = static_cast<uint32_t>(__builtin_ctz(b->plane_copies));
@@ -1120,6 +1161,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     P.log_xyz = 0u;
     P.log_plane_stride = 0u;
     P.pool_entry_fast = b->pool_entry_fast ? 1u : 0u;
+    P.rehit_legacy = b->rehit_strategy == 0 ? 1u : 0u;
     P.bin_shift = 0u;
     P.tally = b->tally.ptr;
     P.exits = b->exits.ptr;
@@ -1179,6 +1221,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     FastTables* fast_host = nullptr;
     if (cached) mode = ce->mode;
     else if (b->capture) mode = 2;
+    else if (b->rehit_strategy == 0) mode = 3;   // the legacy next-face strategy lives in the generic kernels only
     else if (use_filter || use_color) {
       mode = 3;
       if (b->filter_fast && b->scene.max_hits <= 16) {
@@ -1340,7 +1383,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && (log_planes_ok || (!b->mono_by_wl && b->mono_s_log2 <= 12u)));
       bool use_log = !use_bin && log_layout_ok && b->aggregate == 1 && fast_mode &&
                            (P.prob < 1.0f || P.final_layer) &&   // a layer whose every exit continues puts nothing on the image
-                           (b->hit_log < 0 ? m >= (2ull << 20) : b->hit_log != 0);
+                           (b->hit_log < 0 ? m >= ((b->mono_session && !b->mono_by_wl) ? log_min_rays(b->render.visible) : (2ull << 20)) : b->hit_log != 0);
       bool use_log_xyz = use_log && b->xyz_log;
       uint64_t log_cap = 0;
       // Launches of <= 2^21 rays alternate between the two trace streams (next_trace_stream); only those can meet a neighbour that still reads
@@ -1459,7 +1502,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // the same stream.
       hipStream_t ts = nullptr;
       int ts_i = 0;
-      if (int rc = next_trace_stream(b, true, alternate, &ts, &ts_i)) return rc;
+      // (Round 6: a LOGGED trace kernel writes records, its region counts and the twin's other half — nothing the closing fold of the session
+      //  before reads or zeroes — so on a SMALL launch it starts under that fold, and only its passes, which add to the planes, wait for it.  A
+      //  discrete spectrum of many short sessions (bench.py --config 4d: 31 x 0.8 M rays) was one serial chain of generator, trace, split, sums
+      //  and fold, 325 us per session; the trace kernel and generator of session k + 1 now run beside the passes and the fold of session k.
+      //  Launches that fill the chip keep the old order: measured in round 5, nothing to gain there and the kernel's own span stretches.)
+      const bool under_fold = use_log && alternate;
+      if (int rc = next_trace_stream(b, !under_fold, alternate, &ts, &ts_i)) return rc;
       hipEvent_t before_sums = nullptr;   // rule (1), for the routes whose sums write the planes plainly
 #ifndef HALO_NO_PLANE_GATES   // (defined only to see tests/test_gpu_production_routes.py's two-stream test fail without the gates)
       if (b->overlap && !use_log && b->rmw_pending[ts_i ^ 1])   // this trace kernel adds to the planes itself: behind the other stream's sums
@@ -1533,11 +1582,16 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         // passes' spans stretched sevenfold — profiles that no longer say what a kernel costs, for one percent.  Not kept.)
         HIPCHK(b, hipEventRecord(b->ring_ev1[k], ts));          // the trace kernel alone: ev0 .. ev1
         hipStream_t ps = ts;
+        if (under_fold) {   // the passes add to the planes: behind the fold that last touched THEIR planes
+          if (b->mono_two) {   // two plane sets: that is the fold of two sessions ago (it zeroed this set), not the one the trace kernel started under
+            if (b->set_folded_pending[b->mono_set]) HIPCHK(b, hipStreamWaitEvent(ps, b->ev_set_folded[b->mono_set], 0));
+          } else if (int rc = wait_for_aux(b, ts_i)) return rc;
+        }
         HIPCHK(b, hipEventRecord(b->ring_ev2[k], ps));
         HIPCHK(b, hipMemsetAsync(bin_cnt2.ptr, 0, static_cast<size_t>(log_tiles) * 16u * sizeof(uint32_t), ps));
-        hipError_t be = use_log_xyz ? launch_log_route_xyz(b->mono.ptr, P.log_plane_stride, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks),
+        hipError_t be = use_log_xyz ? launch_log_route_xyz(P.mono, P.log_plane_stride, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks),
                                                            bin_list2.ptr, cap2, bin_cnt2.ptr, log_tiles, b->mono_s_log2, P.wl_pool, P.wl_pool_size, frac_bits, P.ovf, P.ovf_flag, P.ovf_copies_log2, ps, before_sums)
-                                    : launch_log_route(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks), bin_list2.ptr, cap2,
+                                    : launch_log_route(P.mono, bin_list.ptr, P.bin_cap, bin_cnt.ptr, static_cast<uint32_t>(blocks), bin_list2.ptr, cap2,
                                                        bin_cnt2.ptr, 1u << log_t_log2, log_planes, b->mono_s_log2, b->render.visible == HALO_VISIBLE_FULL, frac_bits,
                                                        P.ovf, P.ovf_flag, P.ovf_copies_log2, ps, before_sums);
         if (be != hipSuccess) return hip_fail(b, be, "halo_split_kernel launch");
@@ -1553,9 +1607,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         HIPCHK(b, hipEventRecord(b->ring_done[k], ps));
       } else {
       if (use_bin) {
-        hipError_t be = two_level ? launch_bin_two_level(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, lists1, bin_list2.ptr, cap2, bin_cnt2.ptr,
+        hipError_t be = two_level ? launch_bin_two_level(P.mono, bin_list.ptr, P.bin_cap, bin_cnt.ptr, lists1, bin_list2.ptr, cap2, bin_cnt2.ptr,
                                                          bin_tiles, fan_log2, frac_bits, P.ovf, P.ovf_flag, ts, before_sums)
-                                  : launch_bin_accumulate(b->mono.ptr, bin_list.ptr, P.bin_cap, bin_cnt.ptr, bin_tiles, frac_bits, ts);
+                                  : launch_bin_accumulate(P.mono, bin_list.ptr, P.bin_cap, bin_cnt.ptr, bin_tiles, frac_bits, ts);
         if (be != hipSuccess) return hip_fail(b, be, "halo_bin_accumulate_kernel launch");
         if (b->overlap && two_level) {
           HIPCHK(b, hipEventRecord(b->ev_rmw[ts_i], ts));

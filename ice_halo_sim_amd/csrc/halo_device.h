@@ -305,6 +305,7 @@ struct DispatchParams {
                                // in ONE plane | CMF code << kLogWlShift, and the per-tile pass applies the code's CMF row
   uint32_t log_plane_stride;   // ... floats between the X, Y and Z planes (fallback atomics of a full log)
   uint32_t pool_entry_fast;    // prism pools under the hit log: 1 = a sampled FULL prism's entry face is picked slab by slab (halo_trace.inl SlotFast), 0 = the walk over its fan triangles
+  uint32_t rehit_legacy;       // 1: the reference's CPU next-face strategy (option rehit_strategy = 0; generic kernels): a child leaving through the face it stands on is propagated, not emitted outright
   uint32_t no_land;            // 1: production-mode layer with prob >= 1 that is not the last — every exit continues, nothing reaches the image
   double* tally;               // kTallyLines lines of kTallyStride doubles, [kSum*] in each: landed weight, exit weight sum, exit count, pixel hits —
                                // cumulative over the backend's life (the host reads differences); a workgroup adds to line blockIdx % kTallyLines

@@ -2083,7 +2083,22 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
   };
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
   if (next != nullptr) next->land();   // the next pass's pool record goes to LDS: behind every load wait of this pass, in front of its first store
-  for (uint32_t i = 0u; i < P.max_hits; ++i) {
+  // Legacy-CPU next-face strategy (option rehit_strategy = 0; generic kernels only — see the test on the outgoing child below): a child that
+  // "re-hits" is parked here with its path and walked after the ray's main path, by re-entering the loop at its interaction index.
+  constexpr bool kLegacyCapable = !ModeTraits<MODE>::kFast;
+  constexpr int kParkCap = kLegacyCapable ? 2 : 1;
+  struct Parked {
+    float d[3], p[3], w;
+    int face;
+    uint32_t i;
+    PathView pv;
+  };
+  Parked parked[kParkCap];
+  uint8_t parked_path[kParkCap][ModeTraits<MODE>::kTables ? kFilterPathCap : 1];
+  int n_parked = 0;
+  uint32_t i_start = 0u;
+walk_path:
+  for (uint32_t i = i_start; i < P.max_hits; ++i) {
     // --- Fresnel split at `face` ---
     const float4 fn = *reinterpret_cast<const float4*>(sh->face[face]);
     const float cos_t = dot3_fma(d, fn.x, fn.y, fn.z);
@@ -2123,6 +2138,56 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       has_exit = !sp.tir;
     }
     PROBE_MARK(pr, kPhFresnel);
+    if constexpr (kLegacyCapable) {
+      // The reference excludes the face a ray stands on in two ways (traversal_shared.h:23-29).  Its CUDA backend — and this engine by default —
+      // emits the child that leaves through `face` where it is.  Its CPU path (SURVEY's stated ground truth) propagates that child like any
+      // other ray: PropagateSlab over ALL faces, the source face included, accepted above +eps when the nearest face is the source and above
+      // -eps otherwise (optics.cpp:116-155).  On a convex body with the entry point on its face's plane nothing is ever accepted and the two
+      // agree; where a fan's corners were moved off the plane by the vertex merge (or a point sits within rounding of an edge) the CPU path
+      // lets the child "re-hit" and go on as a segment.  Option rehit_strategy = 0 does the same here: the child is parked and walked after
+      // the main path (the inner child's search is the same under both strategies: its source face has n.d < 0 and is never a candidate).
+      if (P.rehit_legacy != 0u && !done && has_exit) {
+        float t_far = 1e30f;
+        int far = -1;
+        for (int fi = 0; fi < face_cnt; fi++) {
+          const float4 g = *reinterpret_cast<const float4*>(sh->face[fi]);
+          const float den = dot3_fma(ex, g.x, g.y, g.z);
+          if (den > kSlabEps) {
+            const float t = -(dot3_fma(p, g.x, g.y, g.z) + g.w) / den;   // lm_traversal::SlabFaceT
+            if (t < t_far) {
+              t_far = t;
+              far = fi;
+            }
+          }
+        }
+        const bool rehit = far >= 0 && t_far > ((far != face) ? -kSlabEps : kSlabEps);
+        if (rehit) has_exit = false;   // it did not leave: the CPU path carries it on as a segment (which a spent hit budget then never traces)
+        if (rehit && i + 1u < P.max_hits && n_parked < kParkCap) {
+          Parked& k = parked[n_parked];
+          for (int a = 0; a < 3; a++) {
+            k.d[a] = ex[a];
+            k.p[a] = HALO_FMA(t_far, ex[a], p[a]);
+          }
+          k.w = ex_w;
+          k.face = far;
+          k.i = i + 1u;
+          k.pv = pv;
+          if constexpr (MODE != kModePlain) {   // FillRayOtherInfo (simulator.cpp:645): the segment's path takes the face it lands on
+            const uint8_t fnum = sh->face_number[far];
+            if constexpr (ModeTraits<MODE>::kTables) {
+              for (uint32_t b = 0u; b < kFilterPathCap; b++) parked_path[n_parked][b] = path[b];
+              if (k.pv.len >= 16u && k.pv.len < kFilterPathCap) parked_path[n_parked][k.pv.len] = fnum;
+            }
+            if (k.pv.len < 16u) {
+              k.pv.reg = pk_shl8(k.pv.reg);
+              k.pv.reg.lo |= fnum;
+            }
+            k.pv.len++;
+          }
+          n_parked++;
+        }
+      }
+    }
     // every lane that entered the loop is still here at every emit (the exit queue's push is a wave-wide step): `live` says who has a candidate
     emit_gate<MODE, MONO, SMALLC>(P, acc, filter, color, carried, gate, R, !done && has_exit, ex[0], ex[1], ex[2], ex_w, cmf_x, cmf_y, cmf_z, wl_idx, P.ci_start + tid, ex_seq, pv,
                                   i + 1u, sums, pr);
@@ -2264,6 +2329,24 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
       }
     }
     PROBE_MARK(pr, kPhSlab);
+  }
+  if constexpr (kLegacyCapable) {
+    if (n_parked > 0) {   // the parked children of this ray, last in first out: each re-enters the loop at its own interaction index
+      const Parked& k = parked[--n_parked];
+      for (int a = 0; a < 3; a++) {
+        d[a] = k.d[a];
+        p[a] = k.p[a];
+      }
+      w = k.w;
+      face = k.face;
+      pv.len = k.pv.len;
+      pv.reg = k.pv.reg;
+      if constexpr (ModeTraits<MODE>::kTables)
+        for (uint32_t b = 0u; b < kFilterPathCap; b++) path[b] = parked_path[n_parked][b];
+      done = false;
+      i_start = k.i;
+      goto walk_path;
+    }
   }
   if (next != nullptr) next->late();
   if (queued) {   // park the count: the lanes here agree on it, the first of them writes

@@ -292,6 +292,12 @@ const char* halo_last_error(halo_handle_t h);
  * 0: the generic walk over faces — same uniform, same cumulative order, A/B knob),
  * "pool_entry_fast" (1 [default]: logged launches over sampled PRISMS pick the entry face of every full eight-face prism slab by slab, from tables
  * its half-wave rebuilds each pass; 0: the walk over the fan triangles — same uniform, same cumulative order; the same prisms, when their slab normals are the regular prism's, search their next face with literal normals — same candidates and comparisons as the table-driven search; A/B knob),
+ * "rehit_strategy" (which of the reference's two next-face strategies the trace follows where they part, src/core/shared/traversal_shared.h:23-29:
+ * 1 [default] = its CUDA backend's — the child that leaves through the face the ray stands on is an outgoing candidate where it is; 0 = its
+ * legacy CPU path's, PropagateSlab optics.cpp:64-158 — that child is propagated over all faces, the source face included, with the relaxed
+ * accept threshold, and one that "re-hits" goes on as a segment.  The two agree on a convex crystal whose entry points lie on their faces'
+ * planes; they part on a fan the vertex merge moved off its plane.  0 runs every launch on the generic kernels (no exit queue, no hit log:
+ * several times slower) — for a caller that needs SURVEY's stated ground truth ray for ray; not inside a session),
  * "shuffle_chunk" (Recombine's shuffle permutes chunks of this many consecutive continuation-pool entries; power of two in
  * [1, 64], default 32 = one 128-byte line per plane read; 1 = the reference's per-ray permutation, cu:1633-1657),
  * scheduling (ABI 6; none of them changes a result): "overlap" (1 [default]: launches of <= 2 Mi rays alternate between two

@@ -158,9 +158,9 @@ def has_degenerate_tables(sc, seed, samples=8):
     return worst
 
 
-def run_case(seed, n=60_000, **oracle_opts):
+def run_case(seed, n=60_000, hip_opts=None, **oracle_opts):
     sc, rd, wl, filters, clock = make_case(seed)
-    hb = hip_backend(seed=seed, capture_exits=1, geom_clock=clock)
+    hb = hip_backend(seed=seed, capture_exits=1, geom_clock=clock, **(hip_opts or {}))
     ob = OracleBackend(seed=seed, capture_exits=1, threads=8, geom_clock=clock, **oracle_opts)
     ob2 = OracleBackend(seed=seed, fma=True, capture_exits=1, threads=8, geom_clock=clock, **oracle_opts)   # the oracle's other rounding: which exits are ill-conditioned
     for b in (hb, ob, ob2):
@@ -652,3 +652,26 @@ def test_the_two_next_face_strategies_of_the_reference_pinned_on_seed_20234():
     extra = abs(int(cpu["exits"][1]) - int(cpu["exits"][0]))
     assert 2 < extra <= 4.0 * cpu["degenerate"] * cpu["exits"][1] + 20, (cpu["exits"], cpu["degenerate"])
     check(20234, cpu)                                                                      # ... and inside the documented allowance
+    # Round 6: the ENGINE can follow the CPU strategy too (option rehit_strategy = 0: the generic kernels propagate the child that leaves
+    # through the face it stands on, and a re-hit goes on as a parked segment) — SURVEY's stated ground truth, no longer only the oracle's.
+    # Against the oracle on the same strategy: the exit counts agree again and the per-ray bars hold with no allowance.
+    legacy = run_case(20234, hip_opts={"rehit_strategy": 0})
+    assert abs(int(legacy["exits"][0]) - int(legacy["exits"][1])) <= 2, legacy["exits"]
+    assert legacy["exits"][1] == cpu["exits"][1] and legacy["exits"][0] != cuda["exits"][0]      # (the engine's count moved by the phantom segments)
+    frac, pix, path, left_out = legacy["cond"]
+    assert frac >= 0.995 and pix >= 0.995 and path >= 0.998, legacy["cond"]
+    assert abs(legacy["landed"][0] - legacy["landed"][1]) <= 3e-4 * max(legacy["landed"][1], 1.0) + 1e-3 + legacy["unmatched_weight"]
+
+
+@pytest.mark.parametrize("seed", [101, 113, 129, 140])
+def test_legacy_next_face_strategy_changes_nothing_on_well_formed_crystals(seed):
+    """... and on crystals whose entry points lie on their faces' planes the two strategies are the same rays: the engine on the CPU strategy
+    (generic kernels, re-hit test on every outgoing child) against the oracle on the CPU strategy, under the suite's ordinary bars — and the
+    engine's exit count is its own count on the default (CUDA) strategy to a few rays in 1e5.  (Seed 129: + 19 of 477 641.  A child that leaves
+    at grazing incidence has n.d of 1e-5 .. 1e-3 on its own face, so t = -(n.p + d) / n.d passes the +1e-5 threshold when the hit point's
+    plane offset is a mere 1e-10 .. 1e-8 INSIDE — which is rounding: the oracle gives + 0 with separately rounded products and + 9 with
+    contracted ones (liboracle_fma.so), the engine, which contracts, + 19.  The reference's own CPU result is not defined more finely.)"""
+    legacy = run_case(seed, hip_opts={"rehit_strategy": 0})
+    check(seed, legacy)
+    assert abs(int(legacy["exits"][0]) - int(legacy["exits"][1])) <= 2 + 1e-4 * legacy["exits"][1], legacy["exits"]   # engine vs oracle, both on the CPU strategy
+    assert abs(int(legacy["exits"][0]) - int(run_case(seed)["exits"][0])) <= 2e-4 * legacy["exits"][0] + 2

@@ -211,8 +211,9 @@ def test_bench_config_4d_discrete_31_entry_spectrum_at_its_own_launch_size():
     spectrum 380..780 nm weighted by the D65 SPD, one session per entry, ceil(25 M / 31) = 806 452 roots each, stochastic prism, full sky.
     The workload object is bench.py's own.  Seven of its 31 sessions (every fifth wavelength: both ends, the SPD's peak, weights from 49.98
     to 117.8) run back to back at THEIR launch size on the route the backend picks for them — sampled-prism pool (GEOM 2), scalar plane of a
-    discrete wavelength, direct atomics (launches under 2 Mi rays stay off the hit log) — and the image, landed weight and exit count are
-    the oracle's for the same seeded rays and the same per-session weights."""
+    discrete wavelength, the hit log (a full-sky render takes it from 512 Ki rays: every exit lands, round 6), each session's trace kernel
+    queued under the closing fold of the session before — and the image, landed weight and exit count are the oracle's for the same seeded
+    rays and the same per-session weights."""
     import bench
     wk = bench.workload("4d")
     assert len(wk["wls"]) == 31 and wk["rays"] == -(-25_000_000 // 31)
@@ -229,7 +230,7 @@ def test_bench_config_4d_discrete_31_entry_spectrum_at_its_own_launch_size():
     route = hb.last_route()
     hip, ora = hb.ReadbackXyzAccum(), ob.ReadbackXyzAccum()
     hb.close(), ob.close()
-    assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, 1 << 2, abi.ACCUM_SCALAR), (route.mode_mask, route.geom_mask, route.accum_mask)
+    assert (route.mode_mask, route.geom_mask, route.accum_mask) == (1, 1 << 2, abi.ACCUM_LOG), (route.mode_mask, route.geom_mask, route.accum_mask)
     assert route.plane_cnt == 1
     assert exits_h == pytest.approx(exits_o, rel=1e-4)
     err = _check_single_layer(hip, ora)
