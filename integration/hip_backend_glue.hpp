@@ -16,6 +16,7 @@
 #define CORE_BACKEND_HIP_BACKEND_GLUE_H_
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -442,6 +443,11 @@ class HipBackendGlue final : public TraceBackend {
       // for: back-to-back sessions then overlap the host's work with the device's.  Layers that feed a Recombine still return their
       // continuation count synchronously.
       be_->SetOption("async", 1);
+      // LUMICE_HIP_NEXT_FACE=cpu: follow the legacy CPU path's next-face strategy (PropagateSlab's relaxed threshold on the child that leaves
+      // through its own face, optics.cpp:116-155) instead of the CUDA backend's source-face skip — ray-for-ray comparisons against the
+      // legacy backend on crystals whose tables are not clean polytopes; several times slower (generic kernels).  Default: the CUDA strategy.
+      if (const char* nf = std::getenv("LUMICE_HIP_NEXT_FACE"))
+        if (std::string(nf) == "cpu") be_->SetOption("rehit_strategy", 0);
     } catch (const halo::BackendUnavailableError& e) {
       throw BackendUnavailableError(e.what());
     }

@@ -236,3 +236,42 @@ def test_reference_filter_documents_on_the_production_kernels(name):
         th, to, to2 = h["lanes"].sum(axis=(1, 2), dtype=np.float64), a["lane_sums"], b["lane_sums"]
         for k in range(len(to)):
             assert within(th[k], to[k], to2[k], 2e-2 * max(float(to.max()), 1.0) + 0.5), (name, k, th[k], to[k], to2[k])
+
+
+def test_shape_pool_clock_does_not_bias_entry_exit_filter_admission():
+    """test/parity-cross-backend/backend/test_cuda_kshape_filter_parity.cpp, both arms, on this engine.  Its scene: one layer, a stochastic
+    hexagonal prism (height and six face distances gauss(1, 0.15), cuda_test_helpers.hpp:150-161) on the default fixed axis, sun (30, 0, 0.5),
+    max_hits 6, an EntryExit(min_len = 3) filter with both faces wild — a filter that CONSUMES the recorded path — 1024 rays per batch, eight
+    seeds, 64 x 64 fisheye.  Arm 1 (AC1, :196-240): the shape-pool clock only redistributes shape draws, so the mean admitted weight over the
+    seeds is the same with a new shape per ray (geom_clock 1) as with one per 8 rays, inside 3 x the pooled standard error; both arms admit
+    something.  Arm 2 (:241-293), which the reference can only hold to a loose ballpark (its CPU and CUDA paths trace different ray
+    populations), is exact here: at clock 8 the engine admits the oracle's exits, count for count and weight for weight, every seed."""
+    import math
+    ee = scenes.simple_filter(scenes.filter_term("entry_exit", min_len=3), "")
+    g = {"type": "gauss", "mean": 1.0, "std": 0.15}
+    ent = scenes.entry(scenes.prism_crystal(g, [g] * 6), scenes.axis(), 1.0, 0, 1)
+    sc = scenes.scene([(0.0, [ent])], max_hits=6, sun_altitude=30.0, sun_azimuth=0.0, sun_diameter=0.5)
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, 64, 64, fov=180.0, el=90.0, visible=abi.VISIBLE_UPPER)
+    wl, n = scenes.wl_discrete(550.0), 1024
+    w = {1: [], 8: []}
+    for seed in range(1, 9):
+        for clock in (1, 8):
+            hb = hip_backend(seed=seed, geom_clock=clock)
+            hb.set_filters([ee])
+            st = run_session(hb, sc, rd, wl, n)[0]
+            hb.close()
+            w[clock].append(float(st.exit_w_sum))
+            if clock == 8:
+                ob = OracleBackend(seed=seed, threads=2, geom_clock=8)
+                ob.set_filters([ee])
+                so = run_session(ob, sc, rd, wl, n)[0]
+                ob.close()
+                assert int(st.exit_count) == int(so.exit_count) and 0 < so.exit_count < n * 6, (seed, st.exit_count, so.exit_count)
+                assert float(st.exit_w_sum) == pytest.approx(float(so.exit_w_sum), rel=2e-4), seed
+
+    def stats(xs):
+        m = sum(xs) / len(xs)
+        return m, math.sqrt(sum((x - m) ** 2 for x in xs) / len(xs))
+    (m1, s1), (m8, s8) = stats(w[1]), stats(w[8])
+    assert m1 > 0.0 and m8 > 0.0
+    assert abs(m1 - m8) < 3.0 * math.sqrt(s1 * s1 + s8 * s8) / math.sqrt(8.0), (m1, s1, m8, s8)

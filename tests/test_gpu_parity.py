@@ -782,6 +782,34 @@ def test_sample_count_getters_report_real_draws():
     hb.close()
 
 
+@pytest.mark.parametrize("case,stochastic", [("all_fixed", False), ("azimuth_only", True), ("latitude_only", True), ("roll_only", True), ("full_sphere", True)])
+def test_axis_determinism_truth_table_decides_the_orientation_sample_count(case, stochastic):
+    """AxisDistribution::IsAxisDeterministic (math.cpp:567-575) — the reference's truth table, test_math.cpp:357-394, one case per test there:
+    the default axis (all three kNoRandom) draws nothing; a random azimuth ALONE, latitude alone, ROLL alone (the field a shape-side
+    predicate never looks at) or a full-sphere axis each make every ray an orientation sample.  What the backend reports through
+    GetLastBatchStochasticOrientationSampleCount is that predicate applied where it draws — and the rays say the same: with a fixed axis
+    every ray meets the crystal in one orientation (the entry reflections leave in at most one direction per face, widened by the sun's
+    half-degree disc), with any random slot they fan out over the sky."""
+    u = lambda m, s: {"type": "uniform", "mean": m, "std": s}
+    ax = {"all_fixed": scenes.axis(), "azimuth_only": scenes.axis(zenith=0.0, azimuth=u(0, 360), roll=0.0), "latitude_only": scenes.axis(zenith={"type": "gauss", "mean": 90, "std": 5.0}, azimuth=0.0, roll=0.0),
+          "roll_only": scenes.axis(zenith=90.0, azimuth=0.0, roll=u(0, 360)), "full_sphere": scenes.axis(zenith=u(90, 360), azimuth=u(0, 360), roll=u(0, 360))}[case]
+    if case == "all_fixed":
+        assert (ax.azimuth.type, ax.latitude.type, ax.roll.type) == (abi.DIST_NONE,) * 3      # the default-constructed axis, test_math.cpp:362-368
+    sc = scenes.scene([(0.0, [scenes.entry(scenes.prism_crystal(1.2), ax, 1.0, 1)])], max_hits=3, sun_diameter=0.5)
+    n = 20_000
+    hb = hip_backend(seed=11, capture_exits=1)
+    run_session(hb, sc, scenes.config2_render(160, 90), scenes.wl_discrete(550.0), n)
+    crystals, orients = hb.last_sample_counts()
+    ex = hb.DrainExits()
+    hb.close()
+    assert crystals == 0                                  # a fixed shape under any axis: deterministic on the shape side (the two predicates are independent)
+    assert orients == (n if stochastic else 0)
+    first = ex[ex["seq"] == 0]                            # the entry reflection of every root
+    assert len(first) > n // 2
+    cells = len(np.unique(np.round(np.asarray(first["dir"], np.float64).reshape(-1, 3) / 0.05), axis=0))
+    assert (cells > 100) == stochastic and (stochastic or cells <= 8 * 8), (case, cells)   # <= 8 faces, each direction within a few 0.05 cells of itself
+
+
 def test_stochastic_trace_device_pool_equals_host_pool():
     """Tracing with device-generated shape pools gives the same rays as with host-built pools (uniform draws: same bits)."""
     u = lambda m, s: {"type": "uniform", "mean": m, "std": s}

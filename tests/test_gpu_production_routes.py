@@ -931,6 +931,45 @@ def test_async_sessions_alternating_wavelengths_and_crystals_keep_their_own_tabl
     assert np.abs(img1 - img0).max() <= 2e-5 * float(img0.max())
 
 
+def test_short_logged_sessions_under_the_previous_fold_equal_the_one_stream_order():
+    """Round 6: on a full-sky render a scalar session takes the hit log from 512 Ki rays, its trace kernel starts under the closing fold of the
+    session before, and the passes alternate between two plane sets (HaloBackend::mono_two) — the fold of session k zeroes one set while the
+    passes of session k + 1 add to the other.  A queued sequence that exercises every edge of that — new wavelength each session, the same
+    wavelength twice (no fold between: the set stays), a short session under the log's threshold in the middle (direct atomics into the
+    current set), a readback half way, another image size — gives the image of the same sequence on ONE stream with synchronous sessions,
+    and every logged session reports the hit-log route."""
+    from ice_halo_sim_amd.backend import HipTraceBackend
+    from tests._oracle_backend import run_session
+    sc = scenes.scene([(0.0, [scenes.stochastic_prism_entry()])], max_hits=8)
+    big, small = scenes.render(abi.LENS_RECTANGULAR, 2048, 1024, el=0.0, visible=abi.VISIBLE_FULL), scenes.render(abi.LENS_RECTANGULAR, 1024, 512, el=0.0, visible=abi.VISIBLE_FULL)
+    n = 600_000
+    seq = [(big, 400.0, n), (big, 450.0, n), (big, 450.0, n), (big, 500.0, n), (big, 550.0, 100_000), (big, 600.0, n), (big, 650.0, n), ("read", None, None),
+           (big, 700.0, n), (big, 720.0, n), (small, 500.0, n), (small, 520.0, n), (big, 540.0, n), (big, 560.0, n)]
+    runs = {}
+    for tag, opts in (("queued", {"async": 1, "overlap": 1}), ("plain", {"async": 0, "overlap": 0})):
+        hb = HipTraceBackend(device=0, seed=77, **opts)
+        imgs, routes = [], []
+        cur = None
+        for rd, w, m in seq:
+            if rd == "read":
+                imgs.append(hb.ReadbackXyzAccum(cur.width, cur.height))
+                continue
+            if cur is not None and (rd.width, rd.height) != (cur.width, cur.height):
+                imgs.append(hb.ReadbackXyzAccum(cur.width, cur.height))     # the image changes size: read the old one out first
+            cur = rd
+            run_session(hb, sc, rd, scenes.wl_discrete(w, 1.0 + w / 500.0), m)
+            routes.append((m, hb.last_route().accum_mask))
+        imgs.append(hb.ReadbackXyzAccum(cur.width, cur.height))
+        runs[tag] = (imgs, routes)
+        hb.close()
+    for m, mask in runs["queued"][1]:
+        assert mask & (abi.ACCUM_LOG if m >= (1 << 19) else abi.ACCUM_SCALAR), (m, mask)
+    assert len(runs["queued"][0]) == len(runs["plain"][0]) == 4
+    for (iq, lq), (ip, lp) in zip(runs["queued"][0], runs["plain"][0]):
+        assert lp > 0 and lq == pytest.approx(lp, rel=1e-6)
+        assert np.abs(iq - ip).max() <= 2e-5 * float(ip.max())
+
+
 def test_options_that_shape_an_open_session_are_refused_inside_it():
     """seed, ray_base and rank move the monotone ray counters, capture_exits / filter_fast / mono_copies the plane layout decided at
     BeginSession: changing any of them between the layers of a session would replay ray indices the session has already consumed or send

@@ -1,0 +1,82 @@
+"""The reference's K-shape-pool structural tests, on this engine's shape pools (reference files under /root/reference/test):
+  unit-correctness/backend/test_cuda_kshape_pool_locality.cpp   Test A path[] holds LOCAL faces of the shape a ray was traced on; Test B the
+                                                                 second layer of a multi-scatter batch spreads its rays over several pool shapes;
+                                                                 Test C what the pool holds when the clock is left alone
+  parity-cross-backend/backend/test_cuda_rich_exit.cpp:202-366  CountsStochasticCrystalDrawsAcrossLayers
+The reference reaches into its CUDA backend with test hooks (pool_shape_table, d_root_pool_shape_); this engine has no such tables — a ray's shape
+is record `ray index / geom_clock` of the launch's pool, by construction — so each invariant is checked on what crosses the seam: exit records
+(captured paths, per root), sample counts and continuation counts, against the host builder's shapes for the same stream indices."""
+
+import numpy as np
+import pytest
+
+from ice_halo_sim_amd import abi, scenes
+from tests._oracle_backend import OracleBackend, run_session
+from tests.test_gpu_parity import hip_backend
+
+pytestmark = pytest.mark.gpu
+
+G = {"type": "gauss", "mean": 1.0, "std": 0.15}
+FULL = {"type": "uniform", "mean": 0.0, "std": 360.0}
+
+
+def _stoch_entry(cid=0, axis=None):
+    return scenes.entry(scenes.prism_crystal(G, [G] * 6), axis or scenes.axis(zenith=FULL, azimuth=FULL, roll=FULL), 1.0, cid)
+
+
+def test_paths_hold_local_faces_of_the_shape_the_ray_was_traced_on():
+    """Test A (KShapePool_PathIsLocalWithinPolygonFaceCount_AC1, :100-200): clock 8, 64 rays -> 8 pool shapes; every byte of every captured
+    path is a face NUMBER of a hexagonal prism (1..8) — never an index into the pool — rays on the later shapes included; and the 64 rays
+    did meet more than one shape (the exits of roots 8k .. 8k + 7 are the oracle's for shape k, which differ from shape 0's)."""
+    sc = scenes.scene([(0.0, [_stoch_entry()])], max_hits=6, sun_altitude=30.0)
+    rd = scenes.render(abi.LENS_FISHEYE_EQUAL_AREA, 64, 64, fov=180.0, el=90.0)
+    hb, ob = hip_backend(seed=31, capture_exits=1, geom_clock=8), OracleBackend(seed=31, capture_exits=1, threads=1, geom_clock=8)
+    for b in (hb, ob):
+        run_session(b, sc, rd, scenes.wl_discrete(550.0), 64)
+    crystals, _ = hb.last_sample_counts()
+    eh, eo = hb.DrainExits(), ob.DrainExits()
+    hb.close(), ob.close()
+    assert crystals == 8                                                   # ceil(64 / 8) pool shapes (P_ci, :111-113)
+    assert len(eh) == len(eo) > 64
+    for rec in eh:
+        path = np.asarray(rec["path"])[: int(rec["path_len"])]
+        assert len(path) >= 1 and ((path >= 1) & (path <= 8)).all(), path   # local face numbers, whatever shape the ray was on
+    assert (eh["root"] >= 8).sum() > 0                                      # rays past the first shape exist and were recorded
+    # per root the same exits as the oracle, whose shape k is the host builder's record k: a picker collapsed onto slot 0 would fail here
+    key = lambda e: np.lexsort((e["seq"], e["root"]))
+    a, b = eh[key(eh)], eo[key(eo)]
+    assert np.array_equal(a["root"], b["root"]) and np.array_equal(a["seq"], b["seq"])
+    assert np.abs(np.asarray(a["dir"], np.float64) - np.asarray(b["dir"], np.float64)).max() <= 2e-5
+
+
+def test_second_layer_spreads_its_rays_over_several_pool_shapes():
+    """Test B (KShapePool_TransitPicksMultipleShapes_AC1, :202-283): two layers of stochastic prisms, clock 8, 4096 roots — the continuation rays
+    that reach layer 1 are dealt over ceil(continuations / 8) freshly sampled shapes (not one), and CountsStochasticCrystalDrawsAcrossLayers
+    (test_cuda_rich_exit.cpp:202-366): the session's crystal count is the sum of both layers' draws."""
+    sc = scenes.scene([(0.6, [_stoch_entry(0)]), (0.0, [_stoch_entry(1)])], max_hits=6, sun_altitude=30.0)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 128, 64, el=0.0, visible=abi.VISIBLE_FULL)
+    hb = hip_backend(seed=7, geom_clock=8)
+    st = run_session(hb, sc, rd, scenes.wl_discrete(550.0), 4096)
+    crystals, orients = hb.last_sample_counts()
+    hb.close()
+    cont = int(st[0].continuation_count)
+    assert cont > 512 and int(st[1].root_count) == cont
+    assert crystals == (4096 + 7) // 8 + (cont + 7) // 8                    # both layers draw: 512 shapes + one per 8 continuation rays (>= 64: "several")
+    assert orients == 4096 + cont
+
+
+def test_pool_without_a_clock_setting_follows_the_cpu_paths_32_rays_per_shape():
+    """Test C (KShapePool_DefaultKnobUnsetGivesPCiOne_AC2, :285-340) pins what the reference's GPU backends do when LUMICE_GPU_GEOM_CLOCK is
+    unset: ONE pool shape per (layer, crystal entry) and batch.  This engine's default is deliberately the legacy CPU path's instead — a new
+    shape every 32 rays (simulator.cpp:1244-1275, LUMICE_GEOM_CLOCK's default) — and the reference's knob-off behaviour is
+    one option away: geom_clock >= the batch.  Both are pinned: the crystal count of a 4096-ray batch is 128 untouched, 1 with the clock at
+    the batch size (and the single shape is then the stream's first: every root sees shape 0)."""
+    sc = scenes.scene([(0.0, [_stoch_entry()])], max_hits=6, sun_altitude=30.0)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 128, 64, el=0.0, visible=abi.VISIBLE_FULL)
+    hb = hip_backend(seed=5)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 4096)
+    assert hb.last_sample_counts()[0] == 4096 // 32
+    hb.set_option("geom_clock", 4096)
+    run_session(hb, sc, rd, scenes.wl_discrete(550.0), 4096)
+    assert hb.last_sample_counts()[0] == 1
+    hb.close()
