@@ -807,7 +807,8 @@ def test_axis_determinism_truth_table_decides_the_orientation_sample_count(case,
     first = ex[ex["seq"] == 0]                            # the entry reflection of every root
     assert len(first) > n // 2
     cells = len(np.unique(np.round(np.asarray(first["dir"], np.float64).reshape(-1, 3) / 0.05), axis=0))
-    assert (cells > 100) == stochastic and (stochastic or cells <= 8 * 8), (case, cells)   # <= 8 faces, each direction within a few 0.05 cells of itself
+    print(case, "direction cells", cells)
+    assert (cells > 24) == stochastic, (case, cells)   # measured: fixed 4 (the lit faces, each within its own 0.05 cell); roll alone 57, latitude (5 degrees) 98, azimuth 153, full sphere 5713
 
 
 def test_stochastic_trace_device_pool_equals_host_pool():
