@@ -510,6 +510,23 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
 
     for _ in range(warmup):
         step()
+    if args.warm_seconds > 0.0:
+        # Short steps (config 4d: 31 sessions of 0.1 ms kernels) are over before the device has settled — its first timed steps read 13.8 / 9.7 /
+        # 7.8 ms alone, and 12-15 ms for half a second right behind a configuration that had gigabytes of pools to give back (configs 2, 4).
+        # Untimed, like the steps above: keep stepping in chunks of `steps` until two consecutive chunks agree within 5 % (at least
+        # warm_seconds, at most 3 s).
+        t_w, last = time.perf_counter(), None
+        while True:
+            t_c = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            chunk = now - t_c
+            settled = last is not None and abs(chunk - last) <= 0.05 * chunk
+            last = chunk
+            if (settled and now - t_w >= args.warm_seconds) or now - t_w > 3.0:
+                break
     tracer.zero()
     tracer.backend.collect_stats()                            # drop the warm-up tallies
     tracer.backend.collect_timing()
@@ -766,6 +783,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (median reported)")
     ap.add_argument("--rays-per-wl", type=int, default=0, help="root rays per session per GPU per step (0 = the configuration's own)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: per-GPU work fixed; strong: the configuration's rays are the whole job")
+    ap.add_argument("--warm-seconds", type=float, default=0.0, help="extra untimed warm-up after the --warmup steps: chunks of --steps steps until two consecutive chunks agree within 5 %% (at least this long, at most 3 s; the short runs of the other configurations use 0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="default configuration on one GPU: skip the short runs of the other configurations")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
@@ -803,6 +821,7 @@ def main():
     out = measure(args.config, args, ctx, args.steps, args.warmup, args.repeats, with_cpu=not args.no_cpu_baseline)
     if args.config == "1" and world == 1 and not args.no_others and not args.rays_per_wl:
         others = {}
+        args.warm_seconds = max(args.warm_seconds, 0.3)
         for cfg in OTHER_CONFIGS:
             r = measure(cfg, args, ctx, 3, 3, 3, with_cpu=False)   # (3 warm-up steps: a step of 31 short sessions is over before the clocks have ramped — config 4d read 13.8 / 9.7 / 7.8 ms on its first three steps)
             others[cfg] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": 3, "warmup": 3,
