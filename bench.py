@@ -210,7 +210,7 @@ def physical_cores():
     return {"cores": len(pairs) or (os.cpu_count() or 1), "sockets": len(sockets) or 1, "model": model}
 
 
-def cpu_baseline(wk, budget_s=12.0):
+def cpu_baseline(wk, budget_s=18.0):
     """CPU oracle ("port") on all host cores, bounded to ~budget_s of work on the same workload shape."""
     from tests._oracle_backend import OracleBackend, run_session
     cores = os.cpu_count() or 1

@@ -206,6 +206,7 @@ struct HaloBackend {
   bool ring_posts[kRing] = {};
   bool ring_final[kRing] = {};         // the slot's launch belongs to its session's last layer (halo_collect_timing counts those)
   bool ring_busy[kRing] = {};
+  uint64_t ring_use[kRing] = {};       // how many launches have taken the slot (TableCacheEntry::read_use)
   int ring_next = 0;
   // Table cache (round 5): the dispatch-constant tables of a deterministic crystal entry (latitude LUT, wavelength pool, shape, entry-pick
   // tables, filter / colour tables) stay on the device from one dispatch to the next while scene, wavelength, filters, colour and options
@@ -219,8 +220,11 @@ struct HaloBackend {
     // staging their tables out of the slot they were given.  An upload waits (on the stream, not the host) for the last kernel that read ITS
     // slot — two table sets back, as good as always finished — so consecutive sessions of different wavelengths still overlap.
     int cur = 0;
-    hipEvent_t ev_read[2] = {nullptr, nullptr};
-    bool has_read[2] = {false, false};
+    // the slot's last reader = the dispatch-ring slot of the last launch that was given it (its ring_done event is recorded anyway: no
+    // event of the cache's own, one HIP call less per small session) and that ring slot's use count then: a ring slot that has been taken
+    // again since was harvested first, i.e. that launch is over
+    int read_ring[2] = {-1, -1};
+    uint64_t read_use[2] = {0, 0};
   };
   TableCacheEntry tcache[HALO_MAX_LAYERS][HALO_MAX_ENTRIES];
   DevBuf<DispatchSlot> tcache_dev;     // HALO_MAX_LAYERS x HALO_MAX_ENTRIES x 2 slots, reserved on first use
@@ -572,10 +576,6 @@ int halo_destroy(halo_handle_t b) {
   b->counters.release();
   b->ring_dev.release();
   b->tcache_dev.release();
-  for (auto& layer : b->tcache)
-    for (auto& e : layer)
-      for (hipEvent_t ev : e.ev_read)
-        if (ev) (void)hipEventDestroy(ev);
   if (b->ring_host) (void)hipHostFree(b->ring_host);
   if (b->tally_host) (void)hipHostFree(b->tally_host);
   for (int k = 0; k < HaloBackend::kRing; k++) {
@@ -1264,6 +1264,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       const int k = b->ring_next;
       b->ring_next = (k + 1) % HaloBackend::kRing;
       harvest_slot(b, k);  // blocks only if the ring has wrapped onto a dispatch still in flight
+      b->ring_use[k]++;
       DispatchSlot& hs = b->ring_host[k];
       if (ce && !cached) ce->cur ^= 1;   // an upload takes the entry's other slot
       DispatchSlot* ds = ce ? ce_dev + ce->cur : b->ring_dev.ptr + k;
@@ -1290,10 +1291,13 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         // (the fast filter tables are the slot's last member and travel only with the dispatches that use them; the pinned mirror is this
         // ring slot's, so it stays as it is until the copy has run — harvest_slot above)
         // A cache slot is a fixed device address: a kernel of an earlier, queued session (async: nobody harvested it) may still be staging its
-        // tables out of it on a trace stream.  The upload goes behind the last kernel that read this slot (no host wait; ring slots are
+        // tables out of it on a trace stream.  The upload goes behind the last launch that read this slot (no host wait; ring slots are
         // protected by harvest_slot above).  Without this the earlier kernel's late workgroups could pick up THIS session's wavelength pool or
         // shape (tests/test_gpu_production_routes.py::test_async_sessions_alternating_wavelengths).
-        if (ce && ce->has_read[ce->cur]) HIPCHK(b, hipStreamWaitEvent(b->stream, ce->ev_read[ce->cur], 0));
+        if (ce && ce->read_ring[ce->cur] >= 0) {
+          const int rk = ce->read_ring[ce->cur];
+          if (b->ring_busy[rk] && b->ring_use[rk] == ce->read_use[ce->cur]) HIPCHK(b, hipStreamWaitEvent(b->stream, b->ring_done[rk], 0));
+        }
         HIPCHK(b, hipMemcpyAsync(ds, &hs, fast_host ? sizeof(DispatchSlot) : offsetof(DispatchSlot, fast), hipMemcpyHostToDevice, b->stream));
         if (ce) {   // the next dispatch of this entry — the layer's next chunk, the next equal session — finds the tables in place
           ce->valid = true, ce->mode = mode, ce->use_filter = use_filter, ce->use_color = use_color;
@@ -1539,10 +1543,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // a one-shape dispatch of a regular hexagonal prism takes the literal-normal instantiation (kGeomOneHex = 3)
       const int launch_geom = (geom == 0 && entry_fast && b->hex_fast && hex_regular) ? 3 : geom;
       hipError_t le = launch_trace(P, blocks, ts, mode, launch_geom, b->mono_session);
-      if (ce) {   // the slot's last reader (see TableCacheEntry)
-        if (!ce->ev_read[ce->cur]) HIPCHK(b, hipEventCreateWithFlags(&ce->ev_read[ce->cur], hipEventDisableTiming));
-        HIPCHK(b, hipEventRecord(ce->ev_read[ce->cur], ts));
-        ce->has_read[ce->cur] = true;
+      if (ce) {   // the slot's last reader (see TableCacheEntry): this launch, whose ring_done event is recorded below
+        ce->read_ring[ce->cur] = k;
+        ce->read_use[ce->cur] = b->ring_use[k];
       }
       b->mono_dirty = true;
       b->route.launches++;
