@@ -1,6 +1,6 @@
 """Accumulation-route boundaries, HIP against HIP: random image size (64x48 .. 4096x2048), session length around the route thresholds (2 Mi,
 8 Mi rays), wavelength source (discrete, illuminant pools of 1 .. 255 entries), lens / visible range, deterministic or sampled crystals — the
-default routes (hit log, X/Y/Z log, per-entry planes, binned, two-level) against the same session with every hit added by a direct atomic
+default routes (hit log — from 512 Ki rays on full-sky scalar sessions —, X/Y/Z log, per-entry planes, binned, two-level) against the same session with every hit added by a direct atomic
 (options hit_log=0, bin=0).  The image, landed weight and exit count must agree to float-accumulation accuracy.  Prints each case before it
 runs (a memory fault names its case).   python tools/route_fuzz.py [first_seed] [count]"""
 import os, sys
@@ -14,7 +14,8 @@ first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2])
 TWO_LAYERS = len(sys.argv) > 3 and sys.argv[3] == "ms"   # a second scattering layer (prob 0.5 / 1.0): continuation order differs run to run, so the
                                                            # comparison is statistical there (landed 3 %, exits 1 %) — the point is the routes' memory safety
 SIZES = [(64, 48), (333, 211), (512, 256), (1024, 512), (1920, 1080), (2048, 1024), (2048, 2048), (2896, 2896), (4096, 2048), (8192, 1024)]
-RAYS = [(2 << 20) - 1, 2 << 20, (2 << 20) + 77, 3 << 20, (8 << 20) - 1, 8 << 20, 9 << 20]
+RAYS = [(2 << 20) - 1, 2 << 20, (2 << 20) + 77, 3 << 20, (8 << 20) - 1, 8 << 20, 9 << 20,
+        (1 << 19) - 1, 1 << 19, (1 << 19) + 77, 700_000]   # round 6: a full-sky scalar session takes the hit log from 512 Ki rays
 worst = 0.0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
