@@ -1381,7 +1381,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
       // Tiles: as many as the split pass feeds whatever the image size — the per-tile pass has one workgroup per tile — of at least
       // 256 and at most 16 Ki slots (X/Y/Z: 4 Ki) of ONE plane: 512 for X/Y/Z; for a scalar plane 128 where that keeps them within
       // 16 Ki slots (longer runs in the split pass: 0.23 vs 0.25 ms at configs[1]).
-      const uint32_t log_t_log2 = log_planes_ok ? wl_t_log2 : b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(static_cast<uint32_t>(b->log_tiles_log2), b->mono_s_log2 + 2u));
+      const uint32_t log_t_log2 = log_planes_ok ? wl_t_log2 : b->xyz_log ? std::min<uint32_t>(9u, b->mono_s_log2 + 2u) : std::max<uint32_t>(b->mono_s_log2 >= 4u ? b->mono_s_log2 - 4u : 0u, std::min<uint32_t>(static_cast<uint32_t>(m < (4ull << 20) ? std::max(b->log_tiles_log2, 8) : b->log_tiles_log2), b->mono_s_log2 + 2u));   // (a small launch takes 256 tiles: its per-tile pass is one workgroup per tile, and 128 of them leave half the chip idle — config 4d 2.85 -> 3.18 G rays/s; big launches keep 128 for the split's longer runs)
       const uint32_t log_planes = log_planes_ok ? b->plane_cnt : 1u;
       const uint32_t log_tiles = log_planes << log_t_log2;   // lists the split pass feeds
       const bool log_layout_ok = b->xyz_log ? (b->mono_s_log2 <= 11u) : (b->mono_session && (log_planes_ok || (!b->mono_by_wl && b->mono_s_log2 <= 12u)));

@@ -80,3 +80,51 @@ def test_pool_without_a_clock_setting_follows_the_cpu_paths_32_rays_per_shape():
     run_session(hb, sc, rd, scenes.wl_discrete(550.0), 4096)
     assert hb.last_sample_counts()[0] == 1
     hb.close()
+
+
+def test_ray_base_high_word_reaches_the_gen_gate_and_transit_streams():
+    """test_cuda_rich_exit.cpp:368-607 (CudaRngHiWiring: GenStreamWireUp, GateStreamWireUp, GateMsMode1StreamWireUp, TransitStreamWireUp): the
+    high word of the 64-bit ray base (SplitPcgRayBase, trace_backend.hpp:184; epochs 0, 0, 2^32, 2 x 2^32) must reach every stream's seed.
+    The reference needs test hooks to look at each stream's output; here all three streams show in what crosses the seam, and the oracle
+    takes the same base (`ray_base`), so each epoch is checked twice: (1) hi == 0 twice is the same rays bit for bit, and each other epoch
+    moves > 90 % of the entry reflections (gen stream), changes which exits continue (gate stream: another continuation count) and the
+    second layer's exits (transit stream: new orientations); (2) at every epoch the engine's exits are the ORACLE's at that epoch, root for
+    root — a stream that ignored its high word would reproduce epoch 0 and fail the comparison at epochs 1 and 2."""
+    full = {"type": "uniform", "mean": 0.0, "std": 360.0}
+    e0 = scenes.entry(scenes.prism_crystal(1.0), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 0)
+    e1 = scenes.entry(scenes.prism_crystal(1.3), scenes.axis(zenith=full, azimuth=full, roll=full), 1.0, 1)
+    sc = scenes.scene([(0.6, [e0]), (0.0, [e1])], max_hits=8, sun_altitude=30.0)
+    rd = scenes.render(abi.LENS_RECTANGULAR, 128, 64, el=0.0, visible=abi.VISIBLE_FULL)
+    n = 4096
+    got = []
+    for base in (0, 0, 1 << 32, 2 << 32):
+        hb, ob = hip_backend(seed=42, capture_exits=1, shuffle_chunk=1), OracleBackend(seed=42, capture_exits=1, threads=1)
+        for b in (hb, ob):
+            b.set_option("ray_base", base)
+        sh, so = run_session(hb, sc, rd, scenes.wl_discrete(550.0), n), run_session(ob, sc, rd, scenes.wl_discrete(550.0), n)
+        eh, eo = hb.DrainExits(), ob.DrainExits()
+        hb.close(), ob.close()
+        # layer 0 traces the same rays on both sides: same continuation count (gate stream), same exits root for root (gen stream)
+        assert int(sh[0].continuation_count) == int(so[0].continuation_count), base
+        l0h, l0o = eh[eh["layer"] == 0], eo[eo["layer"] == 0]
+        k = lambda e: np.lexsort((e["seq"], e["root"]))
+        a, b2 = l0h[k(l0h)], l0o[k(l0o)]
+        assert len(a) == len(b2) and np.array_equal(a["root"], b2["root"]) and np.array_equal(a["seq"], b2["seq"]), base
+        assert np.abs(np.asarray(a["dir"], np.float64) - np.asarray(b2["dir"], np.float64)).max() <= 2e-5, base
+        # layer 1: the pool's order differs between the two (ballot-compacted shards here, sequential there), so the second layer agrees
+        # statistically (the suite's multi-layer rule) — the per-epoch identity is carried by layer 0 and the continuation count
+        l1h, l1o = eh[eh["layer"] == 1], eo[eo["layer"] == 1]
+        assert len(l1o) > 0 and abs(len(l1h) - len(l1o)) <= 0.03 * len(l1o), (base, len(l1h), len(l1o))
+        assert np.asarray(l1h["weight"], np.float64).sum() == pytest.approx(np.asarray(l1o["weight"], np.float64).sum(), rel=3e-2), base
+        first = a[a["seq"] == 0]
+        got.append((np.asarray(first["dir"], np.float32).copy(), np.asarray(first["root"]).copy(), int(sh[0].continuation_count),
+                    float(np.asarray(l1h["weight"], np.float64).sum())))
+    assert np.array_equal(got[0][0], got[1][0]) and got[0][2:] == got[1][2:]                 # hi == 0 twice: deterministic
+    for i, j in ((0, 2), (0, 3), (2, 3)):
+        common = np.intersect1d(got[i][1], got[j][1])
+        di = got[i][0][np.searchsorted(got[i][1], common)]
+        dj = got[j][0][np.searchsorted(got[j][1], common)]
+        moved = (np.square(di.astype(np.float64) - dj).sum(axis=1) > 1e-10).mean()
+        assert moved > 0.9, (i, j, moved)                                                     # gen stream
+        assert got[i][2] != got[j][2]                                                         # gate stream: other rays continue
+        assert got[i][3] != got[j][3]                                                         # transit stream: another second layer
