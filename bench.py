@@ -236,7 +236,7 @@ def cpu_baseline(wk, budget_s=18.0):
     return {"value": len(wls) * per_wl / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "host": {"threads_used": threads, "logical_cpus": cores, "physical_cores": physical["cores"], "sockets": physical["sockets"], "model": physical["model"],
                      "note": "`cores` above = OpenMP threads used (the contract's field); physical_cores = sockets x cores per socket from /proc/cpuinfo"},
-            "sample": "same workload shape, %d session(s) x %d root rays (%.1f s of CPU work), OpenMP over rays" % (len(wls), per_wl, dt),
+            "sample": "same workload shape, %d session(s) x %d root rays (%.1f s of CPU work), OpenMP over rays in dynamic chunks of 4096 (the reference's protocol dispatches 128 rays per worker task, doc/performance-testing.md:109: the coarser chunk only flatters this number)" % (len(wls), per_wl, dt),
             "note": "kind=port: the reference's own CPU path (Simulator / CpuTraceBackend) needs spdlog + nlohmann-json >= 3.4, absent from this image, "
                     "and may not be built against stand-ins; this is the repo's C restatement of it (oracle/halo_oracle.c). Calibration of the real "
                     "reference: %.2f M rays/s on %d threads in the %s; the oracle runs %.1fx (1 thread) / %.1fx (6 threads) the compiled reference there (%s), "

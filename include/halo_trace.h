@@ -281,7 +281,8 @@ const char* halo_last_error(halo_handle_t h);
  * halo_bind_accumulator is always folded at halo_end, its owner reads it without asking; 0: fold at every halo_end),
  * "gen_serial" (0 [default]: stochastic pyramids are built by teams of 32 lanes per crystal; 1: one thread per crystal — the
  * same builder the host runs; records are bit-identical either way, A/B knob),
- * "hit_log" (-1 [default]: production-mode launches >= 2 Mi rays on one scalar plane, or on the X/Y/Z planes of an illuminant
+ * "hit_log" (-1 [default]: production-mode launches >= 2 Mi rays on one scalar plane (>= 512 Ki rays when the render's visible range is
+ * FULL: every exit of a full-sky render lands, and that many direct atomics cost more than the log's passes), or on the X/Y/Z planes of an illuminant
  * session (>= 2 Mi rays, image above 512 Ki pixels), append the hits that miss the pixel cache to a log region per workgroup — plain stores instead of
  * memory-side fp32 atomics — which a split pass and a per-tile LDS pass then add to the plane(s); 0 = never (direct atomics),
  * 1 = whenever applicable), "hit_log_cap" (test knob: records per log region, 0 [default] = sized from the launch; what runs
