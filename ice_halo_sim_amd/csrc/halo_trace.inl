@@ -579,6 +579,7 @@ struct AccCtx {
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
   uint32_t* log_n;   // hit-log kernels: the workgroup's log cursor (LDS); nullptr otherwise
+  const ProjDev* proj;   // HALO_PROJ_LDS: the projection's constants staged in LDS for the exit queue's drain (nullptr = the dispatch record's)
 };
 
 // Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
@@ -1273,11 +1274,20 @@ HD void stage_shape(SlotT* slot, const RecT* g, uint32_t l32) {
   if (l32 < (n1 + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->single)[l32] = reinterpret_cast<const uint32_t*>(g->single)[l32];
 }
 
+#ifndef HALO_PROJ_LDS
+#define HALO_PROJ_LDS 1    // round 6: the exit queue's drain of the last-layer plain kernels reads the projection's constants from LDS into VGPRs, not from the
+                           // kernarg segment into SGPRs: ~40 scalars fewer live across the drain (the loop's own scalar state is no longer spilled to VGPR lanes
+                           // around it) and the projection's FMAs take VGPR operands (an SGPR operand makes a VALU instruction 1.56x dearer on this part).  0 = off
+#endif
 // One exit that goes to the image: project, accumulate, tally (the tail of CollectData, simulator.cpp:719-760).
 template <int MODE, bool MONO, bool SMALLC>
 HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
+#if HALO_PROJ_LDS
+  const ProjDev& pj = cache.proj != nullptr ? *cache.proj : P.proj;
+#else
   const ProjDev& pj = P.proj;
+#endif
   Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
@@ -2489,6 +2499,17 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   acc.cache = &T.cache;
   acc.hits = nullptr;
   acc.log_n = nullptr;
+  acc.proj = nullptr;
+#if HALO_PROJ_LDS
+  __shared__ __attribute__((aligned(16))) ProjDev s_proj;
+  // Measured per kernel family (same box, alternating builds): the last-layer plain kernels gain (configs[1] 1.720 -> 1.688 ms per launch, SGPR
+  // spills 49 -> 20); the filter-mode queue kernels LOSE (ms_multi_crystal_complex_filter's first layer 2.46 -> 2.64 ms) and so do the pool kernels,
+  // which project at the emit site (configs[4] 2.07 -> 2.16 ms, 4d 0.129 -> 0.149): it stays with the kernels it pays for (2 / 3 widen it, A/B only).
+  if constexpr ((QUEUE && MODE == kModePlain && LAST) || (HALO_PROJ_LDS == 2 && QUEUE) || (HALO_PROJ_LDS == 3 && ModeTraits<MODE>::kFast)) {   // (visible to the waves behind the barrier that ends the prologue)
+    if (threadIdx.x < sizeof(ProjDev) / 4u) reinterpret_cast<uint32_t*>(&s_proj)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P.proj)[threadIdx.x];
+    acc.proj = &s_proj;
+  }
+#endif
   __shared__ uint32_t s_log_n;
   if constexpr (LOG) {
     acc.log_n = &s_log_n;
