@@ -1274,6 +1274,9 @@ HD void stage_shape(SlotT* slot, const RecT* g, uint32_t l32) {
   if (l32 < (n1 + 3u) / 4u) reinterpret_cast<uint32_t*>(slot->single)[l32] = reinterpret_cast<const uint32_t*>(g->single)[l32];
 }
 
+#ifndef HALO_N_VGPR
+#define HALO_N_VGPR 1
+#endif
 #ifndef HALO_PROJ_LDS
 #define HALO_PROJ_LDS 1    // round 6: the exit queue's drain of the last-layer plain kernels reads the projection's constants from LDS into VGPRs, not from the
                            // kernarg segment into SGPRs: ~40 scalars fewer live across the drain (the loop's own scalar state is no longer spilled to VGPR lanes
@@ -1441,6 +1444,7 @@ HD void emit_gate(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, co
     const bool out = live && !pass;
     sums.exit_w += out ? w : 0.0f;
     sums.exit_n += out ? 1u : 0u;   // (counted per lane: one popcount of the ballot per emit, a scalar add, measured 2.7 % SLOWER at configs[1])
+    // (taking the cull's view axis from the LDS copy of the projection as well — HALO_PROJ_LDS — measured the same: 1.668 vs 1.669 ms)
     const bool want = out && exit_may_land(P.proj, wx, wy, wz, cache.lens, cache.vis);
     const uint64_t m = __ballot(want);
     ExitQueue& Q = *cache.q;
@@ -2045,7 +2049,15 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     wle = P.wl_pool[wl_idx];
     inv_n = 1.0f / wle.n_idx;  // once per ray, IEEE like the reference
   }
+#if HALO_N_VGPR   // the refractive index (dispatch-uniform for a discrete wavelength: the compiler keeps it in an SGPR) pinned into a VGPR: the Fresnel
+                  // split's ~10 operations per interaction that take it then have VGPR operands only (an SGPR operand makes a VALU instruction 1.56x
+                  // dearer on this part) — configs[1] 1.690 -> 1.671 ms per launch, configs[2] and [4] -1 %; same values (round 6)
+  float n_idx_pin = wle.n_idx;
+  asm volatile("" : "+v"(n_idx_pin));
+  const float n_idx = n_idx_pin;
+#else
   const float n_idx = wle.n_idx;
+#endif
   const float cmf_x = wle.cmf_x, cmf_y = wle.cmf_y, cmf_z = wle.cmf_z;
 
   uint8_t path[ModeTraits<MODE>::kTables ? kFilterPathCap : 1];
@@ -2091,7 +2103,13 @@ HD void trace_one(const DispatchParams& P, LdsTables<MONO, SMALLC>& T, const Acc
     o.rf[0] = HALO_FMA(-k_refr, fn.x, rr * d[0]), o.rf[1] = HALO_FMA(-k_refr, fn.y, rr * d[1]), o.rf[2] = HALO_FMA(-k_refr, fn.z, rr * d[2]);
     return o;
   };
+#if HALO_N_VGPR
+  float n2_pin = n_idx * n_idx, one_m_n2_pin = 1.0f - n_idx * n_idx;
+  asm volatile("" : "+v"(n2_pin), "+v"(one_m_n2_pin));
+  const float n2 = n2_pin, one_m_n2 = one_m_n2_pin;
+#else
   const float n2 = n_idx * n_idx, one_m_n2 = 1.0f - n_idx * n_idx;
+#endif
   if (next != nullptr) next->land();   // the next pass's pool record goes to LDS: behind every load wait of this pass, in front of its first store
   // Legacy-CPU next-face strategy (option rehit_strategy = 0; generic kernels only — see the test on the outgoing child below): a child that
   // "re-hits" is parked here with its path and walked after the ray's main path, by re-entering the loop at its interaction index.
