@@ -375,8 +375,8 @@ HD void dual_to_pixel(float xn, float yn, bool upper, int w, int h, float& fx, f
   float r = static_cast<float>(short_res) / 2.0f;
   float cy = static_cast<float>(h) / 2.0f;
   float cx = upper ? static_cast<float>(w) / 2.0f - r : static_cast<float>(w) / 2.0f + r;
-  fx = (upper ? -yn : yn) * r + cx;
-  fy = xn * r + cy;
+  fx = HALO_FMA(upper ? -yn : yn, r, cx);
+  fy = HALO_FMA(xn, r, cy);
 }
 
 struct Hits {
@@ -393,9 +393,12 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
   if (t == HALO_LENS_LINEAR || t == HALO_LENS_FISHEYE_EQUAL_AREA || t == HALO_LENS_FISHEYE_EQUIDISTANT ||
       t == HALO_LENS_FISHEYE_STEREOGRAPHIC || t == HALO_LENS_FISHEYE_ORTHOGRAPHIC) {
     if ((vr == HALO_VISIBLE_UPPER && wz > 0.0f) || (vr == HALO_VISIBLE_LOWER && wz < 0.0f)) return r;
-    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
-    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
-    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
+    // (every sum of products below is spelled as the chain it is evaluated as — like the cull, exit_may_land — so that the instantiations that
+    //  take the projection from SGPRs and the ones that take it from LDS into VGPRs (HALO_PROJ_LDS) put a hit on the same side of a pixel edge:
+    //  left to the compiler's contraction the two differed on one hit in 5 M, tests/test_gpu_production_routes.py::test_hit_log_route_equals_…)
+    float cx = HALO_FMA(p.rot[6], -wz, HALO_FMA(p.rot[3], -wy, p.rot[0] * (-wx)));
+    float cy = HALO_FMA(p.rot[7], -wz, HALO_FMA(p.rot[4], -wy, p.rot[1] * (-wx)));
+    float cz = HALO_FMA(p.rot[8], -wz, HALO_FMA(p.rot[5], -wy, p.rot[2] * (-wx)));
     XY xy;
     if (t == HALO_LENS_LINEAR) {
       if (cz <= 0.0f) return r;
@@ -409,8 +412,8 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
     }
     if (!xy.valid) return r;
     xy.x = -xy.x;
-    r.px0 = static_cast<int>(floorf(xy.x * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
-    r.py0 = static_cast<int>(floorf(xy.y * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
+    r.px0 = static_cast<int>(floorf(HALO_FMA(xy.x, p.scale, static_cast<float>(p.img_w) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_x)));
+    r.py0 = static_cast<int>(floorf(HALO_FMA(xy.y, p.scale, static_cast<float>(p.img_h) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_y)));
     r.count = 1;
     return r;
   }
@@ -419,9 +422,9 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
     float lat = asinf(fminf(fmaxf(-wz, -1.0f), 1.0f));
     while (lon < -kPiF) lon += 2.0f * kPiF;
     while (lon > kPiF) lon -= 2.0f * kPiF;
-    int raw_x = static_cast<int>(floorf(lon * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f));
+    int raw_x = static_cast<int>(floorf(HALO_FMA(lon, p.scale, static_cast<float>(p.img_w) / 2.0f) + 0.5f));
     r.px0 = ((raw_x % p.img_w) + p.img_w) % p.img_w;
-    r.py0 = static_cast<int>(floorf(-lat * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f));
+    r.py0 = static_cast<int>(floorf(HALO_FMA(-lat, p.scale, static_cast<float>(p.img_h) / 2.0f) + 0.5f));
     r.count = 1;
     return r;
   }
@@ -447,13 +450,13 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
   }
   if (t == HALO_LENS_GLOBE) {
     const float kGlobeCameraD = 4.0f;
-    float cx = p.rot[0] * (-wx) + p.rot[3] * (-wy) + p.rot[6] * (-wz);
-    float cy = p.rot[1] * (-wx) + p.rot[4] * (-wy) + p.rot[7] * (-wz);
-    float cz = p.rot[2] * (-wx) + p.rot[5] * (-wy) + p.rot[8] * (-wz);
+    float cx = HALO_FMA(p.rot[6], -wz, HALO_FMA(p.rot[3], -wy, p.rot[0] * (-wx)));
+    float cy = HALO_FMA(p.rot[7], -wz, HALO_FMA(p.rot[4], -wy, p.rot[1] * (-wx)));
+    float cz = HALO_FMA(p.rot[8], -wz, HALO_FMA(p.rot[5], -wy, p.rot[2] * (-wx)));
     if (cz >= -1.0f / kGlobeCameraD) return r;
     float denom = kGlobeCameraD + cz;
-    r.px0 = static_cast<int>(floorf(-cx / denom * p.scale + static_cast<float>(p.img_w) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_x)));
-    r.py0 = static_cast<int>(floorf(cy / denom * p.scale + static_cast<float>(p.img_h) / 2.0f + 0.5f + static_cast<float>(p.lens_shift_y)));
+    r.px0 = static_cast<int>(floorf(HALO_FMA(-cx / denom, p.scale, static_cast<float>(p.img_w) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_x)));
+    r.py0 = static_cast<int>(floorf(HALO_FMA(cy / denom, p.scale, static_cast<float>(p.img_h) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_y)));
     r.count = 1;
     return r;
   }
