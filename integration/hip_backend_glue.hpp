@@ -215,6 +215,11 @@ struct SceneTables {
   std::vector<HaloColorSet> color_sets;   // HaloEntry::color_id indexes this table (1-based)
   std::vector<HaloColorClass> color_classes;
   bool representable = true;              // false -> IsCompatible() answers false (caps exceeded; never truncated)
+  // raypath colour past the engine's caps (HALO_COLOR_MAX_CLASSES classes per session, HALO_COLOR_MAX_TERMS predicates per placement):
+  // the tables above hold what fits, these count what did not.  BeginSession refuses such a scene (default) or renders it degraded and
+  // reports the counts like the reference's GPU backends do (LUMICE_HIP_COLOR_OVERFLOW=degrade; cuda_trace_backend.cu:3296-3304, :3363-3380)
+  size_t color_class_overflow = 0;
+  size_t color_term_overflow = 0;
 };
 
 inline SceneTables ToHalo(const SceneConfig& s, const RaypathColorConfig* color) {
@@ -233,7 +238,7 @@ inline SceneTables ToHalo(const SceneConfig& s, const RaypathColorConfig* color)
   if (color != nullptr && !color->classes_.empty()) {
     gate = BuildColorGateTable(*color, s);
     const ColorClassTable classes = BuildColorClassTable(*color, s, gate);
-    if (classes.classes_.size() > HALO_COLOR_MAX_CLASSES) out.representable = false;
+    if (classes.classes_.size() > HALO_COLOR_MAX_CLASSES) out.color_class_overflow = classes.classes_.size() - HALO_COLOR_MAX_CLASSES;
     for (size_t c = 0; c < classes.classes_.size() && c < HALO_COLOR_MAX_CLASSES; c++) {
       HaloColorClass hc{};
       hc.bits = classes.classes_[c].member_bits_;
@@ -266,7 +271,7 @@ inline SceneTables ToHalo(const SceneConfig& s, const RaypathColorConfig* color)
       if (!out.color_classes.empty()) {                   // this placement's predicates (color_gate_table.hpp:109-113)
         const ColorGatePlacement pl = ColorGatePlacementFor(gate, static_cast<IdType>(l), st.crystal_.id_);
         if (!pl.predicates_.empty()) {
-          if (pl.predicates_.size() > HALO_COLOR_MAX_TERMS) out.representable = false;
+          if (pl.predicates_.size() > HALO_COLOR_MAX_TERMS) out.color_term_overflow += pl.predicates_.size() - HALO_COLOR_MAX_TERMS;
           HaloColorSet cs{};
           cs.term_count = static_cast<int32_t>(std::min<size_t>(pl.predicates_.size(), HALO_COLOR_MAX_TERMS));
           for (int32_t k = 0; k < cs.term_count; k++) {
@@ -312,7 +317,21 @@ class HipBackendGlue final : public TraceBackend {
       seeded_ = true;
     }
     hip_glue::SceneTables t = hip_glue::ToHalo(*spec.scene, spec.raypath_color.get());       // SessionSpec::raypath_color
-    if (!t.representable) throw BackendUnavailableError("scene exceeds the HIP backend's table caps (layers/entries/filter or colour terms)");
+    if (!t.representable) throw BackendUnavailableError("scene exceeds the HIP backend's table caps (layers/entries/filter terms)");
+    // Colour past the caps.  The reference's GPU backends drop the excess, log it and count it (GetLastColorDegradeCounts, trace_backend.hpp:626-632);
+    // the CPU path has no caps.  Default here: refuse, so that the simulator's per-Run fallback (simulator.cpp:1049-1062) renders the scene
+    // in full on the legacy path.  LUMICE_HIP_COLOR_OVERFLOW=degrade keeps the run on the GPU instead: classes past the 16th are dropped
+    // exactly like the reference's (same cap, same count), a placement's predicates past the 16th are dropped and counted as OR-summands
+    // (this engine has no per-symmetry-group cap, so symmetry_group_overflow stays 0).  Recomputed per BeginSession like the reference's.
+    last_color_degrade_ = ColorDegradeCounts{};
+    if (t.color_class_overflow != 0 || t.color_term_overflow != 0) {
+      const char* mode = std::getenv("LUMICE_HIP_COLOR_OVERFLOW");
+      if (mode == nullptr || std::string(mode) != "degrade")
+        throw BackendUnavailableError("raypath colour exceeds the HIP backend's caps (16 classes, 16 predicates per placement); "
+                                      "LUMICE_HIP_COLOR_OVERFLOW=degrade renders it with the excess dropped and counted");
+      last_color_degrade_.color_class_overflow = t.color_class_overflow;
+      last_color_degrade_.or_summand_overflow = t.color_term_overflow;
+    }
     const HaloRender rd = hip_glue::ToHalo(*spec.render);
     HaloWl wl{};
     if (const auto* ill = std::get_if<IlluminantType>(&spec.scene->light_source_.spectrum_)) {
@@ -409,9 +428,10 @@ class HipBackendGlue final : public TraceBackend {
   // --- sample-count getters (trace_backend.hpp:587, :625): real counts of what the kernels drew in the last session ----------
   size_t GetLastBatchStochasticCrystalSampleCount() const override { return be_ ? be_->GetLastBatchStochasticCrystalSampleCount() : 0; }
   size_t GetLastBatchStochasticOrientationSampleCount() const override { return be_ ? be_->GetLastBatchStochasticOrientationSampleCount() : 0; }
-  // GetLastColorDegradeCounts (trace_backend.hpp:632): nothing degrades silently here — a scene beyond the colour caps is
+  // GetLastColorDegradeCounts (trace_backend.hpp:632): all zeros unless LUMICE_HIP_COLOR_OVERFLOW=degrade let a scene past the caps through
+  // (BeginSession above); otherwise nothing degrades — a scene beyond the colour caps is
   // refused in BeginSession (BackendUnavailableError -> per-Run fallback to the legacy path, simulator.cpp:1049-1062)
-  ColorDegradeCounts GetLastColorDegradeCounts() const override { return {}; }
+  ColorDegradeCounts GetLastColorDegradeCounts() const override { return last_color_degrade_; }
 
  private:
   struct Handle : LayerHandle {
@@ -455,6 +475,7 @@ class HipBackendGlue final : public TraceBackend {
   int device_ = 0;
   uint32_t pinned_seed_ = 0u;   // constructor seed (tests): the engine exists and is seeded from the start
   bool seeded_ = false;          // a non-zero seed has been applied (constructor or a SessionSpec)
+  ColorDegradeCounts last_color_degrade_{};   // of the last BeginSession (all zeros unless LUMICE_HIP_COLOR_OVERFLOW=degrade)
   std::unique_ptr<halo::HipTraceBackend> be_;
 };
 

@@ -81,7 +81,8 @@ FilterConfig Simple(IdType id, SimpleFilterParam p, uint8_t sym, FilterConfig::A
 
 void Emit(const char* name, const SceneConfig& sc, const RaypathColorConfig* color, const std::vector<RenderConfig>& renders) {
   const hip_glue::SceneTables t = hip_glue::ToHalo(sc, color);
-  std::printf("{\"name\": \"%s\", \"representable\": %s, \"scene\": \"%s\", \"entries\": [", name, t.representable ? "true" : "false", Hex(&t.scene, sizeof(HaloScene)).c_str());
+  std::printf("{\"name\": \"%s\", \"representable\": %s, \"color_class_overflow\": %zu, \"color_term_overflow\": %zu, \"scene\": \"%s\", \"entries\": [", name,
+              t.representable ? "true" : "false", t.color_class_overflow, t.color_term_overflow, Hex(&t.scene, sizeof(HaloScene)).c_str());
   bool first = true;
   for (int l = 0; l < t.scene.layer_count; l++)
     for (int e = 0; e < t.scene.layers[l].entry_count; e++) {
@@ -272,6 +273,18 @@ int main() {
     c2.match_ = { ref(0, 2, DirectionFilterParam{ 0.0f, 22.0f, 3.0f }, FilterConfig::kSymNone) };
     rc.classes_ = { c0, c1, c2 };
     Emit("raypath_color_two_layers", sc, &rc, { Render(1, LensParam::kFisheyeEqualArea, 180.0f, 512, 256, 0.0f, 30.0f, 0.0f, RenderConfig::kUpper) });
+    // 7. the same scene past the engine's colour caps: 19 classes (3 over HALO_COLOR_MAX_CLASSES) of which the last 16 put 16 distinct
+    //    predicates on placement (0, 1) — with the one c0 and c1 share that makes 17 (1 over HALO_COLOR_MAX_TERMS).  The tables must hold the first
+    //    16 of each unchanged and the counts say what was dropped (ColorDegradeCounts, def.hpp:43-51)
+    RaypathColorConfig big = rc;
+    for (int k = 0; k < 16; k++) {
+      ColorClassConfig c;
+      c.color_[k % 3] = 0.5f;
+      c.combine_ = "any";
+      c.match_ = { ref(0, 1, RaypathFilterParam{ { static_cast<IdType>(3 + k % 6), static_cast<IdType>(1 + k / 6), 2 } }, FilterConfig::kSymNone) };
+      big.classes_.push_back(c);
+    }
+    Emit("raypath_color_past_the_caps", sc, &big, { Render(1, LensParam::kFisheyeEqualArea, 180.0f, 512, 256, 0.0f, 30.0f, 0.0f, RenderConfig::kUpper) });
   }
   return 0;
 }

@@ -187,6 +187,17 @@ def run_case(seed, n=60_000, hip_opts=None, **oracle_opts):
     n_un = int(round((1.0 - out["match"][0]) * (len(eh) + len(eo)))) + 1
     wmax = max(float(eh["weight"].max()) if len(eh) else 0.0, float(eo["weight"].max()) if len(eo) else 0.0)
     out["unmatched_weight"] = n_un * wmax if out["match"][0] < 1.0 else 0.0
+    # exits that pair up within the direction bar but land in the frame on ONE side only (a point within 1e-6 of the frame's or the visible
+    # hemisphere's border): their whole weight is in one landed sum and not in the other (seed 40119: one exit of weight 0.619 in 945)
+    out["border"] = (0, 0.0)
+    if len(eo) and len(eh):
+        kh = (eh["layer"].astype(np.int64) << 48) | (eh["root"].astype(np.int64) << 8) | eh["seq"].astype(np.int64)
+        ko = (eo["layer"].astype(np.int64) << 48) | (eo["root"].astype(np.int64) << 8) | eo["seq"].astype(np.int64)
+        oh, oo = np.argsort(kh), np.argsort(ko)
+        _, ch, co = np.intersect1d(kh[oh], ko[oo], return_indices=True)
+        xa, xb = eh[oh][ch], eo[oo][co]
+        one_side = ((xa["pixel"] < 0) != (xb["pixel"] < 0)) & (np.abs(xa["dir"] - xb["dir"]).max(axis=1) <= 2e-5)
+        out["border"] = (int(one_side.sum()), float(np.maximum(xa["weight"][one_side], xb["weight"][one_side]).sum()))
     out["l2"] = rel_l2(block_mean(ih, 4), block_mean(io, 4)) if io.sum() > 0 else 0.0
     by = block_mean(io, 4)[..., 1].astype(np.float64)
     out["n_eff"] = float(by.sum() ** 2 / max((by * by).sum(), 1e-300))   # how many blocks carry the image (one heavy exit in a few dozen: seed 11011)
@@ -207,7 +218,14 @@ def check(seed, r):
     oracles differ by on it.
     (2) small sparse images at 60 k rays, where ONE exit crossing a pixel border is 1 % of a block-mean distance: that bar is 5e-2 +
     2 / sqrt(blocks that carry the image) here, the per-ray bars carry the comparison; (3) illuminant weights of ~100 per exit: the
-    landed weights may differ by what the unmatched exits weigh."""
+    landed weights may differ by what the unmatched exits weigh.
+    Round 6's sweep of 400 new seeds (tests/golden/FUZZ_SWEEPS.md) added two: (4) an exit that pairs up (directions 9e-7 apart) and lies
+    ON the frame's border lands on one side only — its whole weight is in one landed sum (seed 40119); such exits are counted (at most
+    2 + 1e-4 of the exits) and their weight is allowed for; (5) with every axis fixed the oracle pair is ONE sample of the rounding, not a
+    distribution: on seed 40254 (sun 0.28 degrees below a fixed pyramid's basal plane, sun diameter 0: 20 k identical rays) the two oracles
+    agree with each other on 0.984 of the exits, the product with the oracle on 0.981 (0.983 conditioned) — on OTHER exits than the oracle
+    pair's, so the per-exit widening does not cover them — and the strict build on 0.99991 unconditioned.  For fixed-axes scenes the
+    conditioned bar is therefore the oracle pair's own agreement less 0.01, never above 0.995."""
     deg = float(r["degenerate"])   # the fraction of an entry's crystal instances on which the two sides follow the reference's two next-face strategies (has_degenerate_tables)
     if deg > 0.02:
         assert r["exits"][0] == pytest.approx(r["exits"][1], rel=6e-2, abs=20), (seed, r)
@@ -215,10 +233,12 @@ def check(seed, r):
         return
     assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3 + 2.0 * deg, abs=20), (seed, r)
     frac, pix, path, left_out = r["cond"]
-    assert frac >= 0.995 - 2.0 * deg and pix >= 0.995 - 2.0 * deg and path >= 0.998 - 2.0 * deg, (seed, r)
+    frac_bar = min(0.995, r["oracle_pair"] - 0.01) if r["fixed_axes"] else 0.995
+    assert frac >= frac_bar - 2.0 * deg and pix >= 0.995 - 2.0 * deg and path >= 0.998 - 2.0 * deg, (seed, r)
     assert left_out <= 2e-3 * r["n_exits"][1] + 5, (seed, r)
     assert r["match"][0] >= min(0.995, r["oracle_pair"] - 0.03), (seed, r)          # and never far below what the oracles reach between themselves
-    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3 + r["unmatched_weight"], (seed, r)
+    assert r["border"][0] <= 2 + 1e-4 * r["n_exits"][1], (seed, r)
+    assert abs(r["landed"][0] - r["landed"][1]) <= 3e-4 * max(r["landed"][1], 1.0) + 1e-3 + r["unmatched_weight"] + r["border"][1], (seed, r)
     assert r["l2"] <= 5e-2 + 2.0 / np.sqrt(max(r["n_eff"], 1.0)), (seed, r)
 
 
@@ -227,7 +247,8 @@ def _seeds():
     if spec:
         a, b = spec.split(":")
         return list(range(int(a), int(b)))
-    return list(range(100, 148)) + [20234]   # 20234: two instances with a segment thinner than the vertex merge (has_degenerate_tables)
+    # 20234: two instances with a segment thinner than the vertex merge (has_degenerate_tables); 40119 / 40254: check()'s cases (4) and (5)
+    return list(range(100, 148)) + [20234, 40119, 40254]
 
 
 @pytest.mark.parametrize("seed", _seeds())

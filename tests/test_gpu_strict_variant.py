@@ -25,6 +25,11 @@ BARS = {247: 0.998, 411: 0.998, 702: 0.993, 11584: 0.998}
 # (tools/strict_sweep.py, profiles/r06_strict_sweep.txt): every seed >= 0.99915 (the product build >= 0.9985 on the same list — the conditioning is
 # only ever needed on fixed-orientation scenes like the four above).  The worst eight of that sweep stay pinned here at 0.998.
 SWEEP_WORST = {137: 0.998, 20234: 0.998, 104: 0.998, 121: 0.998, 100: 0.998, 130: 0.998, 129: 0.998, 122: 0.998}
+# Round 6, sweep of seeds 40000..40399: seed 40254 (sun 0.28 degrees under a FIXED pyramid's basal plane, sun diameter 0 — 20 k identical rays, so the
+# oracle pair is one sample of the rounding): oracle pair 0.98403, product 0.98070 (0.98300 conditioned — the product differs on other exits
+# than the pair does, so the widening misses them), strict build 0.99991 unconditioned.  The claim stays falsifiable on it: the strict build
+# must meet the plain bar, and the product must be no further from the oracle than the oracle's two roundings are from each other.
+SINGLE_SAMPLE = {40254: 0.998}
 
 DRIVER = r"""
 import json, sys
@@ -45,7 +50,7 @@ def _start(lib):
         env["HALO_LIB"] = lib
     else:
         env.pop("HALO_LIB", None)
-    return subprocess.Popen([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS) + sorted(SWEEP_WORST))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    return subprocess.Popen([sys.executable, "-c", DRIVER % (ROOT, sorted(BARS) + sorted(SWEEP_WORST) + sorted(SINGLE_SAMPLE))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
 def _finish(proc):
@@ -81,3 +86,7 @@ def test_strict_build_meets_the_unconditioned_per_ray_bars():
     for seed, bar in SWEEP_WORST.items():                                          # the whole seed list's worst eight, no conditioning
         assert strict[seed]["match"] >= bar, (seed, strict[seed])
         assert product[seed]["match"] >= 0.995, (seed, product[seed])               # (random orientations: the product meets the plain bar too)
+    for seed, bar in SINGLE_SAMPLE.items():
+        s, p = strict[seed], product[seed]
+        assert s["fixed"] >= 1 and s["match"] >= bar, (seed, s)
+        assert p["cond"] >= p["pair"] - 0.01 and p["match"] >= p["pair"] - 0.01, (seed, p)

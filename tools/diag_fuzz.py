@@ -35,6 +35,12 @@ for seed in [int(a) for a in sys.argv[1:]]:
     if bad.any():
         print("  differing pairs: |dw|/w percentiles 50/90/99/max %s | dir diff 50/99/max %s | their weights median %.3g" % (
             np.round(np.percentile(dw[bad], [50, 90, 99, 100]), 6), np.round(np.percentile(dd[bad], [50, 99, 100]), 7), np.median(b["weight"][bad])))
+    # exits that pair up but land elsewhere: another pixel, or inside the frame on one side only (what the landed weights may differ by)
+    ph, po = a["pixel"].astype(np.int64), b["pixel"].astype(np.int64)
+    moved = ph != po
+    one_side = moved & ((ph < 0) | (po < 0))
+    print("  paired exits in another pixel: %d, of them in the frame on one side only: %d (weights %s; direction differences %s)" % (
+        moved.sum(), one_side.sum(), np.round(b["weight"][one_side][:6], 5), np.abs(a["dir"] - b["dir"]).max(axis=1)[one_side][:6]))
     bad_roots = np.unique(np.concatenate([only_h >> 8, only_o >> 8, a["root"][bad].astype(np.int64)]))
     print("  rays with any difference: %d of %d (%.3f %%)" % (len(bad_roots), 60000, 100.0 * len(bad_roots) / 60000))
     # which crystal entry the differing rays belong to (rays are dealt out to the entries in order, PartitionCrystalRayNum)
