@@ -190,6 +190,7 @@ def run_case(seed, n=60_000, hip_opts=None, **oracle_opts):
     # exits that pair up within the direction bar but land in the frame on ONE side only (a point within 1e-6 of the frame's or the visible
     # hemisphere's border): their whole weight is in one landed sum and not in the other (seed 40119: one exit of weight 0.619 in 945)
     out["border"] = (0, 0.0)
+    out["moved_roots"] = 0
     if len(eo) and len(eh):
         kh = (eh["layer"].astype(np.int64) << 48) | (eh["root"].astype(np.int64) << 8) | eh["seq"].astype(np.int64)
         ko = (eo["layer"].astype(np.int64) << 48) | (eo["root"].astype(np.int64) << 8) | eo["seq"].astype(np.int64)
@@ -198,6 +199,8 @@ def run_case(seed, n=60_000, hip_opts=None, **oracle_opts):
         xa, xb = eh[oh][ch], eo[oo][co]
         one_side = ((xa["pixel"] < 0) != (xb["pixel"] < 0)) & (np.abs(xa["dir"] - xb["dir"]).max(axis=1) <= 2e-5)
         out["border"] = (int(one_side.sum()), float(np.maximum(xa["weight"][one_side], xb["weight"][one_side]).sum()))
+        moved = (xa["pixel"] != xb["pixel"]) & (np.abs(xa["dir"] - xb["dir"]).max(axis=1) <= 2e-5)
+        out["moved_roots"] = int(len(np.unique(xa["root"][moved])))    # RAYS with a paired exit in another pixel (a plate sends one direction out many times)
     out["l2"] = rel_l2(block_mean(ih, 4), block_mean(io, 4)) if io.sum() > 0 else 0.0
     by = block_mean(io, 4)[..., 1].astype(np.float64)
     out["n_eff"] = float(by.sum() ** 2 / max((by * by).sum(), 1e-300))   # how many blocks carry the image (one heavy exit in a few dozen: seed 11011)
@@ -225,7 +228,10 @@ def check(seed, r):
     distribution: on seed 40254 (sun 0.28 degrees below a fixed pyramid's basal plane, sun diameter 0: 20 k identical rays) the two oracles
     agree with each other on 0.984 of the exits, the product with the oracle on 0.981 (0.983 conditioned) — on OTHER exits than the oracle
     pair's, so the per-exit widening does not cover them — and the strict build on 0.99991 unconditioned.  For fixed-axes scenes the
-    conditioned bar is therefore the oracle pair's own agreement less 0.01, never above 0.995."""
+    conditioned bar is therefore the oracle pair's own agreement less 0.01, never above 0.995.  And one from the 2000 seeds after that: (6) the
+    same-pixel fraction is taken over the exits on which the two oracles agree to the bit — 337 of 33 449 on seed 41973 — and ONE ray whose
+    direction sits 1 ulp from a pixel column's border leaves a plate five times in that direction: 5 / 337 = 1.5 %.  The fraction stays the
+    bar; where it fails, the RAYS with a paired exit (directions within 2e-5) in another pixel must be no more than 2 + 1e-4 of the exits."""
     deg = float(r["degenerate"])   # the fraction of an entry's crystal instances on which the two sides follow the reference's two next-face strategies (has_degenerate_tables)
     if deg > 0.02:
         assert r["exits"][0] == pytest.approx(r["exits"][1], rel=6e-2, abs=20), (seed, r)
@@ -234,7 +240,8 @@ def check(seed, r):
     assert r["exits"][0] == pytest.approx(r["exits"][1], rel=1e-3 + 2.0 * deg, abs=20), (seed, r)
     frac, pix, path, left_out = r["cond"]
     frac_bar = min(0.995, r["oracle_pair"] - 0.01) if r["fixed_axes"] else 0.995
-    assert frac >= frac_bar - 2.0 * deg and pix >= 0.995 - 2.0 * deg and path >= 0.998 - 2.0 * deg, (seed, r)
+    assert frac >= frac_bar - 2.0 * deg and path >= 0.998 - 2.0 * deg, (seed, r)
+    assert pix >= 0.995 - 2.0 * deg or r["moved_roots"] <= 2 + 1e-4 * r["n_exits"][1], (seed, r)
     assert left_out <= 2e-3 * r["n_exits"][1] + 5, (seed, r)
     assert r["match"][0] >= min(0.995, r["oracle_pair"] - 0.03), (seed, r)          # and never far below what the oracles reach between themselves
     assert r["border"][0] <= 2 + 1e-4 * r["n_exits"][1], (seed, r)
@@ -247,8 +254,8 @@ def _seeds():
     if spec:
         a, b = spec.split(":")
         return list(range(int(a), int(b)))
-    # 20234: two instances with a segment thinner than the vertex merge (has_degenerate_tables); 40119 / 40254: check()'s cases (4) and (5)
-    return list(range(100, 148)) + [20234, 40119, 40254]
+    # 20234: two instances with a segment thinner than the vertex merge (has_degenerate_tables); 40119 / 40254 / 41973: check()'s cases (4), (5) and (6)
+    return list(range(100, 148)) + [20234, 40119, 40254, 41973]
 
 
 @pytest.mark.parametrize("seed", _seeds())

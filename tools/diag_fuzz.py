@@ -41,6 +41,10 @@ for seed in [int(a) for a in sys.argv[1:]]:
     one_side = moved & ((ph < 0) | (po < 0))
     print("  paired exits in another pixel: %d, of them in the frame on one side only: %d (weights %s; direction differences %s)" % (
         moved.sum(), one_side.sum(), np.round(b["weight"][one_side][:6], 5), np.abs(a["dir"] - b["dir"]).max(axis=1)[one_side][:6]))
+    for k in np.nonzero(moved)[0][:8]:
+        print("     moved: root %d seq %d len %d pixel hip %d (row %d col %d) oracle %d (row %d col %d) dir hip %s oracle %s w %.5g" % (
+            a["root"][k], a["seq"][k], a["path_len"][k], ph[k], ph[k] // rd.width, ph[k] % rd.width, po[k], po[k] // rd.width, po[k] % rd.width,
+            np.array2string(a["dir"][k], precision=8), np.array2string(b["dir"][k], precision=8), b["weight"][k]))
     bad_roots = np.unique(np.concatenate([only_h >> 8, only_o >> 8, a["root"][bad].astype(np.int64)]))
     print("  rays with any difference: %d of %d (%.3f %%)" % (len(bad_roots), 60000, 100.0 * len(bad_roots) / 60000))
     # which crystal entry the differing rays belong to (rays are dealt out to the entries in order, PartitionCrystalRayNum)
