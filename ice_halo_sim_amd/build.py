@@ -46,7 +46,11 @@ def build(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(bdir, src + ".o")
         if src.endswith(".hip"):
-            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage"] + common
+            # -fno-slp-vectorize (round 6): the SLP vectoriser pairs independent fp32 operations into v_pk_add / v_pk_mul / v_pk_fma, which on gfx950
+            # cost 4.5 cycles per wave64 instruction against 2 x 2.8 for the plain forms AND need their operands moved into register pairs first
+            # (profiles/r06_micro_valu_rate_bench.txt; 95 packed instructions and 23 moves in the headline kernel): a net loss in an issue-bound
+            # kernel.  Same values (a packed half rounds like the plain instruction); configs[1] 1.661 -> 1.588 ms per launch, configs[2] / [4] -3 / -2 %.
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"] + common
             if PROBE:
                 cmd.append("-DHALO_PROBE=1")
             cmd += os.environ.get("HALO_DEFS", "").split()

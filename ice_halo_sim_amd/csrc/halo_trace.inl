@@ -242,14 +242,17 @@ HD float invert_lat_lut(float xi, const float* lut) {
   const float* th = lut;
   const float* cdf = lut + kLutNodes;
   xi = fminf(fmaxf(xi, cdf[0]), cdf[kLutNodes - 1]);
-  uint32_t lo = 0u, hi = kLutNodes - 1u;
+  // The reference's bisection (lo = 0, hi = 256; mid = (lo + hi) / 2; cdf[mid] <= xi ? lo = mid : hi = mid; 8 rounds) has hi - lo = 256 >> round
+  // whatever the data, so mid is always lo + (128 >> round) and hi need not be carried: the same probes, the same comparisons, the same lo —
+  // in three instructions a round (compare, select, add; the read is at a constant offset from lo) where carrying both ends took seven.
+  static_assert(kLutNodes == 257, "the bisection below is written for 256 intervals");
+  uint32_t lo4 = 0u;   // lo as a byte offset: the probe's address is lo4 plus a constant, no shift per round
 #pragma unroll
-  for (int it = 0; it < 8; it++) {  // 256 intervals → exactly 8 halvings, wave-uniform trip count
-    uint32_t mid = (lo + hi) >> 1u;
-    bool le = cdf[mid] <= xi;
-    lo = le ? mid : lo;
-    hi = le ? hi : mid;
+  for (int it = 0; it < 8; it++) {
+    const uint32_t step4 = 512u >> it;
+    lo4 += (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(cdf) + lo4 + step4) <= xi) ? step4 : 0u;
   }
+  const uint32_t lo = lo4 >> 2;
   float c0 = cdf[lo], c1 = cdf[lo + 1u];
   float denom = c1 - c0;
   float w = denom > 0.0f ? (xi - c0) * fast_rcp(denom) : 0.0f;
@@ -384,7 +387,7 @@ struct Hits {
   int count;
 };
 
-HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1) {   // lens / vis >= 0: the dispatch's lens / visible range, known at compile time
+HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1, const float* pre = nullptr) {   // lens / vis >= 0: the dispatch's lens / visible range, known at compile time
   Hits r;
   r.count = 0;
   r.px0 = r.py0 = r.px1 = r.py1 = 0;
@@ -412,8 +415,11 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
     }
     if (!xy.valid) return r;
     xy.x = -xy.x;
-    r.px0 = static_cast<int>(floorf(HALO_FMA(xy.x, p.scale, static_cast<float>(p.img_w) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_x)));
-    r.py0 = static_cast<int>(floorf(HALO_FMA(xy.y, p.scale, static_cast<float>(p.img_h) / 2.0f) + 0.5f + static_cast<float>(p.lens_shift_y)));
+    // (`pre`: ProjLds' four floats — the conversions below done once per workgroup; nullptr = do them here)
+    const float half_w = pre != nullptr ? pre[0] : static_cast<float>(p.img_w) / 2.0f, half_h = pre != nullptr ? pre[1] : static_cast<float>(p.img_h) / 2.0f;
+    const float shift_x = pre != nullptr ? pre[2] : static_cast<float>(p.lens_shift_x), shift_y = pre != nullptr ? pre[3] : static_cast<float>(p.lens_shift_y);
+    r.px0 = static_cast<int>(floorf(HALO_FMA(xy.x, p.scale, half_w) + 0.5f + shift_x));
+    r.py0 = static_cast<int>(floorf(HALO_FMA(xy.y, p.scale, half_h) + 0.5f + shift_y));
     r.count = 1;
     return r;
   }
@@ -569,6 +575,14 @@ template <>
 struct ExitQueues<false> {
   uint32_t unused;
 };
+// The projection's constants as the exit queue's drain reads them from LDS (HALO_PROJ_LDS), followed by the four int -> float conversions the
+// pixel formulas of the fisheye family begin with (half the image's width and height, the lens shifts): done once per workgroup instead of
+// once per pop of the queue (6 of the ~45 instructions a pop spends on the two pixel coordinates).  The same operations on the same
+// integers: the same floats.
+struct ProjLds {
+  ProjDev p;
+  float half_w, half_h, shift_x, shift_y;
+};
 template <bool MONO, bool SMALLC>
 struct AccCtx {
   int lens, vis;     // >= 0: instantiated for this lens / visible range (the projection's dispatch folds away)
@@ -582,7 +596,7 @@ struct AccCtx {
   PixCache<MONO, SMALLC>* cache;
   HitBuffer* hits;   // nullptr = accumulate directly
   uint32_t* log_n;   // hit-log kernels: the workgroup's log cursor (LDS); nullptr otherwise
-  const ProjDev* proj;   // HALO_PROJ_LDS: the projection's constants staged in LDS for the exit queue's drain (nullptr = the dispatch record's)
+  const ProjLds* proj;   // HALO_PROJ_LDS: the projection's constants staged in LDS for the exit queue's drain (nullptr = the dispatch record's)
 };
 
 // Accumulation planes (halo_device.h MonoSlot): plane `pl`, privatised copy of this workgroup, slot of `pix`.
@@ -1290,11 +1304,13 @@ template <int MODE, bool MONO, bool SMALLC>
 HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, const ColorDev* color, uint64_t cmask, float wx, float wy, float wz, float w,
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
 #if HALO_PROJ_LDS
-  const ProjDev& pj = cache.proj != nullptr ? *cache.proj : P.proj;
+  const ProjDev& pj = cache.proj != nullptr ? cache.proj->p : P.proj;
+  const float* pre = cache.proj != nullptr ? &cache.proj->half_w : nullptr;
 #else
   const ProjDev& pj = P.proj;
+  const float* pre = nullptr;
 #endif
-  Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1);
+  Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1, pre);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
   if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
@@ -2236,8 +2252,6 @@ walk_path:
     float num_b = 1e30f, den_b = 1.0f;
     int hit = -1;
     bool none_ahead;
-    // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain
-    const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
     if constexpr (HEX) {
       // Regular hexagonal prism: slab k has normal (0,0,1), (1,0,0), (1/2, s60, 0), (-1/2, s60, 0) — the builder's exact table
       // values, here literals — and face ids (0,1), (2,5), (3,6), (4,7); both faces of a slab have the same plane constant.  The
@@ -2250,15 +2264,20 @@ walk_path:
       // order, the same products and comparisons: the values are bit for bit the old ones (negation is exact).
       constexpr float kS60 = 0.86602540378443864676f;
       const float ndb = -hex_d_basal, nds = -hex_d_side;
+      const float hd = d[0] * 0.5f, hp = p[0] * 0.5f;
       uint32_t cb = 0xFFFFFFFFu;   // winner's code; all ones = none
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float2v s60 = {kS60, kS60};
-        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? __builtin_elementwise_fma(Y, s60, X * 0.5f) : __builtin_elementwise_fma(Y, s60, X * -0.5f);
-        const uint32_t sgn = __float_as_uint(r.x) & 0x80000000u;
-        const float t = __uint_as_float(__float_as_uint(r.y) ^ sgn);
+        // (n.d, n.p) of slab k.  The two oblique slabs are four scalar fmas on two shared half-products (x * -0.5 == -(x * 0.5) exactly).  Until
+        // the end of round 6 these were packed pairs (v_pk_mul / v_pk_fma on {d, p}): a packed fp32 instruction costs 1.6 plain ones on this part
+        // AND its operands must first be moved into register pairs — 4 packed + 4 moves against 6 plain instructions per interaction, same values
+        // (configs[1] 1.661 -> 1.626 ms per launch).
+        const float nd = (k == 0) ? d[2] : (k == 1) ? d[0] : HALO_FMA(d[1], kS60, k == 2 ? hd : -hd);
+        const float np = (k == 0) ? p[2] : (k == 1) ? p[0] : HALO_FMA(p[1], kS60, k == 2 ? hp : -hp);
+        const uint32_t sgn = __float_as_uint(nd) & 0x80000000u;
+        const float t = __uint_as_float(__float_as_uint(np) ^ sgn);
         const float num = ((k == 0) ? ndb : nds) - t;
-        const float den = fabsf(r.x);
+        const float den = fabsf(nd);
         const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
         num_b = better ? num : num_b;
         den_b = better ? den : den_b;
@@ -2274,15 +2293,16 @@ walk_path:
       // candidates, order, products and comparisons as the table-driven search below: x * 1 + 0 and 0 * z + acc are exact.
       constexpr float kS60 = 0.86602540378443864676f;
       const float4 dp4 = *reinterpret_cast<const float4*>(slot_fast->d_plus), dm4 = *reinterpret_cast<const float4*>(slot_fast->d_minus);
+      const float hd = d[0] * 0.5f, hp = p[0] * 0.5f;
       uint32_t cb = 0xFFFFFFFFu;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float2v s60 = {kS60, kS60};
-        const float2v r = (k == 0) ? Z : (k == 1) ? X : (k == 2) ? __builtin_elementwise_fma(Y, s60, X * 0.5f) : __builtin_elementwise_fma(Y, s60, X * -0.5f);
+        const float nd = (k == 0) ? d[2] : (k == 1) ? d[0] : HALO_FMA(d[1], kS60, k == 2 ? hd : -hd);   // (scalar, like the regular prism's search above)
+        const float np = (k == 0) ? p[2] : (k == 1) ? p[0] : HALO_FMA(p[1], kS60, k == 2 ? hp : -hp);
         const float dpk = (k == 0) ? dp4.x : (k == 1) ? dp4.y : (k == 2) ? dp4.z : dp4.w, dmk = (k == 0) ? dm4.x : (k == 1) ? dm4.y : (k == 2) ? dm4.z : dm4.w;
-        const bool pos = r.x > 0.0f;
-        const float den = fabsf(r.x);
-        const float num = pos ? -(r.y + dpk) : (r.y - dmk);   // (spelled like the table-driven search: the same roundings)
+        const bool pos = nd > 0.0f;
+        const float den = fabsf(nd);
+        const float num = pos ? -(np + dpk) : (np - dmk);   // (spelled like the table-driven search: the same roundings)
         const bool better = (den > kSlabEps) && (num * den_b < num_b * den);
         num_b = better ? num : num_b;
         den_b = better ? den : den_b;
@@ -2292,6 +2312,9 @@ walk_path:
       none_ahead = cb == 0xFFFFFFFFu;
       hit = static_cast<int>(((cb >> 2) & 7u) + (cb >> 31) * (cb & 3u));
     } else {
+    // (n.d, n.p) as one packed pair per plane: v_pk_mul/v_pk_fma, each element an ordinary fma chain (the pairs are assembled once and serve
+    // every plane of the body: 5-20 planes here, where the two literal searches above have two)
+    const float2v X = {d[0], p[0]}, Y = {d[1], p[1]}, Z = {d[2], p[2]};
     const int slab_cnt = sh->slab_cnt, single_cnt = sh->single_cnt;
     for (int k = 0; k < slab_cnt; ++k) {
       // opposite faces +n / -n: den(-n) = -den(+n) and n.p flips sign, so only the face the ray travels towards can be ahead
@@ -2522,12 +2545,16 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   acc.log_n = nullptr;
   acc.proj = nullptr;
 #if HALO_PROJ_LDS
-  __shared__ __attribute__((aligned(16))) ProjDev s_proj;
+  __shared__ __attribute__((aligned(16))) ProjLds s_proj;
   // Measured per kernel family (same box, alternating builds): the last-layer plain kernels gain (configs[1] 1.720 -> 1.688 ms per launch, SGPR
   // spills 49 -> 20); the filter-mode queue kernels LOSE (ms_multi_crystal_complex_filter's first layer 2.46 -> 2.64 ms) and so do the pool kernels,
   // which project at the emit site (configs[4] 2.07 -> 2.16 ms, 4d 0.129 -> 0.149): it stays with the kernels it pays for (2 / 3 widen it, A/B only).
   if constexpr ((QUEUE && MODE == kModePlain && LAST) || (HALO_PROJ_LDS == 2 && QUEUE) || (HALO_PROJ_LDS == 3 && ModeTraits<MODE>::kFast)) {   // (visible to the waves behind the barrier that ends the prologue)
-    if (threadIdx.x < sizeof(ProjDev) / 4u) reinterpret_cast<uint32_t*>(&s_proj)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P.proj)[threadIdx.x];
+    if (threadIdx.x < sizeof(ProjDev) / 4u) reinterpret_cast<uint32_t*>(&s_proj.p)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P.proj)[threadIdx.x];
+    if (threadIdx.x == sizeof(ProjDev) / 4u) {
+      s_proj.half_w = static_cast<float>(P.proj.img_w) / 2.0f, s_proj.half_h = static_cast<float>(P.proj.img_h) / 2.0f;
+      s_proj.shift_x = static_cast<float>(P.proj.lens_shift_x), s_proj.shift_y = static_cast<float>(P.proj.lens_shift_y);
+    }
     acc.proj = &s_proj;
   }
 #endif
