@@ -50,7 +50,12 @@ def build(force=False, verbose=False):
             # cost 4.5 cycles per wave64 instruction against 2 x 2.8 for the plain forms AND need their operands moved into register pairs first
             # (profiles/r06_micro_valu_rate_bench.txt; 95 packed instructions and 23 moves in the headline kernel): a net loss in an issue-bound
             # kernel.  Same values (a packed half rounds like the plain instruction); configs[1] 1.661 -> 1.588 ms per launch, configs[2] / [4] -3 / -2 %.
-            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"] + common
+            # -amdgpu-atomic-optimizer-strategy=None: every same-address atomic of these kernels is wave-aggregated by hand already (ballot + mbcnt,
+            # one lane adds: the hit log's cursor, the exit queue, the continuation shards) and all others have per-lane addresses; the compiler's
+            # optimizer wraps the hand-aggregated ones in a second mbcnt / readfirstlane / multiply sequence (28 VALU + 38 SALU instructions in the
+            # headline kernel, 3 SGPR spills).
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+                   "-Rpass-analysis=kernel-resource-usage"] + common
             if PROBE:
                 cmd.append("-DHALO_PROBE=1")
             cmd += os.environ.get("HALO_DEFS", "").split()

@@ -1313,7 +1313,10 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
   Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1, pre);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
-  if (h.count >= 1 && h.px0 >= 0 && h.px0 < pj.img_w && h.py0 >= 0 && h.py0 < pj.img_h) {
+  // (0 <= x < w as ONE unsigned compare — a negative coordinate is a huge unsigned one, the image's sides are positive — and the three tests
+  //  joined without short-circuit: one branch where `&&` made three nested ones, each with its copies of the ray's sums)
+  const bool in0 = (h.count >= 1) & (static_cast<uint32_t>(h.px0) < static_cast<uint32_t>(pj.img_w)) & (static_cast<uint32_t>(h.py0) < static_cast<uint32_t>(pj.img_h));
+  if (in0) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px0);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (ModeTraits<MODE>::kTables && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
@@ -1322,7 +1325,8 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
     sums.pix_n++;
     primary = static_cast<int>(pix);
   }
-  if (h.count == 2 && h.px1 >= 0 && h.px1 < pj.img_w && h.py1 >= 0 && h.py1 < pj.img_h) {
+  const bool in1 = (h.count == 2) & (static_cast<uint32_t>(h.px1) < static_cast<uint32_t>(pj.img_w)) & (static_cast<uint32_t>(h.py1) < static_cast<uint32_t>(pj.img_h));
+  if (in1) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px1);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (ModeTraits<MODE>::kTables && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
