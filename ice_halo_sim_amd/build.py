@@ -54,8 +54,10 @@ def build(force=False, verbose=False):
             # one lane adds: the hit log's cursor, the exit queue, the continuation shards) and all others have per-lane addresses; the compiler's
             # optimizer wraps the hand-aggregated ones in a second mbcnt / readfirstlane / multiply sequence (28 VALU + 38 SALU instructions in the
             # headline kernel, 3 SGPR spills).
-            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
-                   "-Rpass-analysis=kernel-resource-usage"] + common
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+            if not os.environ.get("HALO_ATOMIC_OPT"):   # (experiment knob: HALO_ATOMIC_OPT=1 leaves the compiler's atomic optimizer on, for the A/B)
+                cmd += ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+            cmd += ["-Rpass-analysis=kernel-resource-usage"] + common
             if PROBE:
                 cmd.append("-DHALO_PROBE=1")
             cmd += os.environ.get("HALO_DEFS", "").split()

@@ -1140,6 +1140,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
     P.wl_pool_size = b->wl_pool_size;
     P.proj = b->proj;
+    P.proj_pre[0] = static_cast<float>(b->proj.img_w) / 2.0f, P.proj_pre[1] = static_cast<float>(b->proj.img_h) / 2.0f;   // the pixel formulas' conversions, once per dispatch
+    P.proj_pre[2] = static_cast<float>(b->proj.lens_shift_x), P.proj_pre[3] = static_cast<float>(b->proj.lens_shift_y);
     P.cont_in = b->cont[out_slot ^ 1].ptr;
     P.cont_in_n = static_cast<uint32_t>(b->cont_in_n);
     P.cont_in_stride = b->cont_stride[out_slot ^ 1];

@@ -261,6 +261,7 @@ struct DispatchParams {
   uint32_t shape_cnt;
   uint32_t geom_clock;
   ProjDev proj;
+  float proj_pre[4];           // directly behind `proj` (ProjPre in halo_trace.inl): float(img_w) / 2, float(img_h) / 2, float(lens_shift_x), float(lens_shift_y)
   const float* lut;            // theta[257] | cdf[257] | flip[257]
   const WlEntryDev* wl_pool;
   const ShapeDev* shapes;

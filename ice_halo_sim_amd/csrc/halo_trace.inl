@@ -387,7 +387,7 @@ struct Hits {
   int count;
 };
 
-HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1, const float* pre = nullptr) {   // lens / vis >= 0: the dispatch's lens / visible range, known at compile time
+HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = -1, int vis = -1) {   // lens / vis >= 0: the dispatch's lens / visible range, known at compile time
   Hits r;
   r.count = 0;
   r.px0 = r.py0 = r.px1 = r.py1 = 0;
@@ -415,9 +415,8 @@ HD Hits project_exit(const ProjDev& p, float wx, float wy, float wz, int lens = 
     }
     if (!xy.valid) return r;
     xy.x = -xy.x;
-    // (`pre`: ProjLds' four floats — the conversions below done once per workgroup; nullptr = do them here)
-    const float half_w = pre != nullptr ? pre[0] : static_cast<float>(p.img_w) / 2.0f, half_h = pre != nullptr ? pre[1] : static_cast<float>(p.img_h) / 2.0f;
-    const float shift_x = pre != nullptr ? pre[2] : static_cast<float>(p.lens_shift_x), shift_y = pre != nullptr ? pre[3] : static_cast<float>(p.lens_shift_y);
+    const float* pre = reinterpret_cast<const float*>(&p + 1);   // ProjLds' / DispatchParams::proj_pre's four floats, directly behind the ProjDev
+    const float half_w = pre[0], half_h = pre[1], shift_x = pre[2], shift_y = pre[3];
     r.px0 = static_cast<int>(floorf(HALO_FMA(xy.x, p.scale, half_w) + 0.5f + shift_x));
     r.py0 = static_cast<int>(floorf(HALO_FMA(xy.y, p.scale, half_h) + 0.5f + shift_y));
     r.count = 1;
@@ -575,14 +574,16 @@ template <>
 struct ExitQueues<false> {
   uint32_t unused;
 };
-// The projection's constants as the exit queue's drain reads them from LDS (HALO_PROJ_LDS), followed by the four int -> float conversions the
-// pixel formulas of the fisheye family begin with (half the image's width and height, the lens shifts): done once per workgroup instead of
-// once per pop of the queue (6 of the ~45 instructions a pop spends on the two pixel coordinates).  The same operations on the same
-// integers: the same floats.
+// The projection's constants followed by the four int -> float conversions the pixel formulas of the fisheye family begin with (half the
+// image's width and height, the lens shifts), made once per dispatch on the host (DispatchParams::proj_pre lies directly behind ::proj) instead
+// of once per exit: the same operations on the same integers, the same floats.  The exit queue's drain reads the whole of it from its LDS copy
+// (HALO_PROJ_LDS).  project_exit takes a ProjDev and reads the four floats BEHIND it: it is only ever handed one of these two.
 struct ProjLds {
   ProjDev p;
   float half_w, half_h, shift_x, shift_y;
 };
+static_assert(offsetof(ProjLds, half_w) == sizeof(ProjDev) && offsetof(DispatchParams, proj_pre) == offsetof(DispatchParams, proj) + sizeof(ProjDev),
+              "the four floats lie directly behind the ProjDev, in LDS and in the dispatch record");
 template <bool MONO, bool SMALLC>
 struct AccCtx {
   int lens, vis;     // >= 0: instantiated for this lens / visible range (the projection's dispatch folds away)
@@ -1305,17 +1306,23 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
                  float cmf_x, float cmf_y, float cmf_z, uint32_t wl_idx, RaySums& sums, Probe& pr) {
 #if HALO_PROJ_LDS
   const ProjDev& pj = cache.proj != nullptr ? cache.proj->p : P.proj;
-  const float* pre = cache.proj != nullptr ? &cache.proj->half_w : nullptr;
 #else
   const ProjDev& pj = P.proj;
-  const float* pre = nullptr;
 #endif
-  Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1, pre);
+  Hits h = project_exit(pj, wx, wy, wz, ModeTraits<MODE>::kFast ? cache.lens : -1, ModeTraits<MODE>::kFast ? cache.vis : -1);
   PROBE_MARK(pr, kPhProject);
   int primary = -1;
   // (0 <= x < w as ONE unsigned compare — a negative coordinate is a huge unsigned one, the image's sides are positive — and the three tests
   //  joined without short-circuit: one branch where `&&` made three nested ones, each with its copies of the ray's sums)
-  const bool in0 = (h.count >= 1) & (static_cast<uint32_t>(h.px0) < static_cast<uint32_t>(pj.img_w)) & (static_cast<uint32_t>(h.py0) < static_cast<uint32_t>(pj.img_h));
+  // ... in the kernels instantiated for a one-hit lens.  The others (dual lenses, the generic-lens kernels) keep the short-circuit form: joined,
+  // their register allocation puts the Hits into scratch (dual fisheye: 536 bytes per lane, ms_multi_crystal's last layer 12 % slower), while the
+  // one-hit kernels spill with the short-circuit form — so the form follows the instantiation (the test folds at compile time).
+  const int lens_k = ModeTraits<MODE>::kFast ? cache.lens : -1;
+  const bool one_hit = lens_k >= 0 && lens_k != HALO_LENS_DUAL_FISHEYE_EQUAL_AREA && lens_k != HALO_LENS_DUAL_FISHEYE_EQUIDISTANT &&
+                       lens_k != HALO_LENS_DUAL_FISHEYE_STEREOGRAPHIC && lens_k != HALO_LENS_DUAL_FISHEYE_ORTHOGRAPHIC;
+  bool in0;
+  if (one_hit) in0 = (h.count >= 1) & (static_cast<uint32_t>(h.px0) < static_cast<uint32_t>(pj.img_w)) & (static_cast<uint32_t>(h.py0) < static_cast<uint32_t>(pj.img_h));
+  else in0 = h.count >= 1 && static_cast<uint32_t>(h.px0) < static_cast<uint32_t>(pj.img_w) && static_cast<uint32_t>(h.py0) < static_cast<uint32_t>(pj.img_h);
   if (in0) {
     uint32_t pix = static_cast<uint32_t>(h.py0) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px0);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
@@ -1325,8 +1332,9 @@ HD int land_exit(const DispatchParams& P, const AccCtx<MONO, SMALLC>& cache, con
     sums.pix_n++;
     primary = static_cast<int>(pix);
   }
-  const bool in1 = (h.count == 2) & (static_cast<uint32_t>(h.px1) < static_cast<uint32_t>(pj.img_w)) & (static_cast<uint32_t>(h.py1) < static_cast<uint32_t>(pj.img_h));
-  if (in1) {
+  // (the second hit of a dual lens keeps the short-circuit form: joined like the first, the dual-lens kernels put the Hits into scratch — 536 bytes
+  //  per lane — and ms_multi_crystal's last layer ran 12 % slower)
+  if (h.count == 2 && static_cast<uint32_t>(h.px1) < static_cast<uint32_t>(pj.img_w) && static_cast<uint32_t>(h.py1) < static_cast<uint32_t>(pj.img_h)) {
     uint32_t pix = static_cast<uint32_t>(h.py1) * static_cast<uint32_t>(pj.img_w) + static_cast<uint32_t>(h.px1);
     accumulate<MONO, SMALLC>(P, cache, pix, wl_idx, w, cmf_x, cmf_y, cmf_z);
     if (ModeTraits<MODE>::kTables && color != nullptr) fan_lanes(P, *color, cmask, pix, cmf_y * w);
@@ -2554,11 +2562,7 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
   // spills 49 -> 20); the filter-mode queue kernels LOSE (ms_multi_crystal_complex_filter's first layer 2.46 -> 2.64 ms) and so do the pool kernels,
   // which project at the emit site (configs[4] 2.07 -> 2.16 ms, 4d 0.129 -> 0.149): it stays with the kernels it pays for (2 / 3 widen it, A/B only).
   if constexpr ((QUEUE && MODE == kModePlain && LAST) || (HALO_PROJ_LDS == 2 && QUEUE) || (HALO_PROJ_LDS == 3 && ModeTraits<MODE>::kFast)) {   // (visible to the waves behind the barrier that ends the prologue)
-    if (threadIdx.x < sizeof(ProjDev) / 4u) reinterpret_cast<uint32_t*>(&s_proj.p)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P.proj)[threadIdx.x];
-    if (threadIdx.x == sizeof(ProjDev) / 4u) {
-      s_proj.half_w = static_cast<float>(P.proj.img_w) / 2.0f, s_proj.half_h = static_cast<float>(P.proj.img_h) / 2.0f;
-      s_proj.shift_x = static_cast<float>(P.proj.lens_shift_x), s_proj.shift_y = static_cast<float>(P.proj.lens_shift_y);
-    }
+    if (threadIdx.x < sizeof(ProjLds) / 4u) reinterpret_cast<uint32_t*>(&s_proj)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&P.proj)[threadIdx.x];   // proj and proj_pre
     acc.proj = &s_proj;
   }
 #endif
