@@ -21,7 +21,7 @@ STRICT = os.path.join(ROOT, "ice_halo_sim_amd", "libhalo_hip_strict.so")
 # unconditioned match_exits of the strict build, measured (profiles/r05_strict_variant.txt): 0.99887 / 0.99962 / 0.99444 / 0.99957 — against
 # 0.9948 / 0.9968 / 0.9811 / 0.9096 of the product and 0.945 / 0.951 / 0.976 / 0.918 between the oracle's own two roundings
 BARS = {247: 0.998, 411: 0.998, 702: 0.993, 11584: 0.998}
-# Round 6: the strict build over ALL 49 seeds of test_random_scene_traces_the_same_rays_as_the_oracle against the unconditioned bars
+# Round 6: the strict build over ALL seeds (49 then; 52 with the sweep's three at the end of the round) of test_random_scene_traces_the_same_rays_as_the_oracle against the unconditioned bars
 # (tools/strict_sweep.py, profiles/r06_strict_sweep.txt): every seed >= 0.99915 (the product build >= 0.9985 on the same list — the conditioning is
 # only ever needed on fixed-orientation scenes like the four above).  The worst eight of that sweep stay pinned here at 0.998.
 SWEEP_WORST = {137: 0.998, 20234: 0.998, 104: 0.998, 121: 0.998, 100: 0.998, 130: 0.998, 129: 0.998, 122: 0.998}
