@@ -2843,23 +2843,26 @@ __global__ void __launch_bounds__(kBlock, (min_waves<MODE, GEOM, MONO, ACC>())) 
 // passes the gate) as template constants.  Lenses of the reference's shipped examples (config_example.json: linear, dual fisheye
 // equal area; the BASELINE configurations: fisheye equal area; bench_config_stoch.json: rectangular) x visible upper / full;
 // anything else runs the generic kernel.
-template <int MODE, int GEOM, bool MONO, int ACC, int LENS>
+// (NOGATE = true: the last layer with prob <= 0.  NOGATE = false, round 6: the logging kernels of the layers BEFORE the last — their gate is open, the lens
+//  and the visible range are as constant as in the last layer, and the generic-lens form of them carried every lens's code: 8723 instructions, 120
+//  spilled SGPRs, 10 spilled VGPRs and scratch against 4612 / 45 / 0 / none for the dual-fisheye instantiation, tools/isa_by_line.py.)
+template <int MODE, int GEOM, bool MONO, int ACC, int LENS, bool NOGATE>
 static void launch_vis(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream) {
-  if (P.proj.visible_range == HALO_VISIBLE_UPPER) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_UPPER, true>), grid, block, 0, stream, P);
-  else if (P.proj.visible_range == HALO_VISIBLE_FULL) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+  if (P.proj.visible_range == HALO_VISIBLE_UPPER) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_UPPER, NOGATE>), grid, block, 0, stream, P);
+  else if (P.proj.visible_range == HALO_VISIBLE_FULL) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC, LENS, HALO_VISIBLE_FULL, NOGATE>), grid, block, 0, stream, P);
   else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P);
 }
-template <int MODE, int GEOM, bool MONO, int ACC>
+template <int MODE, int GEOM, bool MONO, int ACC, bool NOGATE = true>
 static void launch_lens(const DispatchParams& P, dim3 grid, dim3 block, hipStream_t stream) {
-  if (P.prob > 0.0f) {
+  if (NOGATE && P.prob > 0.0f) {
     hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P);
     return;
   }
   switch (P.proj.proj_type) {
-    case HALO_LENS_LINEAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_LINEAR>(P, grid, block, stream); break;
-    case HALO_LENS_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_FISHEYE_EQUAL_AREA>(P, grid, block, stream); break;
-    case HALO_LENS_DUAL_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_DUAL_FISHEYE_EQUAL_AREA>(P, grid, block, stream); break;
-    case HALO_LENS_RECTANGULAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_RECTANGULAR>(P, grid, block, stream); break;
+    case HALO_LENS_LINEAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_LINEAR, NOGATE>(P, grid, block, stream); break;
+    case HALO_LENS_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_FISHEYE_EQUAL_AREA, NOGATE>(P, grid, block, stream); break;
+    case HALO_LENS_DUAL_FISHEYE_EQUAL_AREA: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_DUAL_FISHEYE_EQUAL_AREA, NOGATE>(P, grid, block, stream); break;
+    case HALO_LENS_RECTANGULAR: launch_vis<MODE, GEOM, MONO, ACC, HALO_LENS_RECTANGULAR, NOGATE>(P, grid, block, stream); break;
     default: hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, MONO, ACC>), grid, block, 0, stream, P); break;
   }
 }
@@ -2881,8 +2884,10 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
           return;
         }
       }
-      if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
-      else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) {
+      if (mono) {
+        if constexpr ((MODE == kModePlain || MODE == kModeFilter) && (GEOM == kGeomOne || GEOM == kGeomOneHex)) launch_lens<MODE, GEOM, true, kAccLog, false>(P, grid, block, stream);
+        else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
+      } else if constexpr (GEOM == kGeomPool || GEOM == kGeomPoolPrism) {
         // illuminant sessions over sampled crystals: a full-sky render with a closed gate (bench_config_stoch.json's shape) knows both at
         // compile time (configs[4] 5.52 -> 5.43 ms per step; its lens as a constant gains nothing more: 4.31 vs 4.32 ms per launch)
         if constexpr (MODE == kModePlain) {
