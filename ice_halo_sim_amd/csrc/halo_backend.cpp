@@ -1572,6 +1572,8 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         if (fast_mode && use_log && one && !ran_none && b->mono_session && !P.final_layer && (mode == 0 || mode == 1) && lens_known && vis_known)
           spec |= 2u | 4u;   // (round 6: the logging kernels of the layers before the last know their lens and visible range too; their gate is open)
         if (mode == 0 && use_log && !one && !b->mono_session && P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL) spec |= 4u | 8u;
+        if (mode == 0 && use_log && !one && P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL && P.proj.proj_type == HALO_LENS_RECTANGULAR)
+          spec |= 2u | 4u | 8u;   // (shape-pool kernels, either plane layout: bench_config_stoch.json's render as constants)
         b->route.spec_mask |= spec;
         if (spec == 0u) b->route.generic_launches++;
       }

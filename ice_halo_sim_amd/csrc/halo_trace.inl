@@ -2884,6 +2884,16 @@ static void launch_mono(const DispatchParams& P, dim3 grid, dim3 block, hipStrea
           return;
         }
       }
+      // (round 6, end: the reference's own stochastic benchmark — bench_config_stoch.json: rectangular lens, full sky, closed gate — as constants for
+      //  the shape-pool kernels of both plane layouts.  The pool kernels project at the emit site, and the generic form of them holds every lens's
+      //  code inside the interaction loop: 14 283 instructions, 157 spilled SGPRs, 3 spilled VGPRs and scratch against 9950 / 73 / 0 / none.)
+      if constexpr (MODE == kModePlain && (GEOM == kGeomPool || GEOM == kGeomPoolPrism)) {
+        if (P.prob <= 0.0f && P.proj.visible_range == HALO_VISIBLE_FULL && P.proj.proj_type == HALO_LENS_RECTANGULAR) {
+          if (mono) hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog, HALO_LENS_RECTANGULAR, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+          else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, false, kAccLog, HALO_LENS_RECTANGULAR, HALO_VISIBLE_FULL, true>), grid, block, 0, stream, P);
+          return;
+        }
+      }
       if (mono) {
         if constexpr ((MODE == kModePlain || MODE == kModeFilter) && (GEOM == kGeomOne || GEOM == kGeomOneHex)) launch_lens<MODE, GEOM, true, kAccLog, false>(P, grid, block, stream);
         else hipLaunchKernelGGL((halo_trace_kernel<MODE, GEOM, true, kAccLog>), grid, block, 0, stream, P);
