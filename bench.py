@@ -569,13 +569,29 @@ def measure(cfg, args, ctx, steps, warmup, repeats, with_cpu):
         reduce_events.clear()
         del tracer.reduce_spans[:]
     times = [timed_region() for _ in range(max(repeats, 1))]
+    drain_switched = False
+    if drain_probe is not None and tracer.two and statistics.median(times) > 1.25 * drain_probe[False]:
+        # Safety net.  The probe's two short regions per mode do not always show what the side-stream drain does once the queues are deep: in the
+        # one-GPU gloo rehearsal it probed 43.9 vs 43.0 ms per step, was chosen (within 2 %), and then ran 451 ms per step.  When the chosen
+        # side-stream drain runs a quarter slower than the in-line drain PROBED, the line is measured again with the in-line drain and says so
+        # (every rank sees the same MAX-reduced times, so they all switch).
+        tracer._join()
+        tracer.set_overlap(False)
+        tracer.backend.collect_stats()
+        tracer.backend.collect_timing()
+        for k in first_layer:
+            first_layer[k] = 0
+        reduce_events.clear()
+        del tracer.reduce_spans[:]
+        times = [timed_region() for _ in range(max(repeats, 1))]
+        drain_switched = True
     trace_ms, post_ms, timed_launches = tracer.backend.collect_timing()   # HIP events of the LAST layer's launches: the trace kernels' own spans / their accumulation passes'
     st = tracer.backend.collect_stats()                      # HIP-event kernel times + device tallies of every timed repeat
     route = tracer.backend.last_route()
     overlap_ab = None
     if drain_probe is not None:
         spans = [a.elapsed_time(b) for a, b, _, _ in tracer.reduce_spans]
-        overlap_ab = {"drain_chosen": "side_stream" if tracer.two else "in_line",
+        overlap_ab = {"drain_chosen": "side_stream" if tracer.two else "in_line", "switched_after_the_timed_run": drain_switched,
                       "probe_ms_per_step": {"side_stream": drain_probe[True] * 1e3 / steps, "in_line": drain_probe[False] * 1e3 / steps},
                       "reduce_ms_events_mean": (sum(spans) / len(spans)) if spans else None, "reduces_timed": len(spans),
                       "note": "probe = the faster of two untimed regions per mode, after the warm-up; `value` is measured in the chosen mode. reduce_ms: events on the "

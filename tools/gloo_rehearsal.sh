@@ -10,7 +10,7 @@ import json,sys
 lines=[l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')]
 d=json.loads(lines[-1]); m=d['multi_gpu']
 print(json.dumps({k:d[k] for k in ('metric','value','unit','n_gpus','steps','ms_per_step','scaling')}))
-print('  ranks_seen', m['ranks_seen'], 'backend', m['backend'], 'distinct_devices', m['distinct_devices'], 'reduce_floats', m['reduce_floats'], 'reduce_ms_mean_over_ranks %.3f' % m['reduce_ms_mean_over_ranks'])
+print('  ranks_seen', m['ranks_seen'], 'backend', m['backend'], 'distinct_devices', m['distinct_devices'], 'reduce_floats', m['reduce_floats'], 'reduce_ms_mean_over_ranks', m['reduce_ms_mean_over_ranks'])
 for r in m['ranks']: print('  rank', r['rank'], 'local', r['local_rank'], 'dev', r['device_index'], r['name'], 'uuid', r['uuid'], 'pci', r['pci'], 'pid', r['pid'], 'reduce_ms mean %.3f max %.3f (%d timed)' % (r['reduce_ms_mean'], r['reduce_ms_max'], r['reduces_timed']), 'check sumY %.6g landed %.6g' % (r['check_sum_y'], r['check_landed']))
 print('  check', json.dumps(m['check']))
 print('  reduce_overlap', json.dumps(m.get('reduce_overlap')))
