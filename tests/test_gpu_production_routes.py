@@ -671,6 +671,36 @@ def test_lens_specialised_last_layer_kernels_vs_oracle(lens, visible):
     print("lens %d visible %d: spec %d, block-mean rel L2 %.2e" % (lens, visible, r.spec_mask, err))
 
 
+@pytest.mark.parametrize("lens,visible", [(abi.LENS_LINEAR, abi.VISIBLE_UPPER), (abi.LENS_FISHEYE_EQUAL_AREA, abi.VISIBLE_FULL),
+                                          (abi.LENS_DUAL_FISHEYE_EQUAL_AREA, abi.VISIBLE_UPPER), (abi.LENS_RECTANGULAR, abi.VISIBLE_FULL)])
+def test_lens_specialised_first_layer_logging_kernels_vs_oracle(lens, visible):
+    """Round 6: the logging kernels of the layers BEFORE the last take the lens and the visible range as template constants too
+    (`halo_trace_kernel<0,3,true,kAccLog,LENS,VIS,false>`: their gate is open).  A two-layer scene whose first layer lets half of its outgoing
+    rays land (prob 0.5), 3 Mi roots: the route info must report no generic launch (first layer: lens | visible range; last layer: all four
+    bits), layer 0 must trace the oracle's rays (exit and continuation counts), and the image of both layers must agree with the oracle's
+    within the second layer's shot noise."""
+    col = scenes.column_crystal_entry()
+    sc = scenes.scene([(0.5, [col]), (0.0, [col])], max_hits=7)
+    dual = lens == abi.LENS_DUAL_FISHEYE_EQUAL_AREA
+    rd = scenes.render(lens, 1024, 512, fov=180.0 if lens != abi.LENS_LINEAR else 90.0, el=30.0 if lens != abi.LENS_RECTANGULAR else 0.0, visible=visible,
+                       overlap=0.0872 if dual else 0.0)
+    wl, n = scenes.wl_discrete(550.0), 3 << 20
+    hb = hip_backend(seed=91)
+    st = run_session(hb, sc, rd, wl, n)
+    r = hb.last_route()
+    ih, lh = hb.ReadbackXyzAccum()
+    hb.close()
+    assert r.mode_mask == abi.MODE_PLAIN and r.geom_mask == 1 << 3 and r.accum_mask == abi.ACCUM_LOG, (r.mode_mask, r.geom_mask, r.accum_mask)
+    assert r.spec_mask == abi.SPEC_LAST | abi.SPEC_LENS | abi.SPEC_VIS | abi.SPEC_NOGATE and r.generic_launches == 0, (r.spec_mask, r.generic_launches)
+    io, lo, st_o = _oracle_image(sc, rd, wl, n, 91, acc64=1)
+    assert st[0].exit_count == pytest.approx(st_o[0].exit_count, rel=3e-4) and st[0].continuation_count == pytest.approx(st_o[0].continuation_count, rel=3e-4)
+    assert st[1].root_count == st[0].continuation_count
+    assert lh == pytest.approx(lo, rel=2e-3), (lh, lo)   # measured 1e-4 .. 6e-4: the second layer draws its own continuation order
+    err = rel_l2(block_mean(ih, 16), block_mean(io, 16))
+    print("lens %d visible %d: spec %d generic %d, landed %.6g vs %.6g, 16x16 block-mean rel L2 %.2e" % (lens, visible, r.spec_mask, r.generic_launches, lh, lo, err))
+    assert err <= 1e-2, err   # measured 2.2e-3 .. 3.5e-3
+
+
 def test_unspecialised_lens_runs_the_generic_last_layer_kernel():
     """... and a lens outside that list (fisheye stereographic) reports the generic last-layer kernel — the route info tells the two apart."""
     sc = scenes.config2_scene()
