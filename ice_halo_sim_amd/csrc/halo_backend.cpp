@@ -1020,7 +1020,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     }
     return m;
   };
-  auto blocks_of = [&](uint64_t m) {
+  auto blocks_of = [&](uint64_t m, bool pool) {
     // per-workgroup fixed costs (table staging, pixel-cache zero + flush) are paid per launch, a long tail is paid per
     // round of resident workgroups: aim at >= 32 passes of the ray loop per workgroup, between 4 and blocks_per_cu per CU
     // (measured: 1 M rays 0.27 -> 0.20 ms at 4/CU; 50 M rays 4.02 -> 3.67 ms at 24/CU instead of 8/CU)
@@ -1030,7 +1030,9 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
     // with four same-line fp64 atomics; with those gone, tools/dispatch_probe.cpp, us per session at 1 / 2 / 3 / 4 / 5 / 8 per CU:
     // 2^18 rays 67 / 50 / 45 / 44 / 43 / 44, 2^20 188 / 133 / 122 / 115 / 110 / 111, 2^22 326 / 326 / 276 / 261 / 250 / 259.)
     const uint64_t want = m / (static_cast<uint64_t>(kBlock) * 32u);
-    const int small_k = b->small_blocks_per_cu > 0 ? b->small_blocks_per_cu : 5;
+    // (shape-pool kernels hold four workgroups a CU, not six, and every workgroup of a logged launch is a region for the split pass: three per CU
+    //  there — bench.py --config 4d, 0.8 M rays per session, ms per step at 1 / 2 / 3 / 4 / 5 / 6 / 8 per CU: 7.26 / 5.99 / 5.73 / 5.77 / 5.86 / 6.14 / 6.39)
+    const int small_k = b->small_blocks_per_cu > 0 ? b->small_blocks_per_cu : pool ? 3 : 5;
     const uint64_t lo_cap = static_cast<uint64_t>(b->cu_count) * static_cast<uint64_t>(std::min(b->blocks_per_cu, small_k));
     const uint64_t cap = std::min<uint64_t>(static_cast<uint64_t>(max_blocks), std::max<uint64_t>(lo_cap, want));
     uint64_t nb = std::min<uint64_t>((m + kBlock - 1) / kBlock, cap);
@@ -1045,10 +1047,10 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
   if (!final_layer) {
     uint64_t region = 0;
     for (int ci = 0; ci < L.entry_count; ci++) {
-      const bool det = host::IsDeterministic(L.entries[ci].crystal);
+      const bool det = (rays != nullptr && rays->crystal != nullptr && layer == 0) || host::IsDeterministic(L.entries[ci].crystal);   // (as the launch below decides it: the same workgroup count)
       for (uint64_t off = 0; off < per_ci[ci];) {
         const uint64_t m = chunk_of(per_ci[ci] - off, L.entries[ci].crystal);
-        const uint64_t nb = static_cast<uint64_t>(blocks_of(m));
+        const uint64_t nb = static_cast<uint64_t>(blocks_of(m, !det));
         const uint64_t per_block = (m + nb * kBlock - 1) / (nb * kBlock) * kBlock;   // grid-stride share, rounded up
         region += (nb + kContShards - 1) / kContShards * per_block * static_cast<uint64_t>(b->scene.max_hits);
         off += m;
@@ -1352,7 +1354,7 @@ int halo_trace_layer(halo_handle_t b, uint64_t count, const HaloHostRays* rays, 
         P.host_w = b->host_f.ptr + n * 6 + off;
         P.host_tf = b->host_u.ptr + off;
       }
-      const int blocks = blocks_of(m);
+      const int blocks = blocks_of(m, !deterministic);
       // binned accumulation for big one-plane launches (see halo_trace.inl: HitBuffer)
       // 16384-slot tiles over the session's planes taken as one array (1 plane, or the per-entry planes of a small image)
       const uint64_t bin_slots = (static_cast<uint64_t>(kMonoRows) << b->mono_s_log2) * (b->mono_by_wl ? b->plane_cnt : 1u);
