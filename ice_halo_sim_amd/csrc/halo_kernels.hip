@@ -13,6 +13,19 @@ namespace halo {
 // for the CMF rows of the X/Y/Z pass), so the unsigned sums cannot wrap.  F = 32 (resolution 2.3e-10) for every launch of unit-weight
 // rays up to 2^28; an illuminant session (spd weights ~100) of 2^26 rays runs F = 28.  (Round 3 had F fixed at 32 on the assumption
 // "weight <= 1" and a signed read-out: 4e9 of weight in one slot wrapped negative — ADVICE r3.)  A NaN or negative weight adds nothing.
+// A tile list is read once, by one workgroup, a moment after the split pass wrote it: loaded non-temporally (four dword loads the compiler merges
+// into one `global_load_dwordx4 ... nt`) the per-tile pass of configs[1] takes 108 us instead of 137 — the same pass launched a second time on the
+// same lists takes 107 (round 6, rocprofv3 per-kernel minima on one box; non-temporal STORES in the split pass cost it more than they save here).
+// Short lists (a small session's: they sit in the caches whole) keep the ordinary load — `--config 4d` lost 0.8 % with the other; `once` is
+// workgroup-uniform (the tile's record count).
+constexpr uint32_t kListOnceMin = 1u << 16;
+template <bool ONCE>   // (a run-time choice inside one loop comes out as ordinary loads on both sides: the loop exists twice instead)
+__device__ __forceinline__ uint4 load_list_u4(const uint4* p) {
+  if constexpr (!ONCE) return *p;
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+}
+
 struct FixQ {
   double to_fix, from_fix;
   __device__ __forceinline__ explicit FixQ(uint32_t frac_bits)
@@ -274,16 +287,20 @@ __global__ void __launch_bounds__(kBinBlock) halo_bin_accumulate_range_kernel(fl
   // flight instead of four gave 152 / 149
   const uint4* src4 = reinterpret_cast<const uint4*>(src);
   const uint32_t n2 = n / 2u;
-  for (; i + (kU - 1u) * kBinBlock < n2; i += kU * kBinBlock) {
-    uint4 h[kU];
+  auto stream = [&](auto once) {
+    for (; i + (kU - 1u) * kBinBlock < n2; i += kU * kBinBlock) {
+      uint4 h[kU];
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) h[u] = src4[i + u * kBinBlock];
+      for (uint32_t u = 0; u < kU; ++u) h[u] = load_list_u4<decltype(once)::value>(&src4[i + u * kBinBlock]);
 #pragma unroll
-    for (uint32_t u = 0; u < kU; ++u) {
-      atomicAdd(&acc[h[u].x & mask], fq.fix(__uint_as_float(h[u].y)));
-      atomicAdd(&acc[h[u].z & mask], fq.fix(__uint_as_float(h[u].w)));
+      for (uint32_t u = 0; u < kU; ++u) {
+        atomicAdd(&acc[h[u].x & mask], fq.fix(__uint_as_float(h[u].y)));
+        atomicAdd(&acc[h[u].z & mask], fq.fix(__uint_as_float(h[u].w)));
+      }
     }
-  }
+  };
+  if (n >= kListOnceMin) stream(std::true_type{});
+  else stream(std::false_type{});
   for (uint32_t r = 2u * i; r < n; r += 2u * kBinBlock) {   // what is left of this thread's pairs, and the odd last record
     for (uint32_t q = r; q < min(r + 2u, n); ++q) {
       const uint2 h = src[q];
@@ -381,11 +398,12 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
   const uint32_t n2 = n / 2u;
   constexpr uint32_t kU2 = kU / 2u;
   uint32_t i = threadIdx.x;
+  auto stream = [&](auto once) {
   for (; i + (kU2 - 1u) * kBinBlock < n2; i += kU2 * kBinBlock) {
     uint2 h[kU];
 #pragma unroll
     for (uint32_t u = 0; u < kU2; ++u) {
-      const uint4 q = src4[i + u * kBinBlock];
+      const uint4 q = load_list_u4<decltype(once)::value>(&src4[i + u * kBinBlock]);
       h[2u * u] = make_uint2(q.x, q.y);
       h[2u * u + 1u] = make_uint2(q.z, q.w);
     }
@@ -410,6 +428,9 @@ __global__ void __launch_bounds__(kBinBlock) halo_log_accumulate_kernel(float* _
       for (uint32_t u = 0; u < kU; ++u) add(h[u]);
     }
   }
+  };
+  if (n >= kListOnceMin) stream(std::true_type{});
+  else stream(std::false_type{});
   for (uint32_t r = 2u * i; r < n; r += 2u * kBinBlock) {   // what is left of this thread's pairs, and the odd last record
     add(src[r]);
     if (r + 1u < n) add(src[r + 1u]);
